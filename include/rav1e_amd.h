@@ -1,0 +1,176 @@
+/*
+ * rav1e_amd.h -- C ABI of librav1e_hip.so, the MI355X (gfx950) block-kernel
+ * backend for rav1e's per-block RDO inner loop.
+ *
+ * This is the drop-in boundary: exactly what a new `CpuFeatureLevel::HIP`
+ * row of rav1e's `src/asm` dispatch tables would bind over FFI
+ * (reference dispatch surface: src/cpu_features/x86.rs:97-158; per-family
+ * tables cited at each entry point below).  Two layers:
+ *
+ *  (1) BATCH API (the product).  The reference calls its kernels one block at
+ *      a time (src/me.rs:1445-1454, src/rdo.rs:1328-1352, src/encoder.rs:
+ *      1404-1661); a GPU wants thousands of independent candidates per
+ *      launch, so the host enqueues descriptor arrays and flushes.  All
+ *      pointers are DEVICE pointers unless stated; the caller owns every
+ *      buffer; nothing is retained after a call returns; calls are
+ *      asynchronous on `stream` (a hipStream_t passed as void*, NULL = the
+ *      default stream).  Return value: 0 ok, negative R1_E* on error; results
+ *      are undefined on error.  Thread-safe: no global mutable state.
+ *
+ *  (2) PER-CALL COMPAT SHIMS with the reference's exact asm signatures
+ *      (host pointers, byte strides, values returned directly).  They stage,
+ *      launch and synchronise -- for plumbing / `check_asm`-style parity
+ *      only, never fast.
+ *
+ * Enum integer values are the reference's (they index its dispatch tables):
+ *   BlockSize  src/partition.rs:130-153      TxSize  src/transform/mod.rs:101-123
+ *   TxType     src/transform/mod.rs:56-74    FilterMode  src/mc.rs:100-106
+ */
+#ifndef RAV1E_AMD_H
+#define RAV1E_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R1_OK 0
+#define R1_EINVAL (-1)   /* bad argument / descriptor (reference: assert! panic) */
+#define R1_EHIP (-2)     /* HIP runtime error; see r1_last_error() */
+#define R1_ENOMEM (-3)
+
+/* ---- Plane<T> view (v_frame 0.3.9 PlaneConfig layout; reference use:
+ * src/tiling/plane_region.rs:185 -- element (x,y) lives at
+ * data[(yorigin + y) * stride + xorigin + x]).  `data` is a device pointer to
+ * the start of the allocation; stride is in ELEMENTS. */
+typedef struct R1Plane {
+  void *data;
+  int32_t stride;
+  int32_t alloc_height;
+  int32_t width, height;     /* visible size */
+  int32_t xorigin, yorigin;  /* padding left / above pixel (0,0) */
+  int32_t bytes_per_px;      /* 1 (Pixel = u8) or 2 (Pixel = u16) */
+  int32_t bit_depth;         /* 8, 10 or 12 */
+} R1Plane;
+
+/* rav1e FilterMode (src/mc.rs:100-106) */
+enum { R1_FILTER_REGULAR = 0, R1_FILTER_SMOOTH = 1, R1_FILTER_SHARP = 2,
+       R1_FILTER_BILINEAR = 3 };
+
+/* distortion kinds of r1_dist_batch */
+enum { R1_DIST_SAD = 0, R1_DIST_SATD = 1 };
+
+/* One distortion candidate: block of the launch's (w,h) at (ox,oy) in the
+ * org plane against (rx,ry) in the ref plane (full-pel, plane coordinates;
+ * may lie in the padding as the reference's MV clamp allows,
+ * src/me.rs:339-362). */
+typedef struct R1DistCand {
+  int16_t ox, oy, rx, ry;
+} R1DistCand;
+
+/* One motion-compensation candidate: full-pel position of the block in the
+ * ref plane plus 1/16-pel fractions, i.e. the outputs of get_mv_params
+ * (src/predict.rs:284-297). */
+typedef struct R1McCand {
+  int16_t rx, ry;
+  uint8_t col_frac, row_frac; /* 0..15 */
+  uint8_t mode_x, mode_y;     /* FilterMode */
+} R1McCand;
+
+/* One fused RDO candidate (mc -> dist -> diff -> forward transform). */
+typedef struct R1RdoCand {
+  int16_t ox, oy;             /* block position in the org (source) plane */
+  int16_t rx, ry;             /* full-pel position in the ref plane */
+  uint8_t col_frac, row_frac; /* 0..15 */
+  uint8_t mode_x, mode_y;     /* FilterMode */
+  uint8_t tx_type;            /* TxType for the residual transform */
+  uint8_t reserved[3];
+} R1RdoCand;
+
+typedef struct r1_ctx r1_ctx;
+
+/* ---- context ---- */
+int r1_ctx_create(int device, r1_ctx **out);
+void r1_ctx_destroy(r1_ctx *ctx);
+const char *r1_last_error(void);
+/* ABI version, bumped on any incompatible change */
+int r1_abi_version(void);
+
+/* ---- dist:: (reference: src/dist.rs get_sad 31, get_satd 156; dispatch
+ * tables SAD_FNS/SATD_FNS/_HBD src/asm/x86/dist/mod.rs:483-729).
+ * out[i] = get_sad/get_satd(org@cand[i], ref@cand[i], w, h).  w,h <= 128 and
+ * multiples of 4 (SATD uses 4x4 Hadamards when min(w,h)==4 else 8x8). */
+int r1_dist_batch(r1_ctx *ctx, int kind, const R1Plane *org,
+                  const R1Plane *ref, int w, int h, const R1DistCand *cands,
+                  int n, uint32_t *out, void *stream);
+
+/* ---- transform::forward (reference: src/transform/forward.rs:71-161;
+ * x86 entry src/asm/x86/transform/forward.rs:444-447).
+ * residual: n dense blocks of w*h int16 (row-major, stride = tx width, the
+ * only call site's layout, src/encoder.rs:1544-1552).
+ * coeffs: n dense blocks of w*h coefficients in the reference's transposed,
+ * 32x32-chunked order; int16 when coeff_bytes == 2 (Pixel = u8) or int32
+ * when 4 (Pixel = u16).  Invalid (tx_size, tx_type) -> R1_EINVAL. */
+int r1_fwd_txfm_batch(r1_ctx *ctx, const int16_t *residual, void *coeffs,
+                      int n, int tx_size, int tx_type, int bit_depth,
+                      int coeff_bytes, void *stream);
+
+/* ---- mc:: (reference: src/mc.rs put_8tap 250, prep_8tap 360, mc_avg 454;
+ * dispatch tables PUT_FNS/PREP_FNS/AVG_FNS src/asm/x86/mc.rs:17-78,371-382).
+ * put: dst = n dense w*h pixel blocks (same pixel type as `ref`).
+ * prep: tmp = n dense w*h int16 blocks.  avg: dst from two prep outputs.
+ * w power of two in 2..128 (this ABI: >= 4), h even. */
+int r1_mc_put_batch(r1_ctx *ctx, const R1Plane *ref, int w, int h,
+                    const R1McCand *cands, int n, void *dst, void *stream);
+int r1_mc_prep_batch(r1_ctx *ctx, const R1Plane *ref, int w, int h,
+                     const R1McCand *cands, int n, int16_t *tmp, void *stream);
+int r1_mc_avg_batch(r1_ctx *ctx, const int16_t *tmp1, const int16_t *tmp2,
+                    int w, int h, int n, int bit_depth, int bytes_per_px,
+                    void *dst, void *stream);
+
+/* ---- fused RDO candidate: the headline path.  For each candidate:
+ *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)
+ *   sad    = get_sad(org @ (ox,oy), pred)       if sad_out     (src/dist.rs:31)
+ *   satd   = get_satd(org @ (ox,oy), pred)      if satd_out    (src/dist.rs:156)
+ *   resid  = diff(org, pred)                                    (src/encoder.rs:1355)
+ *   coeffs = forward_transform(resid, tx_size, tx_type)  if coeffs
+ * in one launch with the block staged in LDS; pred never touches HBM unless
+ * pred_out is non-NULL.  tx_size must be the block's own size (w x h <= 64). */
+int r1_rdo_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
+                      int w, int h, int tx_size, const R1RdoCand *cands, int n,
+                      uint32_t *sad_out, uint32_t *satd_out, void *coeffs,
+                      void *pred_out, void *stream);
+
+/* ---- per-call compat shims: reference asm signatures, HOST pointers ----
+ * SadFn / SatdFn (src/asm/x86/dist/mod.rs:21-43): strides in BYTES. */
+uint32_t rav1e_sad_hip(const uint8_t *src, ptrdiff_t src_stride,
+                       const uint8_t *dst, ptrdiff_t dst_stride, int w, int h);
+uint32_t rav1e_satd_hip(const uint8_t *src, ptrdiff_t src_stride,
+                        const uint8_t *dst, ptrdiff_t dst_stride, int w, int h);
+uint32_t rav1e_sad_hbd_hip(const uint16_t *src, ptrdiff_t src_stride,
+                           const uint16_t *dst, ptrdiff_t dst_stride, int w,
+                           int h);
+uint32_t rav1e_satd_hbd_hip(const uint16_t *src, ptrdiff_t src_stride,
+                            const uint16_t *dst, ptrdiff_t dst_stride, int w,
+                            int h, uint32_t bdmax);
+/* PutFn / PutHBDFn (src/asm/x86/mc.rs:17-38); `src` must be readable 3 px
+ * before and 4 px after the block in both dimensions (mc.rs:121-123).
+ * mode_x/mode_y select the table entry the reference indexes with
+ * get_2d_mode_idx (src/asm/x86/mc.rs:82-84). */
+void rav1e_put_8tap_hip(uint8_t *dst, ptrdiff_t dst_stride, const uint8_t *src,
+                        ptrdiff_t src_stride, int w, int h, int mx, int my,
+                        int mode_x, int mode_y);
+void rav1e_put_8tap_hbd_hip(uint16_t *dst, ptrdiff_t dst_stride,
+                            const uint16_t *src, ptrdiff_t src_stride, int w,
+                            int h, int mx, int my, int mode_x, int mode_y,
+                            int bitdepth_max);
+/* forward_transform (Rust-generic entry, src/asm/x86/transform/forward.rs:444) */
+int rav1e_fwd_txfm_hip(const int16_t *input, void *output, size_t stride,
+                       int tx_size, int tx_type, int bd, int coeff_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAV1E_AMD_H */

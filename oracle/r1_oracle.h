@@ -1,0 +1,119 @@
+/*
+ * r1_oracle.h -- CPU oracle for the rav1e block-kernel hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a scalar, plain-C restatement of the
+ * reference's pure-Rust kernels (RAV1E_CPU_TARGET=rust semantics).  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link
+ * or call it, and only as the checker / the timed CPU baseline.  The product
+ * (rav1e_amd/csrc, librav1e_hip.so) never includes or links anything here.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - get_sad / get_satd: pinned by the reference's own known-answer tables
+ *     (src/dist.rs:418-441, 477-500), reproduced in tests/test_oracle_dist.py.
+ *   - forward transform, put/prep_8tap, mc_avg, weighted SSE, cdef_dist:
+ *     the reference holds no golden vectors for these ("parity unpinned" by
+ *     constants); pinned here by spec properties (float DCT/ADST closeness,
+ *     fwd->inv round trip tolerances of src/transform/mod.rs:555-603,
+ *     filter-tap normalisation) and by tests/golden/ vectors produced in the
+ *     build container from the reference source text (see tests/golden/README).
+ *
+ * Conventions: strides are in ELEMENTS (not bytes); `hbd` != 0 means the
+ * pixel type is u16 (rav1e Pixel = u16), else u8.  Pointers address the
+ * top-left sample of the block (the PlaneRegion / PlaneSlice origin).
+ */
+#ifndef R1_ORACLE_H
+#define R1_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dist (src/dist.rs) ---- */
+uint32_t r1o_get_sad(const void *org, ptrdiff_t org_stride, const void *ref,
+                     ptrdiff_t ref_stride, int w, int h, int hbd);
+uint32_t r1o_get_satd(const void *org, ptrdiff_t org_stride, const void *ref,
+                      ptrdiff_t ref_stride, int w, int h, int hbd);
+uint64_t r1o_get_weighted_sse(const void *src1, ptrdiff_t stride1,
+                              const void *src2, ptrdiff_t stride2,
+                              const uint32_t *scale, size_t scale_stride,
+                              int w, int h, int hbd);
+uint32_t r1o_cdef_dist_kernel(const void *src, ptrdiff_t src_stride,
+                              const void *dst, ptrdiff_t dst_stride, int w,
+                              int h, int bit_depth, int hbd);
+uint32_t r1o_apply_ssim_boost(uint32_t input, uint32_t svar, uint32_t dvar,
+                              int bit_depth);
+/* rdo.rs glue: cdef_dist_wxh / sse_wxh with a per-8x8 (resp. per-4x4-cell)
+ * DistortionScale grid (Q14, row stride in entries). */
+uint64_t r1o_cdef_dist_wxh(const void *src1, ptrdiff_t stride1,
+                           const void *src2, ptrdiff_t stride2, int w, int h,
+                           int bit_depth, int hbd, const uint32_t *bias8x8,
+                           size_t bias_stride);
+
+/* ---- mc (src/mc.rs) ---- */
+void r1o_put_8tap(void *dst, ptrdiff_t dst_stride, const void *src,
+                  ptrdiff_t src_stride, int w, int h, int col_frac,
+                  int row_frac, int mode_x, int mode_y, int bit_depth,
+                  int hbd);
+void r1o_prep_8tap(int16_t *tmp, const void *src, ptrdiff_t src_stride, int w,
+                   int h, int col_frac, int row_frac, int mode_x, int mode_y,
+                   int bit_depth, int hbd);
+void r1o_mc_avg(void *dst, ptrdiff_t dst_stride, const int16_t *tmp1,
+                const int16_t *tmp2, int w, int h, int bit_depth, int hbd);
+
+/* ---- forward transform (src/transform/forward*.rs) ---- */
+/* tx_size / tx_type use the reference's enum values (transform/mod.rs:56-123).
+ * coeff32 != 0: output is int32_t (T::Coeff for u16 pixels) else int16_t.
+ * returns 0, or -1 for an invalid (tx_size, tx_type) pair (reference panics). */
+int r1o_forward_transform(const int16_t *input, void *output, size_t stride,
+                          int tx_size, int tx_type, int bd, int coeff32);
+int r1o_tx_width(int tx_size);
+int r1o_tx_height(int tx_size);
+int r1o_valid_av1_transform(int tx_size, int tx_type);
+/* 1-D kernels exposed for property tests. type: 0..12 = TxfmType order
+ * (DCT4,DCT8,DCT16,DCT32,DCT64,ADST4,ADST8,ADST16,Id4,Id8,Id16,Id32,WHT4) */
+void r1o_fwd_txfm_1d(int32_t *coeffs, int txfm_type);
+
+/* encoder.rs:1355 diff */
+void r1o_diff(int16_t *dst, const void *src1, ptrdiff_t stride1,
+              const void *src2, ptrdiff_t stride2, int w, int h, int hbd);
+
+/* ---- batch drivers (oracle/batch.c): host-memory mirrors of the product's
+ * batch C ABI (include/rav1e_amd.h), looping the scalar kernels above over
+ * candidate lists with OpenMP.  Plane/candidate structs have the same layout
+ * as R1Plane / R1DistCand / R1McCand / R1RdoCand so tests can reuse one
+ * ctypes definition; `data` is a HOST pointer here. ---- */
+typedef struct {
+  void *data;
+  int32_t stride, alloc_height, width, height, xorigin, yorigin;
+  int32_t bytes_per_px, bit_depth;
+} r1o_plane;
+typedef struct { int16_t ox, oy, rx, ry; } r1o_dist_cand;
+typedef struct { int16_t rx, ry; uint8_t col_frac, row_frac, mode_x, mode_y; } r1o_mc_cand;
+typedef struct {
+  int16_t ox, oy, rx, ry;
+  uint8_t col_frac, row_frac, mode_x, mode_y, tx_type, reserved[3];
+} r1o_rdo_cand;
+
+void r1o_set_threads(int n);
+int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
+                   int h, const r1o_dist_cand *c, int n, uint32_t *out);
+int r1o_fwd_txfm_batch(const int16_t *residual, void *coeffs, int n,
+                       int tx_size, int tx_type, int bit_depth, int coeff_bytes);
+int r1o_mc_put_batch(const r1o_plane *ref, int w, int h, const r1o_mc_cand *c,
+                     int n, void *dst);
+int r1o_mc_prep_batch(const r1o_plane *ref, int w, int h, const r1o_mc_cand *c,
+                      int n, int16_t *tmp);
+int r1o_mc_avg_batch(const int16_t *t1, const int16_t *t2, int w, int h, int n,
+                     int bit_depth, int bytes_per_px, void *dst);
+int r1o_rdo_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, int h,
+                       int tx_size, const r1o_rdo_cand *c, int n,
+                       uint32_t *sad_out, uint32_t *satd_out, void *coeffs,
+                       void *pred_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+"""ctypes loader for the CPU oracle (oracle/libr1oracle.so) -- test infrastructure.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ODIR, "libr1oracle.so")
+
+
+class Plane(C.Structure):
+    """Layout shared by R1Plane (include/rav1e_amd.h) and r1o_plane."""
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_int32), ("alloc_height", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32), ("xorigin", C.c_int32),
+                ("yorigin", C.c_int32), ("bytes_per_px", C.c_int32), ("bit_depth", C.c_int32)]
+
+
+DIST_CAND = np.dtype([("ox", "<i2"), ("oy", "<i2"), ("rx", "<i2"), ("ry", "<i2")])
+MC_CAND = np.dtype([("rx", "<i2"), ("ry", "<i2"), ("col_frac", "u1"), ("row_frac", "u1"),
+                    ("mode_x", "u1"), ("mode_y", "u1")])
+RDO_CAND = np.dtype([("ox", "<i2"), ("oy", "<i2"), ("rx", "<i2"), ("ry", "<i2"),
+                     ("col_frac", "u1"), ("row_frac", "u1"), ("mode_x", "u1"), ("mode_y", "u1"),
+                     ("tx_type", "u1"), ("reserved", "u1", (3,))])
+assert DIST_CAND.itemsize == 8 and MC_CAND.itemsize == 8 and RDO_CAND.itemsize == 16
+
+
+def build(force=False):
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h", ".inc"))]
+    if force or not os.path.exists(SO) or any(
+            os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
+        subprocess.check_call(["make", "-C", ODIR, "-s", "-B"])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        build()
+    L = C.CDLL(SO)
+    vp, i, sz, pd = C.c_void_p, C.c_int, C.c_size_t, C.c_ssize_t
+    sigs = {
+        "r1o_get_sad": (C.c_uint32, [vp, pd, vp, pd, i, i, i]),
+        "r1o_get_satd": (C.c_uint32, [vp, pd, vp, pd, i, i, i]),
+        "r1o_get_weighted_sse": (C.c_uint64, [vp, pd, vp, pd, vp, sz, i, i, i]),
+        "r1o_cdef_dist_kernel": (C.c_uint32, [vp, pd, vp, pd, i, i, i, i]),
+        "r1o_apply_ssim_boost": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, i]),
+        "r1o_cdef_dist_wxh": (C.c_uint64, [vp, pd, vp, pd, i, i, i, i, vp, sz]),
+        "r1o_put_8tap": (None, [vp, pd, vp, pd, i, i, i, i, i, i, i, i]),
+        "r1o_prep_8tap": (None, [vp, vp, pd, i, i, i, i, i, i, i, i]),
+        "r1o_mc_avg": (None, [vp, pd, vp, vp, i, i, i, i]),
+        "r1o_forward_transform": (i, [vp, vp, sz, i, i, i, i]),
+        "r1o_tx_width": (i, [i]), "r1o_tx_height": (i, [i]),
+        "r1o_valid_av1_transform": (i, [i, i]),
+        "r1o_fwd_txfm_1d": (None, [vp, i]),
+        "r1o_diff": (None, [vp, vp, pd, vp, pd, i, i, i]),
+        "r1o_set_threads": (None, [i]),
+        "r1o_dist_batch": (i, [i, vp, vp, i, i, vp, i, vp]),
+        "r1o_fwd_txfm_batch": (i, [vp, vp, i, i, i, i, i]),
+        "r1o_mc_put_batch": (i, [vp, i, i, vp, i, vp]),
+        "r1o_mc_prep_batch": (i, [vp, i, i, vp, i, vp]),
+        "r1o_mc_avg_batch": (i, [vp, vp, i, i, i, i, i, vp]),
+        "r1o_rdo_cand_batch": (i, [vp, vp, i, i, i, vp, i, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        if hasattr(L, name):
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class HostPlane:
+    """v_frame 0.3.9 Plane<T> layout (PlaneConfig::new): xorigin and stride are
+    rounded up so that row starts are 64-byte aligned; element (x, y) lives at
+    data[(yorigin + y) * stride + xorigin + x] (src/tiling/plane_region.rs:185).
+    rav1e frames use xpad = ypad = 88 for luma (src/frame/mod.rs:22-23)."""
+
+    def __init__(self, width, height, bit_depth=8, xpad=88, ypad=88, fill=None, rng=None):
+        self.bpp = 1 if bit_depth == 8 else 2
+        al = 64 // self.bpp
+        self.width, self.height, self.bit_depth = width, height, bit_depth
+        self.xpad, self.ypad = xpad, ypad
+        self.xorigin = (xpad + al - 1) // al * al
+        self.yorigin = ypad
+        self.stride = (self.xorigin + width + xpad + al - 1) // al * al
+        self.alloc_height = self.yorigin + height + ypad
+        dt = np.uint8 if self.bpp == 1 else np.uint16
+        if rng is not None:
+            self.data = rng.integers(0, 1 << bit_depth, size=(self.alloc_height, self.stride),
+                                     dtype=dt)
+        else:
+            self.data = np.full((self.alloc_height, self.stride), fill or 0, dtype=dt)
+
+    def view(self):
+        """visible area as an array view"""
+        return self.data[self.yorigin:self.yorigin + self.height,
+                         self.xorigin:self.xorigin + self.width]
+
+    def block_ptr(self, x, y):
+        off = ((self.yorigin + y) * self.stride + self.xorigin + x) * self.bpp
+        return C.c_void_p(self.data.ctypes.data + off)
+
+    def cstruct(self, data_ptr=None):
+        return Plane(data_ptr if data_ptr is not None else self.data.ctypes.data, self.stride,
+                     self.alloc_height, self.width, self.height, self.xorigin, self.yorigin,
+                     self.bpp, self.bit_depth)
