@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- RDO-candidate Mpixels/s (dist + fwd_tx + mc) at 4K speed-6.
+
+One "step" = one pass of the fused hot path (put_8tap -> SAD + SATD -> diff ->
+forward DCT, one launch per block size) over every candidate of a synthetic 4K
+frame: for each block of the speed-6 ladder 64/32/16/8 (rav1e_amd/workload.py)
+K candidates with random motion vectors and 1/16-pel fractions.  Inputs are
+resident in HBM before the timed region.  N > 1: one process per GPU, rank r
+owns tile r of the frame (uniform tiling, src/tiling/tiler.rs:56) and the
+ranks exchange their rows of the reconstructed/reference plane with one RCCL
+all-gather per step, issued on a side stream.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), carrying
+`roofline` for the dominant kernel and `cpu_baseline` (the CPU oracle timed on
+the host cores, rank 0 / N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--k", type=int, default=16, help="candidates per block")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="target duration of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--no-events", action="store_true",
+                    help="skip per-kernel event timing (roofline.achieved falls back to step time)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, host_org, host_ref, cands):
+    """Time the CPU oracle (port of the reference's Rust path, OpenMP over
+    candidates) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    L = O.lib()
+    cores = os.cpu_count() or 1
+    L.r1o_set_threads(cores)
+    ho = O.HostPlane(args.width, args.height, args.bit_depth)
+    hr = O.HostPlane(args.width, args.height, args.bit_depth)
+    ho.data, hr.data = host_org, host_ref
+    pa, pb = ho.cstruct(), hr.cstruct()
+    ct = np.int16 if ho.bpp == 1 else np.int32
+
+    def run(frac_n):
+        px = 0
+        t0 = time.perf_counter()
+        for s, c in cands.items():
+            n = max(1, int(len(c) * frac_n))
+            sub = np.ascontiguousarray(c[:: max(1, len(c) // n)][:n])
+            sad = np.zeros(len(sub), np.uint32)
+            satd = np.zeros(len(sub), np.uint32)
+            co = np.zeros((len(sub), s * s), ct)
+            ts = {64: 4, 32: 3, 16: 2, 8: 1}[s]
+            rc = L.r1o_rdo_cand_batch(C.byref(pa), C.byref(pb), s, s, ts, O.ptr(sub), len(sub),
+                                      O.ptr(sad), O.ptr(satd), O.ptr(co), None)
+            assert rc == 0
+            px += len(sub) * s * s
+        return px, time.perf_counter() - t0
+    px, dt = run(0.002)                       # calibration sample
+    rate = px / dt
+    total_px = sum(len(c) * s * s for s, c in cands.items())
+    frac = min(1.0, args.cpu_seconds * rate / total_px)
+    px, dt = run(frac)
+    return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
+            "kind": "port",
+            "sample": "%.3f%% of the step's candidates (every ladder size, strided), %.1f s, "
+                      "OpenMP over candidates" % (100 * frac, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from rav1e_amd import workload as W
+    from rav1e_amd.api import Context, Plane
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert args.gpus == world, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.cuda.current_device()
+    ctx = Context(dev)
+
+    fw, fh, bd = args.width, args.height, args.bit_depth
+    bpp = 1 if bd == 8 else 2
+    # ---- synthetic planes (uniform random, seeds 1 / 2), resident in HBM ----
+    host_org = W.random_plane_array(fw, fh, bd, 1)
+    host_ref = W.random_plane_array(fw, fh, bd, 2)
+    org = Plane.from_numpy(host_org, fw, fh, bd, 88, 88)
+    ref = Plane.from_numpy(host_ref, fw, fh, bd, 88, 88)
+
+    # ---- candidates: whole frame at N=1, tile `rank` otherwise ----
+    rects = W.tile_rects(world, fw, fh)
+    rect = rects[rank] if world > 1 else None
+    cands = W.speed6_ladder(fw, fh, args.k, rect=rect)
+    dcands = {s: torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
+              for s, c in cands.items()}
+    outs = {}
+    for s, c in cands.items():
+        n = len(c)
+        outs[s] = {"sad": torch.empty(n, dtype=torch.int32, device="cuda"),
+                   "satd": torch.empty(n, dtype=torch.int32, device="cuda"),
+                   "coeffs": torch.empty((n, s * s), dtype=torch.int16 if bpp == 1 else torch.int32,
+                                         device="cuda")}
+    my_px = sum(len(c) * s * s for s, c in cands.items())
+
+    # ---- exchange step for N > 1: all-gather of the tile-row slabs of the
+    # reconstructed plane (stand-in payload: this rank's rows of `ref`) ----
+    side = torch.cuda.Stream() if world > 1 else None
+    if world > 1:
+        rows = -(-ref.alloc_height // world)
+        send = ref.data[rank * rows: (rank + 1) * rows].contiguous()
+        if send.shape[0] < rows:
+            send = torch.cat([send, torch.zeros((rows - send.shape[0], ref.stride),
+                                                dtype=send.dtype, device="cuda")])
+        gathered = torch.empty((world * rows, ref.stride), dtype=send.dtype, device="cuda")
+
+    ev = {s: [] for s in cands}
+
+    def step(timed):
+        for s in W.LADDER:
+            n = len(cands[s])
+            if n == 0:
+                continue
+            if timed and not args.no_events:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ctx.rdo_cand_batch(org, ref, s, s, dcands[s], n=n, outs=outs[s])
+            if timed and not args.no_events:
+                e1.record()
+                ev[s].append((e0, e1))
+        if world > 1:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dist.all_gather_into_tensor(gathered, send)
+
+    def fence():
+        if world > 1:
+            torch.cuda.current_stream().wait_stream(side)
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+
+    # ---- aggregate: max time over ranks, total pixels over ranks ----
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        p = torch.tensor([my_px], dtype=torch.float64, device="cuda")
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        total_px = float(p.item())
+    else:
+        total_px = float(my_px)
+
+    if rank == 0:
+        per = {}
+        for s in cands:
+            if ev[s]:
+                ms = [a.elapsed_time(b) for a, b in ev[s]]
+                per[s] = sum(ms) / len(ms)
+        if per:
+            dom = max(per, key=lambda s: per[s])
+            n_dom = len(cands[dom])
+            abytes = W.algorithmic_bytes_per_cand(dom, dom, bpp) * n_dom
+            achieved = abytes / (per[dom] * 1e-3) / 1e9
+            kname = "k_rdo_cand<bpp=%d,%dx%d>" % (bpp, dom, dom)
+        else:
+            dom, per = None, {}
+            abytes = sum(W.algorithmic_bytes_per_cand(s, s, bpp) * len(c) for s, c in cands.items())
+            achieved = abytes / (dt / args.steps) / 1e9
+            kname = "k_rdo_cand (all sizes, step time)"
+        res = {
+            "metric": "RDO-candidate Mpixels/s (dist+fwd_tx+mc) at 4K speed-6",
+            "value": round(total_px * args.steps / dt / 1e6, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u8" if bpp == 1 else "u16",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d %d-bit luma, speed-6 ladder 64/32/16/8, K=%d fused "
+                                   "candidates per block (put_8tap REGULAR -> SAD+SATD -> diff -> "
+                                   "fwd DCT_DCT), MV +-32 px, random 1/16-pel fractions"
+                                   % (fw, fh, bd, args.k),
+                       "candidates_per_step": int(sum(len(c) for c in cands.values())) if world == 1
+                       else None,
+                       "tiles": world,
+                       "parallelism": "tile-per-gpu x%d" % world if world > 1 else "single-gpu"},
+            "roofline": {"bound": "hbm", "kernel": kname,
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(abytes),
+                         "avg_launch_ms": round(per[dom], 4) if dom else None},
+            "kernel_ms": {str(s): round(v, 4) for s, v in per.items()},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline(args, host_org, host_ref, cands)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

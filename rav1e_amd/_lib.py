@@ -1,0 +1,56 @@
+"""ctypes loader for the product library.  Fails loudly: no fallback."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "librav1e_hip.so")
+
+
+class R1Plane(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_int32), ("alloc_height", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32), ("xorigin", C.c_int32),
+                ("yorigin", C.c_int32), ("bytes_per_px", C.c_int32), ("bit_depth", C.c_int32)]
+
+
+# every symbol include/rav1e_amd.h declares: name -> (restype, argtypes)
+_vp, _i, _sz, _pd = C.c_void_p, C.c_int, C.c_size_t, C.c_ssize_t
+_PP = C.POINTER(R1Plane)
+SYMBOLS = {
+    "r1_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "r1_ctx_destroy": (None, [_vp]),
+    "r1_last_error": (C.c_char_p, []),
+    "r1_abi_version": (_i, []),
+    "r1_dist_batch": (_i, [_vp, _i, _PP, _PP, _i, _i, _vp, _i, _vp, _vp]),
+    "r1_fwd_txfm_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "r1_mc_put_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
+    "r1_mc_prep_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
+    "r1_mc_avg_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "r1_rdo_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rav1e_sad_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
+    "rav1e_satd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
+    "rav1e_sad_hbd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
+    "rav1e_satd_hbd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i, C.c_uint32]),
+    "rav1e_put_8tap_hip": (None, [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i, _i]),
+    "rav1e_put_8tap_hbd_hip": (None, [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i, _i, _i]),
+    "rav1e_fwd_txfm_hip": (_i, [_vp, _vp, _sz, _i, _i, _i, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librav1e_hip.so and bind every declared symbol.  Loading works
+    without a GPU (symbols only resolve); calling into it needs a device."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise ImportError(
+            "rav1e_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % SO)
+    L = C.CDLL(SO)
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(L, name)  # AttributeError if the export is missing
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L

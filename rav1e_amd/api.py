@@ -1,0 +1,188 @@
+"""Host-side mirror of the reference's kernel interface over the batch C ABI.
+
+Function names and argument meaning follow the reference (src/dist.rs,
+src/mc.rs, src/transform/forward.rs); the difference is that every call takes a
+whole candidate list.  All tensors live on the GPU (torch is the allocator and
+stream provider only); descriptors are packed as the C structs of
+include/rav1e_amd.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .types import TX_DIMS, valid_av1_transform
+
+DIST_CAND = np.dtype([("ox", "<i2"), ("oy", "<i2"), ("rx", "<i2"), ("ry", "<i2")])
+MC_CAND = np.dtype([("rx", "<i2"), ("ry", "<i2"), ("col_frac", "u1"), ("row_frac", "u1"),
+                    ("mode_x", "u1"), ("mode_y", "u1")])
+RDO_CAND = np.dtype([("ox", "<i2"), ("oy", "<i2"), ("rx", "<i2"), ("ry", "<i2"),
+                     ("col_frac", "u1"), ("row_frac", "u1"), ("mode_x", "u1"), ("mode_y", "u1"),
+                     ("tx_type", "u1"), ("reserved", "u1", (3,))])
+
+
+class R1Error(RuntimeError):
+    pass
+
+
+class Plane:
+    """Plane<T> with v_frame 0.3.9's PlaneConfig layout, resident in HBM.
+
+    xorigin / stride are rounded so row starts are 64-byte aligned; element
+    (x, y) is data[(yorigin + y) * stride + xorigin + x]
+    (src/tiling/plane_region.rs:185).  rav1e luma planes use 88 px of padding
+    (src/frame/mod.rs:22-23)."""
+
+    def __init__(self, width, height, bit_depth=8, xpad=88, ypad=88, device="cuda"):
+        self.bpp = 1 if bit_depth == 8 else 2
+        al = 64 // self.bpp
+        self.width, self.height, self.bit_depth = width, height, bit_depth
+        self.xpad, self.ypad = xpad, ypad
+        self.xorigin = (xpad + al - 1) // al * al
+        self.yorigin = ypad
+        self.stride = (self.xorigin + width + xpad + al - 1) // al * al
+        self.alloc_height = self.yorigin + height + ypad
+        dt = torch.uint8 if self.bpp == 1 else torch.int16  # raw 16-bit storage
+        self.data = torch.zeros((self.alloc_height, self.stride), dtype=dt, device=device)
+
+    @classmethod
+    def from_numpy(cls, arr, width, height, bit_depth, xpad, ypad, device="cuda"):
+        """arr: the full (alloc_height, stride) host array of a HostPlane-style layout."""
+        p = cls(width, height, bit_depth, xpad, ypad, device)
+        assert arr.shape == (p.alloc_height, p.stride), (arr.shape, p.alloc_height, p.stride)
+        src = arr if p.bpp == 1 else arr.view(np.int16)
+        p.data.copy_(torch.from_numpy(np.ascontiguousarray(src)))
+        return p
+
+    def cstruct(self):
+        return _lib.R1Plane(self.data.data_ptr(), self.stride, self.alloc_height, self.width,
+                            self.height, self.xorigin, self.yorigin, self.bpp, self.bit_depth)
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_cands(cands, dtype):
+    """numpy structured array (or device uint8 tensor) -> device byte tensor"""
+    if isinstance(cands, torch.Tensor):
+        return cands
+    a = np.ascontiguousarray(cands, dtype=dtype)
+    return torch.from_numpy(a.view(np.uint8).reshape(-1)).cuda()
+
+
+class Context:
+    """r1_ctx handle (one per process/GPU).  Thread-safe in the library."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise R1Error("rav1e_amd needs a HIP device; there is no CPU fallback")
+        h = C.c_void_p()
+        rc = self.lib.r1_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise R1Error("r1_ctx_create: %s" % self.lib.r1_last_error().decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.r1_ctx_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise R1Error("%s failed (%d): %s" % (what, rc, self.lib.r1_last_error().decode()))
+
+    # ---- dist:: ----
+    def dist_batch(self, kind, org, ref, w, h, cands, n=None, out=None):
+        """get_sad / get_satd (src/dist.rs:31,156) over a candidate list."""
+        dc = _dev_cands(cands, DIST_CAND)
+        n = dc.numel() // DIST_CAND.itemsize if n is None else n
+        if out is None:
+            out = torch.empty(n, dtype=torch.int32, device="cuda")
+        po, pr = org.cstruct(), ref.cstruct()
+        self._check(self.lib.r1_dist_batch(self.h, int(kind), C.byref(po), C.byref(pr), w, h,
+                                           dc.data_ptr(), n, out.data_ptr(), _stream_ptr()),
+                    "r1_dist_batch")
+        return out
+
+    # ---- transform::forward ----
+    def forward_transform_batch(self, residual, tx_size, tx_type, bit_depth, coeff_bytes=None,
+                                out=None):
+        """forward_transform (src/transform/forward.rs:71) over n dense blocks.
+        residual: int16 device tensor (n, h, w)."""
+        w, h = TX_DIMS[int(tx_size)]
+        n = residual.numel() // (w * h)
+        if coeff_bytes is None:
+            coeff_bytes = 2 if bit_depth == 8 else 4
+        if out is None:
+            out = torch.empty((n, w * h), dtype=torch.int16 if coeff_bytes == 2 else torch.int32,
+                              device="cuda")
+        self._check(self.lib.r1_fwd_txfm_batch(self.h, residual.data_ptr(), out.data_ptr(), n,
+                                               int(tx_size), int(tx_type), bit_depth, coeff_bytes,
+                                               _stream_ptr()), "r1_fwd_txfm_batch")
+        return out
+
+    # ---- mc:: ----
+    def put_8tap_batch(self, ref, w, h, cands, n=None, out=None):
+        dc = _dev_cands(cands, MC_CAND)
+        n = dc.numel() // MC_CAND.itemsize if n is None else n
+        if out is None:
+            out = torch.empty((n, h, w), dtype=torch.uint8 if ref.bpp == 1 else torch.int16,
+                              device="cuda")
+        pr = ref.cstruct()
+        self._check(self.lib.r1_mc_put_batch(self.h, C.byref(pr), w, h, dc.data_ptr(), n,
+                                             out.data_ptr(), _stream_ptr()), "r1_mc_put_batch")
+        return out
+
+    def prep_8tap_batch(self, ref, w, h, cands, n=None, out=None):
+        dc = _dev_cands(cands, MC_CAND)
+        n = dc.numel() // MC_CAND.itemsize if n is None else n
+        if out is None:
+            out = torch.empty((n, h, w), dtype=torch.int16, device="cuda")
+        pr = ref.cstruct()
+        self._check(self.lib.r1_mc_prep_batch(self.h, C.byref(pr), w, h, dc.data_ptr(), n,
+                                              out.data_ptr(), _stream_ptr()), "r1_mc_prep_batch")
+        return out
+
+    def mc_avg_batch(self, tmp1, tmp2, w, h, bit_depth, out=None):
+        n = tmp1.numel() // (w * h)
+        bpp = 1 if bit_depth == 8 else 2
+        if out is None:
+            out = torch.empty((n, h, w), dtype=torch.uint8 if bpp == 1 else torch.int16,
+                              device="cuda")
+        self._check(self.lib.r1_mc_avg_batch(self.h, tmp1.data_ptr(), tmp2.data_ptr(), w, h, n,
+                                             bit_depth, bpp, out.data_ptr(), _stream_ptr()),
+                    "r1_mc_avg_batch")
+        return out
+
+    # ---- fused candidate ----
+    def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,
+                       want_coeffs=True, want_pred=False, outs=None):
+        """mc -> sad/satd -> diff -> forward_transform for every candidate."""
+        from .types import TxSize
+        tx_size = int(TxSize.by_dims(w, h))
+        dc = _dev_cands(cands, RDO_CAND)
+        n = dc.numel() // RDO_CAND.itemsize if n is None else n
+        o = outs or {}
+        if want_sad and "sad" not in o:
+            o["sad"] = torch.empty(n, dtype=torch.int32, device="cuda")
+        if want_satd and "satd" not in o:
+            o["satd"] = torch.empty(n, dtype=torch.int32, device="cuda")
+        if want_coeffs and "coeffs" not in o:
+            o["coeffs"] = torch.empty((n, w * h), dtype=torch.int16 if org.bpp == 1 else torch.int32,
+                                      device="cuda")
+        if want_pred and "pred" not in o:
+            o["pred"] = torch.empty((n, h, w), dtype=torch.uint8 if org.bpp == 1 else torch.int16,
+                                    device="cuda")
+        po, pr = org.cstruct(), ref.cstruct()
+
+        def p(k, want):
+            return o[k].data_ptr() if want else None
+        self._check(self.lib.r1_rdo_cand_batch(self.h, C.byref(po), C.byref(pr), w, h, tx_size,
+                                               dc.data_ptr(), n, p("sad", want_sad),
+                                               p("satd", want_satd), p("coeffs", want_coeffs),
+                                               p("pred", want_pred), _stream_ptr()),
+                    "r1_rdo_cand_batch")
+        return o

@@ -1,0 +1,198 @@
+// mc_common.hpp -- AV1 sub-pel interpolation filters and the put/prep
+// arithmetic shared by mc.hip and rdo_cand.hip.
+//
+// Restates (reference file:line):
+//   SUBPEL_FILTERS     src/mc.rs:110-219 (AV1 spec tables: regular, smooth,
+//                      sharp, bilinear, 4-tap regular, 4-tap smooth)
+//   get_filter         src/mc.rs:238-247
+//   put_8tap           src/mc.rs:250-353     prep_8tap  src/mc.rs:360-451
+//   mc_avg             src/mc.rs:454-479     PREP_BIAS  src/mc.rs:355-357
+#pragma once
+#include "common.hpp"
+
+namespace r1mc {
+
+// taps as int8 pairs would not hold 128 (the frac-0 row), which the kernels
+// never multiply with (frac 0 takes the copy / 1-D paths), so int16 it is.
+__constant__ int16_t kSubpel[6][16][8] = {
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 2, -6, 126, 8, -2, 0, 0},
+     {0, 2, -10, 122, 18, -4, 0, 0}, {0, 2, -12, 116, 28, -8, 2, 0},
+     {0, 2, -14, 110, 38, -10, 2, 0}, {0, 2, -14, 102, 48, -12, 2, 0},
+     {0, 2, -16, 94, 58, -12, 2, 0}, {0, 2, -14, 84, 66, -12, 2, 0},
+     {0, 2, -14, 76, 76, -14, 2, 0}, {0, 2, -12, 66, 84, -14, 2, 0},
+     {0, 2, -12, 58, 94, -16, 2, 0}, {0, 2, -12, 48, 102, -14, 2, 0},
+     {0, 2, -10, 38, 110, -14, 2, 0}, {0, 2, -8, 28, 116, -12, 2, 0},
+     {0, 0, -4, 18, 122, -10, 2, 0}, {0, 0, -2, 8, 126, -6, 2, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 2, 28, 62, 34, 2, 0, 0},
+     {0, 0, 26, 62, 36, 4, 0, 0}, {0, 0, 22, 62, 40, 4, 0, 0},
+     {0, 0, 20, 60, 42, 6, 0, 0}, {0, 0, 18, 58, 44, 8, 0, 0},
+     {0, 0, 16, 56, 46, 10, 0, 0}, {0, -2, 16, 54, 48, 12, 0, 0},
+     {0, -2, 14, 52, 52, 14, -2, 0}, {0, 0, 12, 48, 54, 16, -2, 0},
+     {0, 0, 10, 46, 56, 16, 0, 0}, {0, 0, 8, 44, 58, 18, 0, 0},
+     {0, 0, 6, 42, 60, 20, 0, 0}, {0, 0, 4, 40, 62, 22, 0, 0},
+     {0, 0, 4, 36, 62, 26, 0, 0}, {0, 0, 2, 34, 62, 28, 2, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {-2, 2, -6, 126, 8, -2, 2, 0},
+     {-2, 6, -12, 124, 16, -6, 4, -2}, {-2, 8, -18, 120, 26, -10, 6, -2},
+     {-4, 10, -22, 116, 38, -14, 6, -2}, {-4, 10, -22, 108, 48, -18, 8, -2},
+     {-4, 10, -24, 100, 60, -20, 8, -2}, {-4, 10, -24, 90, 70, -22, 10, -2},
+     {-4, 12, -24, 80, 80, -24, 12, -4}, {-2, 10, -22, 70, 90, -24, 10, -4},
+     {-2, 8, -20, 60, 100, -24, 10, -4}, {-2, 8, -18, 48, 108, -22, 10, -4},
+     {-2, 6, -14, 38, 116, -22, 10, -4}, {-2, 6, -10, 26, 120, -18, 8, -2},
+     {-2, 4, -6, 16, 124, -12, 6, -2}, {0, 2, -2, 8, 126, -6, 2, -2}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, 0, 120, 8, 0, 0, 0},
+     {0, 0, 0, 112, 16, 0, 0, 0}, {0, 0, 0, 104, 24, 0, 0, 0},
+     {0, 0, 0, 96, 32, 0, 0, 0}, {0, 0, 0, 88, 40, 0, 0, 0},
+     {0, 0, 0, 80, 48, 0, 0, 0}, {0, 0, 0, 72, 56, 0, 0, 0},
+     {0, 0, 0, 64, 64, 0, 0, 0}, {0, 0, 0, 56, 72, 0, 0, 0},
+     {0, 0, 0, 48, 80, 0, 0, 0}, {0, 0, 0, 40, 88, 0, 0, 0},
+     {0, 0, 0, 32, 96, 0, 0, 0}, {0, 0, 0, 24, 104, 0, 0, 0},
+     {0, 0, 0, 16, 112, 0, 0, 0}, {0, 0, 0, 8, 120, 0, 0, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, -4, 126, 8, -2, 0, 0},
+     {0, 0, -8, 122, 18, -4, 0, 0}, {0, 0, -10, 116, 28, -6, 0, 0},
+     {0, 0, -12, 110, 38, -8, 0, 0}, {0, 0, -12, 102, 48, -10, 0, 0},
+     {0, 0, -14, 94, 58, -10, 0, 0}, {0, 0, -12, 84, 66, -10, 0, 0},
+     {0, 0, -12, 76, 76, -12, 0, 0}, {0, 0, -10, 66, 84, -12, 0, 0},
+     {0, 0, -10, 58, 94, -14, 0, 0}, {0, 0, -10, 48, 102, -12, 0, 0},
+     {0, 0, -8, 38, 110, -12, 0, 0}, {0, 0, -6, 28, 116, -10, 0, 0},
+     {0, 0, -4, 18, 122, -8, 0, 0}, {0, 0, -2, 8, 126, -4, 0, 0}},
+    {{0, 0, 0, 128, 0, 0, 0, 0}, {0, 0, 30, 62, 34, 2, 0, 0},
+     {0, 0, 26, 62, 36, 4, 0, 0}, {0, 0, 22, 62, 40, 4, 0, 0},
+     {0, 0, 20, 60, 42, 6, 0, 0}, {0, 0, 18, 58, 44, 8, 0, 0},
+     {0, 0, 16, 56, 46, 10, 0, 0}, {0, 0, 14, 54, 48, 12, 0, 0},
+     {0, 0, 12, 52, 52, 12, 0, 0}, {0, 0, 12, 48, 54, 14, 0, 0},
+     {0, 0, 10, 46, 56, 16, 0, 0}, {0, 0, 8, 44, 58, 18, 0, 0},
+     {0, 0, 6, 42, 60, 20, 0, 0}, {0, 0, 4, 40, 62, 22, 0, 0},
+     {0, 0, 4, 36, 62, 26, 0, 0}, {0, 0, 2, 34, 62, 30, 0, 0}}};
+
+// mc.rs:238-247: blocks whose filtered dimension is <= 4 use the 4-tap sets.
+__device__ __forceinline__ const int16_t *get_filter(int mode, int frac,
+                                                     int length) {
+  const int idx = (mode == R1_FILTER_BILINEAR || length > 4)
+                      ? mode
+                      : (mode < 1 ? mode : 1) + 4;
+  return kSubpel[idx][frac];
+}
+
+__device__ __forceinline__ int32_t round_shift(int32_t v, int b) {
+  return (v + ((1 << b) >> 1)) >> b;
+}
+__device__ __forceinline__ int32_t clamp_px(int32_t v, int32_t maxv) {
+  return v < 0 ? 0 : (v > maxv ? maxv : v);
+}
+__device__ __forceinline__ int intermediate_bits(int bit_depth) {
+  return bit_depth == 12 ? 2 : 4;
+}
+
+// ---- staging of the reference window into LDS ----
+// A "slab" is up to 64 adjacent columns of one candidate block.  Its window is
+// rows [ry-3, ry+h+4) x columns [rx-3, rx+P+4) of the reference plane -- the
+// exact read footprint the reference documents (src/asm/x86/mc.rs:121-123).
+// Rows are stored with a stride of `ws` bytes (multiple of 4).  `nl` lanes
+// (lane index `l`) cooperate; global reads are unaligned dword loads, the
+// last partial dword of a row is read bytewise so nothing outside the
+// documented footprint is touched.
+template <int BPP>
+__device__ __forceinline__ void stage_window(uint8_t *win, int ws,
+                                             const R1Plane &ref, int rx, int ry,
+                                             int P, int h, int l, int nl) {
+  const int row_bytes = (P + 7) * BPP;
+  const int nd = (row_bytes + 3) >> 2;
+  const int total = (h + 7) * nd;
+  const size_t gstride = (size_t)ref.stride * BPP;
+  const uint8_t *g0 = px_addr<BPP>(ref, rx - 3, ry - 3);
+  for (int i = l; i < total; i += nl) {
+    const int r = i / nd, d = i - r * nd;
+    const uint8_t *g = g0 + r * gstride + d * 4;
+    uint32_t v;
+    if (d * 4 + 4 <= row_bytes) {
+      v = ld_u32(g);
+    } else {
+      v = 0;
+      for (int b = 0; b < row_bytes - d * 4; b++) v |= (uint32_t)g[b] << (8 * b);
+    }
+    *(uint32_t *)(win + r * ws + d * 4) = v;
+  }
+}
+
+// One column of put_8tap / prep_8tap from a staged window.  `c` is the column
+// inside the slab, `w`/`h` the full block size (they select the 4-tap filter
+// variants).  emit(r, value) receives each output sample: the clamped pixel
+// for put, the int16 intermediate for prep.
+// HT > 0 fixes the height at compile time so that every row loop unrolls and
+// emit() may target a register array (used by the fused RDO kernel).
+template <int BPP, bool PREP, int HT, typename Emit>
+__device__ __forceinline__ void mc_column(const uint8_t *win, int ws, int c,
+                                          int w, int h_rt, int col_frac,
+                                          int row_frac, int mode_x, int mode_y,
+                                          int bit_depth, Emit emit) {
+  const int h = HT > 0 ? HT : h_rt;
+  const int ib = intermediate_bits(bit_depth);
+  const int32_t maxv = (1 << bit_depth) - 1;
+  const int32_t bias = bit_depth == 8 ? 0 : 8192;  // PREP_BIAS
+  const uint8_t *col = win + c * BPP;
+  if (col_frac == 0 && row_frac == 0) {
+#pragma unroll
+    for (int r = 0; r < h; r++) {
+      const int32_t p = ld_px<BPP>(col + (r + 3) * ws + 3 * BPP);
+      emit(r, PREP ? (int32_t)(int16_t)((int16_t)(p << ib) - (int16_t)bias) : p);
+    }
+  } else if (col_frac == 0) {
+    const int16_t *yf = get_filter(mode_y, row_frac, h);
+    int32_t f[8], t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) f[k] = yf[k];
+#pragma unroll
+    for (int k = 0; k < 7; k++) t[k + 1] = ld_px<BPP>(col + k * ws + 3 * BPP);
+#pragma unroll
+    for (int r = 0; r < h; r++) {
+#pragma unroll
+      for (int k = 0; k < 7; k++) t[k] = t[k + 1];
+      t[7] = ld_px<BPP>(col + (r + 7) * ws + 3 * BPP);
+      int32_t s = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) s += f[k] * t[k];
+      emit(r, PREP ? (int32_t)(int16_t)(round_shift(s, 7 - ib) - bias)
+                   : clamp_px(round_shift(s, 7), maxv));
+    }
+  } else if (row_frac == 0) {
+    const int16_t *xf = get_filter(mode_x, col_frac, w);
+    int32_t f[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) f[k] = xf[k];
+#pragma unroll
+    for (int r = 0; r < h; r++) {
+      int32_t s = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) s += f[k] * ld_px<BPP>(col + (r + 3) * ws + k * BPP);
+      emit(r, PREP ? (int32_t)(int16_t)(round_shift(s, 7 - ib) - bias)
+                   : clamp_px(round_shift(round_shift(s, 7 - ib), ib), maxv));
+    }
+  } else {
+    const int16_t *xf = get_filter(mode_x, col_frac, w);
+    const int16_t *yf = get_filter(mode_y, row_frac, h);
+    int32_t fx[8], fy[8], m[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { fx[k] = xf[k]; fy[k] = yf[k]; }
+    auto hrow = [&](int rr) -> int32_t {
+      int32_t s = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) s += fx[k] * ld_px<BPP>(col + rr * ws + k * BPP);
+      return (int32_t)(int16_t)round_shift(s, 7 - ib);  // i16 intermediate
+    };
+#pragma unroll
+    for (int k = 0; k < 7; k++) m[k + 1] = hrow(k);
+#pragma unroll
+    for (int r = 0; r < h; r++) {
+#pragma unroll
+      for (int k = 0; k < 7; k++) m[k] = m[k + 1];
+      m[7] = hrow(r + 7);
+      int32_t s = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) s += fy[k] * m[k];
+      emit(r, PREP ? (int32_t)(int16_t)(round_shift(s, 7) - bias)
+                   : clamp_px(round_shift(s, 7 + ib), maxv));
+    }
+  }
+}
+
+}  // namespace r1mc

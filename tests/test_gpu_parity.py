@@ -1,0 +1,319 @@
+"""GPU parity: every batch entry point of librav1e_hip.so, called through the
+C ABI, against the CPU oracle on the same seeded inputs (bit-exact), plus the
+committed golden fixtures and the reference's known-answer tables."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+BLOCK_SIZES = [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16),
+               (32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128),
+               (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+TX_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8),
+            (16, 32), (32, 16), (32, 64), (64, 32), (4, 16), (16, 4), (8, 32), (32, 8),
+            (16, 64), (64, 16)]
+
+
+def dev_plane(hp):
+    from rav1e_amd.api import Plane
+    return Plane.from_numpy(hp.data, hp.width, hp.height, hp.bit_depth, hp.xpad, hp.ypad)
+
+
+def planes(bd, w=320, h=192, seed=0, pads=(88, 88)):
+    rng = np.random.default_rng(seed)
+    a = O.HostPlane(w, h, bd, pads[0], pads[0], rng=rng)
+    b = O.HostPlane(w, h, bd, pads[1], pads[1], rng=rng)
+    return a, b
+
+
+def rand_dist_cands(rng, n, pw, ph, w, h, slack):
+    c = np.zeros(n, O.DIST_CAND)
+    c["ox"] = rng.integers(0, pw - w + 1, n)
+    c["oy"] = rng.integers(0, ph - h + 1, n)
+    c["rx"] = rng.integers(-slack, pw - w + slack + 1, n)   # may reach into the padding
+    c["ry"] = rng.integers(-slack, ph - h + slack + 1, n)
+    return c
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_dist_batch_all_block_sizes(ctx, oracle, bd):
+    a, b = planes(bd, seed=bd, pads=(88, 152))   # different strides / alignments
+    da, db = dev_plane(a), dev_plane(b)
+    rng = np.random.default_rng(100 + bd)
+    for (w, h) in BLOCK_SIZES:
+        n = 193 if w * h <= 1024 else 37    # ragged: not a multiple of any group size
+        c = rand_dist_cands(rng, n, a.width, a.height, w, h, 40)
+        for kind in (0, 1):
+            want = np.zeros(n, np.uint32)
+            pa, pb = a.cstruct(), b.cstruct()
+            import ctypes as C
+            assert oracle.r1o_dist_batch(kind, C.byref(pa), C.byref(pb), w, h, O.ptr(c), n,
+                                         O.ptr(want)) == 0
+            got = ctx.dist_batch(kind, da, db, w, h, c).cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, want), (bd, w, h, kind)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_dist_reference_known_answers(ctx, bd):
+    """The reference's own SAD/SATD tables (src/dist.rs:418-441,477-500)."""
+    from test_oracle_dist import SAD, SATD, reference_test_planes
+    a, b = reference_test_planes(bd)
+    da, db = dev_plane(a), dev_plane(b)
+    c = np.zeros(1, O.DIST_CAND)
+    c["ox"], c["oy"], c["rx"], c["ry"] = 32, 40, 32, 40
+    for kind, table in ((0, SAD), (1, SATD)):
+        for w, h, v in table:
+            got = int(ctx.dist_batch(kind, da, db, w, h, c).cpu().numpy().view(np.uint32)[0])
+            assert got == v, (kind, w, h)
+
+
+def test_dist_empty_and_bad_args(ctx):
+    from rav1e_amd.api import R1Error
+    a, b = planes(8)
+    da, db = dev_plane(a), dev_plane(b)
+    assert ctx.dist_batch(0, da, db, 8, 8, np.zeros(0, O.DIST_CAND)).numel() == 0
+    with pytest.raises(R1Error):
+        ctx.dist_batch(0, da, db, 12, 8, np.zeros(1, O.DIST_CAND))   # not a block size
+    with pytest.raises(R1Error):
+        ctx.dist_batch(7, da, db, 8, 8, np.zeros(1, O.DIST_CAND))
+
+
+def test_fwd_txfm_golden(ctx):
+    """All 480 (bd, size, type) cases derived from the reference source text."""
+    import torch
+    G = np.load(os.path.join(GOLD, "fwd_tx_golden.npz"))
+    for k in G["keys2d"]:
+        bd, ts, tt = map(int, k.split("_"))
+        res = torch.from_numpy(np.ascontiguousarray(G["res2d_" + k])).cuda()
+        want = G["coef2d_" + k]
+        got = ctx.forward_transform_batch(res, ts, tt, bd, coeff_bytes=4).cpu().numpy()[0]
+        assert np.array_equal(got, want), k
+        if bd == 8:
+            got16 = ctx.forward_transform_batch(res, ts, tt, bd, coeff_bytes=2).cpu().numpy()[0]
+            assert np.array_equal(got16, want.astype(np.int16)), k
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_fwd_txfm_batch_vs_oracle(ctx, oracle, bd):
+    import torch
+    from rav1e_amd.types import valid_av1_transform
+    rng = np.random.default_rng(bd)
+    lim = (1 << bd) - 1
+    cb = 2 if bd == 8 else 4
+    for ts, (w, h) in enumerate(TX_SIZES):
+        for tt in range(17):
+            if not valid_av1_transform(ts, tt):
+                continue
+            n = 67 if w * h <= 256 else 9    # ragged vs blocks-per-wave
+            res = rng.integers(-lim, lim + 1, size=(n, h, w)).astype(np.int16)
+            want = np.zeros((n, w * h), np.int16 if cb == 2 else np.int32)
+            assert oracle.r1o_fwd_txfm_batch(O.ptr(res), O.ptr(want), n, ts, tt, bd, cb) == 0
+            got = ctx.forward_transform_batch(torch.from_numpy(res).cuda(), ts, tt, bd, cb)
+            assert np.array_equal(got.cpu().numpy(), want), (bd, ts, tt)
+
+
+def test_fwd_txfm_full_i16_range_wraps_like_rust_release(ctx, oracle):
+    """i32 wrapping semantics for arbitrary int16 input (forward.rs:42-44)."""
+    import torch
+    rng = np.random.default_rng(5)
+    for ts in (0, 1, 2, 3, 4, 11, 18):
+        w, h = TX_SIZES[ts]
+        res = rng.integers(-32768, 32768, size=(5, h, w)).astype(np.int16)
+        want = np.zeros((5, w * h), np.int32)
+        oracle.r1o_fwd_txfm_batch(O.ptr(res), O.ptr(want), 5, ts, 0, 12, 4)
+        got = ctx.forward_transform_batch(torch.from_numpy(res).cuda(), ts, 0, 12, 4)
+        assert np.array_equal(got.cpu().numpy(), want), ts
+
+
+def test_fwd_txfm_invalid_pair_is_einval(ctx):
+    import torch
+    from rav1e_amd.api import R1Error
+    with pytest.raises(R1Error):
+        ctx.forward_transform_batch(torch.zeros((1, 64, 64), dtype=torch.int16).cuda(), 4, 1, 8)
+
+
+def rand_mc_cands(rng, n, pw, ph, w, h, slack):
+    c = np.zeros(n, O.MC_CAND)
+    c["rx"] = rng.integers(-slack, pw - w + slack + 1, n)
+    c["ry"] = rng.integers(-slack, ph - h + slack + 1, n)
+    c["col_frac"] = rng.integers(0, 16, n)
+    c["row_frac"] = rng.integers(0, 16, n)
+    c["mode_x"] = rng.integers(0, 4, n)
+    c["mode_y"] = rng.integers(0, 4, n)
+    # make sure the four structural cases all occur
+    c["col_frac"][: n // 4] = 0
+    c["row_frac"][n // 8: n // 4 + n // 8] = 0
+    return c
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_mc_put_prep_avg_vs_oracle(ctx, oracle, bd):
+    import ctypes as C
+    a, _ = planes(bd, seed=20 + bd)
+    da = dev_plane(a)
+    rng = np.random.default_rng(200 + bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    sizes = [(2, 2), (2, 4), (4, 2), (4, 4), (4, 8), (8, 4), (8, 8), (16, 8), (8, 16), (16, 16),
+             (32, 32), (64, 64), (128, 128), (128, 64), (64, 128), (16, 64), (4, 16), (32, 8)]
+    for (w, h) in sizes:
+        n = 41 if w * h <= 1024 else 7
+        c = rand_mc_cands(rng, n, a.width, a.height, w, h, 60)
+        pa = a.cstruct()
+        want_put = np.zeros((n, h, w), dt)
+        want_prep = np.zeros((n, h, w), np.int16)
+        assert oracle.r1o_mc_put_batch(C.byref(pa), w, h, O.ptr(c), n, O.ptr(want_put)) == 0
+        assert oracle.r1o_mc_prep_batch(C.byref(pa), w, h, O.ptr(c), n, O.ptr(want_prep)) == 0
+        got_put = ctx.put_8tap_batch(da, w, h, c).cpu().numpy().view(dt)
+        got_prep = ctx.prep_8tap_batch(da, w, h, c)
+        assert np.array_equal(got_put, want_put), (bd, w, h, "put")
+        assert np.array_equal(got_prep.cpu().numpy(), want_prep), (bd, w, h, "prep")
+        # compound average of the prep output with a shuffled copy of itself
+        import torch
+        t2 = got_prep.flip(0).contiguous()
+        want_avg = np.zeros((n, h, w), dt)
+        oracle.r1o_mc_avg_batch(O.ptr(want_prep), O.ptr(np.ascontiguousarray(want_prep[::-1])),
+                                w, h, n, bd, a.bpp, O.ptr(want_avg))
+        got_avg = ctx.mc_avg_batch(got_prep, t2, w, h, bd).cpu().numpy().view(dt)
+        assert np.array_equal(got_avg, want_avg), (bd, w, h, "avg")
+
+
+def test_mc_golden(ctx):
+    """tests/golden/mc_golden.npz: reference tap data + independent model."""
+    G = np.load(os.path.join(GOLD, "mc_golden.npz"))
+    from rav1e_amd.api import Plane
+    for k in G["cases"]:
+        bd, w, h, cf, rf, mx, my, _ = map(int, k.split("_"))
+        win = G["win_" + k]
+        hp = O.HostPlane(w, h, bd, 4, 4)           # window = block + 3/4 px of padding
+        # place the window so that block origin (0,0) sits at win[3,3]
+        hp.data[hp.yorigin - 3: hp.yorigin + h + 4, hp.xorigin - 3: hp.xorigin + w + 4] = win
+        dp = Plane.from_numpy(hp.data, w, h, bd, 4, 4)
+        c = np.zeros(1, O.MC_CAND)
+        c["col_frac"], c["row_frac"], c["mode_x"], c["mode_y"] = cf, rf, mx, my
+        dt = np.uint8 if bd == 8 else np.uint16
+        put = ctx.put_8tap_batch(dp, w, h, c).cpu().numpy().view(dt)[0]
+        prep = ctx.prep_8tap_batch(dp, w, h, c).cpu().numpy()[0]
+        assert np.array_equal(put, G["put_" + k]), k
+        assert np.array_equal(prep, G["prep_" + k]), k
+
+
+def rand_rdo_cands(rng, n, pw, ph, w, h, slack, ts):
+    from rav1e_amd.types import valid_av1_transform
+    c = np.zeros(n, O.RDO_CAND)
+    c["ox"] = rng.integers(0, pw - w + 1, n)
+    c["oy"] = rng.integers(0, ph - h + 1, n)
+    c["rx"] = rng.integers(-slack, pw - w + slack + 1, n)
+    c["ry"] = rng.integers(-slack, ph - h + slack + 1, n)
+    c["col_frac"] = rng.integers(0, 16, n)
+    c["row_frac"] = rng.integers(0, 16, n)
+    c["col_frac"][: n // 4] = 0
+    c["row_frac"][n // 8: n // 4 + n // 8] = 0
+    c["mode_x"] = rng.integers(0, 4, n)
+    c["mode_y"] = rng.integers(0, 4, n)
+    valid = [t for t in range(16) if valid_av1_transform(ts, t)]
+    c["tx_type"] = rng.choice(valid, n)
+    return c
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_rdo_cand_fused_vs_oracle(ctx, oracle, bd):
+    import ctypes as C
+    a, b = planes(bd, seed=40 + bd, pads=(88, 120))
+    da, db = dev_plane(a), dev_plane(b)
+    rng = np.random.default_rng(300 + bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    ct = np.int16 if bd == 8 else np.int32
+    for ts, (w, h) in enumerate(TX_SIZES):
+        n = 45 if w * h <= 1024 else 11
+        c = rand_rdo_cands(rng, n, a.width, a.height, w, h, 50, ts)
+        pa, pb = a.cstruct(), b.cstruct()
+        wsad, wsatd = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        wco = np.zeros((n, w * h), ct)
+        wpred = np.zeros((n, h, w), dt)
+        assert oracle.r1o_rdo_cand_batch(C.byref(pa), C.byref(pb), w, h, ts, O.ptr(c), n,
+                                         O.ptr(wsad), O.ptr(wsatd), O.ptr(wco), O.ptr(wpred)) == 0
+        o = ctx.rdo_cand_batch(da, db, w, h, c, want_pred=True)
+        assert np.array_equal(o["pred"].cpu().numpy().view(dt), wpred), (bd, w, h, "pred")
+        assert np.array_equal(o["sad"].cpu().numpy().view(np.uint32), wsad), (bd, w, h, "sad")
+        assert np.array_equal(o["satd"].cpu().numpy().view(np.uint32), wsatd), (bd, w, h, "satd")
+        assert np.array_equal(o["coeffs"].cpu().numpy(), wco), (bd, w, h, "coeffs")
+        # partial outputs: distortion only (the ME / pre-screen use)
+        o2 = ctx.rdo_cand_batch(da, db, w, h, c, want_coeffs=False, want_sad=False)
+        assert np.array_equal(o2["satd"].cpu().numpy().view(np.uint32), wsatd)
+
+
+def test_rdo_cand_zero_mv_residual_properties(ctx):
+    """Size-independent property at full frame size: a candidate predicting a
+    plane from itself at zero MV has zero SAD/SATD and all-zero coefficients;
+    linearity: SAD equals the sum over its four quadrant candidates."""
+    a, _ = planes(8, 1920, 1080, seed=9)
+    da = dev_plane(a)
+    rng = np.random.default_rng(9)
+    n = 4096
+    c = np.zeros(n, O.RDO_CAND)
+    c["ox"] = rng.integers(0, 1920 - 64, n)
+    c["oy"] = rng.integers(0, 1080 - 64, n)
+    c["rx"], c["ry"] = c["ox"], c["oy"]
+    o = ctx.rdo_cand_batch(da, da, 64, 64, c)
+    assert not o["sad"].any() and not o["satd"].any() and not o["coeffs"].any()
+    # linearity of SAD over a 2x2 split, different planes
+    b = O.HostPlane(1920, 1080, 8, rng=np.random.default_rng(10))
+    db = dev_plane(b)
+    c["rx"] = rng.integers(-8, 1920 - 64 + 8, n)
+    c["ry"] = rng.integers(-8, 1080 - 64 + 8, n)
+    c["col_frac"] = rng.integers(0, 16, n)
+    c["row_frac"] = rng.integers(0, 16, n)
+    # quadrant candidates must use the same filter family: 64 and 32 are both > 4
+    big = ctx.rdo_cand_batch(da, db, 64, 64, c, want_coeffs=False, want_satd=False)["sad"]
+    tot = None
+    for qx in (0, 32):
+        for qy in (0, 32):
+            q = c.copy()
+            q["ox"] += qx; q["oy"] += qy; q["rx"] += qx; q["ry"] += qy
+            s = ctx.rdo_cand_batch(da, db, 32, 32, q, want_coeffs=False, want_satd=False)["sad"]
+            tot = s.clone() if tot is None else tot + s
+    assert bool((tot == big).all())
+
+
+def test_compat_shims_host_pointers(ctx, oracle):
+    """Reference asm signatures (byte strides, host pointers)."""
+    from rav1e_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(11)
+    for bd in (8, 10):
+        a, b = planes(bd, 128, 128, seed=60 + bd, pads=(16, 24))
+        for (w, h) in ((4, 4), (8, 8), (16, 32), (64, 64), (128, 128)):
+            x, y = int(rng.integers(0, 128 - w + 1)), int(rng.integers(0, 128 - h + 1))
+            args = (a.block_ptr(x, y), a.stride * a.bpp, b.block_ptr(x, y), b.stride * b.bpp, w, h)
+            oa = (a.block_ptr(x, y), a.stride, b.block_ptr(x, y), b.stride, w, h, int(bd > 8))
+            if bd == 8:
+                assert L.rav1e_sad_hip(*args) == oracle.r1o_get_sad(*oa)
+                assert L.rav1e_satd_hip(*args) == oracle.r1o_get_satd(*oa)
+            else:
+                assert L.rav1e_sad_hbd_hip(*args) == oracle.r1o_get_sad(*oa)
+                assert L.rav1e_satd_hbd_hip(*args, 1023) == oracle.r1o_get_satd(*oa)
+        # put_8tap shim at the reference's bench MVs (benches/mc.rs:30-127)
+        dt = np.uint8 if bd == 8 else np.uint16
+        for (mx, my) in ((0, 0), (0, 4), (4, 0), (4, 4)):
+            want = np.zeros((16, 16), dt)
+            got = np.zeros((16, 16), dt)
+            oracle.r1o_put_8tap(O.ptr(want), 16, a.block_ptr(40, 40), a.stride, 16, 16, mx, my,
+                                0, 0, bd, int(bd > 8))
+            if bd == 8:
+                L.rav1e_put_8tap_hip(O.ptr(got), 16, a.block_ptr(40, 40), a.stride, 16, 16, mx,
+                                     my, 0, 0)
+            else:
+                L.rav1e_put_8tap_hbd_hip(O.ptr(got), 32, a.block_ptr(40, 40), a.stride * 2, 16,
+                                         16, mx, my, 0, 0, 1023)
+            assert np.array_equal(got, want), (bd, mx, my)
+    res = rng.integers(-255, 256, size=(8, 8)).astype(np.int16)
+    want = np.zeros(64, np.int16)
+    got = np.zeros(64, np.int16)
+    oracle.r1o_forward_transform(O.ptr(res), O.ptr(want), 8, 1, 0, 8, 0)
+    assert L.rav1e_fwd_txfm_hip(O.ptr(res), O.ptr(got), 8, 1, 0, 8, 2) == 0
+    assert np.array_equal(got, want)
