@@ -74,11 +74,15 @@ def cpu_baseline(args, host_org, host_ref, cands):
             assert rc == 0
             px += len(sub) * s * s
         return px, time.perf_counter() - t0
-    px, dt = run(0.002)                       # calibration sample
-    rate = px / dt
-    total_px = sum(len(c) * s * s for s, c in cands.items())
-    frac = min(1.0, args.cpu_seconds * rate / total_px)
-    px, dt = run(frac)
+    frac, px, dt = 0.002, 0, 0.0
+    while True:                               # grow the sample until it is measurable
+        px, dt = run(frac)
+        if dt >= 1.5 or frac >= 1.0:
+            break
+        frac = min(1.0, frac * 4)
+    if dt < 0.6 * args.cpu_seconds and frac < 1.0:
+        frac = min(1.0, frac * args.cpu_seconds / dt)
+        px, dt = run(frac)
     return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
             "kind": "port",
             "sample": "%.3f%% of the step's candidates (every ladder size, strided), %.1f s, "

@@ -131,14 +131,14 @@ extern "C" int r1_dist_batch(r1_ctx *ctx, int kind, const R1Plane *org,
                              const R1Plane *ref, int w, int h,
                              const R1DistCand *cands, int n, uint32_t *out,
                              void *stream) {
-  R1_REQUIRE(ctx && org && ref && out);
+  R1_REQUIRE(ctx && org && ref);
   R1_REQUIRE(kind == R1_DIST_SAD || kind == R1_DIST_SATD);
   R1_REQUIRE(org->bytes_per_px == ref->bytes_per_px);
   R1_REQUIRE(org->bytes_per_px == 1 || org->bytes_per_px == 2);
   R1_REQUIRE(r1_is_pow2(w) && r1_is_pow2(h) && w >= 4 && h >= 4 && w <= 128 &&
              h <= 128);
   if (n <= 0) return R1_OK;
-  R1_REQUIRE(cands);
+  R1_REQUIRE(cands && out);
   hipStream_t st = (hipStream_t)stream;
   const bool small = (w < h ? w : h) == 4;
   // SAD has no tile-size rule; use the widest tile the block allows.

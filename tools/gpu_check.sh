@@ -13,7 +13,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | 
 echo "== bench"
 timeout 900 python bench.py --steps 10 --warmup 2 2>&1 | tail -3 | tee $OUT/bench.log
 echo "== rocprof"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --cpu-seconds 0 > /tmp/prof_$TAG.log 2>&1; tail -2 /tmp/prof_$TAG.log)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --cpu-seconds 0 > /tmp/prof_$TAG.log 2>&1; tail -2 /tmp/prof_$TAG.log)
 find /tmp/prof_$TAG -name "*kernel_stats*" -exec cp {} $OUT/ \; 2>/dev/null
-find /tmp/prof_$TAG -name "*kernel_stats*" | head -3
+find /tmp/prof_$TAG -type f | head -8
 ls $OUT
