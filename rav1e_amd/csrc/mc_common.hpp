@@ -100,17 +100,29 @@ __device__ __forceinline__ void stage_window(uint8_t *win, int ws,
   const int total = (h + 7) * nd;
   const size_t gstride = (size_t)ref.stride * BPP;
   const uint8_t *g0 = px_addr<BPP>(ref, rx - 3, ry - 3);
-  for (int i = l; i < total; i += nl) {
-    const int r = i / nd, d = i - r * nd;
-    const uint8_t *g = g0 + r * gstride + d * 4;
-    uint32_t v;
-    if (d * 4 + 4 <= row_bytes) {
-      v = ld_u32(g);
-    } else {
-      v = 0;
-      for (int b = 0; b < row_bytes - d * 4; b++) v |= (uint32_t)g[b] << (8 * b);
+  // batches of 4 independent loads per lane so that the global-load latency
+  // is paid once per batch, not once per dword
+  for (int i0 = l; i0 < total; i0 += 4 * nl) {
+    uint32_t v[4];
+    int off[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * nl;
+      v[u] = 0;
+      off[u] = -1;
+      if (i < total) {
+        const int r = i / nd, d = i - r * nd;
+        // the last dword of a row may be partial: read the 4 bytes that END at
+        // the row end and shift, so nothing outside the footprint is touched
+        const int over = d * 4 + 4 - row_bytes;
+        const int back = over > 0 ? over : 0;
+        v[u] = ld_u32(g0 + r * gstride + d * 4 - back) >> (8 * back);
+        off[u] = r * ws + d * 4;
+      }
     }
-    *(uint32_t *)(win + r * ws + d * 4) = v;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (off[u] >= 0) *(uint32_t *)(win + off[u]) = v[u];
   }
 }
 

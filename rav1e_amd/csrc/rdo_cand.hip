@@ -11,33 +11,184 @@
 // src/encoder.rs:1533-1552) restructured as a batch.
 //
 // Mapping (wave = 64, one wave per workgroup): a wave owns NC = 64 / max(W,H)
-// candidates.  Phase A stages each candidate's (H+7)x(W+7) reference window
-// in LDS.  Phase B: lane = (candidate, column) runs the separable 8-tap filter
-// down its column (8-deep register window), subtracts from the source pixels
-// and keeps the whole residual COLUMN in registers.  SAD is a lane sum; SATD
-// runs the vertical Hadamard on 8 registers and the horizontal one across the
-// 8 neighbouring lanes with wave shuffles.  Phase C runs the column transform
-// on the same registers, transposes through LDS (odd stride, aliasing the
-// dead window), and phase D runs the row transform with lane = (candidate,
-// row), storing coefficients in the reference's transposed 32x32-chunk order.
-#include "mc_common.hpp"
+// candidates.
+//  A  every lane pulls its source column into registers (H loads in flight)
+//     while the wave stages each candidate's (H+7)x(W+7) reference window in
+//     LDS (batched unaligned dword loads).
+//  B  lane = (candidate, column) filters its column.  8-bit pixels: three
+//     aligned LDS dwords per window row, v_alignbyte to the lane's byte
+//     phase, pixels biased by -128 so that the horizontal 8 taps are two
+//     v_dot4_i32_i8; the i16 intermediates are packed in pairs and the
+//     vertical 8 taps are 4 (even rows) or 5 (odd rows) v_dot2_i32_i16.
+//     All four (col_frac==0?, row_frac==0?) cases of mc.rs:264-352 go through
+//     this one code path: a 128-valued tap at phase 0 reproduces the copy and
+//     1-D paths bit for bit (see the derivation at mc8_column).
+//     The residual COLUMN stays in registers.  SAD is a lane sum.  SATD: the
+//     vertical Hadamard on 8 registers, the horizontal one across the 8
+//     neighbouring lanes with DPP (quad_perm / row_half_mirror) -- no LDS.
+//  C  column transform on the same registers (24-bit multiplies, exact here),
+//     transpose through LDS (odd stride, aliasing the dead window).
+//  D  lane = (candidate, row): row transform, stores in the reference's
+//     transposed 32x32-chunk coefficient order.
 #include <type_traits>
+
+#include "mc_common.hpp"
 #include "tx_common.hpp"
 
 namespace {
 using r1tx::T;
 
-// Horizontal (cross-lane) Hadamard over groups of TS adjacent lanes, applied
-// to one register.  Lane pairs (l, l^m): the lower lane keeps a+b, the upper
-// a-b -- the butterfly of dist.rs:55-57 with the data spread over lanes.
+#include "mc_taps_packed.inc"
+
+// ---- cross-lane Hadamard with DPP --------------------------------------
+// DPP controls: quad_perm [1,0,3,2] = 0xB1 (lane ^ 1), [2,3,0,1] = 0x4E
+// (lane ^ 2), row_half_mirror = 0x141 (lane -> 7 - lane inside each 8).
+template <int CTRL>
+__device__ __forceinline__ int32_t dpp(int32_t x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
+}
+// One butterfly stage across lanes: partner value p, the "lower" lane of a
+// pair keeps x + p, the "upper" lane p - x.  sm = upper ? -1 : 0.
+template <int CTRL>
+__device__ __forceinline__ int32_t bfly_lanes(int32_t x, int32_t sm) {
+  return ((x ^ sm) - sm) + dpp<CTRL>(x);
+}
+// |Hadamard across the TS lanes of a tile| of x, as this lane's share of the
+// tile's sum: the last butterfly stage is folded into the abs because
+// |a + b| + |a - b| = 2 max(|a|, |b|) -- each lane of the final pair
+// contributes max(|a|, |b|).
+// The 8-lane version pairs lanes with masks {1, 2, 7}: those span (Z/2)^3, so
+// the three stages are a Walsh-Hadamard transform in a relabelled lane order
+// -- the same multiset of coefficients as masks {1, 2, 4}, hence the same sum
+// of absolute values (dist.rs:214).  "Upper" lanes are those whose coordinate
+// w.r.t. the basis {1, 2, 7} is 1: y1 = b0 ^ b2, y2 = b1 ^ b2 (y3 = b2).
+struct LaneSigns { int32_t s1, s2; };
 template <int TS>
-__device__ __forceinline__ int32_t hadamard_lanes(int32_t x, int lane) {
-#pragma unroll
-  for (int m = 1; m < TS; m <<= 1) {
-    const int32_t p = __shfl_xor(x, m, WAVE);
-    x = (lane & m) ? p - x : x + p;
+__device__ __forceinline__ LaneSigns lane_signs(int lane) {
+  LaneSigns s;
+  if constexpr (TS == 8) {
+    s.s1 = -(int32_t)((lane ^ (lane >> 2)) & 1);
+    s.s2 = -(int32_t)(((lane >> 1) ^ (lane >> 2)) & 1);
+  } else {
+    s.s1 = -(int32_t)(lane & 1);
+    s.s2 = 0;
   }
-  return x;
+  return s;
+}
+template <int TS>
+__device__ __forceinline__ uint32_t habs_lanes(int32_t x, LaneSigns sg) {
+  x = bfly_lanes<0xB1>(x, sg.s1);
+  if constexpr (TS == 8) x = bfly_lanes<0x4E>(x, sg.s2);
+  const int32_t ax = iabs32(x);
+  const int32_t ap = TS == 8 ? dpp<0x141>(ax) : dpp<0x4E>(ax);
+  return (uint32_t)(ax > ap ? ax : ap);
+}
+
+// ---- 8-bit fast path of put_8tap for one column ---------------------------
+// Unified 2-D evaluation.  With x-taps t (sum 128) and y-taps u (sum 128),
+// ib = 4 (8-bit): mid = (sum t*p + 4) >> 3, out = clamp((sum u*mid + 1024) >> 11).
+//  * col_frac == 0 (t = 128 at tap 3): mid = 16 p exactly, out =
+//    (16 S + 1024) >> 11 = (S + 64) >> 7 = round_shift(S, 7)     (mc.rs:272-291)
+//  * row_frac == 0 (u = 128 at tap 3): out = (128 mid + 1024) >> 11 =
+//    (mid + 8) >> 4 = round_shift(round_shift(S, 3), 4)            (mc.rs:292-312)
+//  * both 0: out = p                                              (mc.rs:265-271)
+// so one path is bit-exact for all four cases.  The 128 tap does not fit int8:
+// phase-0 rows carry 127 and the centre pixel is added once (any_cf0 only).
+template <int W, int H, int WS>
+__device__ __forceinline__ void mc8_column(const uint8_t *win, int c,
+                                           const R1RdoCand &cd, bool any_cf0,
+                                           int32_t *pred) {
+  const int mx = cd.mode_x, my = cd.mode_y;
+  const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
+  const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
+  const int cf = cd.col_frac, rf = cd.row_frac;
+  const uint32_t fx0 = kTapI8[fxi][cf][0], fx1 = kTapI8[fxi][cf][1];
+  uint32_t ty[4], tz[5];
+#pragma unroll
+  for (int j = 0; j < 4; j++) ty[j] = kTapI16[fyi][rf][j];
+  tz[0] = ty[0] << 16;
+#pragma unroll
+  for (int j = 1; j < 4; j++) tz[j] = __builtin_amdgcn_alignbit(ty[j], ty[j - 1], 16);
+  tz[4] = ty[3] >> 16;
+  // sum f*(q+128) = dot(f,q) + 128*sum(f); + rounding 1 << 2
+  const int32_t bias = (cf == 0 ? 127 * 128 : 128 * 128) + 4;
+  constexpr int WSD = WS / 4;
+  const uint32_t *wrow = (const uint32_t *)win + (c >> 2);
+  const uint32_t sh = (uint32_t)(c & 3);
+  constexpr int NM = H + 8;   // H + 7 intermediates, padded to even
+  int32_t mid[NM];
+#pragma unroll
+  for (int r = 0; r < H + 7; r++) {
+    const uint32_t d0 = wrow[r * WSD], d1 = wrow[r * WSD + 1], d2 = wrow[r * WSD + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    int32_t acc = __builtin_amdgcn_sdot4((int)(lo ^ 0x80808080u), (int)fx0, bias, false);
+    acc = __builtin_amdgcn_sdot4((int)(hi ^ 0x80808080u), (int)fx1, acc, false);
+    if (any_cf0) acc += cf == 0 ? (int32_t)(lo >> 24) : 0;
+    mid[r] = acc >> 3;
+  }
+  mid[H + 7] = 0;
+  typedef short v2s __attribute__((ext_vector_type(2)));
+  uint32_t pk[NM / 2];
+#pragma unroll
+  for (int j = 0; j < NM / 2; j++)
+    pk[j] = __builtin_amdgcn_perm((uint32_t)mid[2 * j + 1], (uint32_t)mid[2 * j], 0x05040100u);
+#pragma unroll
+  for (int r = 0; r < H; r++) {
+    int32_t acc = 1024;   // rounding of the final >> 11
+    if ((r & 1) == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[r / 2 + j]),
+                                     __builtin_bit_cast(v2s, ty[j]), acc, false);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 5; j++)
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[r / 2 + j]),
+                                     __builtin_bit_cast(v2s, tz[j]), acc, false);
+    }
+    acc >>= 11;
+    pred[r] = acc < 0 ? 0 : (acc > 255 ? 255 : acc);
+  }
+}
+
+// SATD contribution of one residual column (TS rows at a time).
+template <int TS, int H>
+__device__ __forceinline__ uint32_t satd_column(const T *v, int lane) {
+  const LaneSigns sg = lane_signs<TS>(lane);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int g = 0; g < H / TS; g++) {
+    int32_t a[TS];
+#pragma unroll
+    for (int k = 0; k < TS; k++) a[k] = v[g * TS + k];
+    // vertical pass on the lane's own TS rows (dist.rs:126-131)
+    if constexpr (TS == 4) {
+      const int32_t a0 = a[0] + a[1], a1 = a[0] - a[1];
+      const int32_t a2 = a[2] + a[3], a3 = a[2] - a[3];
+      a[0] = a0 + a2; a[1] = a1 + a3; a[2] = a0 - a2; a[3] = a1 - a3;
+    } else {
+      int32_t b[8], d[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        b[2 * k] = a[2 * k] + a[2 * k + 1];
+        b[2 * k + 1] = a[2 * k] - a[2 * k + 1];
+      }
+      d[0] = b[0] + b[2]; d[2] = b[0] - b[2];
+      d[1] = b[1] + b[3]; d[3] = b[1] - b[3];
+      d[4] = b[4] + b[6]; d[6] = b[4] - b[6];
+      d[5] = b[5] + b[7]; d[7] = b[5] - b[7];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        a[k] = d[k] + d[k + 4];
+        a[k + 4] = d[k] - d[k + 4];
+      }
+    }
+    // horizontal pass across the TS lanes of the tile (dist.rs:132-138)
+#pragma unroll
+    for (int k = 0; k < TS; k++) acc += habs_lanes<TS>(a[k], sg);
+  }
+  return acc;
 }
 
 template <int BPP, int WL, int HL, typename CT>
@@ -63,74 +214,56 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   R1RdoCand cd = {};
   if (live) cd = cands[cand];
 
-  // ---- A: stage the reference window ----
+  // ---- A: source column into registers, reference window into LDS ----
+  T v[H];
+#pragma unroll
+  for (int r = 0; r < H; r++) v[r] = 0;
+  const bool col_live = live && c < W;
+  if (col_live) {
+    const uint8_t *po = px_addr<BPP>(org, cd.ox + c, cd.oy);
+    const size_t so = (size_t)org.stride * BPP;
+#pragma unroll
+    for (int r = 0; r < H; r++) v[r] = ld_px<BPP>(po + r * so);
+  }
   uint8_t *win = smem + cl * (H + 7) * WS;
   if (live) r1mc::stage_window<BPP>(win, WS, ref, cd.rx, cd.ry, W, H, c, P);
   __syncthreads();
 
   // ---- B: prediction column, residual, SAD / SATD ----
-  T v[H];
+  if constexpr (BPP == 1) {
+    const bool any_cf0 = __any(live && cd.col_frac == 0);
+    if (col_live) {
+      int32_t pred[H];
+      mc8_column<W, H, WS>(win, c, cd, any_cf0, pred);
+      if (pred_out) {
+        uint8_t *pp = (uint8_t *)pred_out + (size_t)cand * W * H + c;
 #pragma unroll
-  for (int r = 0; r < H; r++) v[r] = 0;
-  uint32_t sad = 0;
-  const bool col_live = live && c < W;
-  if (col_live) {
-    const uint8_t *po = px_addr<BPP>(org, cd.ox + c, cd.oy);
-    const size_t so = (size_t)org.stride * BPP;
-    uint8_t *pp = pred_out ? (uint8_t *)pred_out + ((size_t)cand * W * H + c) * BPP
-                           : nullptr;
-    r1mc::mc_column<BPP, false, H>(
-        win, WS, c, W, H, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y,
-        ref.bit_depth, [&](int r, int32_t p) {
-          const int32_t o = ld_px<BPP>(po + r * so);
-          v[r] = o - p;
-          if (pp) {
-            if constexpr (BPP == 1) pp[(size_t)r * W] = (uint8_t)p;
-            else *(uint16_t *)(pp + (size_t)r * W * 2) = (uint16_t)p;
-          }
-        });
+        for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint8_t)pred[r];
+      }
 #pragma unroll
-    for (int r = 0; r < H; r++) sad += (uint32_t)iabs32(v[r]);
+      for (int r = 0; r < H; r++) v[r] -= pred[r];
+    }
+  } else {
+    if (col_live) {
+      uint8_t *pp = pred_out ? (uint8_t *)pred_out + ((size_t)cand * W * H + c) * BPP
+                             : nullptr;
+      r1mc::mc_column<BPP, false, H>(
+          win, WS, c, W, H, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y,
+          ref.bit_depth, [&](int r, int32_t p) {
+            v[r] = v[r] - p;
+            if (pp) *(uint16_t *)(pp + (size_t)r * W * 2) = (uint16_t)p;
+          });
+    }
   }
   if (sad_out) {
+    uint32_t sad = 0;
+#pragma unroll
+    for (int r = 0; r < H; r++) sad += (uint32_t)iabs32(v[r]);
     const uint32_t s = group_sum<P>(sad);
     if (live && c == 0) sad_out[cand] = s;
   }
   if (satd_out) {
-    uint32_t acc = 0;
-#pragma unroll
-    for (int g = 0; g < H / TS; g++) {
-      int32_t a[TS];
-#pragma unroll
-      for (int k = 0; k < TS; k++) a[k] = v[g * TS + k];
-      // vertical pass on the lane's own TS rows (dist.rs:126-131)
-      if constexpr (TS == 4) {
-        const int32_t a0 = a[0] + a[1], a1 = a[0] - a[1];
-        const int32_t a2 = a[2] + a[3], a3 = a[2] - a[3];
-        a[0] = a0 + a2; a[1] = a1 + a3; a[2] = a0 - a2; a[3] = a1 - a3;
-      } else {
-        int32_t b[8], d[8];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          b[2 * k] = a[2 * k] + a[2 * k + 1];
-          b[2 * k + 1] = a[2 * k] - a[2 * k + 1];
-        }
-        d[0] = b[0] + b[2]; d[2] = b[0] - b[2];
-        d[1] = b[1] + b[3]; d[3] = b[1] - b[3];
-        d[4] = b[4] + b[6]; d[6] = b[4] - b[6];
-        d[5] = b[5] + b[7]; d[7] = b[5] - b[7];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          a[k] = d[k] + d[k + 4];
-          a[k + 4] = d[k] - d[k + 4];
-        }
-      }
-      // horizontal pass across the TS lanes of the tile (dist.rs:132-138)
-#pragma unroll
-      for (int k = 0; k < TS; k++)
-        acc += (uint32_t)iabs32(hadamard_lanes<TS>(a[k], lane));
-    }
-    const uint32_t s = group_sum<P>(acc);
+    const uint32_t s = group_sum<P>(satd_column<TS, H>(v, lane));
     constexpr int LN = TS == 4 ? 2 : 3;
     if (live && c == 0) satd_out[cand] = (s + ((1u << LN) >> 1)) >> LN;
   }
@@ -148,7 +281,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
     }
 #pragma unroll
     for (int r = 0; r < H; r++) v[r] = r1tx::shift_fwd(v[r], sh.s[0]);
-    r1tx::fwd_1d<H>(v, r1tx::vtx_1d(tx_type));
+    r1tx::fwd_1d_m24<H>(v, r1tx::vtx_1d(tx_type));
     const int cc = cl * W + (r1tx::lr_flip(tx_type) ? W - 1 - c : c);
 #pragma unroll
     for (int r = 0; r < H; r++)
@@ -164,7 +297,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
       T u[W];
 #pragma unroll
       for (int k = 0; k < W; k++) u[k] = buf[r * LSTRIDE + cl2 * W + k];
-      r1tx::fwd_1d<W>(u, r1tx::htx_1d(tt));
+      r1tx::fwd_1d_m24<W>(u, r1tx::htx_1d(tt));
       constexpr int OS = H < 32 ? H : 32, WC = W < 32 ? W : 32;
       CT *dst = coeffs + cand2 * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31);
 #pragma unroll
@@ -200,6 +333,7 @@ extern "C" int r1_rdo_cand_batch(r1_ctx *ctx, const R1Plane *org,
   R1_REQUIRE(org->bytes_per_px == ref->bytes_per_px);
   R1_REQUIRE(org->bytes_per_px == 1 || org->bytes_per_px == 2);
   R1_REQUIRE(org->bit_depth == ref->bit_depth);
+  R1_REQUIRE((org->bytes_per_px == 1) == (org->bit_depth == 8));
   R1_REQUIRE(tx_size >= 0 && tx_size < 19);
   R1_REQUIRE((1 << r1tx::kTxWLog2[tx_size]) == w &&
              (1 << r1tx::kTxHLog2[tx_size]) == h);

@@ -28,6 +28,24 @@ typedef int32_t T;
 #define TX_ADD_AVG(a, b) (TX_ADD(a, b) >> 1)
 #define TX_SUB_AVG(a, b) (TX_SUB(a, b) >> 1)
 #include "fwd_tx_1d.inc"
+#undef TX_MUL
+
+// Second instantiation for residuals that come from pixels (fused kernel):
+// every multiplier input is then < 2^18.4 in magnitude for all sizes, types
+// and bit depths (tools/tx_range.py, tests/test_tx_range.py), so the
+// full-rate 24-bit multiply returns the same low 32 product bits as the
+// wrapping i32 multiply of forward.rs:43.
+namespace m24 {
+template <int M>
+__device__ __forceinline__ T mul24(T a) {
+  T r;
+  asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "n"(M), "v"(a));
+  return r;
+}
+#define TX_MUL(a, m, s) ((T)((uint32_t)mul24<(m)>(a) + (uint32_t)((1 << (s)) >> 1)) >> (s))
+#include "fwd_tx_1d.inc"
+#undef TX_MUL
+}  // namespace m24
 #undef TX1D_FN
 
 // 1-D transform classes: 0 DCT, 1 ADST, 2 FLIPADST, 3 IDTX, 4 WHT
@@ -84,6 +102,25 @@ __device__ __forceinline__ T shift_fwd(T v, int shift) {
   if (shift >= 0) return (T)((uint32_t)v << shift);
   const int b = -shift;
   return (v + ((1 << b) >> 1)) >> b;
+}
+
+// Same dispatch on the 24-bit-multiply instantiation.
+template <int N>
+__device__ __forceinline__ void fwd_1d_m24(T *c, int k) {
+  if (k == 3) return;
+  if constexpr (N == 4) {
+    if (k == 0) m24::r1_fdct4(c);
+    else if (k == 4) m24::r1_fwht4(c);
+    else m24::r1_fdst_vii_4(c);
+  } else if constexpr (N == 8) {
+    if (k == 0) m24::r1_fdct8(c); else m24::r1_fdst8(c);
+  } else if constexpr (N == 16) {
+    if (k == 0) m24::r1_fdct16(c); else m24::r1_fdst16(c);
+  } else if constexpr (N == 32) {
+    m24::r1_fdct32(c);
+  } else {
+    m24::r1_fdct64(c);
+  }
 }
 
 // One 1-D forward transform of length N on a register array, class `k`
