@@ -91,7 +91,9 @@ __device__ __forceinline__ int intermediate_bits(int bit_depth) {
 // (lane index `l`) cooperate; global reads are unaligned dword loads, the
 // last partial dword of a row is read bytewise so nothing outside the
 // documented footprint is touched.
-template <int BPP>
+// XORM is xor-ed into every staged dword (0x80808080 turns u8 pixels into the
+// biased i8 operands of v_dot4_i32_i8).
+template <int BPP, uint32_t XORM = 0u>
 __device__ __forceinline__ void stage_window(uint8_t *win, int ws,
                                              const R1Plane &ref, int rx, int ry,
                                              int P, int h, int l, int nl) {
@@ -116,7 +118,7 @@ __device__ __forceinline__ void stage_window(uint8_t *win, int ws,
         // the row end and shift, so nothing outside the footprint is touched
         const int over = d * 4 + 4 - row_bytes;
         const int back = over > 0 ? over : 0;
-        v[u] = ld_u32(g0 + r * gstride + d * 4 - back) >> (8 * back);
+        v[u] = (ld_u32(g0 + r * gstride + d * 4 - back) >> (8 * back)) ^ XORM;
         off[u] = r * ws + d * 4;
       }
     }

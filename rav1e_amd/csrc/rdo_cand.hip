@@ -115,40 +115,45 @@ __device__ __forceinline__ void mc8_column(const uint8_t *win, int c,
   constexpr int WSD = WS / 4;
   const uint32_t *wrow = (const uint32_t *)win + (c >> 2);
   const uint32_t sh = (uint32_t)(c & 3);
-  constexpr int NM = H + 8;   // H + 7 intermediates, padded to even
-  int32_t mid[NM];
-#pragma unroll
-  for (int r = 0; r < H + 7; r++) {
+  typedef short v2s __attribute__((ext_vector_type(2)));
+  // the window holds pixels already biased by -128 (staged with xor 0x80)
+  auto hrow = [&](int r) -> int32_t {
     const uint32_t d0 = wrow[r * WSD], d1 = wrow[r * WSD + 1], d2 = wrow[r * WSD + 2];
     const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
     const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    int32_t acc = __builtin_amdgcn_sdot4((int)(lo ^ 0x80808080u), (int)fx0, bias, false);
-    acc = __builtin_amdgcn_sdot4((int)(hi ^ 0x80808080u), (int)fx1, acc, false);
-    if (any_cf0) acc += cf == 0 ? (int32_t)(lo >> 24) : 0;
-    mid[r] = acc >> 3;
-  }
-  mid[H + 7] = 0;
-  typedef short v2s __attribute__((ext_vector_type(2)));
-  uint32_t pk[NM / 2];
+    int32_t acc = __builtin_amdgcn_sdot4((int)lo, (int)fx0, bias, false);
+    acc = __builtin_amdgcn_sdot4((int)hi, (int)fx1, acc, false);
+    if (any_cf0) acc += cf == 0 ? (int32_t)((lo >> 24) ^ 0x80u) : 0;
+    return acc >> 3;
+  };
+  auto hpair = [&](int r) -> uint32_t {   // rows r, r+1 packed as i16 x 2
+    const int32_t m0 = hrow(r);
+    const int32_t m1 = r + 1 < H + 7 ? hrow(r + 1) : 0;
+    return __builtin_amdgcn_perm((uint32_t)m1, (uint32_t)m0, 0x05040100u);
+  };
+  // rolling window of 5 packed pairs: output rows 2j and 2j+1 need the
+  // intermediates 2j .. 2j+8
+  uint32_t pk[5];
 #pragma unroll
-  for (int j = 0; j < NM / 2; j++)
-    pk[j] = __builtin_amdgcn_perm((uint32_t)mid[2 * j + 1], (uint32_t)mid[2 * j], 0x05040100u);
+  for (int j = 0; j < 4; j++) pk[j] = hpair(2 * j);
 #pragma unroll
-  for (int r = 0; r < H; r++) {
-    int32_t acc = 1024;   // rounding of the final >> 11
-    if ((r & 1) == 0) {
+  for (int j = 0; j < H / 2; j++) {
+    pk[4] = hpair(2 * j + 8);
+    int32_t a0 = 1024, a1 = 1024;   // rounding of the final >> 11
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[r / 2 + j]),
-                                     __builtin_bit_cast(v2s, ty[j]), acc, false);
-    } else {
+    for (int k = 0; k < 4; k++)
+      a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]),
+                                  __builtin_bit_cast(v2s, ty[k]), a0, false);
 #pragma unroll
-      for (int j = 0; j < 5; j++)
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[r / 2 + j]),
-                                     __builtin_bit_cast(v2s, tz[j]), acc, false);
-    }
-    acc >>= 11;
-    pred[r] = acc < 0 ? 0 : (acc > 255 ? 255 : acc);
+    for (int k = 0; k < 5; k++)
+      a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]),
+                                  __builtin_bit_cast(v2s, tz[k]), a1, false);
+    a0 >>= 11;
+    a1 >>= 11;
+    pred[2 * j] = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0);
+    pred[2 * j + 1] = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) pk[k] = pk[k + 1];
   }
 }
 
@@ -226,7 +231,9 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
     for (int r = 0; r < H; r++) v[r] = ld_px<BPP>(po + r * so);
   }
   uint8_t *win = smem + cl * (H + 7) * WS;
-  if (live) r1mc::stage_window<BPP>(win, WS, ref, cd.rx, cd.ry, W, H, c, P);
+  if (live)
+    r1mc::stage_window<BPP, BPP == 1 ? 0x80808080u : 0u>(win, WS, ref, cd.rx, cd.ry,
+                                                          W, H, c, P);
   __syncthreads();
 
   // ---- B: prediction column, residual, SAD / SATD ----
@@ -272,11 +279,15 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   // ---- C: column transform on the residual registers ----
   __syncthreads();  // every lane is done reading the window; LDS becomes buf
   const int tx_type = cd.tx_type;
+  const bool any_ud = __any(live && r1tx::ud_flip(tx_type));
   if (col_live) {
-    if (r1tx::ud_flip(tx_type)) {
+    if (any_ud) {   // wave-uniform: skipped when no candidate of the wave flips
+      const bool ud = r1tx::ud_flip(tx_type);
 #pragma unroll
       for (int r = 0; r < H / 2; r++) {
-        const T t = v[r]; v[r] = v[H - 1 - r]; v[H - 1 - r] = t;
+        const T t0 = v[r], t1 = v[H - 1 - r];
+        v[r] = ud ? t1 : t0;
+        v[H - 1 - r] = ud ? t0 : t1;
       }
     }
 #pragma unroll
