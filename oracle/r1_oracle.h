@@ -76,6 +76,35 @@ int r1o_valid_av1_transform(int tx_size, int tx_type);
  * (DCT4,DCT8,DCT16,DCT32,DCT64,ADST4,ADST8,ADST16,Id4,Id8,Id16,Id32,WHT4) */
 void r1o_fwd_txfm_1d(int32_t *coeffs, int txfm_type);
 
+/* ---- inverse transform (src/transform/inverse.rs) ---- */
+/* cls: 0 DCT 1 ADST 2 FLIPADST 3 IDTX 4 WHT; returns -1 if no such kernel */
+int r1o_inv_txfm_1d(int32_t *coeffs, int cls, int n, int range_bits);
+/* dst holds the prediction on entry, the reconstruction on return */
+int r1o_inverse_transform_add(const void *coeffs, void *dst, ptrdiff_t stride,
+                              int tx_size, int tx_type, int bd, int coeff32,
+                              int hbd);
+int r1o_inv_txfm_add_batch(const void *coeffs, int coeff_stride, const void *pred,
+                           void *rec, int n, int tx_size, int tx_type,
+                           int bit_depth, int coeff_bytes, int bytes_per_px);
+
+/* ---- quantize (src/quantize/mod.rs, src/scan_order.rs) ---- */
+void r1o_gen_scan(int kind, int W, int H, uint16_t *scan);
+int r1o_scan_kind(int tx_type);
+int r1o_get_scan(int tx_size, int tx_type, uint16_t *scan, uint16_t *iscan);
+int r1o_get_log_tx_scale(int tx_size);
+uint16_t r1o_dc_q(int qindex, int delta_q, int bit_depth);
+uint16_t r1o_ac_q(int qindex, int delta_q, int bit_depth);
+uint32_t r1o_divu(uint32_t x, uint32_t d);
+int r1o_quantize(const void *coeffs, void *qcoeffs, int tx_size, int tx_type,
+                 int qindex, int bit_depth, int is_intra, int dc_delta_q,
+                 int ac_delta_q, int coeff32);
+void r1o_dequantize(const void *qcoeffs, void *rcoeffs, int tx_size, int qindex,
+                    int bit_depth, int dc_delta_q, int ac_delta_q, int coeff32);
+int r1o_quantize_batch(const void *coeffs, int coeff_stride, int n, int tx_size,
+                       int tx_type, int qindex, int bit_depth, int is_intra,
+                       int dc_delta_q, int ac_delta_q, int coeff_bytes,
+                       void *qcoeffs, uint16_t *eobs, void *rcoeffs);
+
 /* encoder.rs:1355 diff */
 void r1o_diff(int16_t *dst, const void *src1, ptrdiff_t stride1,
               const void *src2, ptrdiff_t stride2, int w, int h, int hbd);

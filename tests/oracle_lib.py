@@ -62,6 +62,19 @@ def lib():
         "r1o_tx_width": (i, [i]), "r1o_tx_height": (i, [i]),
         "r1o_valid_av1_transform": (i, [i, i]),
         "r1o_fwd_txfm_1d": (None, [vp, i]),
+        "r1o_inv_txfm_1d": (i, [vp, i, i, i]),
+        "r1o_inverse_transform_add": (i, [vp, vp, pd, i, i, i, i, i]),
+        "r1o_inv_txfm_add_batch": (i, [vp, i, vp, vp, i, i, i, i, i, i]),
+        "r1o_gen_scan": (None, [i, i, i, vp]),
+        "r1o_scan_kind": (i, [i]),
+        "r1o_get_scan": (i, [i, i, vp, vp]),
+        "r1o_get_log_tx_scale": (i, [i]),
+        "r1o_dc_q": (C.c_uint16, [i, i, i]),
+        "r1o_ac_q": (C.c_uint16, [i, i, i]),
+        "r1o_divu": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+        "r1o_quantize": (i, [vp, vp, i, i, i, i, i, i, i, i]),
+        "r1o_dequantize": (None, [vp, vp, i, i, i, i, i, i]),
+        "r1o_quantize_batch": (i, [vp, i, i, i, i, i, i, i, i, i, i, vp, vp, vp]),
         "r1o_diff": (None, [vp, vp, pd, vp, pd, i, i, i]),
         "r1o_set_threads": (None, [i]),
         "r1o_dist_batch": (i, [i, vp, vp, i, i, vp, i, vp]),

@@ -1,0 +1,75 @@
+"""Pin the quantizer oracle: scan-order rule vs the reference's literal tables
+(SHA-256 committed by tests/golden/gen_quant_golden.py), quantize/dequantize vs
+an independent model's vectors, divu exactness (src/quantize/mod.rs:169-178)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+import oracle_lib as O
+
+HERE = os.path.dirname(__file__)
+G = np.load(os.path.join(HERE, "golden", "quant_golden.npz"))
+SHA = json.load(open(os.path.join(HERE, "golden", "scan_sha256.json")))
+TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+
+
+def test_scan_rule_matches_reference_tables(oracle):
+    assert len(SHA) == 19 * 16
+    for ts in range(19):
+        n = min(TX_W[ts], 32) * min(TX_H[ts], 32)
+        for tt in range(16):
+            scan, iscan = np.zeros(1024, np.uint16), np.zeros(1024, np.uint16)
+            assert oracle.r1o_get_scan(ts, tt, O.ptr(scan), O.ptr(iscan)) == n
+            assert hashlib.sha256(scan[:n].astype("<u2").tobytes()).hexdigest() == SHA["%d_%d" % (ts, tt)]
+            assert np.array_equal(iscan[scan[:n]], np.arange(n))
+
+
+def test_divu_pair_is_exact_division(oracle):
+    # the reference's own test (quantize/mod.rs:169-178) plus large operands
+    for d in list(range(1, 1024)) + [1336, 5247, 21387, 65535]:
+        for x in (0, 1, d - 1, d, d + 1, 999, 123456789, 2 ** 31, 2 ** 32 - 1):
+            assert oracle.r1o_divu(x, d) == x // d, (x, d)
+
+
+def test_quantize_dequantize_vectors(oracle):
+    keys = [k for k in G.files if k.endswith("_co")]
+    assert len(keys) == 570
+    for k in keys:
+        _, ts, tt, bd, intra, qi, dcd, acd, _ = k.split("_")
+        ts, tt, bd, intra, qi, dcd, acd = map(int, (ts, tt, bd, intra, qi, dcd, acd))
+        co = G[k]
+        c32 = co.dtype == np.int32
+        n = min(TX_W[ts], 32) * min(TX_H[ts], 32)
+        q = np.zeros((co.shape[0], n), co.dtype)
+        r = np.zeros_like(q)
+        eobs = np.zeros(co.shape[0], np.uint16)
+        cc = np.ascontiguousarray(co)
+        assert oracle.r1o_quantize_batch(O.ptr(cc), co.shape[1], co.shape[0], ts, tt, qi, bd, intra,
+                                         dcd, acd, 4 if c32 else 2, O.ptr(q), O.ptr(eobs),
+                                         O.ptr(r)) == 0
+        assert np.array_equal(eobs, G[k[:-3] + "_eob"]), k
+        assert np.array_equal(q, G[k[:-3] + "_q"]), k
+        assert np.array_equal(r, G[k[:-3] + "_r"]), k
+
+
+def test_eob_is_last_nonzero_in_scan_order(oracle):
+    """the reference's debug_assert (quantize/mod.rs:344-352)"""
+    rng = np.random.default_rng(5)
+    for ts, tt in ((1, 0), (2, 10), (3, 0), (8, 11), (4, 0)):
+        n = min(TX_W[ts], 32) * min(TX_H[ts], 32)
+        scan = np.zeros(1024, np.uint16)
+        oracle.r1o_get_scan(ts, tt, O.ptr(scan), None)
+        for _ in range(20):
+            co = (rng.integers(-400, 401, n) * (rng.random(n) < 0.1)).astype(np.int32)
+            q = np.zeros(n, np.int32)
+            eob = oracle.r1o_quantize(O.ptr(co), O.ptr(q), ts, tt, 100, 10, 0, 0, 0, 1)
+            nz = np.nonzero(q[scan[:n]])[0]
+            assert eob == (nz[-1] + 1 if len(nz) else 0)
+
+
+def test_wht_rejected(oracle):
+    co = np.zeros(16, np.int32)
+    assert oracle.r1o_quantize(O.ptr(co), O.ptr(co.copy()), 0, 16, 100, 8, 0, 0, 0, 1) == -1
