@@ -117,6 +117,44 @@ int r1_fwd_txfm_batch(r1_ctx *ctx, const int16_t *residual, void *coeffs,
                       int n, int tx_size, int tx_type, int bit_depth,
                       int coeff_bytes, void *stream);
 
+/* ---- transform::inverse (reference: inverse_transform_add,
+ * src/transform/inverse.rs:1633-1705; InvTxfmFunc tables
+ * src/asm/x86/transform/inverse.rs, wrapper src/asm/shared/transform/inverse.rs:30-36).
+ * coeffs: block i at coeffs + i*coeff_stride (elements); only the first
+ * min(w,32)*min(h,32) entries are read, in the forward transform's transposed
+ * order (so the output of r1_fwd_txfm_batch / r1_quantize_batch's rcoeffs can
+ * be passed unchanged).  int16 when bytes_per_px == 1, int32 when 2
+ * (T::Coeff).  pred / rec: n dense w*h pixel blocks; rec may alias pred (the
+ * reference adds in place). */
+int r1_inv_txfm_add_batch(r1_ctx *ctx, const void *coeffs, int coeff_stride,
+                          const void *pred, void *rec, int n, int tx_size,
+                          int tx_type, int bit_depth, int bytes_per_px,
+                          void *stream);
+
+/* ---- quantize:: (reference: QuantizationContext::{update,quantize}
+ * src/quantize/mod.rs:219-355, dequantize 363-384 with its dispatch
+ * src/asm/x86/quantize.rs; scan orders src/scan_order.rs). */
+typedef struct R1QuantParams {
+  uint8_t qindex;       /* base_q_idx of the block */
+  uint8_t bit_depth;    /* 8, 10, 12 */
+  uint8_t is_intra;     /* selects the rounding biases (mod.rs:258-265) */
+  int8_t dc_delta_q, ac_delta_q;
+  uint8_t reserved[3];
+} R1QuantParams;
+/* block i reads coeffs + i*coeff_stride (>= coded area entries, the layout
+ * r1_fwd_txfm_batch writes); qcoeffs / rcoeffs: dense coded-area blocks
+ * (min(w,32)*min(h,32)), fully written (zeros beyond eob); eobs[i] = the
+ * reference's return value.  rcoeffs may be NULL (no fused dequantize).
+ * coeff_bytes 2 (T::Coeff = i16) or 4 (i32).  tx_type 16 (WHT) -> R1_EINVAL
+ * (the reference's scan table has 16 columns). */
+int r1_quantize_batch(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n,
+                      int tx_size, int tx_type, const R1QuantParams *params,
+                      int coeff_bytes, void *qcoeffs, uint16_t *eobs,
+                      void *rcoeffs, void *stream);
+int r1_dequantize_batch(r1_ctx *ctx, const void *qcoeffs, int n, int tx_size,
+                        const R1QuantParams *params, int coeff_bytes,
+                        void *rcoeffs, void *stream);
+
 /* ---- mc:: (reference: src/mc.rs put_8tap 250, prep_8tap 360, mc_avg 454;
  * dispatch tables PUT_FNS/PREP_FNS/AVG_FNS src/asm/x86/mc.rs:17-78,371-382).
  * put: dst = n dense w*h pixel blocks (same pixel type as `ref`).

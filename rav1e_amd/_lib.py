@@ -12,6 +12,11 @@ class R1Plane(C.Structure):
                 ("yorigin", C.c_int32), ("bytes_per_px", C.c_int32), ("bit_depth", C.c_int32)]
 
 
+class R1QuantParams(C.Structure):
+    _fields_ = [("qindex", C.c_uint8), ("bit_depth", C.c_uint8), ("is_intra", C.c_uint8),
+                ("dc_delta_q", C.c_int8), ("ac_delta_q", C.c_int8), ("reserved", C.c_uint8 * 3)]
+
+
 # every symbol include/rav1e_amd.h declares: name -> (restype, argtypes)
 _vp, _i, _sz, _pd = C.c_void_p, C.c_int, C.c_size_t, C.c_ssize_t
 _PP = C.POINTER(R1Plane)
@@ -22,6 +27,10 @@ SYMBOLS = {
     "r1_abi_version": (_i, []),
     "r1_dist_batch": (_i, [_vp, _i, _PP, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_fwd_txfm_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "r1_inv_txfm_add_batch": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "r1_quantize_batch": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(R1QuantParams), _i, _vp, _vp,
+                               _vp, _vp]),
+    "r1_dequantize_batch": (_i, [_vp, _vp, _i, _i, C.POINTER(R1QuantParams), _i, _vp, _vp]),
     "r1_mc_put_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_prep_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_avg_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -124,6 +124,59 @@ class Context:
                                                _stream_ptr()), "r1_fwd_txfm_batch")
         return out
 
+    # ---- transform::inverse ----
+    def inverse_transform_add_batch(self, coeffs, pred, tx_size, tx_type, bit_depth, out=None):
+        """inverse_transform_add (src/transform/inverse.rs:1633) over n blocks.
+        coeffs: (n, stride) int16/int32 device tensor (stride >= coded area);
+        pred: (n, h, w) pixels; returns the reconstruction (pass out=pred for
+        the reference's in-place behaviour)."""
+        w, h = TX_DIMS[int(tx_size)]
+        n = pred.numel() // (w * h)
+        bpp = 1 if bit_depth == 8 else 2
+        if out is None:
+            out = torch.empty_like(pred)
+        self._check(self.lib.r1_inv_txfm_add_batch(
+            self.h, coeffs.data_ptr(), coeffs.stride(0) if coeffs.dim() > 1 else coeffs.numel() // n,
+            pred.data_ptr(), out.data_ptr(), n, int(tx_size), int(tx_type), bit_depth, bpp,
+            _stream_ptr()), "r1_inv_txfm_add_batch")
+        return out
+
+    # ---- quantize:: ----
+    @staticmethod
+    def _qparams(qindex, bit_depth, is_intra, dc_delta_q=0, ac_delta_q=0):
+        return _lib.R1QuantParams(int(qindex), int(bit_depth), int(bool(is_intra)), int(dc_delta_q),
+                                  int(ac_delta_q))
+
+    def quantize_batch(self, coeffs, tx_size, tx_type, qindex, bit_depth, is_intra,
+                       dc_delta_q=0, ac_delta_q=0, want_rcoeffs=True):
+        """QuantizationContext::quantize (+ dequantize) over n blocks
+        (src/quantize/mod.rs:268-384).  coeffs: (n, stride) device tensor.
+        -> dict(qcoeffs, eobs, rcoeffs) over the coded area."""
+        w, h = TX_DIMS[int(tx_size)]
+        area = min(w, 32) * min(h, 32)
+        n = coeffs.shape[0]
+        cb = coeffs.element_size()
+        q = torch.empty((n, area), dtype=coeffs.dtype, device="cuda")
+        r = torch.empty((n, area), dtype=coeffs.dtype, device="cuda") if want_rcoeffs else None
+        eobs = torch.empty(n, dtype=torch.int16, device="cuda")
+        qp = self._qparams(qindex, bit_depth, is_intra, dc_delta_q, ac_delta_q)
+        self._check(self.lib.r1_quantize_batch(
+            self.h, coeffs.data_ptr(), coeffs.stride(0), n, int(tx_size), int(tx_type), C.byref(qp),
+            cb, q.data_ptr(), eobs.data_ptr(), r.data_ptr() if r is not None else None,
+            _stream_ptr()), "r1_quantize_batch")
+        return {"qcoeffs": q, "eobs": eobs, "rcoeffs": r}
+
+    def dequantize_batch(self, qcoeffs, tx_size, qindex, bit_depth, dc_delta_q=0, ac_delta_q=0):
+        """rust::dequantize (src/quantize/mod.rs:363-384) over n coded-area blocks."""
+        n = qcoeffs.shape[0]
+        r = torch.empty_like(qcoeffs)
+        qp = self._qparams(qindex, bit_depth, 0, dc_delta_q, ac_delta_q)
+        self._check(self.lib.r1_dequantize_batch(self.h, qcoeffs.data_ptr(), n, int(tx_size),
+                                                 C.byref(qp), qcoeffs.element_size(),
+                                                 r.data_ptr(), _stream_ptr()),
+                    "r1_dequantize_batch")
+        return r
+
     # ---- mc:: ----
     def put_8tap_batch(self, ref, w, h, cands, n=None, out=None):
         dc = _dev_cands(cands, MC_CAND)

@@ -36,6 +36,12 @@ extern "C" int r1_ctx_create(int device, r1_ctx **out) {
     r1_set_error("hipStreamCreate failed");
     return R1_EHIP;
   }
+  c->scan_dev = nullptr;
+  if (r1_scan_tables_create(c) != R1_OK) {
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return R1_EHIP;
+  }
   *out = c;
   return R1_OK;
 }
@@ -44,6 +50,7 @@ extern "C" void r1_ctx_destroy(r1_ctx *c) {
   if (!c) return;
   if (c->stage) (void)hipFree(c->stage);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  r1_scan_tables_destroy(c);
   (void)hipStreamDestroy(c->own_stream);
   delete c;
 }

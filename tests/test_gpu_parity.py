@@ -317,3 +317,131 @@ def test_compat_shims_host_pointers(ctx, oracle):
     oracle.r1o_forward_transform(O.ptr(res), O.ptr(want), 8, 1, 0, 8, 0)
     assert L.rav1e_fwd_txfm_hip(O.ptr(res), O.ptr(got), 8, 1, 0, 8, 2) == 0
     assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------- inverse tx
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_inv_txfm_golden_vectors(ctx):
+    """480 (size, type, bit depth) cases produced by executing the reference's
+    own inverse.rs text (tests/golden/gen_inv_tx_golden.py)."""
+    G = np.load(os.path.join(GOLD, "inv_tx_golden.npz"))
+    keys = [k for k in G.files if k.startswith("d2_") and k.endswith("_co")]
+    assert len(keys) == 480
+    for k in keys:
+        _, ts, tt, bd, _ = k.split("_")
+        ts, tt, bd = int(ts), int(tt), int(bd)
+        co, pred, rec = G[k], G[k[:-3] + "_pred"], G[k[:-3] + "_rec"]
+        if bd == 8:
+            ok = np.abs(co).max(axis=1) < 32768       # T::Coeff = i16
+            if not ok.any():
+                continue
+            got = ctx.inverse_transform_add_batch(_t(co[ok].astype(np.int16)),
+                                                  _t(pred[ok].astype(np.uint8)), ts, tt, bd)
+            assert np.array_equal(got.cpu().numpy(), rec[ok].astype(np.uint8)), k
+        else:
+            got = ctx.inverse_transform_add_batch(_t(co), _t(pred.astype(np.int16)), ts, tt, bd)
+            assert np.array_equal(got.cpu().numpy().view(np.uint16), rec), k
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_inv_txfm_random_vs_oracle(ctx, oracle, bd):
+    rng = np.random.default_rng(300 + bd)
+    bpp = 1 if bd == 8 else 2
+    ct = np.int16 if bd == 8 else np.int32
+    pt = np.uint8 if bd == 8 else np.uint16
+    for ts, (w, h) in enumerate(TX_SIZES):
+        area = min(w, 32) * min(h, 32)
+        types = [t for t in range(17) if oracle.r1o_valid_av1_transform(ts, t)]
+        for tt in types:
+            n = 37
+            stride = w * h                       # the forward transform's block stride
+            co = np.zeros((n, stride), ct)
+            amp = 1 << (bd + 4)
+            co[:, :area] = rng.integers(-amp, amp, (n, area))
+            co[: n // 3, :area] *= (rng.random((n // 3, area)) < 0.1)
+            if ct == np.int32:
+                co[-1, :area] = rng.integers(-(1 << 24), 1 << 24, area)   # clamp paths
+            pred = rng.integers(0, 1 << bd, (n, h, w)).astype(pt)
+            want = np.zeros_like(pred)
+            assert oracle.r1o_inv_txfm_add_batch(O.ptr(co), stride, O.ptr(pred), O.ptr(want), n, ts,
+                                                 tt, bd, co.itemsize, bpp) == 0
+            dp = _t(pred if bpp == 1 else pred.view(np.int16))
+            got = ctx.inverse_transform_add_batch(_t(co), dp, ts, tt, bd).cpu().numpy()
+            assert np.array_equal(got.view(pt), want), (bd, ts, tt)
+
+
+def test_fwd_inv_roundtrip_on_device(ctx):
+    """the reference's own round-trip property (src/transform/mod.rs:555-603),
+    entirely on the GPU: forward_transform -> inverse_transform_add."""
+    import torch
+    from test_oracle_inv_tx import ROUNDTRIPS
+    rng = np.random.default_rng(9)
+    for ts, tt, tol in ROUNDTRIPS:
+        w, h = TX_SIZES[ts]
+        n = 64
+        src = rng.integers(0, 256, (n, h, w))
+        dst = rng.integers(0, 256, (n, h, w))
+        res = _t((src - dst).astype(np.int16))
+        freq = ctx.forward_transform_batch(res, ts, tt, 8)
+        rec = ctx.inverse_transform_add_batch(freq, _t(dst.astype(np.uint8)), ts, tt, 8)
+        err = np.abs(rec.cpu().numpy().astype(np.int32) - src).max()
+        assert err <= tol, (ts, tt, err)
+
+
+# ------------------------------------------------------------------ quantize
+def test_quantize_golden_vectors(ctx):
+    G = np.load(os.path.join(GOLD, "quant_golden.npz"))
+    keys = [k for k in G.files if k.endswith("_co")]
+    assert len(keys) == 570
+    for k in keys:
+        _, ts, tt, bd, intra, qi, dcd, acd, _ = k.split("_")
+        ts, tt, bd, intra, qi, dcd, acd = map(int, (ts, tt, bd, intra, qi, dcd, acd))
+        o = ctx.quantize_batch(_t(G[k]), ts, tt, qi, bd, intra, dcd, acd)
+        assert np.array_equal(o["eobs"].cpu().numpy().view(np.uint16), G[k[:-3] + "_eob"]), k
+        assert np.array_equal(o["qcoeffs"].cpu().numpy(), G[k[:-3] + "_q"]), k
+        assert np.array_equal(o["rcoeffs"].cpu().numpy(), G[k[:-3] + "_r"]), k
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_quantize_random_vs_oracle(ctx, oracle, bd):
+    rng = np.random.default_rng(500 + bd)
+    ct = np.int16 if bd == 8 else np.int32
+    for ts, (w, h) in enumerate(TX_SIZES):
+        area = min(w, 32) * min(h, 32)
+        for tt in (0, 10, 11) if max(w, h) <= 16 else (0,):
+            for qi, intra in ((60, 0), (160, 1), (255, 0)):
+                n = 203                                  # ragged vs every group size
+                stride = w * h
+                acq = oracle.r1o_ac_q(qi, 0, bd)
+                co = np.zeros((n, stride), ct)
+                v = rng.integers(-3 * acq, 3 * acq + 1, (n, area))
+                v[: n // 2] *= (rng.random((n // 2, area)) < 0.07)
+                v[n // 2: 3 * n // 4] = rng.integers(-2, 3, (3 * n // 4 - n // 2, area)) + \
+                    rng.choice([0, acq // 2, acq, -acq], (3 * n // 4 - n // 2, area))
+                co[:, :area] = np.clip(v, np.iinfo(ct).min, np.iinfo(ct).max)
+                co[0] = 0
+                q = np.zeros((n, area), ct)
+                r = np.zeros((n, area), ct)
+                eobs = np.zeros(n, np.uint16)
+                assert oracle.r1o_quantize_batch(O.ptr(co), stride, n, ts, tt, qi, bd, intra, 0, 0,
+                                                 co.itemsize, O.ptr(q), O.ptr(eobs), O.ptr(r)) == 0
+                o = ctx.quantize_batch(_t(co), ts, tt, qi, bd, intra)
+                assert np.array_equal(o["eobs"].cpu().numpy().view(np.uint16), eobs), (bd, ts, tt, qi)
+                assert np.array_equal(o["qcoeffs"].cpu().numpy(), q), (bd, ts, tt, qi)
+                assert np.array_equal(o["rcoeffs"].cpu().numpy(), r), (bd, ts, tt, qi)
+                r2 = ctx.dequantize_batch(o["qcoeffs"], ts, qi, bd).cpu().numpy()
+                assert np.array_equal(r2, r)
+
+
+def test_quantize_rejects_wht_and_bad_pairs(ctx):
+    import torch
+    from rav1e_amd.api import R1Error
+    co = torch.zeros((4, 16), dtype=torch.int16, device="cuda")
+    with pytest.raises(R1Error):
+        ctx.quantize_batch(co, 0, 16, 100, 8, 0)
+    with pytest.raises(R1Error):
+        ctx.quantize_batch(torch.zeros((4, 4096), dtype=torch.int16, device="cuda"), 4, 1, 100, 8, 0)
