@@ -60,7 +60,8 @@ enum { R1_FILTER_REGULAR = 0, R1_FILTER_SMOOTH = 1, R1_FILTER_SHARP = 2,
        R1_FILTER_BILINEAR = 3 };
 
 /* distortion kinds of r1_dist_batch */
-enum { R1_DIST_SAD = 0, R1_DIST_SATD = 1 };
+enum { R1_DIST_SAD = 0, R1_DIST_SATD = 1,
+       /* r1_dist_scaled_batch: */ R1_DIST_WSSE = 2, R1_DIST_CDEF = 3 };
 
 /* One distortion candidate: block of the launch's (w,h) at (ox,oy) in the
  * org plane against (rx,ry) in the ref plane (full-pel, plane coordinates;
@@ -105,6 +106,24 @@ int r1_abi_version(void);
 int r1_dist_batch(r1_ctx *ctx, int kind, const R1Plane *org,
                   const R1Plane *ref, int w, int h, const R1DistCand *cands,
                   int n, uint32_t *out, void *stream);
+
+/* ---- candidate-level pixel-domain distortion with the DistortionScale bias
+ * (reference: sse_wxh src/rdo.rs:177-224 -> get_weighted_sse src/dist.rs:234-283
+ * [kind R1_DIST_WSSE]; cdef_dist_wxh src/rdo.rs:142-173 -> cdef_dist_kernel
+ * src/dist.rs:302-372 + apply_ssim_boost src/activity.rs:159-186
+ * [kind R1_DIST_CDEF]; x86 tables src/asm/x86/dist/{sse,cdef_dist}.rs).
+ * scales: the frame's distortion_scales grid (src/rdo.rs:443-459), one Q14
+ * u32 per 8x8 LUMA importance block, entry [(luma_y >> 3) * scale_stride +
+ * (luma_x >> 3)] where luma_xy = (plane_xy << dec) of each 4x4 cell (WSSE) or
+ * 8x8 kernel (CDEF) -- exactly what the compute_bias closure at
+ * src/rdo.rs:283-303 looks up.  NULL = DistortionScale::default() (1 << 14).
+ * out[i] = the reference's Distortion (u64), before `* fi.dist_scale[p]`.
+ * w, h: multiples of 4, <= 128 (visible block size after frame clipping). */
+int r1_dist_scaled_batch(r1_ctx *ctx, int kind, const R1Plane *org,
+                         const R1Plane *ref, int w, int h,
+                         const R1DistCand *cands, int n, const uint32_t *scales,
+                         int scale_stride, int xdec, int ydec, uint64_t *out,
+                         void *stream);
 
 /* ---- transform::forward (reference: src/transform/forward.rs:71-161;
  * x86 entry src/asm/x86/transform/forward.rs:444-447).

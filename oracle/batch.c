@@ -113,3 +113,52 @@ int r1o_rdo_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, int h,
   }
   return bad ? -1 : 0;
 }
+
+/* sse_wxh / cdef_dist_wxh (src/rdo.rs:142-224) over a candidate list, with
+ * compute_bias = distortion_scale (src/rdo.rs:443-459): one Q14
+ * DistortionScale per 8x8 LUMA importance block of the frame,
+ * scales[(luma_y >> 3) * scale_stride + (luma_x >> 3)]; NULL = default 1<<14.
+ * kind 2: weighted SSE (any plane decimation), kind 3: cdef_dist (luma). */
+int r1o_dist_scaled_batch(int kind, const r1o_plane *org, const r1o_plane *ref,
+                          int w, int h, const r1o_dist_cand *c, int n,
+                          const uint32_t *scales, int scale_stride, int xdec,
+                          int ydec, uint64_t *out) {
+  const int hbd = org->bytes_per_px == 2;
+  if (ref->bytes_per_px != org->bytes_per_px) return -1;
+  if (kind != 2 && kind != 3) return -1;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    const void *o = at(org, c[i].ox, c[i].oy), *r = at(ref, c[i].rx, c[i].ry);
+    if (kind == 2) {
+      /* sse_wxh: per-4x4-cell scale buffer, stride = next_pow2(ceil(w/4)) */
+      uint32_t buf[32 * 32];
+      const int nbw = (w + 3) / 4, nbh = (h + 3) / 4;
+      int bs = 1;
+      while (bs < nbw) bs <<= 1;
+      for (int by = 0; by < nbh; by++)
+        for (int bx = 0; bx < nbw; bx++) {
+          const int lx = (c[i].ox + bx * 4) << xdec, ly = (c[i].oy + by * 4) << ydec;
+          buf[by * bs + bx] =
+              scales ? scales[(size_t)(ly >> 3) * scale_stride + (lx >> 3)] : (1u << 14);
+        }
+      out[i] = r1o_get_weighted_sse(o, org->stride, r, ref->stride, buf, bs, w, h, hbd);
+    } else {
+      uint64_t sum = 0;
+      const int bpp = org->bytes_per_px;
+      for (int y = 0; y < h; y += 8)
+        for (int x = 0; x < w; x += 8) {
+          const int kh = h - y < 8 ? h - y : 8, kw = w - x < 8 ? w - x : 8;
+          const uint64_t v = r1o_cdef_dist_kernel(
+              (const uint8_t *)o + ((size_t)y * org->stride + x) * bpp, org->stride,
+              (const uint8_t *)r + ((size_t)y * ref->stride + x) * bpp, ref->stride, kw, kh,
+              org->bit_depth, hbd);
+          const uint64_t sc =
+              scales ? scales[(size_t)((c[i].oy + y) >> 3) * scale_stride + ((c[i].ox + x) >> 3)]
+                     : (1u << 14);
+          sum += (sc * v + (1u << 14 >> 1)) >> 14;
+        }
+      out[i] = sum;
+    }
+  }
+  return 0;
+}

@@ -129,6 +129,10 @@ typedef struct {
 void r1o_set_threads(int n);
 int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
                    int h, const r1o_dist_cand *c, int n, uint32_t *out);
+int r1o_dist_scaled_batch(int kind, const r1o_plane *org, const r1o_plane *ref,
+                          int w, int h, const r1o_dist_cand *c, int n,
+                          const uint32_t *scales, int scale_stride, int xdec,
+                          int ydec, uint64_t *out);
 int r1o_fwd_txfm_batch(const int16_t *residual, void *coeffs, int n,
                        int tx_size, int tx_type, int bit_depth, int coeff_bytes);
 int r1o_mc_put_batch(const r1o_plane *ref, int w, int h, const r1o_mc_cand *c,

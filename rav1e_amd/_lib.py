@@ -26,6 +26,7 @@ SYMBOLS = {
     "r1_last_error": (C.c_char_p, []),
     "r1_abi_version": (_i, []),
     "r1_dist_batch": (_i, [_vp, _i, _PP, _PP, _i, _i, _vp, _i, _vp, _vp]),
+    "r1_dist_scaled_batch": (_i, [_vp, _i, _PP, _PP, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "r1_fwd_txfm_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "r1_inv_txfm_add_batch": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "r1_quantize_batch": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(R1QuantParams), _i, _vp, _vp,

@@ -107,6 +107,23 @@ class Context:
                     "r1_dist_batch")
         return out
 
+    def dist_scaled_batch(self, kind, org, ref, w, h, cands, scales=None, xdec=0, ydec=0,
+                          n=None, out=None):
+        """sse_wxh (kind 2) / cdef_dist_wxh (kind 3) of src/rdo.rs:142-224 over a
+        candidate list; scales: (rows, stride) int32 device tensor of Q14
+        DistortionScale per 8x8 luma importance block, or None."""
+        dc = _dev_cands(cands, DIST_CAND)
+        n = dc.numel() // DIST_CAND.itemsize if n is None else n
+        if out is None:
+            out = torch.empty(n, dtype=torch.int64, device="cuda")
+        po, pr = org.cstruct(), ref.cstruct()
+        self._check(self.lib.r1_dist_scaled_batch(
+            self.h, int(kind), C.byref(po), C.byref(pr), w, h, dc.data_ptr(), n,
+            scales.data_ptr() if scales is not None else None,
+            scales.stride(0) if scales is not None else 0, xdec, ydec, out.data_ptr(),
+            _stream_ptr()), "r1_dist_scaled_batch")
+        return out
+
     # ---- transform::forward ----
     def forward_transform_batch(self, residual, tx_size, tx_type, bit_depth, coeff_bytes=None,
                                 out=None):

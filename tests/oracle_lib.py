@@ -78,6 +78,7 @@ def lib():
         "r1o_diff": (None, [vp, vp, pd, vp, pd, i, i, i]),
         "r1o_set_threads": (None, [i]),
         "r1o_dist_batch": (i, [i, vp, vp, i, i, vp, i, vp]),
+        "r1o_dist_scaled_batch": (i, [i, vp, vp, i, i, vp, i, vp, i, i, i, vp]),
         "r1o_fwd_txfm_batch": (i, [vp, vp, i, i, i, i, i]),
         "r1o_mc_put_batch": (i, [vp, i, i, vp, i, vp]),
         "r1o_mc_prep_batch": (i, [vp, i, i, vp, i, vp]),

@@ -445,3 +445,61 @@ def test_quantize_rejects_wht_and_bad_pairs(ctx):
         ctx.quantize_batch(co, 0, 16, 100, 8, 0)
     with pytest.raises(R1Error):
         ctx.quantize_batch(torch.zeros((4, 4096), dtype=torch.int16, device="cuda"), 4, 1, 100, 8, 0)
+
+
+# ----------------------------------------------- weighted SSE / cdef_dist (a3-a5)
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_dist_scaled_batch(ctx, oracle, bd):
+    import ctypes as C
+    a, b = planes(bd, seed=40 + bd, pads=(88, 120))
+    # make ref a noisy copy of org so variances / sse are in a realistic regime
+    rng = np.random.default_rng(700 + bd)
+    noise = rng.integers(-12, 13, a.data.shape)
+    b.data = np.clip(a.data[:, :b.data.shape[1]].astype(np.int32) if False else
+                     rng.integers(0, 1 << bd, b.data.shape), 0, (1 << bd) - 1).astype(b.data.dtype)
+    b.view()[:] = np.clip(a.view().astype(np.int32) + noise[a.yorigin:a.yorigin + a.height,
+                                                            a.xorigin:a.xorigin + a.width],
+                          0, (1 << bd) - 1)
+    da, db = dev_plane(a), dev_plane(b)
+    gw, gh = (a.width + 7) // 8, (a.height + 7) // 8
+    scales = rng.integers(1 << 10, 1 << 17, (gh, gw + 3)).astype(np.uint32)   # stride != width
+    import torch
+    dscales = torch.from_numpy(scales.view(np.int32)).cuda()
+    sizes = BLOCK_SIZES + [(12, 20), (24, 8), (40, 64), (8, 12), (4, 4), (120, 72)]
+    for (w, h) in sizes:
+        n = 97 if w * h <= 1024 else 19
+        c = np.zeros(n, O.DIST_CAND)
+        c["ox"] = rng.integers(0, a.width - w + 1, n) & ~3
+        c["oy"] = rng.integers(0, a.height - h + 1, n) & ~3
+        c["rx"] = c["ox"] + rng.integers(-2, 3, n)
+        c["ry"] = c["oy"] + rng.integers(-2, 3, n)
+        pa, pb = a.cstruct(), b.cstruct()
+        for kind, xdec, ydec, sc in ((2, 0, 0, True), (2, 0, 0, False), (3, 0, 0, True),
+                                     (3, 0, 0, False), (2, 1, 1, True)):
+            if xdec:   # chroma-style lookup: luma position = plane position << 1
+                if 2 * w > a.width or 2 * h > a.height:
+                    continue
+                c2 = c.copy()   # a chroma block at (x, y) covers luma (2x, 2y)..(2x+2w, 2y+2h)
+                c2["ox"] = rng.integers(0, (a.width - 2 * w) // 2 + 1, n) & ~3
+                c2["oy"] = rng.integers(0, (a.height - 2 * h) // 2 + 1, n) & ~3
+                c2["rx"], c2["ry"] = c2["ox"], c2["oy"]
+            else:
+                c2 = c
+            want = np.zeros(n, np.uint64)
+            assert oracle.r1o_dist_scaled_batch(kind, C.byref(pa), C.byref(pb), w, h, O.ptr(c2), n,
+                                                O.ptr(scales) if sc else None, scales.shape[1],
+                                                xdec, ydec, O.ptr(want)) == 0
+            got = ctx.dist_scaled_batch(kind, da, db, w, h, c2, dscales if sc else None, xdec, ydec)
+            assert np.array_equal(got.cpu().numpy().view(np.uint64), want), (bd, w, h, kind, xdec, sc)
+
+
+def test_dist_scaled_identity_is_zero(ctx):
+    """sse / cdef_dist of a block against itself is 0 for every size."""
+    a, _ = planes(8, seed=3)
+    da = dev_plane(a)
+    for (w, h) in BLOCK_SIZES:
+        c = np.zeros(8, O.DIST_CAND)
+        c["ox"] = c["rx"] = np.arange(8) * 8
+        c["oy"] = c["ry"] = 16
+        for kind in (2, 3):
+            assert not ctx.dist_scaled_batch(kind, da, da, w, h, c).cpu().numpy().any()
