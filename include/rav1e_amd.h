@@ -187,6 +187,62 @@ int r1_mc_avg_batch(r1_ctx *ctx, const int16_t *tmp1, const int16_t *tmp2,
                     int w, int h, int n, int bit_depth, int bytes_per_px,
                     void *dst, void *stream);
 
+/* ---- predict:: (reference: get_intra_edges src/partition.rs:639-898,
+ * PredictionMode::predict_intra src/predict.rs:205-249, dispatch_predict_intra
+ * 705-784 with its kernels 786-1505, pred_cfl_ac 1020-1063; x86 dispatch
+ * src/asm/x86/predict.rs).  PredictionMode values 0..13 are the reference's
+ * (src/predict.rs:75-89). */
+#define R1_INTRA_EDGE_LEN 257  /* IntraEdgeBuffer: 4 * MAX_TX_SIZE + 1 (partition.rs:600) */
+
+/* Inputs of get_intra_edges for one transform block.  (x, y): position
+ * relative to the tile (`po`).  flags: bit0 enable_intra_edge_filter, bit1 =
+ * has_top_right(..), bit2 = has_bottom_left(..) -- those two are decisions on
+ * the partition tree (encoder state, src/partition.rs:400-560) and stay on
+ * the host.  mode < 0 = None (every edge is needed). */
+typedef struct R1IntraEdgeCand {
+  int16_t x, y;
+  int8_t mode;
+  int8_t angle_delta;   /* IntraParam::AngleDelta, else 0 */
+  uint8_t flags;
+  uint8_t reserved;
+} R1IntraEdgeCand;
+/* edges: n buffers of `edge_stride` (>= 257) pixels in the reference's layout:
+ * left right-aligned ending at index 128 (bottom -> top), top-left at 128,
+ * above from 129.  lens[2i], lens[2i+1] = init_left, init_above of
+ * IntraEdge::new.  Tile = (tile_x, tile_y, tile_w, tile_h) in plane pixels. */
+int r1_intra_edges_batch(r1_ctx *ctx, const R1Plane *rec, int tile_x, int tile_y,
+                         int tile_w, int tile_h, int tx_size,
+                         const R1IntraEdgeCand *cands, int n, void *edges,
+                         int edge_stride, uint8_t *lens, void *stream);
+
+/* Arguments of dispatch_predict_intra for one block (after predict_intra's
+ * PAETH / CFL remaps, which depend only on the block position). */
+typedef struct R1IntraCand {
+  uint8_t mode;        /* PredictionMode 0..13 */
+  uint8_t variant;     /* PredictionVariant: 0 NONE, 1 LEFT, 2 TOP, 3 BOTH */
+  int16_t angle;       /* p_angle; alpha for UV_CFL_PRED */
+  uint8_t ief;         /* ief_params: 0 None, 1 Some(no smooth neighbour), 2 Some(smooth) */
+  uint8_t avail_w;     /* min(tx width, plane width - block x)  (predict.rs:1346) */
+  uint8_t avail_h;     /* min(tx height, plane height - block y) */
+  uint8_t reserved;
+} R1IntraCand;
+/* dst: n dense w*h pixel blocks.  ac: n dense w*h int16 (CFL only, else NULL). */
+int r1_predict_intra_batch(r1_ctx *ctx, int tx_size, const R1IntraCand *cands, int n,
+                           const void *edges, int edge_stride, const uint8_t *lens,
+                           const int16_t *ac, int bit_depth, int bytes_per_px,
+                           void *dst, void *stream);
+
+/* pred_cfl_ac: (x, y) = luma position of the block in plane pixels; bw x bh =
+ * chroma block size; w_pad / h_pad in 4-pixel units (luma_ac, predict.rs:667-702). */
+typedef struct R1CflAcCand {
+  int16_t x, y;
+  uint8_t w_pad, h_pad;
+  uint8_t reserved[2];
+} R1CflAcCand;
+int r1_cfl_ac_batch(r1_ctx *ctx, const R1Plane *luma, int bw, int bh, int xdec,
+                    int ydec, const R1CflAcCand *cands, int n, int16_t *ac,
+                    void *stream);
+
 /* ---- fused RDO candidate: the headline path.  For each candidate:
  *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)
  *   sad    = get_sad(org @ (ox,oy), pred)       if sad_out     (src/dist.rs:31)

@@ -105,6 +105,24 @@ int r1o_quantize_batch(const void *coeffs, int coeff_stride, int n, int tx_size,
                        int dc_delta_q, int ac_delta_q, int coeff_bytes,
                        void *qcoeffs, uint16_t *eobs, void *rcoeffs);
 
+/* ---- intra prediction (src/predict.rs, src/partition.rs:639-898) ---- */
+int r1o_intra_mode_to_angle(int mode);
+int r1o_select_ief_strength(int width, int height, int smooth, int angle_delta);
+int r1o_select_ief_upsample(int width, int height, int smooth, int angle_delta);
+int r1o_dispatch_predict_intra(int mode, int variant, void *dst, ptrdiff_t stride,
+                               int tx_size, int bit_depth, const int16_t *ac, int angle,
+                               int ief, const void *edge, int left_len, int above_len,
+                               int avail_w, int avail_h, int hbd);
+int r1o_predict_intra(int mode, int x, int y, void *dst, ptrdiff_t stride, int tx_size,
+                      int bit_depth, const int16_t *ac, int angle_delta, int alpha, int ief,
+                      const void *edge, int left_len, int above_len, int avail_w, int avail_h,
+                      int hbd);
+void r1o_pred_cfl_ac(int16_t *ac, const void *luma, ptrdiff_t stride, int bw, int bh,
+                     int w_pad, int h_pad, int xdec, int ydec, int hbd);
+void r1o_get_intra_edges(void *edge, int lens[2], const void *tile, ptrdiff_t stride, int x,
+                         int y, int rect_w, int rect_h, int tx_size, int bit_depth, int mode,
+                         int enable_ief, int angle_delta, int has_tr, int has_bl, int hbd);
+
 /* encoder.rs:1355 diff */
 void r1o_diff(int16_t *dst, const void *src1, ptrdiff_t stride1,
               const void *src2, ptrdiff_t stride2, int w, int h, int hbd);

@@ -32,6 +32,9 @@ SYMBOLS = {
     "r1_quantize_batch": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(R1QuantParams), _i, _vp, _vp,
                                _vp, _vp]),
     "r1_dequantize_batch": (_i, [_vp, _vp, _i, _i, C.POINTER(R1QuantParams), _i, _vp, _vp]),
+    "r1_intra_edges_batch": (_i, [_vp, _PP, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "r1_predict_intra_batch": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "r1_cfl_ac_batch": (_i, [_vp, _PP, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_put_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_prep_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_avg_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

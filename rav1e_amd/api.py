@@ -17,6 +17,13 @@ from .types import TX_DIMS, valid_av1_transform
 DIST_CAND = np.dtype([("ox", "<i2"), ("oy", "<i2"), ("rx", "<i2"), ("ry", "<i2")])
 MC_CAND = np.dtype([("rx", "<i2"), ("ry", "<i2"), ("col_frac", "u1"), ("row_frac", "u1"),
                     ("mode_x", "u1"), ("mode_y", "u1")])
+INTRA_EDGE_CAND = np.dtype([("x", "<i2"), ("y", "<i2"), ("mode", "i1"), ("angle_delta", "i1"),
+                            ("flags", "u1"), ("reserved", "u1")])
+INTRA_CAND = np.dtype([("mode", "u1"), ("variant", "u1"), ("angle", "<i2"), ("ief", "u1"),
+                       ("avail_w", "u1"), ("avail_h", "u1"), ("reserved", "u1")])
+CFL_AC_CAND = np.dtype([("x", "<i2"), ("y", "<i2"), ("w_pad", "u1"), ("h_pad", "u1"),
+                        ("reserved", "u1", (2,))])
+EDGE_LEN = 257
 RDO_CAND = np.dtype([("ox", "<i2"), ("oy", "<i2"), ("rx", "<i2"), ("ry", "<i2"),
                      ("col_frac", "u1"), ("row_frac", "u1"), ("mode_x", "u1"), ("mode_y", "u1"),
                      ("tx_type", "u1"), ("reserved", "u1", (3,))])
@@ -193,6 +200,45 @@ class Context:
                                                  r.data_ptr(), _stream_ptr()),
                     "r1_dequantize_batch")
         return r
+
+    # ---- predict:: ----
+    def intra_edges_batch(self, rec, tile, tx_size, cands, n=None):
+        """get_intra_edges (src/partition.rs:639-898) for n transform blocks of
+        one tile.  tile = (x, y, w, h) in plane pixels.  -> (edges (n, 257), lens (n, 2))"""
+        dc = _dev_cands(cands, INTRA_EDGE_CAND)
+        n = dc.numel() // INTRA_EDGE_CAND.itemsize if n is None else n
+        edges = torch.empty((n, EDGE_LEN), dtype=torch.uint8 if rec.bpp == 1 else torch.int16,
+                            device="cuda")
+        lens = torch.empty((n, 2), dtype=torch.uint8, device="cuda")
+        pr = rec.cstruct()
+        self._check(self.lib.r1_intra_edges_batch(self.h, C.byref(pr), tile[0], tile[1], tile[2],
+                                                  tile[3], int(tx_size), dc.data_ptr(), n,
+                                                  edges.data_ptr(), EDGE_LEN, lens.data_ptr(),
+                                                  _stream_ptr()), "r1_intra_edges_batch")
+        return edges, lens
+
+    def predict_intra_batch(self, tx_size, cands, edges, lens, bit_depth, ac=None, n=None):
+        """dispatch_predict_intra (src/predict.rs:705-784) for n blocks -> (n, h, w) pixels."""
+        w, h = TX_DIMS[int(tx_size)]
+        dc = _dev_cands(cands, INTRA_CAND)
+        n = dc.numel() // INTRA_CAND.itemsize if n is None else n
+        bpp = 1 if bit_depth == 8 else 2
+        out = torch.empty((n, h, w), dtype=torch.uint8 if bpp == 1 else torch.int16, device="cuda")
+        self._check(self.lib.r1_predict_intra_batch(
+            self.h, int(tx_size), dc.data_ptr(), n, edges.data_ptr(), edges.stride(0),
+            lens.data_ptr(), ac.data_ptr() if ac is not None else None, bit_depth, bpp,
+            out.data_ptr(), _stream_ptr()), "r1_predict_intra_batch")
+        return out
+
+    def cfl_ac_batch(self, luma, bw, bh, xdec, ydec, cands, n=None):
+        """pred_cfl_ac (src/predict.rs:1020-1063) -> (n, bh*bw) int16"""
+        dc = _dev_cands(cands, CFL_AC_CAND)
+        n = dc.numel() // CFL_AC_CAND.itemsize if n is None else n
+        ac = torch.empty((n, bw * bh), dtype=torch.int16, device="cuda")
+        pl = luma.cstruct()
+        self._check(self.lib.r1_cfl_ac_batch(self.h, C.byref(pl), bw, bh, xdec, ydec, dc.data_ptr(),
+                                             n, ac.data_ptr(), _stream_ptr()), "r1_cfl_ac_batch")
+        return ac
 
     # ---- mc:: ----
     def put_8tap_batch(self, ref, w, h, cands, n=None, out=None):

@@ -1,0 +1,508 @@
+// predict.hip -- batched intra prediction and intra-edge gathering
+// (reference: rust::dispatch_predict_intra src/predict.rs:705-784 and the
+// kernels it selects, 786-1505; get_intra_edges src/partition.rs:639-898;
+// x86 dispatch src/asm/x86/predict.rs).
+//
+// k_intra_edges: one wave per candidate.  Every entry of the reference's
+// IntraEdgeBuffer (left right-aligned ending at index 128, bottom->top;
+// top-left at 128; above from 129) has a closed-form source -- a pixel of the
+// reconstructed tile, a replicated pixel or a frame-edge base value -- so the
+// 257 entries are produced independently by the 64 lanes (no serial fill).
+// The partition-tree availability answers (has_top_right / has_bottom_left)
+// are encoder state and arrive as flags.
+//
+// k_intra_predict: lane = (candidate, column), NC = 64 / W candidates per
+// wave; the candidate's raw edge is staged in LDS.  Directional modes with the
+// intra edge filter build the filtered / upsampled edges in LDS (ping-pong,
+// all taps read the unfiltered copy exactly like filter_edge's scratch
+// array), then every lane walks its column with the reference's index
+// arithmetic.  Rows are stored as W consecutive pixels per candidate
+// (coalesced).
+#include "common.hpp"
+
+#define R1_TABLE_QUAL __constant__
+#include "intra_tables.inc"
+
+namespace {
+
+enum { DC_PRED = 0, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED,
+       D203_PRED, D67_PRED, SMOOTH_PRED, SMOOTH_V_PRED, SMOOTH_H_PRED, PAETH_PRED,
+       UV_CFL_PRED };
+constexpr int MAXTX = 64;
+constexpr int EDGE_LEN = 4 * MAXTX + 1;
+
+__device__ __forceinline__ int mode_angle(int mode) {
+  constexpr int16_t a[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};
+  return mode >= 0 && mode < 9 ? a[mode] : 0;
+}
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+
+// select_ief_strength / select_ief_upsample (predict.rs:1133-1201)
+__device__ __forceinline__ int ief_strength(int wh, bool smooth, int delta) {
+  const int d = iabs(delta);
+  if (smooth) {
+    if (wh <= 8) return d >= 64 ? 2 : (d >= 40 ? 1 : 0);
+    if (wh <= 16) return d >= 48 ? 2 : (d >= 20 ? 1 : 0);
+    if (wh <= 24) return d >= 4 ? 3 : 0;
+    return 3;
+  }
+  if (wh <= 8) return d >= 56 ? 1 : 0;
+  if (wh <= 16) return d >= 40 ? 1 : 0;
+  if (wh <= 24) return d >= 32 ? 3 : (d >= 16 ? 2 : (d >= 8 ? 1 : 0));
+  if (wh <= 32) return d >= 32 ? 3 : (d >= 4 ? 2 : 1);
+  return 3;
+}
+__device__ __forceinline__ bool ief_upsample(int wh, bool smooth, int delta) {
+  const int d = iabs(delta);
+  if (d == 0 || d >= 40) return false;
+  return smooth ? wh <= 8 : wh <= 16;
+}
+
+template <int BPP>
+__device__ __forceinline__ int32_t ldp(const void *p, size_t i) {
+  if constexpr (BPP == 1) return ((const uint8_t *)p)[i];
+  else return ((const uint16_t *)p)[i];
+}
+template <int BPP>
+__device__ __forceinline__ void stp(void *p, size_t i, int32_t v) {
+  if constexpr (BPP == 1) ((uint8_t *)p)[i] = (uint8_t)v;
+  else ((uint16_t *)p)[i] = (uint16_t)v;
+}
+
+// ------------------------------------------------------------------ edges
+template <int BPP>
+__global__ __launch_bounds__(64) void k_intra_edges(
+    R1Plane rec, int tile_x, int tile_y, int rect_w, int rect_h, int txw, int txh,
+    const R1IntraEdgeCand *__restrict__ cands, int n, void *__restrict__ edges,
+    int edge_stride, uint8_t *__restrict__ lens) {
+  const int cand = blockIdx.x;
+  if (cand >= n) return;
+  const R1IntraEdgeCand cd = cands[cand];
+  const int x = cd.x, y = cd.y, bd = rec.bit_depth;
+  const int32_t base = 128 << (bd - 8);
+  bool needs_left = true, needs_topleft = true, needs_top = true, needs_topright = true,
+       needs_bottomleft = true, tl_filter = false;
+  if (cd.mode >= 0) {
+    int mode = cd.mode;
+    if (mode == PAETH_PRED)
+      mode = (x == 0 && y == 0) ? DC_PRED : (x == 0 ? V_PRED : (y == 0 ? H_PRED : PAETH_PRED));
+    const bool directional = mode >= V_PRED && mode <= D67_PRED;
+    const int p_angle = mode_angle(mode) + cd.angle_delta * 3;
+    const bool dc_or_cfl = mode == DC_PRED || mode == UV_CFL_PRED;
+    needs_left = (!dc_or_cfl || x != 0) || (p_angle > 90 && p_angle != 180);
+    needs_topleft = mode == PAETH_PRED || (directional && p_angle != 90 && p_angle != 180);
+    needs_top = (!dc_or_cfl || y != 0) || (p_angle != 90 && p_angle < 180);
+    needs_topright = directional && p_angle < 90;
+    needs_bottomleft = directional && p_angle > 180;
+    tl_filter = (cd.flags & 1) && p_angle > 90 && p_angle < 180;
+  }
+  const uint8_t *t0 = px_addr<BPP>(rec, tile_x, tile_y);
+  const size_t st = (size_t)rec.stride;
+  auto DST = [&](int yy, int xx) -> int32_t { return ldp<BPP>(t0, (size_t)yy * st + xx); };
+  const int th = y + txh > rect_h ? rect_h - y : txh;     // visible rows / cols of the block
+  const int tw = x + txw > rect_w ? rect_w - x : txw;
+  int tr_avail = 0, bl_avail = 0;
+  if (needs_topright && y != 0 && (cd.flags & 2)) {
+    tr_avail = rect_w - x - txw;
+    tr_avail = tr_avail > txw ? txw : (tr_avail < 0 ? 0 : tr_avail);
+  }
+  if (needs_bottomleft && x != 0 && (cd.flags & 4)) {
+    bl_avail = rect_h - y - txh;
+    bl_avail = bl_avail > txh ? txh : (bl_avail < 0 ? 0 : bl_avail);
+  }
+  // left[i], i = distance below the block's top row (index 127 - i)
+  auto left_at = [&](int i) -> int32_t {
+    if (i < txh) {
+      if (x != 0) return DST(y + (i < th ? i : th - 1), x - 1);
+      return y != 0 ? DST(y - 1, 0) : base + 1;
+    }
+    const int k = i - txh;                                // bottom-left part
+    if (k < bl_avail) return DST(y + txh + k, x - 1);
+    // replicate left[2*MAX - txh - num_avail] = the entry just above
+    const int j = txh + bl_avail - 1;
+    if (j >= txh) return DST(y + txh + bl_avail - 1, x - 1);
+    if (x != 0) return DST(y + (j < th ? j : th - 1), x - 1);
+    return y != 0 ? DST(y - 1, 0) : base + 1;
+  };
+  auto above_at = [&](int i) -> int32_t {
+    if (i < txw) {
+      if (y != 0) return DST(y - 1, x + (i < tw ? i : tw - 1));
+      return x != 0 ? DST(0, x - 1) : base - 1;
+    }
+    const int k = i - txw;                                // top-right part
+    if (k < tr_avail) return DST(y - 1, x + txw + k);
+    const int j = txw + tr_avail - 1;
+    if (j >= txw) return DST(y - 1, x + txw + tr_avail - 1);
+    if (y != 0) return DST(y - 1, x + (j < tw ? j : tw - 1));
+    return x != 0 ? DST(0, x - 1) : base - 1;
+  };
+  const int init_left = (needs_left ? txh : 0) + (needs_bottomleft ? txw : 0);
+  const int init_above = (needs_top ? txw : 0) + (needs_topright ? txh : 0);
+  void *e = (uint8_t *)edges + (size_t)cand * edge_stride * BPP;
+  for (int k = threadIdx.x; k < EDGE_LEN; k += 64) {
+    int32_t v = 0;
+    if (k < 2 * MAXTX) {
+      const int i = 2 * MAXTX - 1 - k;
+      // bottom-left entries exist only behind a needed left column; the
+      // reference never builds one without the other
+      if (i < init_left && needs_left) v = left_at(i);
+    } else if (k == 2 * MAXTX) {
+      if (needs_topleft) {
+        v = (x == 0 && y == 0) ? base
+            : (y == 0 ? DST(0, x - 1) : (x == 0 ? DST(y - 1, 0) : DST(y - 1, x - 1)));
+        if (tl_filter && txw + txh >= 24)
+          v = (int32_t)(((uint32_t)left_at(0) * 5 + (uint32_t)v * 6 + (uint32_t)above_at(0) * 5 + 8) >> 4);
+      } else {
+        v = base;
+      }
+    } else {
+      const int i = k - 2 * MAXTX - 1;
+      if (i < init_above && needs_top) v = above_at(i);
+    }
+    stp<BPP>(e, k, v);
+  }
+  if (threadIdx.x == 0) {
+    lens[2 * cand] = (uint8_t)init_left;
+    lens[2 * cand + 1] = (uint8_t)init_above;
+  }
+}
+
+// ---------------------------------------------------------------- predict
+// filter_edge (predict.rs:1203-1233): dst[i] for 1 <= i < size from src
+__device__ __forceinline__ int32_t filt5(const uint16_t *src, int i, int size, int strength) {
+  constexpr uint8_t K[3][5] = {{0, 4, 8, 4, 0}, {0, 5, 6, 5, 0}, {2, 4, 4, 4, 2}};
+  int32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    int k = i + j - 2;
+    k = k < 0 ? 0 : (k > size - 1 ? size - 1 : k);
+    s += K[strength - 1][j] * (int32_t)src[k];
+  }
+  return (s + 8) >> 4;
+}
+
+template <int BPP>
+__global__ __launch_bounds__(64) void k_intra_predict(
+    int wl, int hl, const R1IntraCand *__restrict__ cands, int n,
+    const void *__restrict__ edges, int edge_stride, const uint8_t *__restrict__ lens,
+    const int16_t *__restrict__ ac, int bit_depth, void *__restrict__ dst) {
+  extern __shared__ uint16_t smem[];
+  const int W = 1 << wl, H = 1 << hl;
+  const int NC = 64 >> wl;
+  const int FL = 2 * (W + H) + 1;
+  const int lane = threadIdx.x;
+  const int cl = lane >> wl, c = lane & (W - 1);
+  const long long cand = (long long)blockIdx.x * NC + cl;
+  const bool live = cand < n;
+  uint16_t *raw = smem + cl * EDGE_LEN;
+  uint16_t *work = smem + NC * EDGE_LEN + cl * (4 * FL);   // af0 af1 lf0 lf1
+  R1IntraCand cd = {};
+  int left_len = 0, above_len = 0;
+  if (live) {
+    cd = cands[cand];
+    left_len = lens[2 * cand];
+    above_len = lens[2 * cand + 1];
+    const void *e = (const uint8_t *)edges + (size_t)cand * edge_stride * BPP;
+    for (int k = c; k < EDGE_LEN; k += W) raw[k] = (uint16_t)ldp<BPP>(e, k);
+  }
+  __syncthreads();
+  const int mode = cd.mode, variant = cd.variant, angle = cd.angle;
+  const int32_t smax = (1 << bit_depth) - 1;
+  const uint16_t *above = raw + 2 * MAXTX + 1;
+  const int32_t top_left = raw[2 * MAXTX];
+  // left pixel beside row r (left_slice[height-1-r])
+  auto left_row = [&](int r) -> int32_t { return raw[2 * MAXTX - 1 - r]; };
+  void *out = (uint8_t *)dst + (size_t)cand * W * H * BPP;
+
+  const bool directional = live && mode >= V_PRED && mode <= D67_PRED &&
+                           !(mode == V_PRED && angle == 90) && !(mode == H_PRED && angle == 180);
+  const bool enable = directional && cd.ief != 0;
+  // ---- edge filter / upsample in LDS (wave-uniform barriers, per-lane predicates)
+  int up_a = 0, up_l = 0;
+  const uint16_t *aedge = above;      // !enable: raw above, index 0 = above[0]
+  uint16_t *af0 = work, *af1 = work + FL, *lf0 = work + 2 * FL, *lf1 = work + 3 * FL;
+  const int lb_len = left_len < W + H ? left_len : W + H;
+  if (__any(enable)) {
+    const bool smooth = cd.ief == 2;
+    const int wh = W + H;
+    if (enable) {
+      const int al = above_len < FL - 1 ? above_len : FL - 1;
+      const int ll = lb_len < FL - 1 ? lb_len : FL - 1;
+      for (int k = c; k < FL; k += W) {
+        af0[k] = k == 0 ? 0 : (k - 1 < al ? above[k - 1] : 0);
+        // left_filtered[i] = left[left.len() - i]: i-th pixel downwards from the top
+        lf0[k] = k == 0 ? 0 : (k <= ll ? raw[2 * MAXTX - k] : 0);
+      }
+    }
+    __syncthreads();
+    int npa = 0, npl = 0, sa = 0, sl = 0;
+    if (enable && angle != 90 && angle != 180) {
+      if (c == 0) { af0[0] = (uint16_t)top_left; lf0[0] = (uint16_t)top_left; }
+      npa = (W < cd.avail_w ? W : cd.avail_w) + (angle < 90 ? H : 0) + 1;
+      npl = (H < cd.avail_h ? H : cd.avail_h) + (angle > 180 ? W : 0) + 1;
+      sa = ief_strength(wh, smooth, angle - 90);
+      sl = ief_strength(wh, smooth, angle - 180);
+    }
+    __syncthreads();
+    if (enable)
+      for (int k = c; k < FL; k += W) {
+        af1[k] = (sa && k >= 1 && k < npa) ? (uint16_t)filt5(af0, k, npa, sa) : af0[k];
+        lf1[k] = (sl && k >= 1 && k < npl) ? (uint16_t)filt5(lf0, k, npl, sl) : lf0[k];
+      }
+    __syncthreads();
+    // upsample_edge (predict.rs:1235-1266): af1/lf1 (filtered) -> af0/lf0 (final)
+    if (enable) {
+      up_a = ief_upsample(wh, smooth, angle - 90);
+      up_l = ief_upsample(wh, smooth, angle - 180);
+      const int na = W + (angle < 90 ? H : 0), nl = H + (angle > 180 ? W : 0);
+      auto ups = [&](const uint16_t *s, uint16_t *d, int size) {
+        auto dup = [&](int i) -> int32_t {
+          return i == 0 ? s[0] : (i <= size + 1 ? s[i - 1] : s[size]);
+        };
+        for (int k = c; k < FL; k += W)     // entries outside [1, 2*size] keep s
+          if (k == 0 || k > 2 * size) d[k] = s[k];
+        for (int i = c; i < size; i += W) {
+          int32_t v = -dup(i) + 9 * dup(i + 1) + 9 * dup(i + 2) - dup(i + 3);
+          v = (v + 8) / 16;
+          v = v < 0 ? 0 : (v > smax ? smax : v);
+          d[2 * i + 1] = (uint16_t)v;
+          d[2 * i + 2] = (uint16_t)dup(i + 2);
+        }
+      };
+      if (up_a) ups(af1, af0, na);
+      else for (int k = c; k < FL; k += W) af0[k] = af1[k];
+      if (up_l) ups(lf1, lf0, nl);
+      else for (int k = c; k < FL; k += W) lf0[k] = lf1[k];
+    }
+    __syncthreads();
+    if (enable) aedge = af0;
+  }
+  if (!live) return;
+
+  // left_edge[k] of the reference (after left_filtered.reverse()) = lf0[FL-1-k];
+  // raw case: left_and_left_below_slice[k] = raw[128 - lb_len + k]
+  const int l = enable ? FL - 1 : lb_len - 1;
+  auto ledge = [&](int k) -> int32_t {
+    return enable ? (int32_t)lf0[FL - 1 - k] : (int32_t)raw[2 * MAXTX - lb_len + k];
+  };
+
+  if (directional) {
+    int dx = 0, dy = 0;
+    if (angle < 90) dx = kR1DrIntraDerivative[angle];
+    else if (angle > 90 && angle < 180) dx = kR1DrIntraDerivative[180 - angle];
+    if (angle > 90 && angle < 180) dy = kR1DrIntraDerivative[angle - 90];
+    else if (angle > 180) dy = kR1DrIntraDerivative[270 - angle];
+    const int oa = (enable ? 1 : 0) << up_a, ol = (enable ? 1 : 0) << up_l;
+    const int j = c;
+    for (int i = 0; i < H; i++) {
+      int32_t v;
+      if (angle < 90) {
+        const int idx = (i + 1) * dx;
+        const int base = (idx >> (6 - up_a)) + (j << up_a);
+        const int shift = ((idx << up_a) >> 1) & 31;
+        const int mb = (H + W - 1) << up_a;
+        if (base < mb)
+          v = ((int32_t)aedge[base + oa] * (32 - shift) + (int32_t)aedge[base + 1 + oa] * shift + 16) >> 5;
+        else
+          v = aedge[mb + oa];
+      } else if (angle < 180) {
+        int idx = (j << 6) - (i + 1) * dx;
+        int base = idx >> (6 - up_a);
+        if (base >= -(1 << up_a)) {
+          const int shift = ((idx << up_a) >> 1) & 31;
+          const int32_t a = (!enable && base < 0) ? top_left : (int32_t)aedge[base + oa];
+          const int32_t b = aedge[base + 1 + oa];
+          v = (a * (32 - shift) + b * shift + 16) >> 5;
+        } else {
+          idx = (i << 6) - (j + 1) * dy;
+          base = idx >> (6 - up_l);
+          const int shift = ((idx << up_l) >> 1) & 31;
+          int32_t a, b;
+          if (!enable && base < 0) a = top_left;
+          else if (base + ol == -2) a = ledge(0);
+          else a = ledge(l - (base + ol));
+          if (base + ol == -2) b = ledge(1);
+          else b = ledge(l - (base + ol + 1));
+          v = (a * (32 - shift) + b * shift + 16) >> 5;
+        }
+      } else {
+        const int idx = (j + 1) * dy;
+        const int base = (idx >> (6 - up_l)) + (i << up_l);
+        const int shift = ((idx << up_l) >> 1) & 31;
+        int ia = l - (base + ol), ib = l - (base + ol + 1);
+        ia = ia < 0 ? 0 : ia;
+        ib = ib < 0 ? 0 : ib;
+        v = (ledge(ia) * (32 - shift) + ledge(ib) * shift + 16) >> 5;
+      }
+      stp<BPP>(out, (size_t)i * W + j, v < 0 ? 0 : (v > smax ? smax : v));
+    }
+    return;
+  }
+  // ---- non-directional ----
+  const int ls_len = left_len < H ? left_len : H;
+  if (mode == V_PRED) {
+    const int32_t a = above[c];
+    for (int r = 0; r < H; r++) stp<BPP>(out, (size_t)r * W + c, a);
+  } else if (mode == H_PRED) {
+    for (int r = 0; r < H; r++) stp<BPP>(out, (size_t)r * W + c, left_row(r));
+  } else if (mode == PAETH_PRED) {
+    const int32_t rt = above[c];
+    for (int r = 0; r < H; r++) {
+      const int32_t rl = left_row(r);
+      const int32_t base = rt + rl - top_left;
+      const int32_t pl = iabs(base - rl), pt = iabs(base - rt), ptl = iabs(base - top_left);
+      stp<BPP>(out, (size_t)r * W + c, (pl <= pt && pl <= ptl) ? rl : (pt <= ptl ? rt : top_left));
+    }
+  } else if (mode == SMOOTH_PRED || mode == SMOOTH_V_PRED || mode == SMOOTH_H_PRED) {
+    const uint32_t below_pred = raw[2 * MAXTX - ls_len], right_pred = above[W - 1];
+    const uint32_t a = above[c], wc = kR1SmWeights[W + c];
+    for (int r = 0; r < H; r++) {
+      const uint32_t lft = (uint32_t)left_row(r), wr = kR1SmWeights[H + r];
+      uint32_t p;
+      if (mode == SMOOTH_PRED)
+        p = (wr * a + (256 - wr) * below_pred + wc * lft + (256 - wc) * right_pred + 256) >> 9;
+      else if (mode == SMOOTH_H_PRED)
+        p = (wc * lft + (256 - wc) * right_pred + 128) >> 8;
+      else
+        p = (wr * a + (256 - wr) * below_pred + 128) >> 8;
+      stp<BPP>(out, (size_t)r * W + c, (int32_t)p);
+    }
+  } else {   // DC_PRED / UV_CFL_PRED
+    uint32_t avg;
+    if (variant == 0) {
+      avg = 128u << (bit_depth - 8);
+    } else if (variant == 1) {
+      uint32_t s = 0;
+      for (int i = 0; i < ls_len; i++) s += raw[2 * MAXTX - ls_len + i];
+      avg = (s + (uint32_t)(H >> 1)) / (uint32_t)H;
+    } else if (variant == 2) {
+      uint32_t s = 0;
+      for (int i = 0; i < W; i++) s += above[i];
+      avg = (s + (uint32_t)(W >> 1)) / (uint32_t)W;
+    } else {
+      uint32_t s = 0;
+      for (int i = 0; i < H; i++) s += raw[2 * MAXTX - ls_len + i];
+      for (int i = 0; i < W; i++) s += above[i];
+      avg = (s + (uint32_t)((W + H) >> 1)) / (uint32_t)(W + H);
+    }
+    if (mode == UV_CFL_PRED && angle != 0) {
+      const int16_t *acb = ac + cand * (W * H);
+      for (int r = 0; r < H; r++) {
+        const int32_t q6 = (int32_t)(int16_t)angle * (int32_t)acb[r * W + c];
+        const int32_t q0 = (iabs(q6) + 32) >> 6;
+        const int32_t v = (int32_t)avg + (q6 < 0 ? -q0 : q0);
+        stp<BPP>(out, (size_t)r * W + c, v < 0 ? 0 : (v > smax ? smax : v));
+      }
+    } else {
+      for (int r = 0; r < H; r++) stp<BPP>(out, (size_t)r * W + c, (int32_t)avg);
+    }
+  }
+}
+
+// pred_cfl_ac (predict.rs:1020-1063): one wave per candidate
+template <int BPP>
+__global__ __launch_bounds__(64) void k_cfl_ac(R1Plane luma, int bw, int bh, int xdec, int ydec,
+                                               const R1CflAcCand *__restrict__ cands, int n,
+                                               int16_t *__restrict__ ac) {
+  const int cand = blockIdx.x;
+  if (cand >= n) return;
+  const R1CflAcCand cd = cands[cand];
+  const int mlw = (bw - cd.w_pad * 4) << xdec, mlh = (bh - cd.h_pad * 4) << ydec;
+  const int mx = (mlw > 8 ? mlw : 8) - (1 << xdec), my = (mlh > 8 ? mlh : 8) - (1 << ydec);
+  const uint8_t *p0 = px_addr<BPP>(luma, cd.x, cd.y);
+  const size_t st = (size_t)luma.stride;
+  int16_t *out = ac + (size_t)cand * bw * bh;
+  int32_t sum = 0;
+  for (int i = threadIdx.x; i < bw * bh; i += 64) {
+    const int sy = i / bw, sx = i - sy * bw;
+    const int ly = sy << ydec, lx = sx << xdec;
+    const int y = ly < my ? ly : my, x = lx < mx ? lx : mx;
+    int32_t s = ldp<BPP>(p0, y * st + x);
+    if (xdec) s += ldp<BPP>(p0, y * st + x + 1);
+    if (ydec) s += ldp<BPP>(p0, (y + 1) * st + x) + ldp<BPP>(p0, (y + 1) * st + x + 1);
+    s = (int16_t)(s << (3 - xdec - ydec));
+    out[i] = (int16_t)s;
+    sum += s;
+  }
+  sum = (int32_t)group_sum<64>((uint32_t)sum);
+  const int shift = 31 - __clz(bw * bh);
+  const int16_t avg = (int16_t)((sum + (1 << (shift - 1))) >> shift);
+  __syncthreads();
+  for (int i = threadIdx.x; i < bw * bh; i += 64) out[i] = (int16_t)(out[i] - avg);
+}
+
+}  // namespace
+
+extern "C" int r1_intra_edges_batch(r1_ctx *ctx, const R1Plane *rec, int tile_x, int tile_y,
+                                    int tile_w, int tile_h, int tx_size,
+                                    const R1IntraEdgeCand *cands, int n, void *edges,
+                                    int edge_stride, uint8_t *lens, void *stream) {
+  R1_REQUIRE(ctx && rec);
+  R1_REQUIRE(rec->bytes_per_px == 1 || rec->bytes_per_px == 2);
+  R1_REQUIRE(tx_size >= 0 && tx_size < 19);
+  R1_REQUIRE(edge_stride >= EDGE_LEN);
+  R1_REQUIRE(tile_x >= 0 && tile_y >= 0 && tile_w > 0 && tile_h > 0);
+  if (n <= 0) return R1_OK;
+  R1_REQUIRE(cands && edges && lens);
+  // rect_w / rect_h: dst.rect() clipped to the plane (partition.rs:701-704)
+  const int rect_w = tile_w < rec->width - tile_x ? tile_w : rec->width - tile_x;
+  const int rect_h = tile_h < rec->height - tile_y ? tile_h : rec->height - tile_y;
+  static const uint8_t wl[19] = {2, 3, 4, 5, 6, 2, 3, 3, 4, 4, 5, 5, 6, 2, 4, 3, 5, 4, 6};
+  static const uint8_t hl[19] = {2, 3, 4, 5, 6, 3, 2, 4, 3, 5, 4, 6, 5, 4, 2, 5, 3, 6, 4};
+  hipStream_t st = (hipStream_t)stream;
+  if (rec->bytes_per_px == 1)
+    hipLaunchKernelGGL((k_intra_edges<1>), dim3(n), dim3(64), 0, st, *rec, tile_x, tile_y, rect_w,
+                       rect_h, 1 << wl[tx_size], 1 << hl[tx_size], cands, n, edges, edge_stride, lens);
+  else
+    hipLaunchKernelGGL((k_intra_edges<2>), dim3(n), dim3(64), 0, st, *rec, tile_x, tile_y, rect_w,
+                       rect_h, 1 << wl[tx_size], 1 << hl[tx_size], cands, n, edges, edge_stride, lens);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_predict_intra_batch(r1_ctx *ctx, int tx_size, const R1IntraCand *cands, int n,
+                                      const void *edges, int edge_stride, const uint8_t *lens,
+                                      const int16_t *ac, int bit_depth, int bytes_per_px,
+                                      void *dst, void *stream) {
+  R1_REQUIRE(ctx);
+  R1_REQUIRE(tx_size >= 0 && tx_size < 19);
+  R1_REQUIRE(bit_depth == 8 || bit_depth == 10 || bit_depth == 12);
+  R1_REQUIRE(bytes_per_px == 1 || bytes_per_px == 2);
+  R1_REQUIRE((bytes_per_px == 1) == (bit_depth == 8));
+  R1_REQUIRE(edge_stride >= EDGE_LEN);
+  if (n <= 0) return R1_OK;
+  R1_REQUIRE(cands && edges && lens && dst);
+  static const uint8_t wl[19] = {2, 3, 4, 5, 6, 2, 3, 3, 4, 4, 5, 5, 6, 2, 4, 3, 5, 4, 6};
+  static const uint8_t hl[19] = {2, 3, 4, 5, 6, 3, 2, 4, 3, 5, 4, 6, 5, 4, 2, 5, 3, 6, 4};
+  const int W = 1 << wl[tx_size], H = 1 << hl[tx_size];
+  const int NC = 64 / W, FL = 2 * (W + H) + 1;
+  const size_t lds = (size_t)NC * (EDGE_LEN + 4 * FL) * sizeof(uint16_t);
+  const unsigned grid = (unsigned)((n + NC - 1) / NC);
+  hipStream_t st = (hipStream_t)stream;
+  if (bytes_per_px == 1)
+    hipLaunchKernelGGL((k_intra_predict<1>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
+                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, bit_depth, dst);
+  else
+    hipLaunchKernelGGL((k_intra_predict<2>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
+                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, bit_depth, dst);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_cfl_ac_batch(r1_ctx *ctx, const R1Plane *luma, int bw, int bh, int xdec,
+                               int ydec, const R1CflAcCand *cands, int n, int16_t *ac,
+                               void *stream) {
+  R1_REQUIRE(ctx && luma);
+  R1_REQUIRE(luma->bytes_per_px == 1 || luma->bytes_per_px == 2);
+  R1_REQUIRE(r1_is_pow2(bw) && r1_is_pow2(bh) && bw >= 4 && bh >= 4 && bw <= 64 && bh <= 64);
+  R1_REQUIRE(xdec >= 0 && xdec <= 1 && ydec >= 0 && ydec <= 1 && (ydec == 0 || xdec == 1));
+  if (n <= 0) return R1_OK;
+  R1_REQUIRE(cands && ac);
+  hipStream_t st = (hipStream_t)stream;
+  if (luma->bytes_per_px == 1)
+    hipLaunchKernelGGL((k_cfl_ac<1>), dim3(n), dim3(64), 0, st, *luma, bw, bh, xdec, ydec, cands, n, ac);
+  else
+    hipLaunchKernelGGL((k_cfl_ac<2>), dim3(n), dim3(64), 0, st, *luma, bw, bh, xdec, ydec, cands, n, ac);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}

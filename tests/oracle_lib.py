@@ -75,6 +75,13 @@ def lib():
         "r1o_quantize": (i, [vp, vp, i, i, i, i, i, i, i, i]),
         "r1o_dequantize": (None, [vp, vp, i, i, i, i, i, i]),
         "r1o_quantize_batch": (i, [vp, i, i, i, i, i, i, i, i, i, i, vp, vp, vp]),
+        "r1o_intra_mode_to_angle": (i, [i]),
+        "r1o_select_ief_strength": (i, [i, i, i, i]),
+        "r1o_select_ief_upsample": (i, [i, i, i, i]),
+        "r1o_dispatch_predict_intra": (i, [i, i, vp, pd, i, i, vp, i, i, vp, i, i, i, i, i]),
+        "r1o_predict_intra": (i, [i, i, i, vp, pd, i, i, vp, i, i, i, vp, i, i, i, i, i]),
+        "r1o_pred_cfl_ac": (None, [vp, vp, pd, i, i, i, i, i, i, i]),
+        "r1o_get_intra_edges": (None, [vp, vp, vp, pd, i, i, i, i, i, i, i, i, i, i, i, i]),
         "r1o_diff": (None, [vp, vp, pd, vp, pd, i, i, i]),
         "r1o_set_threads": (None, [i]),
         "r1o_dist_batch": (i, [i, vp, vp, i, i, vp, i, vp]),

@@ -503,3 +503,150 @@ def test_dist_scaled_identity_is_zero(ctx):
         c["oy"] = c["ry"] = 16
         for kind in (2, 3):
             assert not ctx.dist_scaled_batch(kind, da, da, w, h, c).cpu().numpy().any()
+
+
+# ------------------------------------------------------------ intra prediction
+def _intra_cands(modes, variants, angles, iefs, aws, ahs):
+    from rav1e_amd.api import INTRA_CAND
+    c = np.zeros(len(modes), INTRA_CAND)
+    c["mode"], c["variant"], c["angle"], c["ief"] = modes, variants, angles, iefs
+    c["avail_w"], c["avail_h"] = aws, ahs
+    return c
+
+
+def test_predict_reference_known_answers(ctx):
+    """src/predict.rs:1523-1618 (4x4: ten modes + 27 directional angles)."""
+    from test_oracle_predict import ANGLE_EXPECTED, ANGLES, KAT, KAT_EDGE
+    modes = [k[0] for k in KAT] + [3] * len(ANGLES)
+    variants = [k[1] for k in KAT] + [3] * len(ANGLES)
+    angles = [k[2] for k in KAT] + ANGLES
+    n = len(modes)
+    c = _intra_cands(modes, variants, angles, [0] * n, [4] * n, [4] * n)
+    edges = _t(np.tile(KAT_EDGE, (n, 1)))
+    lens = _t(np.array([[4, 4]] * len(KAT) + [[8, 8]] * len(ANGLES), np.uint8))
+    got = ctx.predict_intra_batch(0, c, edges, lens, 8).cpu().numpy().reshape(n, 16)
+    want = np.array([k[3] for k in KAT] + ANGLE_EXPECTED)
+    assert np.array_equal(got, want)
+
+
+def test_predict_spec_model_vectors(ctx):
+    """4272 vectors of the AV1-spec-formulation model (every size, angle delta,
+    edge filter / upsample path; tests/golden/gen_predict_golden.py)."""
+    Z = np.load(os.path.join(GOLD, "predict_golden.npz"))
+    G = {k: Z[k] for k in Z.files}
+    for ts, (w, h) in enumerate(TX_SIZES):
+        for bd in (8, 10):
+            idx = np.nonzero((G["ts"] == ts) & (G["bd"] == bd))[0]
+            if not len(idx):
+                continue
+            c = _intra_cands(G["mode"][idx], G["variant"][idx], G["angle"][idx], G["ief"][idx],
+                             G["avail_w"][idx], G["avail_h"][idx])
+            e = G["edges"][idx]
+            edges = _t(e.astype(np.uint8) if bd == 8 else e.view(np.int16))
+            lens = _t(np.stack([G["left_len"][idx], G["above_len"][idx]], 1).astype(np.uint8))
+            ac = np.zeros((len(idx), w * h), np.int16)
+            for k, i in enumerate(idx):
+                a, b = G["ac_off"][i], G["ac_off"][i + 1]
+                if b > a:
+                    ac[k] = G["ac"][a:b]
+            got = ctx.predict_intra_batch(ts, c, edges, lens, bd, ac=_t(ac)).cpu().numpy()
+            got = got.astype(np.uint16) if bd == 8 else got.view(np.uint16)
+            for k, i in enumerate(idx):
+                want = G["out"][G["off"][i]:G["off"][i] + w * h].reshape(h, w)
+                assert np.array_equal(got[k], want), (ts, bd, int(G["mode"][i]), int(G["angle"][i]),
+                                                      int(G["ief"][i]))
+
+
+@pytest.mark.parametrize("bd", [8, 12])
+def test_intra_edges_and_predict_vs_oracle(ctx, oracle, bd):
+    """get_intra_edges on a reconstructed tile (random geometry incl. tile /
+    frame borders and clipped blocks), then predict_intra from those edges,
+    both against the oracle call by call."""
+    from rav1e_amd.api import INTRA_EDGE_CAND
+    rng = np.random.default_rng(900 + bd)
+    hp = O.HostPlane(200, 136, bd, rng=rng)        # frame not a multiple of 64
+    dp = dev_plane(hp)
+    hbd = int(bd > 8)
+    dt = np.uint16 if hbd else np.uint8
+    tiles = [(0, 0, 128, 136), (128, 0, 128, 136)]  # second tile is clipped by the frame
+    for ts in (0, 1, 2, 3, 4, 5, 8, 13, 16, 9):
+        w, h = TX_SIZES[ts]
+        for (tx0, ty0, tw_, th_) in tiles:
+            rect_w, rect_h = min(tw_, hp.width - tx0), min(th_, hp.height - ty0)
+            n = 120
+            ec = np.zeros(n, INTRA_EDGE_CAND)
+            gx, gy = max(1, (rect_w + w - 1) // w), max(1, (rect_h + h - 1) // h)
+            ec["x"] = rng.integers(0, gx, n) * w
+            ec["y"] = rng.integers(0, gy, n) * h
+            ec["x"][:8], ec["y"][:8] = 0, 0
+            ec["mode"] = rng.integers(-1, 14, n)
+            ec["angle_delta"] = np.where((ec["mode"] >= 1) & (ec["mode"] <= 8),
+                                         rng.integers(-3, 4, n), 0)
+            ec["flags"] = rng.integers(0, 8, n)
+            edges, lens = ctx.intra_edges_batch(dp, (tx0, ty0, tw_, th_), ts, ec)
+            ge, gl = edges.cpu().numpy().view(dt), lens.cpu().numpy()
+            tile_ptr = hp.block_ptr(tx0, ty0)
+            want_e = np.zeros((n, 257), dt)
+            want_l = np.zeros((n, 2), np.int32)
+            for i in range(n):
+                li = (O.C.c_int * 2)()
+                f = int(ec["flags"][i])
+                oracle.r1o_get_intra_edges(O.ptr(want_e[i]), li, tile_ptr, hp.stride,
+                                           int(ec["x"][i]), int(ec["y"][i]), rect_w, rect_h, ts, bd,
+                                           int(ec["mode"][i]), f & 1, int(ec["angle_delta"][i]),
+                                           (f >> 1) & 1, (f >> 2) & 1, hbd)
+                want_l[i] = li[0], li[1]
+                il, ia = li[0], li[1]
+                assert tuple(gl[i]) == (il, ia), (ts, i)
+                assert np.array_equal(ge[i, 128 - il:129 + ia], want_e[i, 128 - il:129 + ia]), \
+                    (ts, i, int(ec["mode"][i]), int(ec["x"][i]), int(ec["y"][i]), f)
+            # predict from the device-built edges with the same (mode, position)
+            modes = np.where(ec["mode"] < 0, 0, ec["mode"]).astype(np.int32)
+            valid = ec["mode"] >= 0
+            var = np.where((ec["x"] == 0) & (ec["y"] == 0), 0,
+                           np.where(ec["y"] == 0, 1, np.where(ec["x"] == 0, 2, 3)))
+            pm = modes.copy()
+            pa = np.where(pm == 12, 1, 0)
+            pm = np.where(pa & (var == 0), 0, np.where(pa & (var == 2), 1,
+                          np.where(pa & (var == 1), 2, pm)))
+            alpha = rng.integers(-16, 17, n)
+            pm = np.where((pm == 13) & (alpha == 0), 0, pm)
+            base_angle = np.array([0, 90, 180, 45, 135, 113, 157, 203, 67] + [0] * 5)[pm]
+            angle = np.where(pm == 13, alpha, base_angle + 3 * ec["angle_delta"])
+            ief = np.where(ec["flags"] & 1, rng.integers(1, 3, n), 0)
+            aw = np.minimum(w, hp.width - (tx0 + ec["x"])).clip(1, 64)
+            ah = np.minimum(h, hp.height - (ty0 + ec["y"])).clip(1, 64)
+            ic = _intra_cands(pm, var, angle, ief, aw, ah)
+            ac = rng.integers(-2000, 2000, (n, w * h)).astype(np.int16)
+            got = ctx.predict_intra_batch(ts, ic, edges, lens, bd, ac=_t(ac)).cpu().numpy().view(dt)
+            for i in np.nonzero(valid)[0]:
+                out = np.zeros((h, w), dt)
+                assert oracle.r1o_dispatch_predict_intra(
+                    int(pm[i]), int(var[i]), O.ptr(out), w, ts, bd, O.ptr(ac[i]), int(angle[i]),
+                    int(ief[i]), O.ptr(want_e[i]), int(want_l[i, 0]), int(want_l[i, 1]), int(aw[i]),
+                    int(ah[i]), hbd) == 0
+                assert np.array_equal(got[i], out), (ts, i, int(pm[i]), int(angle[i]), int(ief[i]))
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_cfl_ac_vs_oracle(ctx, oracle, bd):
+    from rav1e_amd.api import CFL_AC_CAND
+    rng = np.random.default_rng(77 + bd)
+    hp = O.HostPlane(256, 128, bd, rng=rng)
+    dp = dev_plane(hp)
+    hbd = int(bd > 8)
+    for (bw, bh) in ((4, 4), (8, 8), (16, 16), (32, 32), (8, 16), (16, 8), (4, 16), (32, 8)):
+        for (xdec, ydec) in ((1, 1), (1, 0), (0, 0)):
+            n = 50
+            c = np.zeros(n, CFL_AC_CAND)
+            c["x"] = rng.integers(0, (hp.width - (bw << xdec)) // 8 + 1, n) * 8
+            c["y"] = rng.integers(0, (hp.height - (bh << ydec)) // 8 + 1, n) * 8
+            c["w_pad"] = rng.integers(0, max(1, bw // 4), n)
+            c["h_pad"] = rng.integers(0, max(1, bh // 4), n)
+            got = ctx.cfl_ac_batch(dp, bw, bh, xdec, ydec, c).cpu().numpy()
+            for i in range(n):
+                want = np.zeros(bw * bh, np.int16)
+                oracle.r1o_pred_cfl_ac(O.ptr(want), hp.block_ptr(int(c["x"][i]), int(c["y"][i])),
+                                       hp.stride, bw, bh, int(c["w_pad"][i]), int(c["h_pad"][i]),
+                                       xdec, ydec, hbd)
+                assert np.array_equal(got[i], want), (bw, bh, xdec, ydec, i)
