@@ -243,6 +243,43 @@ int r1_cfl_ac_batch(r1_ctx *ctx, const R1Plane *luma, int bw, int bh, int xdec,
                     int ydec, const R1CflAcCand *cands, int n, int16_t *ac,
                     void *stream);
 
+/* ---- cdef:: (reference: cdef_find_dir src/cdef.rs:84-143, cdef_filter_block
+ * 198-298, cdef_filter_superblock / cdef_filter_tile 405-625; x86 dispatch
+ * src/asm/x86/cdef.rs:83-110).  Edge flags = the reference's CDEF_HAVE_*. */
+enum { R1_CDEF_HAVE_LEFT = 1, R1_CDEF_HAVE_RIGHT = 2, R1_CDEF_HAVE_TOP = 4,
+       R1_CDEF_HAVE_BOTTOM = 8, R1_CDEF_HAVE_ALL = 15 };
+typedef struct R1CdefDirCand { int16_t x, y; } R1CdefDirCand;   /* 8x8 luma block, plane px */
+int r1_cdef_find_dir_batch(r1_ctx *ctx, const R1Plane *luma, const R1CdefDirCand *cands,
+                           int n, uint8_t *dir_out, int32_t *var_out, void *stream);
+/* One cdef_filter_block call: block at (x, y) of plane `in` (size (8>>xdec) x
+ * (8>>ydec)), written to the same position of `out` (a different plane). */
+typedef struct R1CdefBlockCand {
+  int16_t x, y;
+  int16_t pri_strength, sec_strength;  /* already shifted / adjusted, as passed to the asm */
+  uint8_t dir, damping, edges, reserved;
+} R1CdefBlockCand;
+int r1_cdef_filter_block_batch(r1_ctx *ctx, const R1Plane *in, const R1Plane *out,
+                               int xdec, int ydec, const R1CdefBlockCand *cands, int n,
+                               void *stream);
+/* cdef_filter_tile for plane p of the whole frame (the reference's only call,
+ * src/encoder.rs:3301-3321): skip test over the four 4x4 blocks of every 8x8,
+ * direction search on luma, adjust_strength, chroma direction map, edge
+ * flags, filter or copy.  skip_mi: Block::skip per 4x4 luma unit (TileBlocks);
+ * cdef_index_sb: per 64x64 superblock; params = the FrameInvariants fields
+ * cdef_filter_superblock reads. */
+typedef struct R1CdefParams {
+  uint8_t y_strengths[8], uv_strengths[8];   /* fi.cdef_y_strengths / cdef_uv_strengths */
+  uint8_t damping;                           /* fi.cdef_damping */
+  uint8_t bit_depth;
+  uint8_t reserved[2];
+} R1CdefParams;
+int r1_cdef_filter_frame_plane(r1_ctx *ctx, const R1Plane *luma, const R1Plane *in,
+                               const R1Plane *out, int p, int xdec, int ydec,
+                               int tile_w, int tile_h, const uint8_t *skip_mi,
+                               int mi_stride, int mi_cols, int mi_rows,
+                               const uint8_t *cdef_index_sb, int sb_stride,
+                               const R1CdefParams *params, void *stream);
+
 /* ---- fused RDO candidate: the headline path.  For each candidate:
  *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)
  *   sad    = get_sad(org @ (ox,oy), pred)       if sad_out     (src/dist.rs:31)

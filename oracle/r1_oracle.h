@@ -123,6 +123,14 @@ void r1o_get_intra_edges(void *edge, int lens[2], const void *tile, ptrdiff_t st
                          int y, int rect_w, int rect_h, int tx_size, int bit_depth, int mode,
                          int enable_ief, int angle_delta, int has_tr, int has_bl, int hbd);
 
+/* ---- CDEF (src/cdef.rs) ---- */
+int r1o_cdef_find_dir(const void *img, ptrdiff_t stride, uint32_t *var, int coeff_shift,
+                      int hbd);
+void r1o_cdef_filter_block(void *dst, ptrdiff_t dstride, const void *input, ptrdiff_t istride,
+                           int pri_strength, int sec_strength, int dir, int damping,
+                           int bit_depth, int xdec, int ydec, int edges, int hbd);
+int r1o_cdef_adjust_strength(int strength, int var);
+
 /* encoder.rs:1355 diff */
 void r1o_diff(int16_t *dst, const void *src1, ptrdiff_t stride1,
               const void *src2, ptrdiff_t stride2, int w, int h, int hbd);
@@ -144,6 +152,12 @@ typedef struct {
   uint8_t col_frac, row_frac, mode_x, mode_y, tx_type, reserved[3];
 } r1o_rdo_cand;
 
+void r1o_cdef_filter_tile_plane(const r1o_plane *luma, const r1o_plane *in, const r1o_plane *out,
+                                int p, int xdec, int ydec, int tile_w, int tile_h,
+                                const uint8_t *skip_mi, int mi_stride, int mi_cols,
+                                int mi_rows, const uint8_t *cdef_index_sb, int sb_stride,
+                                const uint8_t *y_strengths, const uint8_t *uv_strengths,
+                                int damping, int bit_depth);
 void r1o_set_threads(int n);
 int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
                    int h, const r1o_dist_cand *c, int n, uint32_t *out);

@@ -17,6 +17,11 @@ class R1QuantParams(C.Structure):
                 ("dc_delta_q", C.c_int8), ("ac_delta_q", C.c_int8), ("reserved", C.c_uint8 * 3)]
 
 
+class R1CdefParams(C.Structure):
+    _fields_ = [("y_strengths", C.c_uint8 * 8), ("uv_strengths", C.c_uint8 * 8),
+                ("damping", C.c_uint8), ("bit_depth", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
 # every symbol include/rav1e_amd.h declares: name -> (restype, argtypes)
 _vp, _i, _sz, _pd = C.c_void_p, C.c_int, C.c_size_t, C.c_ssize_t
 _PP = C.POINTER(R1Plane)
@@ -35,6 +40,10 @@ SYMBOLS = {
     "r1_intra_edges_batch": (_i, [_vp, _PP, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "r1_predict_intra_batch": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "r1_cfl_ac_batch": (_i, [_vp, _PP, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "r1_cdef_find_dir_batch": (_i, [_vp, _PP, _vp, _i, _vp, _vp, _vp]),
+    "r1_cdef_filter_block_batch": (_i, [_vp, _PP, _PP, _i, _i, _vp, _i, _vp]),
+    "r1_cdef_filter_frame_plane": (_i, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i, _i,
+                                        _vp, _i, C.POINTER(R1CdefParams), _vp]),
     "r1_mc_put_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_prep_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_avg_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

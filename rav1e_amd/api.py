@@ -23,6 +23,10 @@ INTRA_CAND = np.dtype([("mode", "u1"), ("variant", "u1"), ("angle", "<i2"), ("ie
                        ("avail_w", "u1"), ("avail_h", "u1"), ("reserved", "u1")])
 CFL_AC_CAND = np.dtype([("x", "<i2"), ("y", "<i2"), ("w_pad", "u1"), ("h_pad", "u1"),
                         ("reserved", "u1", (2,))])
+CDEF_DIR_CAND = np.dtype([("x", "<i2"), ("y", "<i2")])
+CDEF_BLOCK_CAND = np.dtype([("x", "<i2"), ("y", "<i2"), ("pri_strength", "<i2"),
+                            ("sec_strength", "<i2"), ("dir", "u1"), ("damping", "u1"),
+                            ("edges", "u1"), ("reserved", "u1")])
 EDGE_LEN = 257
 RDO_CAND = np.dtype([("ox", "<i2"), ("oy", "<i2"), ("rx", "<i2"), ("ry", "<i2"),
                      ("col_frac", "u1"), ("row_frac", "u1"), ("mode_x", "u1"), ("mode_y", "u1"),
@@ -239,6 +243,44 @@ class Context:
         self._check(self.lib.r1_cfl_ac_batch(self.h, C.byref(pl), bw, bh, xdec, ydec, dc.data_ptr(),
                                              n, ac.data_ptr(), _stream_ptr()), "r1_cfl_ac_batch")
         return ac
+
+    # ---- cdef:: ----
+    def cdef_find_dir_batch(self, luma, cands, n=None):
+        """cdef_find_dir (src/cdef.rs:84-143) -> (dir uint8, var int32)"""
+        dc = _dev_cands(cands, CDEF_DIR_CAND)
+        n = dc.numel() // CDEF_DIR_CAND.itemsize if n is None else n
+        d = torch.empty(n, dtype=torch.uint8, device="cuda")
+        v = torch.empty(n, dtype=torch.int32, device="cuda")
+        pl = luma.cstruct()
+        self._check(self.lib.r1_cdef_find_dir_batch(self.h, C.byref(pl), dc.data_ptr(), n,
+                                                    d.data_ptr(), v.data_ptr(), _stream_ptr()),
+                    "r1_cdef_find_dir_batch")
+        return d, v
+
+    def cdef_filter_block_batch(self, src, dst, xdec, ydec, cands, n=None):
+        """cdef_filter_block (src/cdef.rs:198-298) for n blocks, src plane -> dst plane"""
+        dc = _dev_cands(cands, CDEF_BLOCK_CAND)
+        n = dc.numel() // CDEF_BLOCK_CAND.itemsize if n is None else n
+        a, b = src.cstruct(), dst.cstruct()
+        self._check(self.lib.r1_cdef_filter_block_batch(self.h, C.byref(a), C.byref(b), xdec, ydec,
+                                                        dc.data_ptr(), n, _stream_ptr()),
+                    "r1_cdef_filter_block_batch")
+
+    def cdef_filter_frame_plane(self, luma, src, dst, p, xdec, ydec, tile_w, tile_h, skip_mi,
+                                cdef_index_sb, y_strengths, uv_strengths, damping, bit_depth):
+        """cdef_filter_tile (src/cdef.rs:600-625) for plane p of the whole frame.
+        skip_mi: (mi_rows, mi_cols) uint8 device tensor; cdef_index_sb: (sb_rows, sb_cols)."""
+        prm = _lib.R1CdefParams()
+        for i in range(8):
+            prm.y_strengths[i] = int(y_strengths[i])
+            prm.uv_strengths[i] = int(uv_strengths[i])
+        prm.damping, prm.bit_depth = int(damping), int(bit_depth)
+        l, a, b = luma.cstruct(), src.cstruct(), dst.cstruct()
+        self._check(self.lib.r1_cdef_filter_frame_plane(
+            self.h, C.byref(l), C.byref(a), C.byref(b), p, xdec, ydec, tile_w, tile_h,
+            skip_mi.data_ptr(), skip_mi.stride(0), skip_mi.shape[1], skip_mi.shape[0],
+            cdef_index_sb.data_ptr(), cdef_index_sb.stride(0), C.byref(prm), _stream_ptr()),
+            "r1_cdef_filter_frame_plane")
 
     # ---- mc:: ----
     def put_8tap_batch(self, ref, w, h, cands, n=None, out=None):

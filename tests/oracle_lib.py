@@ -82,6 +82,11 @@ def lib():
         "r1o_predict_intra": (i, [i, i, i, vp, pd, i, i, vp, i, i, i, vp, i, i, i, i, i]),
         "r1o_pred_cfl_ac": (None, [vp, vp, pd, i, i, i, i, i, i, i]),
         "r1o_get_intra_edges": (None, [vp, vp, vp, pd, i, i, i, i, i, i, i, i, i, i, i, i]),
+        "r1o_cdef_find_dir": (i, [vp, pd, vp, i, i]),
+        "r1o_cdef_filter_block": (None, [vp, pd, vp, pd, i, i, i, i, i, i, i, i, i]),
+        "r1o_cdef_adjust_strength": (i, [i, i]),
+        "r1o_cdef_filter_tile_plane": (None, [vp, vp, vp, i, i, i, i, i, vp, i, i, i, vp, i, vp, vp,
+                                              i, i]),
         "r1o_diff": (None, [vp, vp, pd, vp, pd, i, i, i]),
         "r1o_set_threads": (None, [i]),
         "r1o_dist_batch": (i, [i, vp, vp, i, i, vp, i, vp]),

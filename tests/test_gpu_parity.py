@@ -650,3 +650,78 @@ def test_cfl_ac_vs_oracle(ctx, oracle, bd):
                                        hp.stride, bw, bh, int(c["w_pad"][i]), int(c["h_pad"][i]),
                                        xdec, ydec, hbd)
                 assert np.array_equal(got[i], want), (bw, bh, xdec, ydec, i)
+
+
+# ------------------------------------------------------------------------ CDEF
+def _plane_from(arr, bd, pad=16):
+    from rav1e_amd.api import Plane
+    h, w = arr.shape
+    hp = O.HostPlane(w, h, bd, pad, pad, rng=np.random.default_rng(1))   # garbage in the padding
+    hp.view()[:] = arr
+    return hp, Plane.from_numpy(hp.data, w, h, bd, pad, pad)
+
+
+def test_cdef_frames_spec_model(ctx):
+    """whole-frame CDEF (3 planes, 4:2:0 / 4:2:2 / 4:4:4, 8/10/12-bit) against the
+    independent spec-formulation model's vectors, plus the direction maps."""
+    from rav1e_amd.api import CDEF_DIR_CAND
+    Z = np.load(os.path.join(GOLD, "cdef_golden.npz"))
+    G = {k: Z[k] for k in Z.files}
+    for c in range(10):
+        k = "c%d" % c
+        W, H, xdec, ydec, bd, damping = (int(v) for v in G[k + "_meta"])
+        dt = np.uint16 if bd > 8 else np.uint8
+        planes_ = [_plane_from(G[k + "_in%d" % p].astype(dt), bd) for p in range(3)]
+        skip, ci = _t(G[k + "_skip"]), _t(G[k + "_ci"])
+        for p in range(3):
+            xd, yd = (0, 0) if p == 0 else (xdec, ydec)
+            _, dst = _plane_from(np.zeros_like(G[k + "_in%d" % p]).astype(dt), bd)
+            ctx.cdef_filter_frame_plane(planes_[0][1], planes_[p][1], dst, p, xd, yd, W, H, skip, ci,
+                                        G[k + "_ystr"], G[k + "_uvstr"], damping, bd)
+            got = dst.data.cpu().numpy().view(dt)[16:16 + (H >> yd), dst.xorigin:dst.xorigin + (W >> xd)]
+            assert np.array_equal(got.astype(np.uint16), G[k + "_out%d" % p]), (c, p)
+        # direction search as its own batch
+        nby, nbx = H // 8, W // 8
+        dc = np.zeros(nby * nbx, CDEF_DIR_CAND)
+        dc["x"] = np.tile(np.arange(nbx) * 8, nby)
+        dc["y"] = np.repeat(np.arange(nby) * 8, nbx)
+        d, v = ctx.cdef_find_dir_batch(planes_[0][1], dc)
+        d, v = d.cpu().numpy().reshape(nby, nbx), v.cpu().numpy().reshape(nby, nbx)
+        ns = ~np.array([[G[k + "_skip"][2 * by:2 * by + 2, 2 * bx:2 * bx + 2].all()
+                         for bx in range(nbx)] for by in range(nby)])
+        assert np.array_equal(d[ns], G[k + "_dir"][ns]) and np.array_equal(v[ns], G[k + "_var"][ns])
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_cdef_filter_block_vs_oracle(ctx, oracle, bd):
+    """cdef_filter_block with every edge-flag combination, direction and tap parity."""
+    from rav1e_amd.api import CDEF_BLOCK_CAND
+    rng = np.random.default_rng(60 + bd)
+    dt = np.uint16 if bd > 8 else np.uint8
+    img = np.clip(np.cumsum(rng.integers(-9, 10, (96, 128)), axis=1) + (1 << (bd - 1)), 0,
+                  (1 << bd) - 1).astype(dt)
+    hp, dp = _plane_from(img, bd)
+    for (xdec, ydec) in ((0, 0), (1, 1), (1, 0)):
+        xs, ys = 8 >> xdec, 8 >> ydec
+        n = min(256, (128 // xs - 2) * (96 // ys - 2))
+        c = np.zeros(n, CDEF_BLOCK_CAND)
+        # distinct destination blocks so the comparison is well defined
+        pos = rng.permutation((128 // xs - 2) * (96 // ys - 2))[:n]
+        c["x"] = (pos % (128 // xs - 2) + 1) * xs
+        c["y"] = (pos // (128 // xs - 2) + 1) * ys
+        c["pri_strength"] = rng.integers(0, 16, n) << (bd - 8)
+        c["sec_strength"] = rng.choice([0, 1, 2, 4], n) << (bd - 8)
+        c["dir"] = rng.integers(0, 8, n)
+        c["damping"] = rng.integers(3, 7, n) + (bd - 8)
+        c["edges"] = np.arange(n) % 16
+        out_h, out_d = _plane_from(np.zeros_like(img), bd)
+        ctx.cdef_filter_block_batch(dp, out_d, xdec, ydec, c)
+        got = out_d.data.cpu().numpy().view(dt)[16:16 + 96, out_d.xorigin:out_d.xorigin + 128]
+        for i in range(n):
+            want = np.zeros((ys, xs), dt)
+            x, y = int(c["x"][i]), int(c["y"][i])
+            oracle.r1o_cdef_filter_block(O.ptr(want), xs, hp.block_ptr(x, y), hp.stride,
+                                         int(c["pri_strength"][i]), int(c["sec_strength"][i]),
+                                         int(c["dir"][i]), int(c["damping"][i]), bd, xdec, ydec,
+                                         int(c["edges"][i]), int(bd > 8))
+            assert np.array_equal(got[y:y + ys, x:x + xs], want), (bd, xdec, ydec, i)
