@@ -93,6 +93,7 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
+    from rav1e_amd import tiles
     from rav1e_amd import workload as W
     from rav1e_amd.api import Context, Plane
 
@@ -119,9 +120,7 @@ def main():
     ref = Plane.from_numpy(host_ref, fw, fh, bd, 88, 88)
 
     # ---- candidates: whole frame at N=1, tile `rank` otherwise ----
-    rects = W.tile_rects(world, fw, fh)
-    rect = rects[rank] if world > 1 else None
-    cands = W.speed6_ladder(fw, fh, args.k, rect=rect)
+    cands = tiles.shard_candidates(fw, fh, args.k, rank, world)
     dcands = {s: torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
               for s, c in cands.items()}
     outs = {}
@@ -137,31 +136,29 @@ def main():
     # reconstructed plane (stand-in payload: this rank's rows of `ref`) ----
     side = torch.cuda.Stream() if world > 1 else None
     if world > 1:
-        rows = -(-ref.alloc_height // world)
-        send = ref.data[rank * rows: (rank + 1) * rows].contiguous()
-        if send.shape[0] < rows:
-            send = torch.cat([send, torch.zeros((rows - send.shape[0], ref.stride),
-                                                dtype=send.dtype, device="cuda")])
-        gathered = torch.empty((world * rows, ref.stride), dtype=send.dtype, device="cuda")
+        send, gathered = tiles.make_exchange_buffers(ref.data, rank, world)
 
     ev = {s: [] for s in cands}
+    # per-kernel events feed `roofline` (N = 1); at N > 1 they would only add
+    # host work to steps that are a fraction of a millisecond long
+    use_events = not args.no_events and world == 1
 
     def step(timed):
         for s in W.LADDER:
             n = len(cands[s])
             if n == 0:
                 continue
-            if timed and not args.no_events:
+            if timed and use_events:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             ctx.rdo_cand_batch(org, ref, s, s, dcands[s], n=n, outs=outs[s])
-            if timed and not args.no_events:
+            if timed and use_events:
                 e1.record()
                 ev[s].append((e0, e1))
         if world > 1:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gathered, send)
+                tiles.exchange_rows(send, gathered)
 
     def fence():
         if world > 1:

@@ -1,0 +1,88 @@
+"""The N > 1 path on CPU: two processes, gloo backend (127.0.0.1 rendezvous).
+Checks the tile sharding (disjoint, complete) and the per-frame exchange step
+(all-gather of reconstructed rows rebuilds the whole plane on every rank)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rav1e_amd import tiles, workload as W
+    fw, fh, k = 1920, 1080, 2
+    mine = tiles.shard_candidates(fw, fh, k, rank, world)
+    # every rank can rebuild the whole list: sharding is a partition of it
+    whole = W.speed6_ladder(fw, fh, k)
+    counts = torch.tensor([len(mine[s]) for s in W.LADDER], dtype=torch.int64)
+    tot = counts.clone()
+    dist.all_reduce(tot)
+    ok_counts = [int(t) == len(whole[s]) for t, s in zip(tot, W.LADDER)]
+    # membership: my candidates are exactly the whole-frame ones inside my tile
+    rect = W.tile_rects(world, fw, fh)[rank]
+    ok_member = True
+    for s in W.LADDER:
+        w_ = whole[s]
+        inside = (w_["ox"] >= rect[0]) & (w_["ox"] < rect[2]) & (w_["oy"] >= rect[1]) & (w_["oy"] < rect[3])
+        ok_member &= np.array_equal(w_[inside], mine[s])
+    # exchange step: each rank knows only its rows of the "reconstructed" plane
+    lay = W.plane_layout(fw, fh, 8)
+    full = torch.from_numpy(W.random_plane_array(fw, fh, 8, seed=5))
+    local = torch.zeros_like(full)
+    rows, lo, hi = tiles.owned_rows(lay["alloc_height"], rank, world)
+    local[lo:hi] = full[lo:hi]
+    send, gathered = tiles.make_exchange_buffers(local, rank, world)
+    tiles.exchange_rows(send, gathered)
+    ok_plane = torch.equal(gathered[: lay["alloc_height"]], full)
+    q.put((rank, all(ok_counts), bool(ok_member), bool(ok_plane)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_tile_sharding_and_exchange_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, okc, okm, okp in res:
+        assert okc and okm and okp, (rank, okc, okm, okp)
+
+
+def test_tile_rects_match_reference_layout():
+    """--tiles 8 on 4K -> 4 tile columns x 2 tile rows of 15x17 superblocks
+    (src/encoder.rs:248-277, src/tiling/tiler.rs:56-150)."""
+    from rav1e_amd import workload as W
+    r = W.tile_rects(8, 3840, 2160)
+    assert len(r) == 8 and W.tile_split(8, 3840, 2160) == (4, 2)
+    assert r[0] == (0, 0, 960, 1088) and r[7] == (2880, 1088, 3840, 2160)
+    cover = np.zeros((2160 // 8, 3840 // 8), np.int32)
+    for (x0, y0, x1, y1) in r:
+        cover[y0 // 8:y1 // 8, x0 // 8:x1 // 8] += 1
+    assert (cover == 1).all()
+    r1080 = W.tile_rects(8, 1920, 1080)
+    assert W.tile_split(8, 1920, 1080) == (4, 2) and r1080[3][2] == 1920
