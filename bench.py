@@ -89,6 +89,30 @@ def cpu_baseline(args, host_org, host_ref, cands):
                       "OpenMP over candidates" % (100 * frac, dt)}
 
 
+def pmc_traffic(bpp, size, fw, fh, k):
+    """HBM bytes per launch of the dominant kernel from the PMC counters
+    (FETCH_SIZE / WRITE_SIZE), collected in separate `rocprofv3 --pmc` passes of
+    this same workload (tools/gpu_pmc.sh) and summarised by tools/pmc_summary.py
+    under profiles/.  A counter pass cannot run inside the timed bench, so the
+    figure is read from the committed summary and only reported when it was
+    taken on the default workload."""
+    import glob
+    if (fw, fh, k) != (3840, 2160, 16):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    lg = {64: 6, 32: 5, 16: 4, 8: 3}[size]
+    key = "k_rdo_cand<%d,%d,%d,%s>" % (bpp, lg, lg, "short" if bpp == 1 else "int")
+    if key not in d or "hbm_traffic_bytes" not in d[key]:
+        return None, None
+    return int(d[key]["hbm_traffic_bytes"]), (
+        "%s: 2*FETCH_SIZE + WRITE_SIZE KiB per dispatch (gfx950 FETCH_SIZE correction, "
+        "MI355X_MICROARCH.md); below the algorithmic bytes because the K candidates of a "
+        "block share window rows in L2/MALL" % os.path.basename(files[-1]))
+
+
 def main():
     args = parse()
     import torch
@@ -198,11 +222,13 @@ def main():
             abytes = W.algorithmic_bytes_per_cand(dom, dom, bpp) * n_dom
             achieved = abytes / (per[dom] * 1e-3) / 1e9
             kname = "k_rdo_cand<bpp=%d,%dx%d>" % (bpp, dom, dom)
+            traffic, traffic_note = pmc_traffic(bpp, dom, fw, fh, args.k)
         else:
             dom, per = None, {}
             abytes = sum(W.algorithmic_bytes_per_cand(s, s, bpp) * len(c) for s, c in cands.items())
             achieved = abytes / (dt / args.steps) / 1e9
             kname = "k_rdo_cand (all sizes, step time)"
+            traffic, traffic_note = None, None
         res = {
             "metric": "RDO-candidate Mpixels/s (dist+fwd_tx+mc) at 4K speed-6",
             "value": round(total_px * args.steps / dt / 1e6, 2),
@@ -224,7 +250,8 @@ def main():
                        "parallelism": "tile-per-gpu x%d" % world if world > 1 else "single-gpu"},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": int(abytes),
                          "avg_launch_ms": round(per[dom], 4) if dom else None},
             "kernel_ms": {str(s): round(v, 4) for s, v in per.items()},

@@ -320,6 +320,34 @@ void rav1e_put_8tap_hbd_hip(uint16_t *dst, ptrdiff_t dst_stride,
 int rav1e_fwd_txfm_hip(const int16_t *input, void *output, size_t stride,
                        int tx_size, int tx_type, int bd, int coeff_bytes);
 
+/* InvTxfmFunc / InvTxfmHBDFunc (src/asm/shared/transform/inverse.rs:15-19)
+ * with the dispatch-table indices (tx_size, tx_type) explicit; dst holds the
+ * prediction on entry; strides in BYTES; eob is ignored like in the Rust path. */
+int rav1e_inv_txfm_add_hip(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *coeff,
+                           int eob, int tx_size, int tx_type);
+int rav1e_inv_txfm_add_hbd_hip(uint16_t *dst, ptrdiff_t dst_stride, const int32_t *coeff,
+                               int eob, int bitdepth_max, int tx_size, int tx_type);
+/* CdefDirLBDFn / CdefDirHBDFn, CdefFilterFn / CdefFilterHBDFn
+ * (src/asm/x86/cdef.rs:16-37,184-191); `tmp` points at the block inside the
+ * reference's padded u16 tile (2 pixels of padding on every side). */
+int rav1e_cdef_dir_hip(const uint8_t *img, ptrdiff_t stride, uint32_t *var);
+int rav1e_cdef_dir_hbd_hip(const uint16_t *img, ptrdiff_t stride, uint32_t *var,
+                           int bitdepth_max);
+void rav1e_cdef_filter_hip(uint8_t *dst, ptrdiff_t dst_stride, const uint16_t *tmp,
+                           ptrdiff_t tmp_stride, int pri_strength, int sec_strength,
+                           int dir, int damping, int xdec, int ydec);
+void rav1e_cdef_filter_hbd_hip(uint16_t *dst, ptrdiff_t dst_stride, const uint16_t *tmp,
+                               ptrdiff_t tmp_stride, int pri_strength, int sec_strength,
+                               int dir, int damping, int bitdepth_max, int xdec, int ydec);
+/* intra prediction: the asm entry points take the pointer to the top-left
+ * element of the edge buffer (src/asm/x86/predict.rs:20-36); mode / variant
+ * select the table entry, ief = 0 none / 1 edge filter / 2 + smooth neighbour
+ * (the flags the reference folds into `angle`, predict.rs:301-303). */
+int rav1e_ipred_hip(void *dst, ptrdiff_t dst_stride, const void *topleft, int width,
+                    int height, int angle, int mode, int variant, int ief, int left_len,
+                    int above_len, int avail_w, int avail_h, const int16_t *ac,
+                    int bit_depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,13 @@ SYMBOLS = {
     "rav1e_satd_hbd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i, C.c_uint32]),
     "rav1e_put_8tap_hip": (None, [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i, _i]),
     "rav1e_put_8tap_hbd_hip": (None, [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i, _i, _i]),
+    "rav1e_inv_txfm_add_hip": (_i, [_vp, _pd, _vp, _i, _i, _i]),
+    "rav1e_inv_txfm_add_hbd_hip": (_i, [_vp, _pd, _vp, _i, _i, _i, _i]),
+    "rav1e_cdef_dir_hip": (_i, [_vp, _pd, _vp]),
+    "rav1e_cdef_dir_hbd_hip": (_i, [_vp, _pd, _vp, _i]),
+    "rav1e_cdef_filter_hip": (None, [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i, _i]),
+    "rav1e_cdef_filter_hbd_hip": (None, [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i, _i, _i]),
+    "rav1e_ipred_hip": (_i, [_vp, _pd, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "rav1e_fwd_txfm_hip": (_i, [_vp, _vp, _sz, _i, _i, _i, _i]),
 }
 

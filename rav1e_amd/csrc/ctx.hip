@@ -199,3 +199,178 @@ extern "C" int rav1e_fwd_txfm_hip(const int16_t *input, void *output,
   SHIM_HIP(hipStreamSynchronize(st));
   return R1_OK;
 }
+
+// ---- inverse transform shims: InvTxfmFunc / InvTxfmHBDFunc
+// (src/asm/shared/transform/inverse.rs:15-19: dst, dst_stride in BYTES... the
+// reference passes plane_cfg.stride in elements as isize and the asm scales it;
+// here strides are in BYTES like the other shims) with the table indices
+// (tx_size, tx_type) as explicit arguments.  `eob` is accepted and ignored
+// (the reference's Rust path ignores it too, inverse.rs:1636).
+namespace {
+int inv_shim(void *dst, ptrdiff_t ds, const void *coeff, int tx_size, int tx_type, int bpp,
+             int bd) {
+  static const uint8_t wl[19] = {2, 3, 4, 5, 6, 2, 3, 3, 4, 4, 5, 5, 6, 2, 4, 3, 5, 4, 6};
+  static const uint8_t hl[19] = {2, 3, 4, 5, 6, 3, 2, 4, 3, 5, 4, 6, 5, 4, 2, 5, 3, 6, 4};
+  if (tx_size < 0 || tx_size >= 19) return R1_EINVAL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  const int w = 1 << wl[tx_size], h = 1 << hl[tx_size];
+  const int area = (w < 32 ? w : 32) * (h < 32 ? h : 32);
+  const size_t cbytes = (size_t)area * (bpp == 1 ? 2 : 4), cb = align256(cbytes);
+  const size_t prow = (size_t)w * bpp, pb = align256(prow * h);
+  uint8_t *d = (uint8_t *)stage(c, cb + pb);
+  hipStream_t st = c->own_stream;
+  SHIM_HIP(hipMemcpyAsync(d, coeff, cbytes, hipMemcpyHostToDevice, st));
+  SHIM_HIP(hipMemcpy2DAsync(d + cb, prow, dst, ds, prow, h, hipMemcpyHostToDevice, st));
+  const int rc = r1_inv_txfm_add_batch(c, d, area, d + cb, d + cb, 1, tx_size, tx_type, bd, bpp, st);
+  if (rc != R1_OK) return rc;
+  SHIM_HIP(hipMemcpy2DAsync(dst, ds, d + cb, prow, prow, h, hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+  return R1_OK;
+}
+}  // namespace
+
+extern "C" int rav1e_inv_txfm_add_hip(uint8_t *dst, ptrdiff_t dst_stride, const int16_t *coeff,
+                                      int eob, int tx_size, int tx_type) {
+  (void)eob;
+  return inv_shim(dst, dst_stride, coeff, tx_size, tx_type, 1, 8);
+}
+extern "C" int rav1e_inv_txfm_add_hbd_hip(uint16_t *dst, ptrdiff_t dst_stride,
+                                          const int32_t *coeff, int eob, int bitdepth_max,
+                                          int tx_size, int tx_type) {
+  (void)eob;
+  return inv_shim(dst, dst_stride, coeff, tx_size, tx_type, 2, bd_from_max(bitdepth_max));
+}
+
+// ---- CDEF shims: CdefDirLBDFn / CdefDirHBDFn (src/asm/x86/cdef.rs:184-191)
+// and CdefFilterFn / CdefFilterHBDFn (cdef.rs:16-37).  The filter takes the
+// reference's pre-padded u16 tile (CDEF_VERY_LARGE where nothing exists), so
+// every halo pixel "exists" and the sentinel does the rest -- the reference's
+// own fast path (cdef.rs:236-296).
+namespace {
+int cdef_dir_shim(const void *img, ptrdiff_t stride, uint32_t *var, int bpp, int bd) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  const size_t row = (size_t)8 * bpp;
+  uint8_t *d = (uint8_t *)stage(c, 1024);
+  hipStream_t st = c->own_stream;
+  SHIM_HIP(hipMemcpy2DAsync(d, row, img, stride, row, 8, hipMemcpyHostToDevice, st));
+  R1CdefDirCand cand = {0, 0};
+  SHIM_HIP(hipMemcpyAsync(d + 256, &cand, sizeof(cand), hipMemcpyHostToDevice, st));
+  R1Plane p = {d, 8, 8, 8, 8, 0, 0, bpp, bd};
+  if (r1_cdef_find_dir_batch(c, &p, (const R1CdefDirCand *)(d + 256), 1, d + 512,
+                             (int32_t *)(d + 516), st) != R1_OK) {
+    fprintf(stderr, "rav1e_amd shim: %s\n", g_err);
+    abort();
+  }
+  uint8_t res[8];
+  SHIM_HIP(hipMemcpyAsync(res, d + 512, 8, hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+  int32_t v;
+  memcpy(&v, res + 4, 4);
+  *var = (uint32_t)v;
+  return res[0];
+}
+
+void cdef_filter_shim(void *dst, ptrdiff_t ds, const uint16_t *tmp, ptrdiff_t tmp_stride_bytes,
+                      int pri, int sec, int dir, int damping, int xdec, int ydec, int bd,
+                      int dst_bpp) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  const int xs = 8 >> xdec, ys = 8 >> ydec, tw = xs + 4, th = ys + 4;
+  const size_t trow = (size_t)tw * 2, tb = align256(trow * th);
+  uint8_t *d = (uint8_t *)stage(c, 2 * tb + 256);
+  hipStream_t st = c->own_stream;
+  const uint8_t *t0 = (const uint8_t *)tmp - 2 * tmp_stride_bytes - 2 * 2;   // padding's top-left
+  SHIM_HIP(hipMemcpy2DAsync(d, trow, t0, tmp_stride_bytes, trow, th, hipMemcpyHostToDevice, st));
+  R1CdefBlockCand cand = {0, 0, (int16_t)pri, (int16_t)sec, (uint8_t)dir, (uint8_t)damping,
+                          R1_CDEF_HAVE_ALL, 0};
+  SHIM_HIP(hipMemcpyAsync(d + 2 * tb, &cand, sizeof(cand), hipMemcpyHostToDevice, st));
+  // both planes are u16 views with the block at (0,0) and a 2-pixel origin
+  R1Plane in = {d, tw, th, xs, ys, 2, 2, 2, bd};
+  R1Plane out = {d + tb, tw, th, xs, ys, 2, 2, 2, bd};
+  if (r1_cdef_filter_block_batch(c, &in, &out, xdec, ydec, (const R1CdefBlockCand *)(d + 2 * tb), 1,
+                                 st) != R1_OK) {
+    fprintf(stderr, "rav1e_amd shim: %s\n", g_err);
+    abort();
+  }
+  uint16_t res[8 * 8];
+  SHIM_HIP(hipMemcpy2DAsync(res, (size_t)xs * 2, d + tb + (2 * tw + 2) * 2, trow, (size_t)xs * 2, ys,
+                            hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < ys; i++)
+    for (int j = 0; j < xs; j++) {
+      if (dst_bpp == 1) ((uint8_t *)dst)[i * ds + j] = (uint8_t)res[i * xs + j];
+      else *(uint16_t *)((uint8_t *)dst + i * ds + j * 2) = res[i * xs + j];
+    }
+}
+}  // namespace
+
+extern "C" int rav1e_cdef_dir_hip(const uint8_t *img, ptrdiff_t stride, uint32_t *var) {
+  return cdef_dir_shim(img, stride, var, 1, 8);
+}
+extern "C" int rav1e_cdef_dir_hbd_hip(const uint16_t *img, ptrdiff_t stride, uint32_t *var,
+                                      int bitdepth_max) {
+  return cdef_dir_shim(img, stride, var, 2, bd_from_max(bitdepth_max));
+}
+extern "C" void rav1e_cdef_filter_hip(uint8_t *dst, ptrdiff_t dst_stride, const uint16_t *tmp,
+                                      ptrdiff_t tmp_stride, int pri_strength, int sec_strength,
+                                      int dir, int damping, int xdec, int ydec) {
+  cdef_filter_shim(dst, dst_stride, tmp, tmp_stride, pri_strength, sec_strength, dir, damping, xdec,
+                   ydec, 8, 1);
+}
+extern "C" void rav1e_cdef_filter_hbd_hip(uint16_t *dst, ptrdiff_t dst_stride, const uint16_t *tmp,
+                                          ptrdiff_t tmp_stride, int pri_strength, int sec_strength,
+                                          int dir, int damping, int bitdepth_max, int xdec,
+                                          int ydec) {
+  cdef_filter_shim(dst, dst_stride, tmp, tmp_stride, pri_strength, sec_strength, dir, damping, xdec,
+                   ydec, bd_from_max(bitdepth_max), 2);
+}
+
+// ---- intra prediction shim: the reference's asm entry points take the
+// pointer to the top-left element of the IntraEdgeBuffer
+// (src/asm/x86/predict.rs:20-36: dst, stride, topleft, width, height, angle).
+// The table indices of the dispatch (mode, variant) and the two facts the asm
+// receives folded into `angle` flags (edge filter on / smooth neighbour,
+// predict.rs:301-303) are explicit here.
+extern "C" int rav1e_ipred_hip(void *dst, ptrdiff_t dst_stride, const void *topleft, int width,
+                               int height, int angle, int mode, int variant, int ief,
+                               int left_len, int above_len, int avail_w, int avail_h,
+                               const int16_t *ac, int bit_depth) {
+  int tx_size = -1;
+  static const uint8_t wl[19] = {2, 3, 4, 5, 6, 2, 3, 3, 4, 4, 5, 5, 6, 2, 4, 3, 5, 4, 6};
+  static const uint8_t hl[19] = {2, 3, 4, 5, 6, 3, 2, 4, 3, 5, 4, 6, 5, 4, 2, 5, 3, 6, 4};
+  for (int t = 0; t < 19; t++)
+    if ((1 << wl[t]) == width && (1 << hl[t]) == height) tx_size = t;
+  if (tx_size < 0 || left_len < 0 || left_len > 128 || above_len < 0 || above_len > 128)
+    return R1_EINVAL;
+  const int bpp = bit_depth == 8 ? 1 : 2;
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  const size_t eb = align256((size_t)R1_INTRA_EDGE_LEN * bpp);
+  const size_t prow = (size_t)width * bpp, pb = align256(prow * height);
+  const size_t ab = align256((size_t)width * height * 2);
+  uint8_t *d = (uint8_t *)stage(c, eb + pb + ab + 512);
+  hipStream_t st = c->own_stream;
+  // rebuild the 257-entry buffer around the top-left pointer
+  SHIM_HIP(hipMemsetAsync(d, 0, eb, st));
+  SHIM_HIP(hipMemcpyAsync(d + (size_t)(128 - left_len) * bpp,
+                          (const uint8_t *)topleft - (size_t)left_len * bpp,
+                          (size_t)(left_len + 1 + above_len) * bpp, hipMemcpyHostToDevice, st));
+  R1IntraCand cand = {(uint8_t)mode, (uint8_t)variant, (int16_t)angle, (uint8_t)ief,
+                      (uint8_t)(avail_w > 64 ? 64 : avail_w), (uint8_t)(avail_h > 64 ? 64 : avail_h), 0};
+  uint8_t lens[2] = {(uint8_t)left_len, (uint8_t)above_len};
+  uint8_t *meta = d + eb + pb + ab;
+  SHIM_HIP(hipMemcpyAsync(meta, &cand, sizeof(cand), hipMemcpyHostToDevice, st));
+  SHIM_HIP(hipMemcpyAsync(meta + 64, lens, 2, hipMemcpyHostToDevice, st));
+  if (ac)
+    SHIM_HIP(hipMemcpyAsync(d + eb + pb, ac, (size_t)width * height * 2, hipMemcpyHostToDevice, st));
+  const int rc = r1_predict_intra_batch(c, tx_size, (const R1IntraCand *)meta, 1, d,
+                                        R1_INTRA_EDGE_LEN, meta + 64,
+                                        ac ? (const int16_t *)(d + eb + pb) : nullptr, bit_depth,
+                                        bpp, d + eb, st);
+  if (rc != R1_OK) return rc;
+  SHIM_HIP(hipMemcpy2DAsync(dst, dst_stride, d + eb, prow, prow, height, hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+  return R1_OK;
+}

@@ -128,6 +128,39 @@ __device__ __forceinline__ void stage_window(uint8_t *win, int ws,
   }
 }
 
+// Compile-time variant for the fused kernel: the whole window of a candidate
+// (TOT dwords per lane) is requested before anything is written to LDS, so a
+// wave pays ONE global-memory round trip for its window instead of one per
+// batch of four loads.
+template <int BPP, uint32_t XORM, int P, int H, int NL>
+__device__ __forceinline__ void stage_window_ct(uint8_t *win, int ws, const R1Plane &ref,
+                                                int rx, int ry, int l) {
+  constexpr int ROW_BYTES = (P + 7) * BPP;
+  constexpr int ND = (ROW_BYTES + 3) >> 2;
+  constexpr int TOTAL = (H + 7) * ND;
+  constexpr int PER = (TOTAL + NL - 1) / NL;
+  const size_t gstride = (size_t)ref.stride * BPP;
+  const uint8_t *g0 = px_addr<BPP>(ref, rx - 3, ry - 3);
+  uint32_t v[PER];
+  int off[PER];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int i = l + u * NL;
+    v[u] = 0;
+    off[u] = -1;
+    if (i < TOTAL) {
+      const int r = i / ND, d = i - r * ND;
+      const int over = d * 4 + 4 - ROW_BYTES;
+      const int back = over > 0 ? over : 0;
+      v[u] = (ld_u32(g0 + r * gstride + d * 4 - back) >> (8 * back)) ^ XORM;
+      off[u] = r * ws + d * 4;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PER; u++)
+    if (off[u] >= 0) *(uint32_t *)(win + off[u]) = v[u];
+}
+
 // One column of put_8tap / prep_8tap from a staged window.  `c` is the column
 // inside the slab, `w`/`h` the full block size (they select the 4-tap filter
 // variants).  emit(r, value) receives each output sample: the clamped pixel

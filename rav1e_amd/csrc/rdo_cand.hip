@@ -232,8 +232,8 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   }
   uint8_t *win = smem + cl * (H + 7) * WS;
   if (live)
-    r1mc::stage_window<BPP, BPP == 1 ? 0x80808080u : 0u>(win, WS, ref, cd.rx, cd.ry,
-                                                          W, H, c, P);
+    r1mc::stage_window_ct<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P>(win, WS, ref, cd.rx,
+                                                                      cd.ry, c);
   __syncthreads();
 
   // ---- B: prediction column, residual, SAD / SATD ----

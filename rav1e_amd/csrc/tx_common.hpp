@@ -42,7 +42,8 @@ __device__ __forceinline__ T mul24(T a) {
   asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "n"(M), "v"(a));
   return r;
 }
-#define TX_MUL(a, m, s) ((T)((uint32_t)mul24<(m)>(a) + (uint32_t)((1 << (s)) >> 1)) >> (s))
+// __mul24 + add folds into one v_mad_i32_i24
+#define TX_MUL(a, m, s) ((T)((uint32_t)__mul24((a), (m)) + (uint32_t)((1 << (s)) >> 1)) >> (s))
 #include "fwd_tx_1d.inc"
 #undef TX_MUL
 }  // namespace m24

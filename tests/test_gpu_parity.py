@@ -725,3 +725,70 @@ def test_cdef_filter_block_vs_oracle(ctx, oracle, bd):
                                          int(c["dir"][i]), int(c["damping"][i]), bd, xdec, ydec,
                                          int(c["edges"][i]), int(bd > 8))
             assert np.array_equal(got[y:y + ys, x:x + xs], want), (bd, xdec, ydec, i)
+
+
+# ------------------------------------------- compat shims of the widened rows
+def test_compat_shims_inverse_cdef_ipred(ctx, oracle):
+    """Per-call shims with the reference's asm-style signatures (host pointers):
+    inverse transform, CDEF direction / filter on the padded u16 tile, intra
+    prediction from the top-left pointer of the edge buffer."""
+    import ctypes as C
+    from rav1e_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(4)
+    # inverse_transform_add, 8-bit and 10-bit, a few sizes / types
+    for ts, tt in ((1, 0), (2, 3), (9, 0), (4, 0)):
+        w, h = TX_SIZES[ts]
+        area = min(w, 32) * min(h, 32)
+        for bd, ct, pt in ((8, np.int16, np.uint8), (10, np.int32, np.uint16)):
+            co = (rng.integers(-2000, 2001, area) * (rng.random(area) < 0.2)).astype(ct)
+            stride = w + 24                      # a plane row, bytes below
+            dst = rng.integers(0, 1 << bd, (h, stride)).astype(pt)
+            want = np.ascontiguousarray(dst[:, :w])
+            assert oracle.r1o_inverse_transform_add(O.ptr(co), O.ptr(want), w, ts, tt, bd,
+                                                    int(bd > 8), int(bd > 8)) == 0
+            if bd == 8:
+                rc = L.rav1e_inv_txfm_add_hip(O.ptr(dst), stride, O.ptr(co), area, ts, tt)
+            else:
+                rc = L.rav1e_inv_txfm_add_hbd_hip(O.ptr(dst), stride * 2, O.ptr(co), area, 1023, ts, tt)
+            assert rc == 0 and np.array_equal(dst[:, :w], want), (ts, tt, bd)
+    # cdef direction
+    for bd, pt in ((8, np.uint8), (10, np.uint16)):
+        img = rng.integers(0, 1 << bd, (8, 24)).astype(pt)
+        v1, v2 = C.c_uint32(), C.c_uint32()
+        want = oracle.r1o_cdef_find_dir(O.ptr(img), 24, C.byref(v1), bd - 8, int(bd > 8))
+        got = (L.rav1e_cdef_dir_hip(O.ptr(img), 24, C.byref(v2)) if bd == 8 else
+               L.rav1e_cdef_dir_hbd_hip(O.ptr(img), 48, C.byref(v2), 1023))
+        assert (got, v2.value) == (want, v1.value)
+    # cdef filter on the reference's padded u16 tile (sentinel = 0x8000)
+    for (xdec, ydec) in ((0, 0), (1, 1)):
+        xs, ys = 8 >> xdec, 8 >> ydec
+        for bd, pt in ((8, np.uint8), (10, np.uint16)):
+            tmp = rng.integers(0, 1 << bd, (12, 12)).astype(np.uint16)
+            tmp[:2, :] = 0x8000                  # no top
+            tmp[:, xs + 2:] = 0x8000             # no right
+            src = tmp[2:2 + ys, 2:2 + xs].astype(pt)
+            # oracle on the equivalent (plane, edges) formulation
+            plane = np.zeros((16, 16), pt)
+            plane[2:14, 2:14] = np.where(tmp == 0x8000, 0, tmp).astype(pt)
+            want = np.zeros((ys, xs), pt)
+            edges = 1 | 8                         # LEFT | BOTTOM
+            oracle.r1o_cdef_filter_block(O.ptr(want), xs, C.c_void_p(plane.ctypes.data + (4 * 16 + 4) * plane.itemsize),
+                                         16, 5 << (bd - 8), 2 << (bd - 8), 3, 5 + (bd - 8), bd, xdec,
+                                         ydec, edges, int(bd > 8))
+            got = np.zeros((ys, xs + 3), pt)
+            tp = C.c_void_p(tmp.ctypes.data + (2 * 12 + 2) * 2)
+            if bd == 8:
+                L.rav1e_cdef_filter_hip(O.ptr(got), xs + 3, tp, 24, 5, 2, 3, 5, xdec, ydec)
+            else:
+                L.rav1e_cdef_filter_hbd_hip(O.ptr(got), (xs + 3) * 2, tp, 24, 5 << 2, 2 << 2, 3, 7, 1023,
+                                            xdec, ydec)
+            assert np.array_equal(got[:, :xs], want), (xdec, ydec, bd)
+            del src
+    # intra prediction from the top-left pointer
+    from test_oracle_predict import KAT, KAT_EDGE
+    for mode, variant, angle, want in KAT:
+        out = np.zeros((4, 4), np.uint8)
+        tl = C.c_void_p(KAT_EDGE.ctypes.data + 128)
+        assert L.rav1e_ipred_hip(O.ptr(out), 4, tl, 4, 4, angle, mode, variant, 0, 4, 4, 4, 4, None, 8) == 0
+        assert out.ravel().tolist() == want, (mode, variant)

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Per-stage microbenchmarks for every hot-path row of SURVEY.md 8(a): one JSON
+line per kernel with Mpixels/s and the achieved fraction of the HBM roofline
+computed from the row's ALGORITHMIC bytes.  Complements
+bench.py (the fused headline candidate).  Run on the GPU box:
+
+    python tools/bench_kernels.py [--bit-depth 8|10] [--reps 20] > gpurun_out/kernels.jsonl
+
+Inputs are synthetic (uniform random planes, seeds as in bench.py) and resident
+in HBM; timing uses HIP events on the launch stream.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HBM_PEAK = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import torch
+    from rav1e_amd import api, workload as W
+    from rav1e_amd.api import Context, Plane
+    from rav1e_amd.types import TxSize
+
+    ctx = Context(0)
+    fw, fh, bd = args.width, args.height, args.bit_depth
+    bpp = 1 if bd == 8 else 2
+    cb = 2 if bpp == 1 else 4
+    ct = torch.int16 if bpp == 1 else torch.int32
+    org = Plane.from_numpy(W.random_plane_array(fw, fh, bd, 1), fw, fh, bd, 88, 88)
+    ref = Plane.from_numpy(W.random_plane_array(fw, fh, bd, 2), fw, fh, bd, 88, 88)
+    rng = np.random.default_rng(3)
+
+    def timeit(fn, reps=args.reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def report(name, ms, pixels, abytes, extra=None):
+        gbs = abytes / (ms * 1e-3) / 1e9
+        d = {"kernel": name, "ms": round(ms, 4), "Mpixels_s": round(pixels / (ms * 1e-3) / 1e6, 1),
+             "algorithmic_GB_s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK, 4),
+             "bit_depth": bd}
+        if extra:
+            d.update(extra)
+        print(json.dumps(d), flush=True)
+
+    def grid_cands(dtype, s, k, mv=32, fields=("ox", "oy", "rx", "ry")):
+        nx, ny = fw // s, fh // s
+        n = nx * ny * k
+        c = np.zeros(n, dtype)
+        bx = np.repeat(np.tile(np.arange(nx, dtype=np.int32) * s, ny), k)
+        by = np.repeat(np.repeat(np.arange(ny, dtype=np.int32) * s, nx), k)
+        if "ox" in fields:
+            c["ox"], c["oy"] = bx, by
+        c["rx"] = bx + rng.integers(-mv, mv + 1, n)
+        c["ry"] = by + rng.integers(-mv, mv + 1, n)
+        return c
+
+    # ---- a1/a2: SAD / SATD, K=32 / K=8 offsets per block ----
+    for s in (64, 32, 16, 8):
+        for kind, k, nm in ((0, 32, "sad"), (1, 8, "satd")):
+            c = grid_cands(api.DIST_CAND, s, k)
+            dc = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
+            out = torch.empty(len(c), dtype=torch.int32, device="cuda")
+            ms = timeit(lambda: ctx.dist_batch(kind, org, ref, s, s, dc, n=len(c), out=out))
+            report("get_%s %dx%d" % (nm, s, s), ms, len(c) * s * s, len(c) * (2 * s * s * bpp + 4),
+                   {"candidates": len(c)})
+    # ---- a3-a5: weighted SSE / cdef_dist with a scale grid ----
+    scales = torch.from_numpy(rng.integers(1 << 12, 1 << 16, ((fh + 7) // 8, (fw + 7) // 8))
+                              .astype(np.int32)).cuda()
+    for s in (64, 16, 8):
+        c = grid_cands(api.DIST_CAND, s, 4, mv=2)
+        dc = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
+        out = torch.empty(len(c), dtype=torch.int64, device="cuda")
+        for kind, nm in ((2, "weighted_sse"), (3, "cdef_dist")):
+            ms = timeit(lambda: ctx.dist_scaled_batch(kind, org, ref, s, s, dc, scales, n=len(c), out=out))
+            report("%s %dx%d" % (nm, s, s), ms, len(c) * s * s,
+                   len(c) * (2 * s * s * bpp + (s // 4) ** 2 * 4 + 8), {"candidates": len(c)})
+    # ---- a6 / a13 / a12: transforms and quantizer on every tx block of a frame ----
+    for s, tsz in ((64, TxSize.TX_64X64), (32, TxSize.TX_32X32), (16, TxSize.TX_16X16),
+                   (8, TxSize.TX_8X8), (4, TxSize.TX_4X4)):
+        n = (fw // s) * (fh // s) * 4
+        res = torch.randint(-255, 256, (n, s, s), dtype=torch.int16, device="cuda")
+        co = torch.empty((n, s * s), dtype=ct, device="cuda")
+        ms = timeit(lambda: ctx.forward_transform_batch(res, int(tsz), 0, bd, out=co))
+        report("forward_transform %dx%d DCT_DCT" % (s, s), ms, n * s * s, n * s * s * (2 + cb),
+               {"blocks": n})
+        area = min(s, 32) ** 2
+        ms = timeit(lambda: ctx.quantize_batch(co, int(tsz), 0, 100, bd, 0))
+        report("quantize+dequantize %dx%d" % (s, s), ms, n * s * s, n * (area * cb + 2 * area * cb + 2),
+               {"blocks": n})
+        q = ctx.quantize_batch(co, int(tsz), 0, 100, bd, 0)
+        pred = torch.randint(0, 1 << bd, (n, s, s), dtype=torch.int32, device="cuda").to(
+            torch.uint8 if bpp == 1 else torch.int16)
+        rec = torch.empty_like(pred)
+        ms = timeit(lambda: ctx.inverse_transform_add_batch(q["rcoeffs"], pred, int(tsz), 0, bd, out=rec))
+        report("inverse_transform_add %dx%d" % (s, s), ms, n * s * s,
+               n * (area * cb + 2 * s * s * bpp), {"blocks": n})
+    # ---- a8 / a9: put_8tap / prep_8tap (all 16x16 fractions, REGULAR) ----
+    for s in (64, 16, 8):
+        c = grid_cands(api.MC_CAND, s, 8, fields=())
+        c["col_frac"] = rng.integers(0, 16, len(c))
+        c["row_frac"] = rng.integers(0, 16, len(c))
+        dc = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
+        out = torch.empty((len(c), s, s), dtype=torch.uint8 if bpp == 1 else torch.int16, device="cuda")
+        ms = timeit(lambda: ctx.put_8tap_batch(ref, s, s, dc, n=len(c), out=out))
+        report("put_8tap %dx%d" % (s, s), ms, len(c) * s * s,
+               len(c) * (((s + 7) ** 2 + s * s) * bpp), {"candidates": len(c)})
+        out16 = torch.empty((len(c), s, s), dtype=torch.int16, device="cuda")
+        ms = timeit(lambda: ctx.prep_8tap_batch(ref, s, s, dc, n=len(c), out=out16))
+        report("prep_8tap %dx%d" % (s, s), ms, len(c) * s * s,
+               len(c) * ((s + 7) ** 2 * bpp + 2 * s * s), {"candidates": len(c)})
+    # ---- a10 / a11: intra edges + prediction on every tx block ----
+    for s, tsz in ((32, TxSize.TX_32X32), (16, TxSize.TX_16X16), (8, TxSize.TX_8X8), (4, TxSize.TX_4X4)):
+        nx, ny = fw // s, fh // s
+        n = nx * ny
+        ec = np.zeros(n, api.INTRA_EDGE_CAND)
+        ec["x"] = np.tile(np.arange(nx) * s, ny)
+        ec["y"] = np.repeat(np.arange(ny) * s, nx)
+        ec["mode"] = rng.integers(0, 13, n)
+        ec["flags"] = 7
+        dec = torch.from_numpy(ec.view(np.uint8).reshape(-1).copy()).cuda()
+        ms = timeit(lambda: ctx.intra_edges_batch(ref, (0, 0, fw, fh), int(tsz), dec, n=n))
+        report("get_intra_edges %dx%d" % (s, s), ms, n * s * s, n * (2 * (2 * s) + 1) * bpp * 2,
+               {"blocks": n})
+        edges, lens = ctx.intra_edges_batch(ref, (0, 0, fw, fh), int(tsz), dec, n=n)
+        ic = np.zeros(n, api.INTRA_CAND)
+        pm = ec["mode"].astype(np.int32)
+        var = np.where((ec["x"] == 0) & (ec["y"] == 0), 0, np.where(ec["y"] == 0, 1,
+                                                                     np.where(ec["x"] == 0, 2, 3)))
+        pm = np.where((pm == 12) & (var == 0), 0, np.where((pm == 12) & (var == 2), 1,
+                      np.where((pm == 12) & (var == 1), 2, pm)))
+        ic["mode"], ic["variant"] = pm, var
+        ic["angle"] = np.array([0, 90, 180, 45, 135, 113, 157, 203, 67] + [0] * 5)[pm]
+        ic["ief"] = 1
+        ic["avail_w"] = ic["avail_h"] = s
+        dic = torch.from_numpy(ic.view(np.uint8).reshape(-1).copy()).cuda()
+        ms = timeit(lambda: ctx.predict_intra_batch(int(tsz), dic, edges, lens, bd, n=n))
+        report("predict_intra %dx%d (mixed modes)" % (s, s), ms, n * s * s,
+               n * ((2 * (2 * s) + 1) * bpp + s * s * bpp), {"blocks": n})
+    # ---- a14: whole-frame CDEF, luma ----
+    dst = Plane(fw, fh, bd)
+    skip = torch.zeros((fh // 4, fw // 4), dtype=torch.uint8, device="cuda")
+    ci = torch.zeros(((fh + 63) // 64, (fw + 63) // 64), dtype=torch.uint8, device="cuda")
+    ystr = [36] * 8
+    ms = timeit(lambda: ctx.cdef_filter_frame_plane(ref, ref, dst, 0, 0, 0, fw, fh, skip, ci, ystr,
+                                                    ystr, 5, bd))
+    report("cdef_filter_tile luma (find_dir + filter)", ms, fw * fh, 2 * fw * fh * bpp)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
