@@ -30,16 +30,21 @@ __device__ __forceinline__ int32_t ldpx(const uint8_t *p) {
   else return *(const uint16_t *)p;
 }
 
-// lane = pixel (i = lane >> 3, j = lane & 7); returns dir (all lanes), var via ref
-template <int BPP>
-__device__ __forceinline__ int find_dir_wave(const uint8_t *blk, size_t stride_bytes,
-                                             int coeff_shift, int32_t *part /* [8*16] LDS */,
+// lane = pixel (i = lane >> 3, j = lane & 7); returns dir (all lanes), var via ref.
+// Every lane adds its pixel into the 8 x 16 partial-sum table in LDS (ds_add:
+// integer adds, order-free; measured cheaper than a gather formulation because
+// the kernel is VALU-bound), then all 128 table entries are squared and
+// weighted in parallel (840 / line length, cdef.rs:110-133) and summed inside
+// 16-lane groups.  i32 adds wrap, so the order does not matter.
+__device__ __forceinline__ int find_dir_wave(int32_t pixel /* of lane (i = lane >> 3, j = lane & 7) */,
+                                             int coeff_shift, int32_t *part /* [128] LDS */,
                                              uint32_t &var) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
-  for (int k = lane; k < 128; k += 64) part[k] = 0;
+  part[lane] = 0;
+  part[lane + 64] = 0;
   __builtin_amdgcn_wave_barrier();
-  const int32_t x = (ldpx<BPP>(blk + i * stride_bytes + j * BPP) >> coeff_shift) - 128;
+  const int32_t x = (pixel >> coeff_shift) - 128;
   atomicAdd(&part[0 * 16 + i + j], x);
   atomicAdd(&part[1 * 16 + i + j / 2], x);
   atomicAdd(&part[2 * 16 + i], x);
@@ -49,30 +54,26 @@ __device__ __forceinline__ int find_dir_wave(const uint8_t *blk, size_t stride_b
   atomicAdd(&part[6 * 16 + j], x);
   atomicAdd(&part[7 * 16 + i / 2 + j], x);
   __builtin_amdgcn_wave_barrier();
-  // lane d < 8 forms cost[d] (cdef.rs:110-133); DIV = 840 / n
-  int32_t cost = 0;
-  if (lane < 8) {
-    const int32_t *p = part + lane * 16;
-    auto sq = [&](int k) -> int32_t { return p[k] * p[k]; };
-    if (lane == 2 || lane == 6) {
-      for (int k = 0; k < 8; k++) cost += sq(k);
-      cost *= 105;
-    } else if (lane == 0 || lane == 4) {
-      constexpr int32_t DIV[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
-      for (int k = 0; k < 7; k++) cost += (sq(k) + sq(14 - k)) * DIV[k + 1];
-      cost += sq(7) * 105;
-    } else {
-      constexpr int32_t DIV[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
-      for (int k = 0; k < 5; k++) cost += sq(3 + k);
-      cost *= 105;
-      for (int k = 0; k < 3; k++) cost += (sq(k) + sq(10 - k)) * DIV[2 * k + 2];
-    }
-  }
-  int best = 0;
-  int32_t best_cost = __shfl(cost, 0, 64);
+  auto weight = [](int d, int m) -> int32_t {
+    constexpr int32_t DIV[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
+    if (d == 2 || d == 6) return m < 8 ? 105 : 0;
+    if (d == 0 || d == 4) return m < 7 ? DIV[m + 1] : (m == 7 ? 105 : (m < 15 ? DIV[15 - m] : 0));
+    return m < 3 ? DIV[2 * m + 2] : (m < 8 ? 105 : (m < 11 ? DIV[22 - 2 * m] : 0));
+  };
   int32_t costs[8];
 #pragma unroll
-  for (int d = 0; d < 8; d++) costs[d] = __shfl(cost, d, 64);
+  for (int half = 0; half < 2; half++) {
+    const int d = half * 4 + (lane >> 4), m = lane & 15;
+    const int32_t pv = part[d * 16 + m];
+    int32_t t = pv * pv * weight(d, m);
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) t += __shfl_xor(t, sft, 64);
+#pragma unroll
+    for (int q = 0; q < 4; q++) costs[half * 4 + q] = __shfl(t, q * 16, 64);
+  }
+  int best = 0;
+  int32_t best_cost = costs[0];
+
 #pragma unroll
   for (int d = 1; d < 8; d++)
     if (costs[d] > best_cost) { best_cost = costs[d]; best = d; }
@@ -94,19 +95,18 @@ __device__ __forceinline__ int32_t constrain(int32_t diff, int32_t threshold, in
   return diff < 0 ? -mag : mag;
 }
 
-// one pixel (i, j) of the block whose top-left input pixel is `in0`
-template <int BPP>
-__device__ __forceinline__ int32_t filter_pixel(const uint8_t *in0, size_t istride_bytes, int i,
-                                                int j, int xs, int ys, int pri, int sec, int dir,
-                                                int damping, int coeff_shift, int edges) {
-  constexpr int8_t D[8][2][2] = {{{-1, 1}, {-2, 2}}, {{0, 1}, {-1, 2}}, {{0, 1}, {0, 2}},
-                                 {{0, 1}, {1, 2}},   {{1, 1}, {2, 2}},  {{1, 0}, {2, 1}},
-                                 {{1, 0}, {2, 0}},   {{1, 0}, {2, -1}}};
-  auto rd = [&](int yy, int xx) -> int32_t {
-    const bool ok = (yy >= 0 || (edges & HAVE_TOP)) && (yy < ys || (edges & HAVE_BOTTOM)) &&
-                    (xx >= 0 || (edges & HAVE_LEFT)) && (xx < xs || (edges & HAVE_RIGHT));
-    return ok ? ldpx<BPP>(in0 + (ptrdiff_t)yy * (ptrdiff_t)istride_bytes + (ptrdiff_t)xx * BPP)
-              : VERY_LARGE;
+// one pixel (i, j) of a block; rd(yy, xx) returns the tap at block-relative
+// (yy, xx) or CDEF_VERY_LARGE where the halo does not exist
+template <typename RD>
+__device__ __forceinline__ int32_t filter_pixel_rd(RD rd, int i, int j, int pri, int sec, int dir,
+                                                   int damping, int coeff_shift) {
+  // cdef_directions (cdef.rs:225-234) packed as nibbles (value + 2) so that the
+  // lookup is two shifts instead of a dependent table load
+  constexpr uint32_t DY0 = 0x33332221u, DX0 = 0x22233333u, DY1 = 0x44443210u, DX1 = 0x12344444u;
+  auto dyx = [&](int d, int k, int &dy, int &dx) {
+    const int sh = 4 * d;
+    dy = (int)(((k == 0 ? DY0 : DY1) >> sh) & 0xf) - 2;
+    dx = (int)(((k == 0 ? DX0 : DX1) >> sh) & 0xf) - 2;
   };
   const int32_t x = rd(i, j);
   int32_t sum = 0, mx = x, mn = x;
@@ -115,9 +115,10 @@ __device__ __forceinline__ int32_t filter_pixel(const uint8_t *in0, size_t istri
   for (int k = 0; k < 2; k++) {
     const int pri_tap = odd ? 3 : (k == 0 ? 4 : 2);
     const int sec_tap = k == 0 ? 2 : 1;
-    const int d0y = D[dir][k][0], d0x = D[dir][k][1];
-    const int d1y = D[(dir + 2) & 7][k][0], d1x = D[(dir + 2) & 7][k][1];
-    const int d2y = D[(dir + 6) & 7][k][0], d2x = D[(dir + 6) & 7][k][1];
+    int d0y, d0x, d1y, d1x, d2y, d2x;
+    dyx(dir, k, d0y, d0x);
+    dyx((dir + 2) & 7, k, d1y, d1x);
+    dyx((dir + 6) & 7, k, d2y, d2x);
     const int32_t p[2] = {rd(i + d0y, j + d0x), rd(i - d0y, j - d0x)};
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -136,6 +137,20 @@ __device__ __forceinline__ int32_t filter_pixel(const uint8_t *in0, size_t istri
   }
   const int32_t v = x + ((8 + sum - (sum < 0)) >> 4);
   return v < mn ? mn : (v > mx ? mx : v);
+}
+
+// taps straight from the input plane, halo availability from the edge flags
+template <int BPP>
+__device__ __forceinline__ int32_t filter_pixel(const uint8_t *in0, size_t istride_bytes, int i,
+                                                int j, int xs, int ys, int pri, int sec, int dir,
+                                                int damping, int coeff_shift, int edges) {
+  auto rd = [&](int yy, int xx) -> int32_t {
+    const bool ok = (yy >= 0 || (edges & HAVE_TOP)) && (yy < ys || (edges & HAVE_BOTTOM)) &&
+                    (xx >= 0 || (edges & HAVE_LEFT)) && (xx < xs || (edges & HAVE_RIGHT));
+    return ok ? ldpx<BPP>(in0 + (ptrdiff_t)yy * (ptrdiff_t)istride_bytes + (ptrdiff_t)xx * BPP)
+              : VERY_LARGE;
+  };
+  return filter_pixel_rd(rd, i, j, pri, sec, dir, damping, coeff_shift);
 }
 
 template <int BPP>
@@ -165,43 +180,64 @@ struct CdefFrameArgs {
   int nbx, nby;
 };
 
+// The 2 x 2 blocks of a workgroup share one LDS tile of the input plane (their
+// region plus the 2-pixel halo), staged once with CDEF_VERY_LARGE where the
+// frame ends.  A halo pixel is missing exactly when it lies outside
+// [0, 8*floor(W/8)) x [0, 8*floor(H/8)) in luma units: that is what the
+// reference's edge flags (`bx + 1 >= xavail >> 3`, first row / column of the
+// frame; cdef.rs:441-459) say for every block at once.
 template <int BPP>
 __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
   __shared__ int32_t part[4][128];
+  __shared__ uint16_t tile[20 * 20];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // 2x2 blocks per workgroup
+  const int xs = 8 >> a.xdec, ys = 8 >> a.ydec;
+  const int TW = 2 * xs + 4, TH = 2 * ys + 4;
   const int gbx = blockIdx.x * 2 + (wave & 1), gby = blockIdx.y * 2 + (wave >> 1);
-  if (gbx >= a.nbx || gby >= a.nby) return;
   const int fbx = gbx >> 3, fby = gby >> 3, bx = gbx & 7, by = gby & 7;
   const int mx = gbx * 2, my = gby * 2;
-  if (!(mx < a.mi_cols && my < a.mi_rows)) return;
+  const bool in_grid = gbx < a.nbx && gby < a.nby && mx < a.mi_cols && my < a.mi_rows;
   const int bd = a.prm.bit_depth, coeff_shift = bd - 8;
-  // edge flags exactly as the by/bx loops of cdef_filter_superblock leave them
   const int in_xoff = fbx * 64, in_yoff = fby * 64;
-  const int xavail = a.luma.width - in_xoff, yavail = a.luma.height - in_yoff;
-  int edges = 0;
-  if (fby > 0 || by > 0) edges |= HAVE_TOP;
-  if (fbx > 0 || bx > 0) edges |= HAVE_LEFT;
-  // BOTTOM survives row `by` iff no row r <= by had r + 1 >= yavail >> 3
-  if (!(by + 1 >= (yavail >> 3))) edges |= HAVE_BOTTOM;
-  if (!(bx + 1 >= (xavail >> 3))) edges |= HAVE_RIGHT;
-  const uint8_t *sk = a.skip_mi + (size_t)my * a.mi_stride + mx;
-  const int skip = sk[0] & sk[1] & sk[a.mi_stride] & sk[a.mi_stride + 1];
-  const int xs = 8 >> a.xdec, ys = 8 >> a.ydec;
+  // ---- every global read of this block is issued here, before the barrier,
+  // so that a wave pays one memory round trip, not five dependent ones ----
+  int skip = 1, ci = 0;
+  int32_t lum = 0;
+  if (in_grid) {
+    const uint8_t *sk = a.skip_mi + (size_t)my * a.mi_stride + mx;
+    skip = sk[0] & sk[1] & sk[a.mi_stride] & sk[a.mi_stride + 1];
+    ci = a.cdef_index_sb[fby * a.sb_stride + fbx];
+    lum = ldpx<BPP>(px_addr<BPP>(a.luma, in_xoff + 8 * bx + (lane & 7), in_yoff + 8 * by + (lane >> 3)));
+  }
+  // plane position of the workgroup's region (no tile offset: whole frame)
+  const int rx0 = (blockIdx.x * 2) * xs, ry0 = (blockIdx.y * 2) * ys;
+  const int lim_x = ((a.luma.width >> 3) << 3) >> a.xdec, lim_y = ((a.luma.height >> 3) << 3) >> a.ydec;
+  {
+    const uint8_t *p0 = (const uint8_t *)a.in.data;
+    for (int t = threadIdx.x; t < TW * TH; t += 256) {
+      const int ty = t / TW, tx = t - ty * TW;
+      const int py = ry0 + ty - 2, px = rx0 + tx - 2;
+      int32_t v = VERY_LARGE;
+      if (py >= 0 && py < lim_y && px >= 0 && px < lim_x)
+        v = ldpx<BPP>(p0 + ((size_t)(a.in.yorigin + py) * a.in.stride + a.in.xorigin + px) * BPP);
+      tile[t] = (uint16_t)v;
+    }
+  }
+  __syncthreads();
+  if (!in_grid) return;
   const int px = (in_xoff >> a.xdec) + bx * xs, py = (in_yoff >> a.ydec) + by * ys;
-  const uint8_t *src = px_addr<BPP>(a.in, px, py);
   uint8_t *dst = (uint8_t *)px_addr<BPP>(a.out, px, py);
-  const size_t sst = (size_t)a.in.stride * BPP, dstb = (size_t)a.out.stride * BPP;
+  const size_t dstb = (size_t)a.out.stride * BPP;
   const int i = lane / xs, j = lane % xs;
   const bool act = lane < xs * ys;
+  // this block's top-left inside the tile
+  const uint16_t *t0 = tile + ((wave >> 1) * ys + 2) * TW + (wave & 1) * xs + 2;
   if (skip) {   // wave-uniform
-    if (act) stpx<BPP>(dst + i * dstb + j * BPP, ldpx<BPP>(src + i * sst + j * BPP));
+    if (act) stpx<BPP>(dst + i * dstb + j * BPP, t0[i * TW + j]);
     return;
   }
   uint32_t var = 0;
-  const int dir = find_dir_wave<BPP>(px_addr<BPP>(a.luma, in_xoff + 8 * bx, in_yoff + 8 * by),
-                                     (size_t)a.luma.stride * BPP, coeff_shift, part[wave], var);
-  const int ci = a.cdef_index_sb[fby * a.sb_stride + fbx];
+  const int dir = find_dir_wave(lum, coeff_shift, part[wave], var);
   const int ysr = a.prm.y_strengths[ci], uvs = a.prm.uv_strengths[ci];
   int lpri, lsec, ldir, ldamp = a.prm.damping + coeff_shift;
   if (a.p == 0) {
@@ -212,18 +248,21 @@ __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
     lsec = sec_y << coeff_shift;
     ldir = pri_y != 0 ? dir : 0;
   } else {
-    constexpr uint8_t UVDIR[8] = {7, 0, 2, 4, 5, 6, 6, 6};
+    // Cdef_Uv_Dir for 4:2:2: {7, 0, 2, 4, 5, 6, 6, 6} packed as nibbles
+    const int uvdir = (int)((0x66654207u >> (4 * dir)) & 0xf);
     const int pri_uv = uvs / 4;
     int sec_uv = uvs % 4;
     sec_uv += sec_uv == 3;
     lpri = pri_uv << coeff_shift;
     lsec = sec_uv << coeff_shift;
     ldamp -= 1;
-    ldir = pri_uv != 0 ? (a.xdec != a.ydec ? UVDIR[dir] : dir) : 0;
+    ldir = pri_uv != 0 ? (a.xdec != a.ydec ? uvdir : dir) : 0;
   }
-  if (act)
+  if (act) {
+    auto rd = [&](int yy, int xx) -> int32_t { return t0[yy * TW + xx]; };
     stpx<BPP>(dst + i * dstb + j * BPP,
-              filter_pixel<BPP>(src, sst, i, j, xs, ys, lpri, lsec, ldir, ldamp, coeff_shift, edges));
+              filter_pixel_rd(rd, i, j, lpri, lsec, ldir, ldamp, coeff_shift));
+  }
 }
 
 template <int BPP>
@@ -233,8 +272,9 @@ __global__ __launch_bounds__(64) void k_cdef_find_dir(R1Plane luma, const R1Cdef
   const int c = blockIdx.x;
   if (c >= n) return;
   uint32_t var;
-  const int d = find_dir_wave<BPP>(px_addr<BPP>(luma, cands[c].x, cands[c].y),
-                                   (size_t)luma.stride * BPP, luma.bit_depth - 8, part, var);
+  const int lane = threadIdx.x;
+  const int32_t pix = ldpx<BPP>(px_addr<BPP>(luma, cands[c].x + (lane & 7), cands[c].y + (lane >> 3)));
+  const int d = find_dir_wave(pix, luma.bit_depth - 8, part, var);
   if (threadIdx.x == 0) {
     dir_out[c] = (uint8_t)d;
     var_out[c] = (int32_t)var;

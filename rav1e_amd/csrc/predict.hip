@@ -72,10 +72,13 @@ __device__ __forceinline__ void stp(void *p, size_t i, int32_t v) {
 // ------------------------------------------------------------------ edges
 template <int BPP>
 __global__ __launch_bounds__(64) void k_intra_edges(
-    R1Plane rec, int tile_x, int tile_y, int rect_w, int rect_h, int txw, int txh,
+    R1Plane rec, int tile_x, int tile_y, int rect_w, int rect_h, int txw, int txh, int lpc_log2,
     const R1IntraEdgeCand *__restrict__ cands, int n, void *__restrict__ edges,
     int edge_stride, uint8_t *__restrict__ lens) {
-  const int cand = blockIdx.x;
+  // lpc = lanes per candidate (power of two covering 2*(txw+txh)+1 entries, <= 64)
+  const int lpc = 1 << lpc_log2, cpw = 64 >> lpc_log2;
+  const int cand = blockIdx.x * cpw + (threadIdx.x >> lpc_log2);
+  const int l = threadIdx.x & (lpc - 1);
   if (cand >= n) return;
   const R1IntraEdgeCand cd = cands[cand];
   const int x = cd.x, y = cd.y, bd = rec.bit_depth;
@@ -139,7 +142,9 @@ __global__ __launch_bounds__(64) void k_intra_edges(
   const int init_left = (needs_left ? txh : 0) + (needs_bottomleft ? txw : 0);
   const int init_above = (needs_top ? txw : 0) + (needs_topright ? txh : 0);
   void *e = (uint8_t *)edges + (size_t)cand * edge_stride * BPP;
-  for (int k = threadIdx.x; k < EDGE_LEN; k += 64) {
+  // only the initialised range [128 - init_left, 129 + init_above) is written;
+  // the reference leaves the rest of the buffer uninitialised as well
+  for (int k = 2 * MAXTX - init_left + l; k < 2 * MAXTX + 1 + init_above; k += lpc) {
     int32_t v = 0;
     if (k < 2 * MAXTX) {
       const int i = 2 * MAXTX - 1 - k;
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(64) void k_intra_edges(
     }
     stp<BPP>(e, k, v);
   }
-  if (threadIdx.x == 0) {
+  if (l == 0) {
     lens[2 * cand] = (uint8_t)init_left;
     lens[2 * cand + 1] = (uint8_t)init_above;
   }
@@ -203,7 +208,9 @@ __global__ __launch_bounds__(64) void k_intra_predict(
     left_len = lens[2 * cand];
     above_len = lens[2 * cand + 1];
     const void *e = (const uint8_t *)edges + (size_t)cand * edge_stride * BPP;
-    for (int k = c; k < EDGE_LEN; k += W) raw[k] = (uint16_t)ldp<BPP>(e, k);
+    // only [128 - left_len, 129 + above_len) is defined (and ever read)
+    for (int k = 2 * MAXTX - left_len + c; k < 2 * MAXTX + 1 + above_len; k += W)
+      raw[k] = (uint16_t)ldp<BPP>(e, k);
   }
   __syncthreads();
   const int mode = cd.mode, variant = cd.variant, angle = cd.angle;
@@ -450,12 +457,17 @@ extern "C" int r1_intra_edges_batch(r1_ctx *ctx, const R1Plane *rec, int tile_x,
   static const uint8_t wl[19] = {2, 3, 4, 5, 6, 2, 3, 3, 4, 4, 5, 5, 6, 2, 4, 3, 5, 4, 6};
   static const uint8_t hl[19] = {2, 3, 4, 5, 6, 3, 2, 4, 3, 5, 4, 6, 5, 4, 2, 5, 3, 6, 4};
   hipStream_t st = (hipStream_t)stream;
+  const int txw = 1 << wl[tx_size], txh = 1 << hl[tx_size];
+  int lpc_log2 = 0;
+  while ((1 << lpc_log2) < 2 * (txw + txh) + 1 && lpc_log2 < 6) lpc_log2++;
+  const int cpw = 64 >> lpc_log2;
+  const unsigned grid = (unsigned)((n + cpw - 1) / cpw);
   if (rec->bytes_per_px == 1)
-    hipLaunchKernelGGL((k_intra_edges<1>), dim3(n), dim3(64), 0, st, *rec, tile_x, tile_y, rect_w,
-                       rect_h, 1 << wl[tx_size], 1 << hl[tx_size], cands, n, edges, edge_stride, lens);
+    hipLaunchKernelGGL((k_intra_edges<1>), dim3(grid), dim3(64), 0, st, *rec, tile_x, tile_y, rect_w,
+                       rect_h, txw, txh, lpc_log2, cands, n, edges, edge_stride, lens);
   else
-    hipLaunchKernelGGL((k_intra_edges<2>), dim3(n), dim3(64), 0, st, *rec, tile_x, tile_y, rect_w,
-                       rect_h, 1 << wl[tx_size], 1 << hl[tx_size], cands, n, edges, edge_stride, lens);
+    hipLaunchKernelGGL((k_intra_edges<2>), dim3(grid), dim3(64), 0, st, *rec, tile_x, tile_y, rect_w,
+                       rect_h, txw, txh, lpc_log2, cands, n, edges, edge_stride, lens);
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }
