@@ -157,6 +157,85 @@ __device__ __forceinline__ void mc8_column(const uint8_t *win, int c,
   }
 }
 
+// ---- 10/12-bit fast path of put_8tap for one column -------------------------
+// Same unified evaluation as mc8_column, on u16 pixels: intermediate_bits
+// ib = 4 (10-bit) or 2 (12-bit);  mid = (sum t*p + 2^(6-ib)) >> (7-ib) fits
+// i16 (mc.rs:314,326), out = clamp((sum u*mid + 2^(6+ib)) >> (7+ib)).
+//  * col_frac == 0 (t = 128 at tap 3): mid = p << ib exactly, out =
+//    (2^ib * S + 2^(6+ib)) >> (7+ib) = round_shift(S, 7)           (mc.rs:272-291)
+//  * row_frac == 0 (u = 128 at tap 3): out = (128 mid + 2^(6+ib)) >> (7+ib)
+//    = round_shift(mid, ib)                                         (mc.rs:292-312)
+//  * both 0: out = p                                               (mc.rs:265-271)
+// The taps (128 included) and the pixels (<= 4095) fit i16, so the 8 horizontal
+// taps are 4 v_dot2_i32_i16 on pixel pairs funnel-shifted to the lane's
+// column, and the vertical taps 4-5 v_dot2_i32_i16 on packed intermediates.
+// The rounding of the vertical pass is pre-added to the intermediates:
+// 2^(6+ib) = 128 * 2^(ib-1) and every tap row sums to 128.
+template <int W, int H, int WS>
+__device__ __forceinline__ void mc16_column(const uint8_t *win, int c, const R1RdoCand &cd,
+                                            int bit_depth, int32_t *pred) {
+  typedef short v2s __attribute__((ext_vector_type(2)));
+  const int mx = cd.mode_x, my = cd.mode_y;
+  const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
+  const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
+  const int cf = cd.col_frac, rf = cd.row_frac;
+  uint32_t tx[4], ty[4], tz[5];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    tx[j] = kTapI16[fxi][cf][j];
+    ty[j] = kTapI16[fyi][rf][j];
+  }
+  tz[0] = ty[0] << 16;
+#pragma unroll
+  for (int j = 1; j < 4; j++) tz[j] = __builtin_amdgcn_alignbit(ty[j], ty[j - 1], 16);
+  tz[4] = ty[3] >> 16;
+  const int ib = bit_depth == 12 ? 2 : 4;
+  const int hsh = 7 - ib, vsh = 7 + ib;
+  const int32_t hbias = (1 << (6 - ib)) + (64 << 0);   // H rounding + (2^(ib-1) << hsh) = 64
+  const int32_t maxv = (1 << bit_depth) - 1;
+  constexpr int WSD = WS / 4;
+  const uint32_t *wrow = (const uint32_t *)win + (c >> 1);
+  const uint32_t sh = (uint32_t)(c & 1) * 16;
+  auto hrow = [&](int r) -> int32_t {
+    const uint32_t *p = wrow + r * WSD;
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+    const uint32_t q0 = __builtin_amdgcn_alignbit(d1, d0, sh);
+    const uint32_t q1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+    const uint32_t q2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+    const uint32_t q3 = __builtin_amdgcn_alignbit(d4, d3, sh);
+    int32_t acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q0), __builtin_bit_cast(v2s, tx[0]), hbias, false);
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q1), __builtin_bit_cast(v2s, tx[1]), acc, false);
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q2), __builtin_bit_cast(v2s, tx[2]), acc, false);
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q3), __builtin_bit_cast(v2s, tx[3]), acc, false);
+    return acc >> hsh;
+  };
+  auto hpair = [&](int r) -> uint32_t {   // rows r, r+1 packed as i16 x 2
+    const int32_t m0 = hrow(r);
+    const int32_t m1 = r + 1 < H + 7 ? hrow(r + 1) : 0;
+    return __builtin_amdgcn_perm((uint32_t)m1, (uint32_t)m0, 0x05040100u);
+  };
+  uint32_t pk[5];
+#pragma unroll
+  for (int j = 0; j < 4; j++) pk[j] = hpair(2 * j);
+#pragma unroll
+  for (int j = 0; j < H / 2; j++) {
+    pk[4] = hpair(2 * j + 8);
+    int32_t a0 = 0, a1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]), __builtin_bit_cast(v2s, ty[k]), a0, false);
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+      a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]), __builtin_bit_cast(v2s, tz[k]), a1, false);
+    a0 >>= vsh;
+    a1 >>= vsh;
+    pred[2 * j] = a0 < 0 ? 0 : (a0 > maxv ? maxv : a0);
+    pred[2 * j + 1] = a1 < 0 ? 0 : (a1 > maxv ? maxv : a1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) pk[k] = pk[k + 1];
+  }
+}
+
 // SATD contribution of one residual column (TS rows at a time).
 template <int TS, int H>
 __device__ __forceinline__ uint32_t satd_column(const T *v, int lane) {
@@ -252,14 +331,15 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
     }
   } else {
     if (col_live) {
-      uint8_t *pp = pred_out ? (uint8_t *)pred_out + ((size_t)cand * W * H + c) * BPP
-                             : nullptr;
-      r1mc::mc_column<BPP, false, H>(
-          win, WS, c, W, H, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y,
-          ref.bit_depth, [&](int r, int32_t p) {
-            v[r] = v[r] - p;
-            if (pp) *(uint16_t *)(pp + (size_t)r * W * 2) = (uint16_t)p;
-          });
+      int32_t pred[H];
+      mc16_column<W, H, WS>(win, c, cd, ref.bit_depth, pred);
+      if (pred_out) {
+        uint16_t *pp = (uint16_t *)pred_out + (size_t)cand * W * H + c;
+#pragma unroll
+        for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint16_t)pred[r];
+      }
+#pragma unroll
+      for (int r = 0; r < H; r++) v[r] -= pred[r];
     }
   }
   if (sad_out) {
