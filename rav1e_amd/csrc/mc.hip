@@ -10,6 +10,9 @@
 // consecutive samples.
 #include "mc_common.hpp"
 
+int r1_mc_fast_launch(bool prep, const R1Plane *ref, int w, int h, const R1McCand *cands, int n,
+                      void *dst, hipStream_t st);
+
 namespace {
 
 template <int BPP, bool PREP>
@@ -78,6 +81,13 @@ int mc_launch(bool prep, const R1Plane *ref, int w, int h, const R1McCand *cands
   R1_REQUIRE(h >= 2 && h <= 128 && (h & 1) == 0);
   if (n <= 0) return R1_OK;
   R1_REQUIRE(cands && dst);
+  // block sizes that are transform sizes take the dot4 / dot2 path of the
+  // fused kernel (rdo_cand.hip); the slab kernel below covers the rest
+  // (w = 2, 128-wide / -high blocks, odd aspect ratios)
+  {
+    const int rc = r1_mc_fast_launch(prep, ref, w, h, cands, n, dst, st);
+    if (rc <= 0) return rc;
+  }
   const int bpp = ref->bytes_per_px;
   const int P = w < 64 ? w : 64, NS = 64 / P, spc = w / P;
   const int ws = (((P + 7) * bpp + 3) >> 2) << 2;

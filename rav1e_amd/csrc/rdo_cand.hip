@@ -94,14 +94,15 @@ __device__ __forceinline__ uint32_t habs_lanes(int32_t x, LaneSigns sg) {
 //  * both 0: out = p                                              (mc.rs:265-271)
 // so one path is bit-exact for all four cases.  The 128 tap does not fit int8:
 // phase-0 rows carry 127 and the centre pixel is added once (any_cf0 only).
-template <int W, int H, int WS>
-__device__ __forceinline__ void mc8_column(const uint8_t *win, int c,
-                                           const R1RdoCand &cd, bool any_cf0,
-                                           int32_t *pred) {
-  const int mx = cd.mode_x, my = cd.mode_y;
+// PREP: prep_8tap (mc.rs:360-451) -- the i16 intermediate of the same filter,
+// (sum u*mid + 64) >> 7 without clamp; the same algebra makes the one path
+// exact for its four cases too (mid = 16 p when col_frac == 0, u = 128 picks
+// mid when row_frac == 0).
+template <int W, int H, int WS, bool PREP = false>
+__device__ __forceinline__ void mc8_column(const uint8_t *win, int c, int cf, int rf, int mx,
+                                           int my, bool any_cf0, int32_t *pred) {
   const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
   const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
-  const int cf = cd.col_frac, rf = cd.row_frac;
   const uint32_t fx0 = kTapI8[fxi][cf][0], fx1 = kTapI8[fxi][cf][1];
   uint32_t ty[4], tz[5];
 #pragma unroll
@@ -139,7 +140,7 @@ __device__ __forceinline__ void mc8_column(const uint8_t *win, int c,
 #pragma unroll
   for (int j = 0; j < H / 2; j++) {
     pk[4] = hpair(2 * j + 8);
-    int32_t a0 = 1024, a1 = 1024;   // rounding of the final >> 11
+    int32_t a0 = PREP ? 64 : 1024, a1 = a0;   // rounding of the final >> 7 / >> 11
 #pragma unroll
     for (int k = 0; k < 4; k++)
       a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]),
@@ -148,10 +149,15 @@ __device__ __forceinline__ void mc8_column(const uint8_t *win, int c,
     for (int k = 0; k < 5; k++)
       a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]),
                                   __builtin_bit_cast(v2s, tz[k]), a1, false);
-    a0 >>= 11;
-    a1 >>= 11;
-    pred[2 * j] = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0);
-    pred[2 * j + 1] = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1);
+    if constexpr (PREP) {
+      pred[2 * j] = a0 >> 7;
+      pred[2 * j + 1] = a1 >> 7;
+    } else {
+      a0 >>= 11;
+      a1 >>= 11;
+      pred[2 * j] = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0);
+      pred[2 * j + 1] = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1);
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) pk[k] = pk[k + 1];
   }
@@ -171,14 +177,13 @@ __device__ __forceinline__ void mc8_column(const uint8_t *win, int c,
 // column, and the vertical taps 4-5 v_dot2_i32_i16 on packed intermediates.
 // The rounding of the vertical pass is pre-added to the intermediates:
 // 2^(6+ib) = 128 * 2^(ib-1) and every tap row sums to 128.
-template <int W, int H, int WS>
-__device__ __forceinline__ void mc16_column(const uint8_t *win, int c, const R1RdoCand &cd,
-                                            int bit_depth, int32_t *pred) {
+// PREP: (sum u*mid + 64) >> 7 - PREP_BIAS (8192), no clamp (mc.rs:355-451).
+template <int W, int H, int WS, bool PREP = false>
+__device__ __forceinline__ void mc16_column(const uint8_t *win, int c, int cf, int rf, int mx,
+                                            int my, int bit_depth, int32_t *pred) {
   typedef short v2s __attribute__((ext_vector_type(2)));
-  const int mx = cd.mode_x, my = cd.mode_y;
   const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
   const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
-  const int cf = cd.col_frac, rf = cd.row_frac;
   uint32_t tx[4], ty[4], tz[5];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -191,7 +196,8 @@ __device__ __forceinline__ void mc16_column(const uint8_t *win, int c, const R1R
   tz[4] = ty[3] >> 16;
   const int ib = bit_depth == 12 ? 2 : 4;
   const int hsh = 7 - ib, vsh = 7 + ib;
-  const int32_t hbias = (1 << (6 - ib)) + (64 << 0);   // H rounding + (2^(ib-1) << hsh) = 64
+  // H rounding, plus (put only) the V rounding 2^(ib-1) << hsh = 64 folded into mid
+  const int32_t hbias = (1 << (6 - ib)) + (PREP ? 0 : 64);
   const int32_t maxv = (1 << bit_depth) - 1;
   constexpr int WSD = WS / 4;
   const uint32_t *wrow = (const uint32_t *)win + (c >> 1);
@@ -220,17 +226,22 @@ __device__ __forceinline__ void mc16_column(const uint8_t *win, int c, const R1R
 #pragma unroll
   for (int j = 0; j < H / 2; j++) {
     pk[4] = hpair(2 * j + 8);
-    int32_t a0 = 0, a1 = 0;
+    int32_t a0 = PREP ? 64 : 0, a1 = a0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
       a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]), __builtin_bit_cast(v2s, ty[k]), a0, false);
 #pragma unroll
     for (int k = 0; k < 5; k++)
       a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]), __builtin_bit_cast(v2s, tz[k]), a1, false);
-    a0 >>= vsh;
-    a1 >>= vsh;
-    pred[2 * j] = a0 < 0 ? 0 : (a0 > maxv ? maxv : a0);
-    pred[2 * j + 1] = a1 < 0 ? 0 : (a1 > maxv ? maxv : a1);
+    if constexpr (PREP) {
+      pred[2 * j] = (a0 >> 7) - 8192;
+      pred[2 * j + 1] = (a1 >> 7) - 8192;
+    } else {
+      a0 >>= vsh;
+      a1 >>= vsh;
+      pred[2 * j] = a0 < 0 ? 0 : (a0 > maxv ? maxv : a0);
+      pred[2 * j + 1] = a1 < 0 ? 0 : (a1 > maxv ? maxv : a1);
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) pk[k] = pk[k + 1];
   }
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
     const bool any_cf0 = __any(live && cd.col_frac == 0);
     if (col_live) {
       int32_t pred[H];
-      mc8_column<W, H, WS>(win, c, cd, any_cf0, pred);
+      mc8_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, any_cf0, pred);
       if (pred_out) {
         uint8_t *pp = (uint8_t *)pred_out + (size_t)cand * W * H + c;
 #pragma unroll
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   } else {
     if (col_live) {
       int32_t pred[H];
-      mc16_column<W, H, WS>(win, c, cd, ref.bit_depth, pred);
+      mc16_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, ref.bit_depth, pred);
       if (pred_out) {
         uint16_t *pp = (uint16_t *)pred_out + (size_t)cand * W * H + c;
 #pragma unroll
@@ -400,6 +411,57 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   }
 }
 
+// put_8tap / prep_8tap alone on the same machinery (blocks whose size is a
+// transform size): window staged with one round trip, dot4 / dot2 columns.
+template <int BPP, int WL, int HL, bool PREP>
+__global__ __launch_bounds__(64) void k_mc_fast(R1Plane ref, const R1McCand *__restrict__ cands,
+                                                int n, void *__restrict__ dst) {
+  constexpr int W = 1 << WL, H = 1 << HL;
+  constexpr int P = W > H ? W : H, NC = 64 / P;
+  constexpr int WS = (((W + 7) * BPP + 3) >> 2) << 2;
+  __shared__ __attribute__((aligned(16))) uint8_t smem[NC * (H + 7) * WS];
+  const int lane = threadIdx.x;
+  const int cl = lane / P, c = lane % P;
+  const long long cand = (long long)blockIdx.x * NC + cl;
+  const bool live = cand < n;
+  R1McCand cd = {};
+  if (live) cd = cands[cand];
+  uint8_t *win = smem + cl * (H + 7) * WS;
+  if (live)
+    r1mc::stage_window_ct<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P>(win, WS, ref, cd.rx, cd.ry, c);
+  __syncthreads();
+  const bool any_cf0 = __any(live && cd.col_frac == 0);
+  if (!(live && c < W)) return;
+  int32_t pred[H];
+  if constexpr (BPP == 1)
+    mc8_column<W, H, WS, PREP>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, any_cf0, pred);
+  else
+    mc16_column<W, H, WS, PREP>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y,
+                                ref.bit_depth, pred);
+  if constexpr (PREP || BPP == 2) {
+    uint16_t *pp = (uint16_t *)dst + (size_t)cand * W * H + c;
+#pragma unroll
+    for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint16_t)pred[r];
+  } else {
+    uint8_t *pp = (uint8_t *)dst + (size_t)cand * W * H + c;
+#pragma unroll
+    for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint8_t)pred[r];
+  }
+}
+
+template <int BPP, int WL, int HL>
+int launch_mc_fast(bool prep, const R1Plane &ref, const R1McCand *cands, int n, void *dst,
+                   hipStream_t st) {
+  constexpr int W = 1 << WL, H = 1 << HL, P = W > H ? W : H, NC = 64 / P;
+  const unsigned grid = (unsigned)((n + NC - 1) / NC);
+  if (prep)
+    hipLaunchKernelGGL((k_mc_fast<BPP, WL, HL, true>), dim3(grid), dim3(64), 0, st, ref, cands, n, dst);
+  else
+    hipLaunchKernelGGL((k_mc_fast<BPP, WL, HL, false>), dim3(grid), dim3(64), 0, st, ref, cands, n, dst);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
 template <int BPP, int WL, int HL>
 int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n,
            uint32_t *sad, uint32_t *satd, void *coeffs, void *pred,
@@ -414,6 +476,31 @@ int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n
 }
 
 }  // namespace
+
+// Used by r1_mc_put_batch / r1_mc_prep_batch (mc.hip) for block sizes that are
+// transform sizes; returns 1 when (w, h) is not one of them.
+int r1_mc_fast_launch(bool prep, const R1Plane *ref, int w, int h, const R1McCand *cands, int n,
+                      void *dst, hipStream_t st) {
+  int ts = -1;
+  for (int t = 0; t < 19; t++)
+    if ((1 << r1tx::kTxWLog2[t]) == w && (1 << r1tx::kTxHLog2[t]) == h) ts = t;
+  if (ts < 0) return 1;
+#define R1_MF_CASE(ID, WL, HL)                                                         \
+  case ID:                                                                             \
+    return ref->bytes_per_px == 1 ? launch_mc_fast<1, WL, HL>(prep, *ref, cands, n, dst, st) \
+                                  : launch_mc_fast<2, WL, HL>(prep, *ref, cands, n, dst, st);
+  switch (ts) {
+    R1_MF_CASE(0, 2, 2) R1_MF_CASE(1, 3, 3) R1_MF_CASE(2, 4, 4)
+    R1_MF_CASE(3, 5, 5) R1_MF_CASE(4, 6, 6) R1_MF_CASE(5, 2, 3)
+    R1_MF_CASE(6, 3, 2) R1_MF_CASE(7, 3, 4) R1_MF_CASE(8, 4, 3)
+    R1_MF_CASE(9, 4, 5) R1_MF_CASE(10, 5, 4) R1_MF_CASE(11, 5, 6)
+    R1_MF_CASE(12, 6, 5) R1_MF_CASE(13, 2, 4) R1_MF_CASE(14, 4, 2)
+    R1_MF_CASE(15, 3, 5) R1_MF_CASE(16, 5, 3) R1_MF_CASE(17, 4, 6)
+    R1_MF_CASE(18, 6, 4)
+  }
+#undef R1_MF_CASE
+  return 1;
+}
 
 extern "C" int r1_rdo_cand_batch(r1_ctx *ctx, const R1Plane *org,
                                  const R1Plane *ref, int w, int h, int tx_size,
