@@ -84,6 +84,31 @@ __device__ __forceinline__ uint32_t habs_lanes(int32_t x, LaneSigns sg) {
   return (uint32_t)(ax > ap ? ax : ap);
 }
 
+// First link of a dot-product chain with a constant accumulator: the VOP3P
+// forms take the constant as an operand (inline 0 / 64, or an SGPR), whereas
+// the compiler's choice -- the accumulate-in-place v_dot*c forms -- needs a
+// v_mov to seed the accumulator first.  One instruction instead of two.
+__device__ __forceinline__ int32_t dot2_seed0(uint32_t a, uint32_t b) {
+  int32_t r;
+  asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ int32_t dot2_seed64(uint32_t a, uint32_t b) {
+  int32_t r;
+  asm("v_dot2_i32_i16 %0, %1, %2, 64" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ int32_t dot2_seed(uint32_t a, uint32_t b, int32_t c_uniform) {
+  int32_t r;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+  return r;
+}
+__device__ __forceinline__ int32_t dot4_seed(uint32_t a, uint32_t b, int32_t c_uniform) {
+  int32_t r;
+  asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+  return r;
+}
+
 // ---- 8-bit fast path of put_8tap for one column ---------------------------
 // Unified 2-D evaluation.  With x-taps t (sum 128) and y-taps u (sum 128),
 // ib = 4 (8-bit): mid = (sum t*p + 4) >> 3, out = clamp((sum u*mid + 1024) >> 11).
@@ -92,8 +117,8 @@ __device__ __forceinline__ uint32_t habs_lanes(int32_t x, LaneSigns sg) {
 //  * row_frac == 0 (u = 128 at tap 3): out = (128 mid + 1024) >> 11 =
 //    (mid + 8) >> 4 = round_shift(round_shift(S, 3), 4)            (mc.rs:292-312)
 //  * both 0: out = p                                              (mc.rs:265-271)
-// so one path is bit-exact for all four cases.  The 128 tap does not fit int8:
-// phase-0 rows carry 127 and the centre pixel is added once (any_cf0 only).
+// so one path is bit-exact for all four cases.  The 128 tap does not fit int8,
+// but every AV1 tap is even: the i8 table stores t / 2 and the shift is one less.
 // PREP: prep_8tap (mc.rs:360-451) -- the i16 intermediate of the same filter,
 // (sum u*mid + 64) >> 7 without clamp; the same algebra makes the one path
 // exact for its four cases too (mid = 16 p when col_frac == 0, u = 128 picks
@@ -111,21 +136,25 @@ __device__ __forceinline__ void mc8_column(const uint8_t *win, int c, int cf, in
 #pragma unroll
   for (int j = 1; j < 4; j++) tz[j] = __builtin_amdgcn_alignbit(ty[j], ty[j - 1], 16);
   tz[4] = ty[3] >> 16;
-  // sum f*(q+128) = dot(f,q) + 128*sum(f); + rounding 1 << 2
-  const int32_t bias = (cf == 0 ? 127 * 128 : 128 * 128) + 4;
+  // The i8 table holds h = t / 2 (all AV1 taps are even; sum h = 64).  With the
+  // staged q = p - 128:  sum t*p = 2 (sum h*q + 128 * 64), so
+  //   mid = (sum t*p + 4) >> 3 = (sum h*q + 8192 + 2) >> 2.
+  // put only: the vertical rounding 1024 = 128 * 8 is pre-added to the
+  // intermediates (every tap row sums to 128): + 8 after the shift = + 32 before.
+  constexpr int32_t bias = 8192 + 2 + (PREP ? 0 : 32);
   constexpr int WSD = WS / 4;
   const uint32_t *wrow = (const uint32_t *)win + (c >> 2);
   const uint32_t sh = (uint32_t)(c & 3);
   typedef short v2s __attribute__((ext_vector_type(2)));
+  (void)any_cf0;
   // the window holds pixels already biased by -128 (staged with xor 0x80)
   auto hrow = [&](int r) -> int32_t {
     const uint32_t d0 = wrow[r * WSD], d1 = wrow[r * WSD + 1], d2 = wrow[r * WSD + 2];
     const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
     const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    int32_t acc = __builtin_amdgcn_sdot4((int)lo, (int)fx0, bias, false);
+    int32_t acc = dot4_seed(lo, fx0, bias);
     acc = __builtin_amdgcn_sdot4((int)hi, (int)fx1, acc, false);
-    if (any_cf0) acc += cf == 0 ? (int32_t)((lo >> 24) ^ 0x80u) : 0;
-    return acc >> 3;
+    return acc >> 2;
   };
   auto hpair = [&](int r) -> uint32_t {   // rows r, r+1 packed as i16 x 2
     const int32_t m0 = hrow(r);
@@ -140,13 +169,15 @@ __device__ __forceinline__ void mc8_column(const uint8_t *win, int c, int cf, in
 #pragma unroll
   for (int j = 0; j < H / 2; j++) {
     pk[4] = hpair(2 * j + 8);
-    int32_t a0 = PREP ? 64 : 1024, a1 = a0;   // rounding of the final >> 7 / >> 11
+    // put: the rounding is already inside the intermediates; prep: + 64
+    int32_t a0 = PREP ? dot2_seed64(pk[0], ty[0]) : dot2_seed0(pk[0], ty[0]);
+    int32_t a1 = PREP ? dot2_seed64(pk[0], tz[0]) : dot2_seed0(pk[0], tz[0]);
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 1; k < 4; k++)
       a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]),
                                   __builtin_bit_cast(v2s, ty[k]), a0, false);
 #pragma unroll
-    for (int k = 0; k < 5; k++)
+    for (int k = 1; k < 5; k++)
       a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]),
                                   __builtin_bit_cast(v2s, tz[k]), a1, false);
     if constexpr (PREP) {
@@ -209,7 +240,7 @@ __device__ __forceinline__ void mc16_column(const uint8_t *win, int c, int cf, i
     const uint32_t q1 = __builtin_amdgcn_alignbit(d2, d1, sh);
     const uint32_t q2 = __builtin_amdgcn_alignbit(d3, d2, sh);
     const uint32_t q3 = __builtin_amdgcn_alignbit(d4, d3, sh);
-    int32_t acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q0), __builtin_bit_cast(v2s, tx[0]), hbias, false);
+    int32_t acc = dot2_seed(q0, tx[0], hbias);
     acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q1), __builtin_bit_cast(v2s, tx[1]), acc, false);
     acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q2), __builtin_bit_cast(v2s, tx[2]), acc, false);
     acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q3), __builtin_bit_cast(v2s, tx[3]), acc, false);
@@ -226,12 +257,13 @@ __device__ __forceinline__ void mc16_column(const uint8_t *win, int c, int cf, i
 #pragma unroll
   for (int j = 0; j < H / 2; j++) {
     pk[4] = hpair(2 * j + 8);
-    int32_t a0 = PREP ? 64 : 0, a1 = a0;
+    int32_t a0 = PREP ? dot2_seed64(pk[0], ty[0]) : dot2_seed0(pk[0], ty[0]);
+    int32_t a1 = PREP ? dot2_seed64(pk[0], tz[0]) : dot2_seed0(pk[0], tz[0]);
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 1; k < 4; k++)
       a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]), __builtin_bit_cast(v2s, ty[k]), a0, false);
 #pragma unroll
-    for (int k = 0; k < 5; k++)
+    for (int k = 1; k < 5; k++)
       a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]), __builtin_bit_cast(v2s, tz[k]), a1, false);
     if constexpr (PREP) {
       pred[2 * j] = (a0 >> 7) - 8192;
@@ -286,11 +318,15 @@ __device__ __forceinline__ uint32_t satd_column(const T *v, int lane) {
   return acc;
 }
 
-template <int BPP, int WL, int HL, typename CT>
+template <int BD, int WL, int HL, typename CT>
 __global__ __launch_bounds__(64) void k_rdo_cand(
     R1Plane org, R1Plane ref, const R1RdoCand *__restrict__ cands, int n,
     uint32_t *__restrict__ sad_out, uint32_t *__restrict__ satd_out,
-    CT *__restrict__ coeffs, void *__restrict__ pred_out, r1tx::Shift3 sh) {
+    CT *__restrict__ coeffs, void *__restrict__ pred_out) {
+  constexpr int BPP = BD == 8 ? 1 : 2;
+  // forward-transform shifts of this (size, bit depth): immediates
+  constexpr int SH0 = r1tx::fwd_shift_ct(WL, HL, BD, 0), SH1 = r1tx::fwd_shift_ct(WL, HL, BD, 1),
+                SH2 = r1tx::fwd_shift_ct(WL, HL, BD, 2);
   constexpr int W = 1 << WL, H = 1 << HL;
   constexpr int P = W > H ? W : H, NC = 64 / P;
   constexpr int TS = (W < H ? W : H) == 4 ? 4 : 8;
@@ -343,7 +379,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   } else {
     if (col_live) {
       int32_t pred[H];
-      mc16_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, ref.bit_depth, pred);
+      mc16_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, BD, pred);
       if (pred_out) {
         uint16_t *pp = (uint16_t *)pred_out + (size_t)cand * W * H + c;
 #pragma unroll
@@ -382,12 +418,12 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
       }
     }
 #pragma unroll
-    for (int r = 0; r < H; r++) v[r] = r1tx::shift_fwd(v[r], sh.s[0]);
+    for (int r = 0; r < H; r++) v[r] = r1tx::shift_fwd_ct<SH0>(v[r]);
     r1tx::fwd_1d_m24<H>(v, r1tx::vtx_1d(tx_type));
     const int cc = cl * W + (r1tx::lr_flip(tx_type) ? W - 1 - c : c);
 #pragma unroll
     for (int r = 0; r < H; r++)
-      buf[r * LSTRIDE + cc] = r1tx::shift_fwd(v[r], sh.s[1]);
+      buf[r * LSTRIDE + cc] = r1tx::shift_fwd_ct<SH1>(v[r]);
   }
   __syncthreads();
   // ---- D: row transform, transposed store ----
@@ -406,7 +442,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
       for (int cg = 0; cg < W; cg += 32)
 #pragma unroll
         for (int k = 0; k < WC; k++)
-          dst[H * cg + k * OS] = (CT)r1tx::shift_fwd(u[k + cg], sh.s[2]);
+          dst[H * cg + k * OS] = (CT)r1tx::shift_fwd_ct<SH2>(u[k + cg]);
     }
   }
 }
@@ -462,15 +498,14 @@ int launch_mc_fast(bool prep, const R1Plane &ref, const R1McCand *cands, int n, 
   return R1_OK;
 }
 
-template <int BPP, int WL, int HL>
+template <int BD, int WL, int HL>
 int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n,
-           uint32_t *sad, uint32_t *satd, void *coeffs, void *pred,
-           r1tx::Shift3 sh, hipStream_t st) {
+           uint32_t *sad, uint32_t *satd, void *coeffs, void *pred, hipStream_t st) {
   constexpr int W = 1 << WL, H = 1 << HL, P = W > H ? W : H, NC = 64 / P;
-  typedef typename std::conditional<BPP == 1, int16_t, int32_t>::type CT;
+  typedef typename std::conditional<BD == 8, int16_t, int32_t>::type CT;
   const unsigned grid = (unsigned)((n + NC - 1) / NC);
-  hipLaunchKernelGGL((k_rdo_cand<BPP, WL, HL, CT>), dim3(grid), dim3(64), 0, st,
-                     org, ref, cands, n, sad, satd, (CT *)coeffs, pred, sh);
+  hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT>), dim3(grid), dim3(64), 0, st,
+                     org, ref, cands, n, sad, satd, (CT *)coeffs, pred);
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }
@@ -519,15 +554,18 @@ extern "C" int r1_rdo_cand_batch(r1_ctx *ctx, const R1Plane *org,
   R1_REQUIRE(cands);
   hipStream_t st = (hipStream_t)stream;
   // the per-candidate tx_type selects the 1-D kernels on the device; the
-  // shifts depend only on (tx_size, bit depth) for every non-WHT type
-  const r1tx::Shift3 sh = r1tx::fwd_shift(tx_size, 0, org->bit_depth);
-#define R1_RC_CASE(ID, WL, HL)                                                \
-  case ID:                                                                    \
-    return org->bytes_per_px == 1                                             \
-               ? launch<1, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,  \
-                                   coeffs, pred_out, sh, st)                  \
-               : launch<2, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,  \
-                                   coeffs, pred_out, sh, st);
+  // shifts depend only on (tx_size, bit depth) for every non-WHT type and are
+  // compile-time constants of the instantiation
+  const int bd = org->bit_depth;
+  R1_REQUIRE(bd == 8 || bd == 10 || bd == 12);
+#define R1_RC_CASE(ID, WL, HL)                                                        \
+  case ID:                                                                            \
+    return bd == 8    ? launch<8, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,   \
+                                          coeffs, pred_out, st)                       \
+           : bd == 10 ? launch<10, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,  \
+                                           coeffs, pred_out, st)                      \
+                      : launch<12, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,  \
+                                           coeffs, pred_out, st);
   switch (tx_size) {
     R1_RC_CASE(0, 2, 2) R1_RC_CASE(1, 3, 3) R1_RC_CASE(2, 4, 4)
     R1_RC_CASE(3, 5, 5) R1_RC_CASE(4, 6, 6) R1_RC_CASE(5, 2, 3)

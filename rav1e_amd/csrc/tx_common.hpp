@@ -97,6 +97,30 @@ inline Shift3 fwd_shift(int tx_size, int tx_type, int bd) {
   return r;
 }
 
+// Compile-time FWD_TXFM_SHIFT_LS (forward_shared.rs:22-64) for non-WHT types:
+// the triple depends only on (tx size class, bit depth), so a kernel
+// instantiated per size and bit depth gets immediate shift amounts (a shift
+// by 0 disappears, the rounding constant folds).
+constexpr int fwd_shift_class(int wl, int hl) {
+  const int mx = wl > hl ? wl : hl, mn = wl > hl ? hl : wl;
+  if (mx == 2) return 0;
+  if (mx == 6 && mn >= 5) return 3;
+  if ((mx == 5 && mn >= 4) || (mx == 6 && mn == 4)) return 2;
+  return 1;
+}
+constexpr int fwd_shift_ct(int wl, int hl, int bd, int stage) {
+  constexpr int8_t tab[4][3][3] = {{{3, 0, 0}, {2, 0, 1}, {0, 0, 3}},
+                                   {{4, -1, 0}, {2, 0, 1}, {0, 0, 3}},
+                                   {{4, -2, 0}, {2, 0, 0}, {0, 0, 2}},
+                                   {{4, -1, -2}, {2, 0, -1}, {0, 0, 1}}};
+  return tab[fwd_shift_class(wl, hl)][(bd - 8) / 2][stage];
+}
+template <int SHIFT>
+__device__ __forceinline__ T shift_fwd_ct(T v) {
+  if constexpr (SHIFT >= 0) return (T)((uint32_t)v << SHIFT);
+  else return (v + ((1 << -SHIFT) >> 1)) >> -SHIFT;
+}
+
 // av1_round_shift_array with bit = -shift (transform/mod.rs:317-331)
 __device__ __forceinline__ T shift_fwd(T v, int shift) {
   // shift > 0: left shift; shift < 0: rounding right shift by -shift
