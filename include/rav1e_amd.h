@@ -280,6 +280,21 @@ int r1_cdef_filter_frame_plane(r1_ctx *ctx, const R1Plane *luma, const R1Plane *
                                const uint8_t *cdef_index_sb, int sb_stride,
                                const R1CdefParams *params, void *stream);
 
+/* ---- lookahead cost maps (SURVEY.md 8f "N1"; reference:
+ * estimate_intra_costs src/api/lookahead.rs:30-123,
+ * estimate_importance_block_difference 125-180, the SATD map of
+ * estimate_inter_costs 226-268).  One launch per frame; the 8x8 importance
+ * blocks are independent.  costs: (height/8) * (width/8) u32, row-major.
+ * mvs: (row, col) int16 pairs in 1/8 pel per importance block
+ * (stats[y*2][x*2].mv; the motion search itself is not part of this call).
+ * sum_out: device u64 = sum over blocks of |mean(org) - mean(ref)| (the
+ * reference divides by the block count in f64). */
+int r1_estimate_intra_costs(r1_ctx *ctx, const R1Plane *luma, uint32_t *costs, void *stream);
+int r1_estimate_inter_costs(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
+                            const int16_t *mvs, uint32_t *costs, void *stream);
+int r1_importance_block_difference(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
+                                   uint64_t *sum_out, void *stream);
+
 /* ---- fused RDO candidate: the headline path.  For each candidate:
  *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)
  *   sad    = get_sad(org @ (ox,oy), pred)       if sad_out     (src/dist.rs:31)

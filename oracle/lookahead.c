@@ -1,0 +1,83 @@
+/*
+ * oracle/lookahead.c -- TEST INFRASTRUCTURE (see r1_oracle.h).
+ * The lookahead cost maps (SURVEY.md 8f "N1"), composed from the scalar
+ * restatements exactly as the reference composes its own kernels:
+ *   estimate_intra_costs                  src/api/lookahead.rs:30-123
+ *     (get_intra_edges -> DC_PRED predict_intra -> get_satd per 8x8 block)
+ *   estimate_importance_block_difference  src/api/lookahead.rs:125-180
+ *   estimate_inter_costs (the SATD map)   src/api/lookahead.rs:226-268
+ *     (the motion vectors come from compute_motion_vectors -- motion search is
+ *      a separate "next" row -- and are an input here)
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "r1_oracle.h"
+
+static inline const uint8_t *pat(const r1o_plane *p, int x, int y) {
+  return (const uint8_t *)p->data +
+         ((size_t)(p->yorigin + y) * p->stride + (size_t)(p->xorigin + x)) * p->bytes_per_px;
+}
+
+/* costs: (height/8) * (width/8) entries, row-major */
+void r1o_estimate_intra_costs(const r1o_plane *plane, int bit_depth, uint32_t *costs) {
+  const int hbd = plane->bytes_per_px == 2, bpp = plane->bytes_per_px;
+  const int wb = plane->width / 8, hb = plane->height / 8;
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < hb; y++)
+    for (int x = 0; x < wb; x++) {
+      uint16_t edge16[257];
+      uint8_t edge8[257];
+      void *edge = hbd ? (void *)edge16 : (void *)edge8;
+      int lens[2];
+      /* dst = plane.as_region(): the tile is the whole plane */
+      r1o_get_intra_edges(edge, lens, pat(plane, 0, 0), plane->stride, x * 8, y * 8, plane->width,
+                          plane->height, 1 /* TX_8X8 */, bit_depth, 0 /* DC_PRED */, 0, 0, 0, 0, hbd);
+      uint16_t pred16[64];
+      uint8_t pred8[64];
+      void *pred = hbd ? (void *)pred16 : (void *)pred8;
+      r1o_predict_intra(0, x * 8, y * 8, pred, 8, 1, bit_depth, NULL, 0, 0, 0, edge, lens[0], lens[1],
+                        8, 8, hbd);
+      costs[y * wb + x] = r1o_get_satd(pat(plane, x * 8, y * 8), plane->stride, pred, 8, 8, 8, hbd);
+      (void)bpp;
+    }
+}
+
+/* returns the integer sum of |mean_org - mean_ref| over the importance blocks
+ * (the reference divides by the block count in f64 afterwards) */
+uint64_t r1o_importance_block_difference(const r1o_plane *org, const r1o_plane *ref) {
+  const int hbd = org->bytes_per_px == 2;
+  const int wb = org->width / 8, hb = org->height / 8;
+  uint64_t total = 0;
+  for (int y = 0; y < hb; y++)
+    for (int x = 0; x < wb; x++) {
+      int64_t so = 0, sr = 0;
+      for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) {
+          const uint8_t *a = pat(org, x * 8 + j, y * 8 + i), *b = pat(ref, x * 8 + j, y * 8 + i);
+          so += hbd ? *(const uint16_t *)a : *a;
+          sr += hbd ? *(const uint16_t *)b : *b;
+        }
+      const int64_t d = (so + 32) / 64 - (sr + 32) / 64;
+      total += (uint64_t)(d < 0 ? -d : d);
+    }
+  return total;
+}
+
+/* mvs: (row, col) int16 pairs in 1/8 pel, one per importance block (the
+ * reference reads stats[y*2][x*2].mv).  costs: per-block SATD. */
+void r1o_estimate_inter_costs(const r1o_plane *org, const r1o_plane *ref, const int16_t *mvs,
+                              uint32_t *costs) {
+  const int hbd = org->bytes_per_px == 2;
+  const int wb = org->width / 8, hb = org->height / 8;
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < hb; y++)
+    for (int x = 0; x < wb; x++) {
+      const int64_t rx = (int64_t)x * 64 + mvs[2 * (y * wb + x) + 1];
+      const int64_t ry = (int64_t)y * 64 + mvs[2 * (y * wb + x)];
+      /* `as isize / 8`: Rust integer division truncates toward zero */
+      const int px = (int)(rx / 8), py = (int)(ry / 8);
+      costs[y * wb + x] = r1o_get_satd(pat(org, x * 8, y * 8), org->stride, pat(ref, px, py),
+                                       ref->stride, 8, 8, hbd);
+    }
+}

@@ -158,6 +158,11 @@ void r1o_cdef_filter_tile_plane(const r1o_plane *luma, const r1o_plane *in, cons
                                 int mi_rows, const uint8_t *cdef_index_sb, int sb_stride,
                                 const uint8_t *y_strengths, const uint8_t *uv_strengths,
                                 int damping, int bit_depth);
+/* lookahead cost maps (src/api/lookahead.rs:30-268) */
+void r1o_estimate_intra_costs(const r1o_plane *plane, int bit_depth, uint32_t *costs);
+uint64_t r1o_importance_block_difference(const r1o_plane *org, const r1o_plane *ref);
+void r1o_estimate_inter_costs(const r1o_plane *org, const r1o_plane *ref, const int16_t *mvs,
+                              uint32_t *costs);
 void r1o_set_threads(int n);
 int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
                    int h, const r1o_dist_cand *c, int n, uint32_t *out);

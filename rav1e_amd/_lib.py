@@ -44,6 +44,9 @@ SYMBOLS = {
     "r1_cdef_filter_block_batch": (_i, [_vp, _PP, _PP, _i, _i, _vp, _i, _vp]),
     "r1_cdef_filter_frame_plane": (_i, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i, _i,
                                         _vp, _i, C.POINTER(R1CdefParams), _vp]),
+    "r1_estimate_intra_costs": (_i, [_vp, _PP, _vp, _vp]),
+    "r1_estimate_inter_costs": (_i, [_vp, _PP, _PP, _vp, _vp, _vp]),
+    "r1_importance_block_difference": (_i, [_vp, _PP, _PP, _vp, _vp]),
     "r1_mc_put_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_prep_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_avg_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

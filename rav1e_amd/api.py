@@ -282,6 +282,37 @@ class Context:
             cdef_index_sb.data_ptr(), cdef_index_sb.stride(0), C.byref(prm), _stream_ptr()),
             "r1_cdef_filter_frame_plane")
 
+    # ---- lookahead cost maps ----
+    def estimate_intra_costs(self, luma):
+        """estimate_intra_costs (src/api/lookahead.rs:30-123) -> (h/8, w/8) int32"""
+        hb, wb = luma.height // 8, luma.width // 8
+        out = torch.empty((hb, wb), dtype=torch.int32, device="cuda")
+        pl = luma.cstruct()
+        self._check(self.lib.r1_estimate_intra_costs(self.h, C.byref(pl), out.data_ptr(),
+                                                     _stream_ptr()), "r1_estimate_intra_costs")
+        return out
+
+    def estimate_inter_costs(self, org, ref, mvs):
+        """SATD map of estimate_inter_costs (lookahead.rs:226-268); mvs: (h/8, w/8, 2)
+        int16 device tensor of (row, col) in 1/8 pel"""
+        hb, wb = org.height // 8, org.width // 8
+        out = torch.empty((hb, wb), dtype=torch.int32, device="cuda")
+        a, b = org.cstruct(), ref.cstruct()
+        self._check(self.lib.r1_estimate_inter_costs(self.h, C.byref(a), C.byref(b), mvs.data_ptr(),
+                                                     out.data_ptr(), _stream_ptr()),
+                    "r1_estimate_inter_costs")
+        return out
+
+    def importance_block_difference(self, org, ref):
+        """estimate_importance_block_difference (lookahead.rs:125-180) -> f64"""
+        out = torch.zeros(1, dtype=torch.int64, device="cuda")
+        a, b = org.cstruct(), ref.cstruct()
+        self._check(self.lib.r1_importance_block_difference(self.h, C.byref(a), C.byref(b),
+                                                            out.data_ptr(), _stream_ptr()),
+                    "r1_importance_block_difference")
+        n = (org.height // 8) * (org.width // 8)
+        return float(out.item()) / n
+
     # ---- mc:: ----
     def put_8tap_batch(self, ref, w, h, cands, n=None, out=None):
         dc = _dev_cands(cands, MC_CAND)

@@ -87,6 +87,9 @@ def lib():
         "r1o_cdef_adjust_strength": (i, [i, i]),
         "r1o_cdef_filter_tile_plane": (None, [vp, vp, vp, i, i, i, i, i, vp, i, i, i, vp, i, vp, vp,
                                               i, i]),
+        "r1o_estimate_intra_costs": (None, [vp, i, vp]),
+        "r1o_importance_block_difference": (C.c_uint64, [vp, vp]),
+        "r1o_estimate_inter_costs": (None, [vp, vp, vp, vp]),
         "r1o_diff": (None, [vp, vp, pd, vp, pd, i, i, i]),
         "r1o_set_threads": (None, [i]),
         "r1o_dist_batch": (i, [i, vp, vp, i, i, vp, i, vp]),

@@ -792,3 +792,37 @@ def test_compat_shims_inverse_cdef_ipred(ctx, oracle):
         tl = C.c_void_p(KAT_EDGE.ctypes.data + 128)
         assert L.rav1e_ipred_hip(O.ptr(out), 4, tl, 4, 4, angle, mode, variant, 0, 4, 4, 4, 4, None, 8) == 0
         assert out.ravel().tolist() == want, (mode, variant)
+
+
+# --------------------------------------------------- lookahead cost maps (N1)
+@pytest.mark.parametrize("bd", [8, 10])
+def test_lookahead_cost_maps(ctx, oracle, bd):
+    """estimate_intra_costs / estimate_inter_costs / importance block difference
+    for a whole frame vs the oracle's composition of get_intra_edges ->
+    DC_PRED -> get_satd (src/api/lookahead.rs:30-268)."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(31 + bd)
+    a = O.HostPlane(328, 184, bd, rng=rng)        # not multiples of 64
+    b = O.HostPlane(328, 184, bd, rng=rng)
+    yy, xx = np.mgrid[0:184, 0:328]
+    a.view()[:] = np.clip((np.sin(xx / 9.0) + np.cos(yy / 5.0)) * 60 * (1 << (bd - 8)) +
+                          (1 << (bd - 1)) + rng.integers(-8, 9, (184, 328)), 0, (1 << bd) - 1)
+    da, db = dev_plane(a), dev_plane(b)
+    hb, wb = 184 // 8, 328 // 8
+    pa, pb = a.cstruct(), b.cstruct()
+    want = np.zeros(hb * wb, np.uint32)
+    oracle.r1o_estimate_intra_costs(C.byref(pa), bd, O.ptr(want))
+    got = ctx.estimate_intra_costs(da).cpu().numpy().view(np.uint32).ravel()
+    assert np.array_equal(got, want)
+    mvs = rng.integers(-300, 301, (hb, wb, 2)).astype(np.int16)
+    want = np.zeros(hb * wb, np.uint32)
+    oracle.r1o_estimate_inter_costs(C.byref(pa), C.byref(pb), O.ptr(mvs), O.ptr(want))
+    got = ctx.estimate_inter_costs(da, db, torch.from_numpy(mvs).cuda()).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got.ravel(), want)
+    tot = oracle.r1o_importance_block_difference(C.byref(pa), C.byref(pb))
+    assert ctx.importance_block_difference(da, db) == tot / (hb * wb)
+    # a flat frame predicts itself: intra cost 0 away from the frame corner
+    flat = O.HostPlane(64, 64, bd, fill=77 << (bd - 8))
+    c = ctx.estimate_intra_costs(dev_plane(flat)).cpu().numpy()
+    assert (c.ravel()[1:] == 0).all() and c[0, 0] != 0
