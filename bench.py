@@ -89,7 +89,7 @@ def cpu_baseline(args, host_org, host_ref, cands):
                       "OpenMP over candidates" % (100 * frac, dt)}
 
 
-def pmc_traffic(bpp, size, fw, fh, k):
+def pmc_traffic(bd, size, fw, fh, k):
     """HBM bytes per launch of the dominant kernel from the PMC counters
     (FETCH_SIZE / WRITE_SIZE), collected in separate `rocprofv3 --pmc` passes of
     this same workload (tools/gpu_pmc.sh) and summarised by tools/pmc_summary.py
@@ -104,7 +104,7 @@ def pmc_traffic(bpp, size, fw, fh, k):
         return None, None
     d = json.load(open(files[-1]))
     lg = {64: 6, 32: 5, 16: 4, 8: 3}[size]
-    key = "k_rdo_cand<%d,%d,%d,%s>" % (bpp, lg, lg, "short" if bpp == 1 else "int")
+    key = "k_rdo_cand<%d,%d,%d,%s>" % (bd, lg, lg, "short" if bd == 8 else "int")
     if key not in d or "hbm_traffic_bytes" not in d[key]:
         return None, None
     return int(d[key]["hbm_traffic_bytes"]), (
@@ -162,6 +162,8 @@ def main():
     if world > 1:
         send, gathered = tiles.make_exchange_buffers(ref.data, rank, world)
 
+    launches = {s: ctx.prepare_rdo_cand(org, ref, s, s, dcands[s], len(cands[s]), outs[s])
+                for s in cands if len(cands[s])}
     ev = {s: [] for s in cands}
     # per-kernel events feed `roofline` (N = 1); at N > 1 they would only add
     # host work to steps that are a fraction of a millisecond long
@@ -175,7 +177,7 @@ def main():
             if timed and use_events:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            ctx.rdo_cand_batch(org, ref, s, s, dcands[s], n=n, outs=outs[s])
+            launches[s]()
             if timed and use_events:
                 e1.record()
                 ev[s].append((e0, e1))
@@ -221,8 +223,8 @@ def main():
             n_dom = len(cands[dom])
             abytes = W.algorithmic_bytes_per_cand(dom, dom, bpp) * n_dom
             achieved = abytes / (per[dom] * 1e-3) / 1e9
-            kname = "k_rdo_cand<bpp=%d,%dx%d>" % (bpp, dom, dom)
-            traffic, traffic_note = pmc_traffic(bpp, dom, fw, fh, args.k)
+            kname = "k_rdo_cand<bd=%d,%dx%d>" % (bd, dom, dom)
+            traffic, traffic_note = pmc_traffic(bd, dom, fw, fh, args.k)
         else:
             dom, per = None, {}
             abytes = sum(W.algorithmic_bytes_per_cand(s, s, bpp) * len(c) for s, c in cands.items())

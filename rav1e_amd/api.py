@@ -346,6 +346,27 @@ class Context:
                     "r1_mc_avg_batch")
         return out
 
+
+    def prepare_rdo_cand(self, org, ref, w, h, dcands, n, outs):
+        """Bind one fused-candidate launch once (descriptor and output tensors
+        stay alive in the returned closure): the per-step host cost is then one
+        ctypes call -- what a native caller of the C ABI pays -- instead of
+        rebuilding the argument structs in Python every step."""
+        from .types import TxSize
+        tx_size = int(TxSize.by_dims(w, h))
+        po, pr = org.cstruct(), ref.cstruct()
+        f = self.lib.r1_rdo_cand_batch
+        args = [self.h, C.byref(po), C.byref(pr), w, h, tx_size, dcands.data_ptr(), n,
+                outs["sad"].data_ptr(), outs["satd"].data_ptr(), outs["coeffs"].data_ptr(), None]
+        keep = (po, pr, dcands, outs)
+
+        def launch():
+            rc = f(*args, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                self._check(rc, "r1_rdo_cand_batch")
+            return keep
+        return launch
+
     # ---- fused candidate ----
     def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,
                        want_coeffs=True, want_pred=False, outs=None):
