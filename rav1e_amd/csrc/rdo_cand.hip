@@ -358,8 +358,8 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   }
   uint8_t *win = smem + cl * (H + 7) * WS;
   if (live)
-    r1mc::stage_window_ct<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P>(win, WS, ref, cd.rx,
-                                                                      cd.ry, c);
+    r1mc::stage_window_fast<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P>(win, WS, ref, cd.rx,
+                                                                        cd.ry, c);
   __syncthreads();
 
   // ---- B: prediction column, residual, SAD / SATD ----
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64) void k_mc_fast(R1Plane ref, const R1McCand *__r
   if (live) cd = cands[cand];
   uint8_t *win = smem + cl * (H + 7) * WS;
   if (live)
-    r1mc::stage_window_ct<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P>(win, WS, ref, cd.rx, cd.ry, c);
+    r1mc::stage_window_fast<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P>(win, WS, ref, cd.rx, cd.ry, c);
   __syncthreads();
   const bool any_cf0 = __any(live && cd.col_frac == 0);
   if (!(live && c < W)) return;
