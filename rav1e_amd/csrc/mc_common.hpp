@@ -200,12 +200,60 @@ __device__ __forceinline__ void stage_window_rows(uint8_t *win, int ws, const R1
     if (lane_on && r0 + u * RP < NR) *(uint32_t *)(w0 + u * RP * ws) = (v[u] >> sh) ^ XORM;
 }
 
+// 8-byte variant of the row mapping: lane l owns the 8-byte chunk ch = l % NDV
+// of rows r0 + u * RP.  The last chunk of a row is read ENDING at the row end
+// (it overlaps its neighbour) so the documented footprint is respected
+// exactly, and shifted into place.  Half as many VMEM instructions as the
+// dword version: for small blocks the kernel is bound by the number of
+// scattered load instructions, not by bytes.
+template <int BPP, uint32_t XORM, int P, int H, int NL>
+__device__ __forceinline__ void stage_window_rows8(uint8_t *win, int ws, const R1Plane &ref,
+                                                   int rx, int ry, int l) {
+  constexpr int ROW_BYTES = (P + 7) * BPP;
+  static_assert(ROW_BYTES >= 8, "window rows are at least 11 bytes");
+  constexpr int NDV = (ROW_BYTES + 7) >> 3;         // 8-byte chunks per row
+  constexpr int RP = NL / NDV;                      // rows per pass
+  static_assert(RP >= 1, "needs a lane per chunk of a row");
+  constexpr int NR = H + 7;
+  constexpr int PASSES = (NR + RP - 1) / RP;
+  constexpr int OVER = NDV * 8 - ROW_BYTES;         // 0..7: overlap of the last chunk
+  constexpr int WSR = ((ROW_BYTES + 3) >> 2) << 2;  // bytes of an LDS row that may be written
+  const int r0 = l / NDV, ch = l - r0 * NDV;
+  const bool lane_on = l < RP * NDV;
+  const int back = ch == NDV - 1 ? OVER : 0;
+  const uint32_t gstride = (uint32_t)ref.stride * BPP;
+  const uint8_t *base = (const uint8_t *)ref.data;
+  uint32_t goff = ((uint32_t)(ref.yorigin + ry - 3 + r0) * (uint32_t)ref.stride +
+                   (uint32_t)(ref.xorigin + rx - 3)) * BPP + (uint32_t)(ch * 8 - back);
+  U32x2 v[PASSES];
+#pragma unroll
+  for (int u = 0; u < PASSES; u++) {
+    v[u].a = 0; v[u].b = 0;
+    if (lane_on && r0 + u * RP < NR) v[u] = ld_u32x2(base + goff);
+    goff += RP * gstride;
+  }
+  uint8_t *w0 = win + r0 * ws + ch * 8;
+  const uint32_t sh = 8u * (uint32_t)back;
+  const bool second = ch * 8 + 4 < WSR;             // the chunk's upper dword lies inside the row
+#pragma unroll
+  for (int u = 0; u < PASSES; u++)
+    if (lane_on && r0 + u * RP < NR) {
+      const uint64_t q = ((((uint64_t)v[u].b) << 32) | v[u].a) >> sh;
+      *(uint32_t *)(w0 + u * RP * ws) = (uint32_t)q ^ XORM;
+      if (second) *(uint32_t *)(w0 + u * RP * ws + 4) = (uint32_t)(q >> 32) ^ XORM;
+    }
+}
+
 // Picks the row-mapped staging when the geometry allows it.
 template <int BPP, uint32_t XORM, int P, int H, int NL>
 __device__ __forceinline__ void stage_window_fast(uint8_t *win, int ws, const R1Plane &ref,
                                                   int rx, int ry, int l) {
   constexpr int ND = ((P + 7) * BPP + 3) >> 2;
-  if constexpr (NL >= ND) stage_window_rows<BPP, XORM, P, H, NL>(win, ws, ref, rx, ry, l);
+  constexpr int NDV = ((P + 7) * BPP + 7) >> 3;
+  // 8-byte chunks pay for the few-lanes-per-candidate shapes (measured: 8x8 -4.6 %,
+  // larger sizes neutral to slightly worse)
+  if constexpr (NL <= 16 && NL >= NDV) stage_window_rows8<BPP, XORM, P, H, NL>(win, ws, ref, rx, ry, l);
+  else if constexpr (NL >= ND) stage_window_rows<BPP, XORM, P, H, NL>(win, ws, ref, rx, ry, l);
   else stage_window_ct<BPP, XORM, P, H, NL>(win, ws, ref, rx, ry, l);
 }
 
