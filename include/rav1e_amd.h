@@ -170,6 +170,17 @@ int r1_quantize_batch(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n,
                       int tx_size, int tx_type, const R1QuantParams *params,
                       int coeff_bytes, void *qcoeffs, uint16_t *eobs,
                       void *rcoeffs, void *stream);
+/* The RDO form of the same call (SURVEY.md 8f "N4", first step): additionally the
+ * transform-domain distortion of encode_tx_block (src/encoder.rs:1616-1640;
+ * coeffs must then hold the full w*h forward-transform output, coeff_stride >=
+ * w*h) and, when est_rate is non-NULL, estimate_rate(qindex, tx_size, tx_dist)
+ * from RDO_RATE_TABLE (src/rdo.rs:127-139) -- what RDOType::TxDistEstRate
+ * uses to rank transform candidates without the entropy coder. */
+int r1_quantize_rdo_batch(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n,
+                          int tx_size, int tx_type, const R1QuantParams *params,
+                          int coeff_bytes, void *qcoeffs, uint16_t *eobs,
+                          void *rcoeffs, uint64_t *tx_dist, uint64_t *est_rate,
+                          void *stream);
 int r1_dequantize_batch(r1_ctx *ctx, const void *qcoeffs, int n, int tx_size,
                         const R1QuantParams *params, int coeff_bytes,
                         void *rcoeffs, void *stream);

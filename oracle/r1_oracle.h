@@ -105,6 +105,14 @@ int r1o_quantize_batch(const void *coeffs, int coeff_stride, int n, int tx_size,
                        int dc_delta_q, int ac_delta_q, int coeff_bytes,
                        void *qcoeffs, uint16_t *eobs, void *rcoeffs);
 
+uint64_t r1o_tx_domain_distortion(const void *coeffs, const void *rcoeffs, int tx_size,
+                                  int coeff32);
+uint64_t r1o_estimate_rate(int qindex, int tx_size, uint64_t fast_distortion);
+int r1o_quantize_rdo_batch(const void *coeffs, int coeff_stride, int n, int tx_size, int tx_type,
+                           int qindex, int bit_depth, int is_intra, int dc_delta_q,
+                           int ac_delta_q, int coeff_bytes, void *qcoeffs, uint16_t *eobs,
+                           void *rcoeffs, uint64_t *tx_dist, uint64_t *est_rate);
+
 /* ---- intra prediction (src/predict.rs, src/partition.rs:639-898) ---- */
 int r1o_intra_mode_to_angle(int mode);
 int r1o_select_ief_strength(int width, int height, int smooth, int angle_delta);

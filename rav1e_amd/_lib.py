@@ -36,6 +36,8 @@ SYMBOLS = {
     "r1_inv_txfm_add_batch": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "r1_quantize_batch": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(R1QuantParams), _i, _vp, _vp,
                                _vp, _vp]),
+    "r1_quantize_rdo_batch": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(R1QuantParams), _i, _vp, _vp,
+                                   _vp, _vp, _vp, _vp]),
     "r1_dequantize_batch": (_i, [_vp, _vp, _i, _i, C.POINTER(R1QuantParams), _i, _vp, _vp]),
     "r1_intra_edges_batch": (_i, [_vp, _PP, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "r1_predict_intra_batch": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),

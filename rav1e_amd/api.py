@@ -194,6 +194,26 @@ class Context:
             _stream_ptr()), "r1_quantize_batch")
         return {"qcoeffs": q, "eobs": eobs, "rcoeffs": r}
 
+    def quantize_rdo_batch(self, coeffs, tx_size, tx_type, qindex, bit_depth, is_intra,
+                           dc_delta_q=0, ac_delta_q=0, want_rate=True):
+        """quantize + dequantize + transform-domain distortion + estimate_rate
+        (src/encoder.rs:1556-1650, src/rdo.rs:127-139) over n blocks; coeffs must
+        hold the full w*h forward-transform output per block."""
+        w, h = TX_DIMS[int(tx_size)]
+        area = min(w, 32) * min(h, 32)
+        n = coeffs.shape[0]
+        q = torch.empty((n, area), dtype=coeffs.dtype, device="cuda")
+        r = torch.empty((n, area), dtype=coeffs.dtype, device="cuda")
+        eobs = torch.empty(n, dtype=torch.int16, device="cuda")
+        dist = torch.empty(n, dtype=torch.int64, device="cuda")
+        rate = torch.empty(n, dtype=torch.int64, device="cuda") if want_rate else None
+        qp = self._qparams(qindex, bit_depth, is_intra, dc_delta_q, ac_delta_q)
+        self._check(self.lib.r1_quantize_rdo_batch(
+            self.h, coeffs.data_ptr(), coeffs.stride(0), n, int(tx_size), int(tx_type), C.byref(qp),
+            coeffs.element_size(), q.data_ptr(), eobs.data_ptr(), r.data_ptr(), dist.data_ptr(),
+            rate.data_ptr() if rate is not None else None, _stream_ptr()), "r1_quantize_rdo_batch")
+        return {"qcoeffs": q, "eobs": eobs, "rcoeffs": r, "tx_dist": dist, "est_rate": rate}
+
     def dequantize_batch(self, qcoeffs, tx_size, qindex, bit_depth, dc_delta_q=0, ac_delta_q=0):
         """rust::dequantize (src/quantize/mod.rs:363-384) over n coded-area blocks."""
         n = qcoeffs.shape[0]

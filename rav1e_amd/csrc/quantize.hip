@@ -31,6 +31,8 @@
 
 #include "tx_common.hpp"
 #include "quant_tables.inc"
+#define R1_TABLE_QUAL __constant__
+#include "rate_table.inc"
 
 namespace {
 
@@ -48,11 +50,30 @@ __device__ __forceinline__ uint32_t divu_pair(uint32_t x, uint32_t a, uint32_t b
   return (uint32_t)((((uint64_t)a * x + b) >> 32) >> s);
 }
 
-template <typename CT, int GL, int NPL>
+// estimate_rate (src/rdo.rs:127-139): piecewise-linear lookup in RDO_RATE_TABLE
+__device__ __forceinline__ unsigned long long estimate_rate(int q_bin, int tx_size,
+                                                            unsigned long long fd) {
+  unsigned long long down = fd / 2000;
+  down = down > 48 ? 48 : down;
+  const unsigned long long up = down + 1;
+  const long long x0 = (long long)(down * 2000);
+  const long long y0 = kR1RdoRateTable[q_bin][tx_size][down], y1 = kR1RdoRateTable[q_bin][tx_size][up];
+  const long long slope = ((y1 - y0) * 256) / 2000;
+  const long long v = y0 + ((((long long)fd - x0) * slope) >> 8);
+  return v < 0 ? 0ull : (unsigned long long)v;
+}
+
+// DIST: also the transform-domain distortion of encode_tx_block
+// (src/encoder.rs:1616-1640: sum (coeff - rcoeff)^2 over the coded area + sum
+// coeff^2 beyond it, rounding shift by 2 * (3 - log_tx_scale)) and the table
+// rate estimate for it.
+template <typename CT, int GL, int NPL, bool DIST>
 __global__ __launch_bounds__(256) void k_quantize(
     const CT *__restrict__ coeffs, int coeff_stride, int n, int area,
     const uint16_t *__restrict__ scan, QParams qp, CT *__restrict__ qcoeffs,
-    uint16_t *__restrict__ eobs, CT *__restrict__ rcoeffs) {
+    uint16_t *__restrict__ eobs, CT *__restrict__ rcoeffs, int full_area, int tx_size,
+    int q_bin, unsigned long long *__restrict__ tx_dist,
+    unsigned long long *__restrict__ est_rate) {
   constexpr int G = 1 << GL, BPW = 64 / G;     // lanes per block, blocks per wave
   __shared__ int32_t lds[4][BPW * G * NPL];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -95,6 +116,7 @@ __global__ __launch_bounds__(256) void k_quantize(
   q0 = __shfl(q0, g << GL, 64);
   const int eob = eob_m1 > 0 ? eob_m1 + 1 : (q0 != 0);
   int carry = 1;   // level_mode starts at 1
+  unsigned long long dist = 0;
 #pragma unroll
   for (int k = 0; k < NPL; k++) {
     const int i = k * G + l;
@@ -124,6 +146,36 @@ __global__ __launch_bounds__(256) void k_quantize(
     int32_t q = act ? (c < 0 ? -(int32_t)aq : (int32_t)aq) : 0;
     if (i == 0) q = q0;
     if (live) mine[pos[k]] = q;
+    if constexpr (DIST) {
+      const int32_t qt = (int32_t)(CT)q;
+      const uint32_t quant = pos[k] == 0 ? qp.dc_q : qp.ac_q;
+      const int32_t off = (1 << qp.lts) - 1;
+      const int32_t r = (int32_t)(CT)((int32_t)((uint32_t)qt * quant + (uint32_t)((qt >> 31) & off)) >> qp.lts);
+      const int32_t dd = (int32_t)((uint32_t)cv[k] - (uint32_t)r);
+      // `(c * c) as u64`: i32 product (wrapping), sign-extended
+      if (live) dist += (unsigned long long)(long long)(int32_t)((uint32_t)dd * (uint32_t)dd);
+    }
+  }
+  if constexpr (DIST) {
+    if (live) {   // coefficients beyond the coded area (64-point sizes): rcoeff = 0
+      const CT *src = coeffs + blk * coeff_stride;
+      for (int i = area + l; i < full_area; i += G) {
+        const int32_t c = (int32_t)src[i];
+        dist += (unsigned long long)(long long)(int32_t)((uint32_t)c * (uint32_t)c);
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) {
+      const uint32_t lo = __shfl_xor((uint32_t)dist, m, 64);
+      const uint32_t hi = __shfl_xor((uint32_t)(dist >> 32), m, 64);
+      dist += ((unsigned long long)hi << 32) | lo;
+    }
+    if (live && l == 0) {
+      const int bits = 2 * (3 - qp.lts);
+      const unsigned long long d = (dist + (1ull << (bits - 1))) >> bits;
+      tx_dist[blk] = d;
+      if (est_rate) est_rate[blk] = estimate_rate(q_bin, tx_size, d);
+    }
   }
   __builtin_amdgcn_wave_barrier();
   // 4: write back (coalesced), dequantize on the way (mod.rs:372-383)
@@ -200,19 +252,21 @@ void gen_scan(int kind, int W, int H, uint16_t *scan) {
   }
 }
 
-template <typename CT>
+template <typename CT, bool DIST>
 int launch_q(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n, int tx_size,
              int kind, const QParams &qp, void *q, uint16_t *eobs, void *r,
-             hipStream_t st) {
+             int q_bin, uint64_t *tx_dist, uint64_t *est_rate, hipStream_t st) {
+  const int full_area = 1 << (r1tx::kTxWLog2[tx_size] + r1tx::kTxHLog2[tx_size]);
   const int area = coded_dim(r1tx::kTxWLog2[tx_size]) * coded_dim(r1tx::kTxHLog2[tx_size]);
   const uint16_t *scan = ctx->scan_dev + ctx->scan_off[tx_size][kind];
 #define R1_Q_LAUNCH(GL, NPL)                                                          \
   do {                                                                                \
     constexpr int BPWG = 4 * (64 >> GL);                                              \
     const unsigned grid = (unsigned)((n + BPWG - 1) / BPWG);                          \
-    hipLaunchKernelGGL((k_quantize<CT, GL, NPL>), dim3(grid), dim3(256), 0, st,       \
+    hipLaunchKernelGGL((k_quantize<CT, GL, NPL, DIST>), dim3(grid), dim3(256), 0, st, \
                        (const CT *)coeffs, coeff_stride, n, area, scan, qp, (CT *)q,  \
-                       eobs, (CT *)r);                                                \
+                       eobs, (CT *)r, full_area, tx_size, q_bin,                      \
+                       (unsigned long long *)tx_dist, (unsigned long long *)est_rate); \
   } while (0)
   switch (area) {
     case 16: R1_Q_LAUNCH(4, 1); break;
@@ -252,19 +306,22 @@ void r1_scan_tables_destroy(r1_ctx *c) {
   c->scan_dev = nullptr;
 }
 
-extern "C" int r1_quantize_batch(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n,
-                                 int tx_size, int tx_type, const R1QuantParams *p,
-                                 int coeff_bytes, void *qcoeffs, uint16_t *eobs,
-                                 void *rcoeffs, void *stream) {
+namespace {
+int quantize_common(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n, int tx_size,
+                    int tx_type, const R1QuantParams *p, int coeff_bytes, void *qcoeffs,
+                    uint16_t *eobs, void *rcoeffs, uint64_t *tx_dist, uint64_t *est_rate,
+                    bool with_dist, void *stream) {
   R1_REQUIRE(ctx && p);
   // av1_scan_orders has TX_TYPES = 16 columns: WHT_WHT would index out of it
   R1_REQUIRE(r1tx::valid_av1_transform(tx_size, tx_type) && tx_type < 16);
   R1_REQUIRE(p->bit_depth == 8 || p->bit_depth == 10 || p->bit_depth == 12);
   R1_REQUIRE(coeff_bytes == 2 || coeff_bytes == 4);
   const int area = coded_dim(r1tx::kTxWLog2[tx_size]) * coded_dim(r1tx::kTxHLog2[tx_size]);
-  R1_REQUIRE(coeff_stride >= area);
+  const int full_area = 1 << (r1tx::kTxWLog2[tx_size] + r1tx::kTxHLog2[tx_size]);
+  R1_REQUIRE(coeff_stride >= (with_dist ? full_area : area));
   if (n <= 0) return R1_OK;
   R1_REQUIRE(coeffs && qcoeffs && eobs);
+  R1_REQUIRE(!with_dist || tx_dist);
   QParams qp;
   const int bc = bd_class(p->bit_depth);
   qp.dc_q = kR1DcQLookup[bc][clampq(p->qindex + p->dc_delta_q)];
@@ -280,12 +337,37 @@ extern "C" int r1_quantize_batch(r1_ctx *ctx, const void *coeffs, int coeff_stri
   const uint32_t dz = (qp.ac_q - off_eob + (1u << qp.lts) - 1) >> qp.lts;
   qp.deadzone = coeff_bytes == 2 ? (int32_t)(int16_t)dz : (int32_t)dz;
   const int kind = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
+  const int q_bin = p->qindex / 32;   // RDO_QUANT_DIV
   hipStream_t st = (hipStream_t)stream;
+  if (with_dist)
+    return coeff_bytes == 2
+               ? launch_q<int16_t, true>(ctx, coeffs, coeff_stride, n, tx_size, kind, qp, qcoeffs,
+                                         eobs, rcoeffs, q_bin, tx_dist, est_rate, st)
+               : launch_q<int32_t, true>(ctx, coeffs, coeff_stride, n, tx_size, kind, qp, qcoeffs,
+                                         eobs, rcoeffs, q_bin, tx_dist, est_rate, st);
   return coeff_bytes == 2
-             ? launch_q<int16_t>(ctx, coeffs, coeff_stride, n, tx_size, kind, qp, qcoeffs,
-                                 eobs, rcoeffs, st)
-             : launch_q<int32_t>(ctx, coeffs, coeff_stride, n, tx_size, kind, qp, qcoeffs,
-                                 eobs, rcoeffs, st);
+             ? launch_q<int16_t, false>(ctx, coeffs, coeff_stride, n, tx_size, kind, qp, qcoeffs,
+                                        eobs, rcoeffs, q_bin, nullptr, nullptr, st)
+             : launch_q<int32_t, false>(ctx, coeffs, coeff_stride, n, tx_size, kind, qp, qcoeffs,
+                                        eobs, rcoeffs, q_bin, nullptr, nullptr, st);
+}
+}  // namespace
+
+extern "C" int r1_quantize_batch(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n,
+                                 int tx_size, int tx_type, const R1QuantParams *p,
+                                 int coeff_bytes, void *qcoeffs, uint16_t *eobs,
+                                 void *rcoeffs, void *stream) {
+  return quantize_common(ctx, coeffs, coeff_stride, n, tx_size, tx_type, p, coeff_bytes, qcoeffs,
+                         eobs, rcoeffs, nullptr, nullptr, false, stream);
+}
+
+extern "C" int r1_quantize_rdo_batch(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n,
+                                     int tx_size, int tx_type, const R1QuantParams *p,
+                                     int coeff_bytes, void *qcoeffs, uint16_t *eobs,
+                                     void *rcoeffs, uint64_t *tx_dist, uint64_t *est_rate,
+                                     void *stream) {
+  return quantize_common(ctx, coeffs, coeff_stride, n, tx_size, tx_type, p, coeff_bytes, qcoeffs,
+                         eobs, rcoeffs, tx_dist, est_rate, true, stream);
 }
 
 extern "C" int r1_dequantize_batch(r1_ctx *ctx, const void *qcoeffs, int n, int tx_size,

@@ -90,6 +90,9 @@ def lib():
         "r1o_estimate_intra_costs": (None, [vp, i, vp]),
         "r1o_importance_block_difference": (C.c_uint64, [vp, vp]),
         "r1o_estimate_inter_costs": (None, [vp, vp, vp, vp]),
+        "r1o_tx_domain_distortion": (C.c_uint64, [vp, vp, i, i]),
+        "r1o_estimate_rate": (C.c_uint64, [i, i, C.c_uint64]),
+        "r1o_quantize_rdo_batch": (i, [vp, i, i, i, i, i, i, i, i, i, i, vp, vp, vp, vp, vp]),
         "r1o_diff": (None, [vp, vp, pd, vp, pd, i, i, i]),
         "r1o_set_threads": (None, [i]),
         "r1o_dist_batch": (i, [i, vp, vp, i, i, vp, i, vp]),

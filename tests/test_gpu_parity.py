@@ -826,3 +826,36 @@ def test_lookahead_cost_maps(ctx, oracle, bd):
     flat = O.HostPlane(64, 64, bd, fill=77 << (bd - 8))
     c = ctx.estimate_intra_costs(dev_plane(flat)).cpu().numpy()
     assert (c.ravel()[1:] == 0).all() and c[0, 0] != 0
+
+
+# ------------------------ N4 (first step): quantize + tx-domain distortion + rate
+@pytest.mark.parametrize("bd", [8, 10])
+def test_quantize_rdo_vs_oracle(ctx, oracle, bd):
+    """r1_quantize_rdo_batch: eob / qcoeffs / rcoeffs as r1_quantize_batch, plus
+    the transform-domain distortion of encode_tx_block and estimate_rate."""
+    rng = np.random.default_rng(800 + bd)
+    ct = np.int16 if bd == 8 else np.int32
+    for ts in (0, 1, 2, 3, 4, 5, 9, 11, 17, 18):
+        w, h = TX_SIZES[ts]
+        area, full = min(w, 32) * min(h, 32), w * h
+        for qi in (40, 130, 255):
+            n = 77
+            acq = oracle.r1o_ac_q(qi, 0, bd)
+            co = np.clip(rng.integers(-4 * acq, 4 * acq + 1, (n, full)) *
+                         (rng.random((n, full)) < 0.3), np.iinfo(ct).min, np.iinfo(ct).max).astype(ct)
+            if ct == np.int16:
+                co[0, :8] = [32767, -32768, 30000, -30000, 1, -1, 0, 5]   # i32 wrap in c*c
+            q = np.zeros((n, area), ct)
+            r = np.zeros((n, area), ct)
+            eobs = np.zeros(n, np.uint16)
+            dist = np.zeros(n, np.uint64)
+            rate = np.zeros(n, np.uint64)
+            assert oracle.r1o_quantize_rdo_batch(O.ptr(co), full, n, ts, 0, qi, bd, 0, 0, 0, co.itemsize,
+                                                 O.ptr(q), O.ptr(eobs), O.ptr(r), O.ptr(dist),
+                                                 O.ptr(rate)) == 0
+            o = ctx.quantize_rdo_batch(_t(co), ts, 0, qi, bd, 0)
+            assert np.array_equal(o["eobs"].cpu().numpy().view(np.uint16), eobs), (bd, ts, qi)
+            assert np.array_equal(o["qcoeffs"].cpu().numpy(), q), (bd, ts, qi)
+            assert np.array_equal(o["rcoeffs"].cpu().numpy(), r), (bd, ts, qi)
+            assert np.array_equal(o["tx_dist"].cpu().numpy().view(np.uint64), dist), (bd, ts, qi)
+            assert np.array_equal(o["est_rate"].cpu().numpy().view(np.uint64), rate), (bd, ts, qi)

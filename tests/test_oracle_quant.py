@@ -73,3 +73,26 @@ def test_eob_is_last_nonzero_in_scan_order(oracle):
 def test_wht_rejected(oracle):
     co = np.zeros(16, np.int32)
     assert oracle.r1o_quantize(O.ptr(co), O.ptr(co.copy()), 0, 16, 100, 8, 0, 0, 0, 1) == -1
+
+
+def test_tx_domain_distortion_and_rate_definition(oracle):
+    """encode_tx_block's transform-domain distortion (src/encoder.rs:1616-1640)
+    and estimate_rate's interpolation (src/rdo.rs:127-139) by definition."""
+    rng = np.random.default_rng(3)
+    for ts in (1, 3, 4, 11):
+        w, h = TX_W[ts], TX_H[ts]
+        area, full = min(w, 32) * min(h, 32), w * h
+        co = rng.integers(-3000, 3001, full).astype(np.int32)
+        rc = (co[:area] + rng.integers(-40, 41, area)).astype(np.int32)
+        raw = int(((co[:area].astype(np.int64) - rc) ** 2).sum() + (co[area:].astype(np.int64) ** 2).sum())
+        lts = int(full > 256) + int(full > 1024)
+        bits = 2 * (3 - lts)
+        want = (raw + (1 << (bits - 1))) >> bits
+        assert oracle.r1o_tx_domain_distortion(O.ptr(co), O.ptr(rc), ts, 1) == want
+    # table end points and interpolation are monotone between two bins
+    for qi in (0, 100, 255):
+        for ts in (0, 4, 18):
+            a = oracle.r1o_estimate_rate(qi, ts, 4000)
+            b = oracle.r1o_estimate_rate(qi, ts, 5000)
+            c = oracle.r1o_estimate_rate(qi, ts, 6000)
+            assert min(a, c) <= b <= max(a, c)
