@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--k", type=int, default=16, help="candidates per block")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target duration of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="dry run: every rank uses cuda:0 (to exercise the N > 1 control flow on a "
+                         "1-GPU box; numbers are meaningless)")
     ap.add_argument("--no-events", action="store_true",
                     help="skip per-kernel event timing (roofline.achieved falls back to step time)")
     return ap.parse_args()
@@ -127,8 +132,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev_index = 0 if args.single_device else local_rank
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
