@@ -319,6 +319,32 @@ int r1_rdo_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
                       uint32_t *sad_out, uint32_t *satd_out, void *coeffs,
                       void *pred_out, void *stream);
 
+/* ---- full RDO candidate (SURVEY.md 8f "N4"): the fused candidate carried
+ * through the quantizer, i.e. what encode_tx_block computes per transform block
+ * for RDOType::TxDistEstRate (src/encoder.rs:1533-1650) with an inter
+ * prediction in front (src/rdo.rs:1073 rdo_tx_size_type -> motion_compensate ->
+ * encode_tx_block):
+ *   pred, sad, satd, resid, coeffs     as r1_rdo_cand_batch
+ *   eob      = quantize(coeffs -> qcoeffs; scan order of the candidate's tx_type)
+ *                                                   (src/quantize/mod.rs:282-361)
+ *   rcoeffs  = dequantize(qcoeffs)                  (src/quantize/mod.rs:363-384)
+ *   tx_dist  = sum (coeffs - rcoeffs)^2, rounded and shifted by tx_scale
+ *                                                   (src/encoder.rs:1615-1650)
+ *   est_rate = estimate_rate(qindex, tx_size, tx_dist)       (src/rdo.rs:127-139)
+ * One launch; prediction, residual, coefficients and rcoeffs never leave the
+ * CU: 14 bytes per candidate go to HBM.  eob_out, tx_dist_out required;
+ * sad_out, satd_out, est_rate_out optional; qcoeffs_out (optional): dense
+ * coded-area blocks (min(w,32)*min(h,32) int16 for 8-bit / int32 otherwise);
+ * coeffs (optional): the unquantized w*h coefficients as r1_rdo_cand_batch.
+ * tx_type >= 16 (WHT) has no scan order and is rejected by the reference's
+ * table bounds; here the result for such a candidate is unspecified. */
+int r1_rdo_full_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w,
+                           int h, int tx_size, const R1RdoCand *cands, int n,
+                           const R1QuantParams *params, uint32_t *sad_out,
+                           uint32_t *satd_out, uint16_t *eob_out, uint64_t *tx_dist_out,
+                           uint64_t *est_rate_out, void *qcoeffs_out, void *coeffs,
+                           void *stream);
+
 /* ---- per-call compat shims: reference asm signatures, HOST pointers ----
  * SadFn / SatdFn (src/asm/x86/dist/mod.rs:21-43): strides in BYTES. */
 uint32_t rav1e_sad_hip(const uint8_t *src, ptrdiff_t src_stride,

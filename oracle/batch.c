@@ -114,6 +114,56 @@ int r1o_rdo_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, int h,
   return bad ? -1 : 0;
 }
 
+/* One inter RDO candidate end to end, the composition encode_tx_block runs
+ * for RDOType::TxDistEstRate (src/encoder.rs:1533-1650): motion-compensated
+ * prediction (put_8tap) -> residual -> forward_transform -> quantize ->
+ * dequantize -> transform-domain distortion -> estimate_rate.  The
+ * per-candidate tx_type selects both the 1-D kernels and the scan order.
+ * qcoeffs (optional): dense coded-area blocks, coefficient size 2 (8-bit) or 4. */
+int r1o_rdo_full_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, int h,
+                            int tx_size, const r1o_rdo_cand *c, int n, int qindex,
+                            int is_intra, int dc_delta_q, int ac_delta_q,
+                            uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
+                            uint64_t *tx_dist_out, uint64_t *est_rate_out,
+                            void *qcoeffs_out) {
+  const int hbd = org->bytes_per_px == 2;
+  const int cb = hbd ? 4 : 2;
+  if (r1o_tx_width(tx_size) != w || r1o_tx_height(tx_size) != h) return -1;
+  const int cw = w < 32 ? w : 32, ch = h < 32 ? h : 32;
+  const size_t carea = (size_t)cw * ch;
+  int bad = 0;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    uint16_t pred16[64 * 64];
+    int16_t resid[64 * 64];
+    int32_t co[64 * 64], qc[32 * 32], rc[32 * 32]; /* room for either width */
+    void *pred = pred16;
+    r1o_put_8tap(pred, w, at(ref, c[i].rx, c[i].ry), ref->stride, w, h,
+                 c[i].col_frac, c[i].row_frac, c[i].mode_x, c[i].mode_y,
+                 ref->bit_depth, hbd);
+    const void *o = at(org, c[i].ox, c[i].oy);
+    if (sad_out) sad_out[i] = r1o_get_sad(o, org->stride, pred, w, w, h, hbd);
+    if (satd_out) satd_out[i] = r1o_get_satd(o, org->stride, pred, w, w, h, hbd);
+    r1o_diff(resid, o, org->stride, pred, w, w, h, hbd);
+    if (r1o_forward_transform(resid, co, w, tx_size, c[i].tx_type, org->bit_depth, hbd)) {
+      bad = 1;
+      continue;
+    }
+    const int eob = r1o_quantize(co, qc, tx_size, c[i].tx_type, qindex, org->bit_depth,
+                                 is_intra, dc_delta_q, ac_delta_q, hbd);
+    if (eob < 0) {
+      bad = 1;
+      continue;
+    }
+    eob_out[i] = (uint16_t)eob;
+    r1o_dequantize(qc, rc, tx_size, qindex, org->bit_depth, dc_delta_q, ac_delta_q, hbd);
+    tx_dist_out[i] = r1o_tx_domain_distortion(co, rc, tx_size, hbd);
+    if (est_rate_out) est_rate_out[i] = r1o_estimate_rate(qindex, tx_size, tx_dist_out[i]);
+    if (qcoeffs_out) memcpy((uint8_t *)qcoeffs_out + i * carea * cb, qc, carea * cb);
+  }
+  return bad ? -1 : 0;
+}
+
 /* sse_wxh / cdef_dist_wxh (src/rdo.rs:142-224) over a candidate list, with
  * compute_bias = distortion_scale (src/rdo.rs:443-459): one Q14
  * DistortionScale per 8x8 LUMA importance block of the frame,

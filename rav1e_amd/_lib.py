@@ -53,6 +53,8 @@ SYMBOLS = {
     "r1_mc_prep_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_avg_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "r1_rdo_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "r1_rdo_full_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, C.POINTER(R1QuantParams),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rav1e_sad_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_satd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_sad_hbd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),

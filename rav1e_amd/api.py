@@ -387,6 +387,58 @@ class Context:
             return keep
         return launch
 
+    def prepare_rdo_full_cand(self, org, ref, w, h, dcands, n, qindex, outs, is_intra=0):
+        """prepare_rdo_cand for r1_rdo_full_cand_batch (outs: sad, satd, eob, tx_dist, est_rate)."""
+        from .types import TxSize
+        tx_size = int(TxSize.by_dims(w, h))
+        po, pr = org.cstruct(), ref.cstruct()
+        qp = self._qparams(qindex, org.bit_depth, is_intra, 0, 0)
+        f = self.lib.r1_rdo_full_cand_batch
+        args = [self.h, C.byref(po), C.byref(pr), w, h, tx_size, dcands.data_ptr(), n, C.byref(qp),
+                outs["sad"].data_ptr(), outs["satd"].data_ptr(), outs["eob"].data_ptr(),
+                outs["tx_dist"].data_ptr(), outs["est_rate"].data_ptr(), None, None]
+        keep = (po, pr, qp, dcands, outs)
+
+        def launch():
+            rc = f(*args, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                self._check(rc, "r1_rdo_full_cand_batch")
+            return keep
+        return launch
+
+    def rdo_full_cand_batch(self, org, ref, w, h, cands, qindex, is_intra=0, dc_delta_q=0,
+                            ac_delta_q=0, n=None, want_sad=True, want_satd=True, want_rate=True,
+                            want_qcoeffs=False, want_coeffs=False):
+        """mc -> sad/satd -> diff -> forward_transform -> quantize -> dequantize ->
+        tx-domain distortion -> estimate_rate for every candidate, one launch."""
+        from .types import TxSize
+        tx_size = int(TxSize.by_dims(w, h))
+        dc = _dev_cands(cands, RDO_CAND)
+        n = dc.numel() // RDO_CAND.itemsize if n is None else n
+        ct = torch.int16 if org.bpp == 1 else torch.int32
+        o = {"eob": torch.empty(n, dtype=torch.int16, device="cuda"),
+             "tx_dist": torch.empty(n, dtype=torch.int64, device="cuda")}
+        if want_sad:
+            o["sad"] = torch.empty(n, dtype=torch.int32, device="cuda")
+        if want_satd:
+            o["satd"] = torch.empty(n, dtype=torch.int32, device="cuda")
+        if want_rate:
+            o["est_rate"] = torch.empty(n, dtype=torch.int64, device="cuda")
+        if want_qcoeffs:
+            o["qcoeffs"] = torch.empty((n, min(w, 32) * min(h, 32)), dtype=ct, device="cuda")
+        if want_coeffs:
+            o["coeffs"] = torch.empty((n, w * h), dtype=ct, device="cuda")
+        po, pr = org.cstruct(), ref.cstruct()
+        qp = self._qparams(qindex, org.bit_depth, is_intra, dc_delta_q, ac_delta_q)
+
+        def p(k):
+            return o[k].data_ptr() if k in o else None
+        self._check(self.lib.r1_rdo_full_cand_batch(
+            self.h, C.byref(po), C.byref(pr), w, h, tx_size, dc.data_ptr(), n, C.byref(qp),
+            p("sad"), p("satd"), p("eob"), p("tx_dist"), p("est_rate"), p("qcoeffs"), p("coeffs"),
+            _stream_ptr()), "r1_rdo_full_cand_batch")
+        return o
+
     # ---- fused candidate ----
     def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,
                        want_coeffs=True, want_pred=False, outs=None):

@@ -30,47 +30,14 @@
 #include <vector>
 
 #include "tx_common.hpp"
-#include "quant_tables.inc"
-#define R1_TABLE_QUAL __constant__
-#include "rate_table.inc"
+#include "quant_common.hpp"
 
 namespace {
 
-struct QParams {
-  uint32_t dc_q, ac_q;
-  uint32_t dc_a, dc_b, dc_s;   // divu_gen(dc_q)
-  uint32_t ac_a, ac_b, ac_s;   // divu_gen(ac_q)
-  uint32_t dc_offset, ac_offset0, ac_offset1;
-  int32_t deadzone;            // already cast to the coefficient type
-  int32_t lts;                 // log_tx_scale
-};
-
-__device__ __forceinline__ uint32_t divu_pair(uint32_t x, uint32_t a, uint32_t b,
-                                              uint32_t s) {
-  return (uint32_t)((((uint64_t)a * x + b) >> 32) >> s);
-}
-
-// estimate_rate (src/rdo.rs:127-139): piecewise-linear lookup in RDO_RATE_TABLE
-__device__ __forceinline__ unsigned long long estimate_rate(int q_bin, int tx_size,
-                                                            unsigned long long fd) {
-  unsigned long long down = fd / 2000;
-  down = down > 48 ? 48 : down;
-  const unsigned long long up = down + 1;
-  const long long x0 = (long long)(down * 2000);
-  const long long y0 = kR1RdoRateTable[q_bin][tx_size][down], y1 = kR1RdoRateTable[q_bin][tx_size][up];
-  const long long slope = ((y1 - y0) * 256) / 2000;
-  const long long v = y0 + ((((long long)fd - x0) * slope) >> 8);
-  return v < 0 ? 0ull : (unsigned long long)v;
-}
-
-// DIST: also the transform-domain distortion of encode_tx_block
-// (src/encoder.rs:1616-1640: sum (coeff - rcoeff)^2 over the coded area + sum
-// coeff^2 beyond it, rounding shift by 2 * (3 - log_tx_scale)) and the table
-// rate estimate for it.
 template <typename CT, int GL, int NPL, bool DIST>
 __global__ __launch_bounds__(256) void k_quantize(
     const CT *__restrict__ coeffs, int coeff_stride, int n, int area,
-    const uint16_t *__restrict__ scan, QParams qp, CT *__restrict__ qcoeffs,
+    const uint16_t *__restrict__ scan, r1q::QParams qp, CT *__restrict__ qcoeffs,
     uint16_t *__restrict__ eobs, CT *__restrict__ rcoeffs, int full_area, int tx_size,
     int q_bin, unsigned long long *__restrict__ tx_dist,
     unsigned long long *__restrict__ est_rate) {
@@ -88,93 +55,24 @@ __global__ __launch_bounds__(256) void k_quantize(
     for (int k = 0; k < NPL; k++) mine[k * G + l] = (int32_t)src[k * G + l];
   }
   __builtin_amdgcn_wave_barrier();
-  // 2: gather in scan order, eob search
-  int32_t cv[NPL];
-  uint16_t pos[NPL];
-  int eob_m1 = 0;
-#pragma unroll
-  for (int k = 0; k < NPL; k++) {
-    pos[k] = scan[k * G + l];
-    cv[k] = live ? mine[pos[k]] : 0;
-    // T::abs() wraps at T::MIN (mod.rs:296: c.abs() on T::Coeff)
-    const int32_t a = (int32_t)(CT)(cv[k] < 0 ? (CT)(0 - (uint32_t)cv[k]) : (CT)cv[k]);
-    if (a >= qp.deadzone) eob_m1 = k * G + l;   // increasing in k: the max survives
-  }
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) {
-    const int o = __shfl_xor(eob_m1, m, 64);
-    eob_m1 = o > eob_m1 ? o : eob_m1;
-  }
-  // 3: DC (lane 0 of the group holds scan position 0 = coefficient 0)
-  int32_t q0 = 0;
-  {
-    const int32_t c = (int32_t)((uint32_t)cv[0] << qp.lts);
-    const uint32_t a = c < 0 ? 0u - (uint32_t)c : (uint32_t)c;
-    const uint32_t v = divu_pair(a + qp.dc_offset, qp.dc_a, qp.dc_b, qp.dc_s);
-    q0 = (int32_t)(CT)(c < 0 ? -(int32_t)v : (int32_t)v);
-  }
-  q0 = __shfl(q0, g << GL, 64);
-  const int eob = eob_m1 > 0 ? eob_m1 + 1 : (q0 != 0);
-  int carry = 1;   // level_mode starts at 1
-  unsigned long long dist = 0;
-#pragma unroll
-  for (int k = 0; k < NPL; k++) {
-    const int i = k * G + l;
-    // wave-uniform early out is not possible per group; predicate instead
-    const bool act = i >= 1 && i < eob;
-    const int32_t c = (int32_t)((uint32_t)cv[k] << qp.lts);
-    const uint32_t a = c < 0 ? 0u - (uint32_t)c : (uint32_t)c;
-    const uint32_t level0 = divu_pair(a, qp.ac_a, qp.ac_b, qp.ac_s);
-    const uint32_t thr = (level0 + 1) * qp.ac_q;
-    const uint32_t up0 = a + qp.ac_offset0 >= thr, up1 = a + qp.ac_offset1 >= thr;
-    // level_mode 0: offset1 iff level0 > 1; level_mode 1: offset1 iff level0 > 0
-    const uint32_t aq0 = level0 + (level0 > 1 ? up1 : up0);
-    const uint32_t aq1 = level0 + (level0 > 0 ? up1 : up0);
-    // transitions (mod.rs:331-335): 0 -> (aq > 1), 1 -> (aq != 0)
-    uint32_t F = act ? ((aq0 > 1 ? 1u : 0u) | (aq1 != 0 ? 2u : 0u)) : 2u;
-#pragma unroll
-    for (int d = 1; d < G; d <<= 1) {
-      const uint32_t p = __shfl_up(F, d, G);
-      if (l >= d) F = ((F >> (p & 1)) & 1) | (((F >> ((p >> 1) & 1)) & 1) << 1);
-    }
-    uint32_t E = __shfl_up(F, 1, G);
-    if (l == 0) E = 2u;
-    const int mode = (E >> carry) & 1;
-    const uint32_t last = __shfl(F, (g << GL) + G - 1, 64);
-    carry = (last >> carry) & 1;
-    const uint32_t aq = mode ? aq1 : aq0;
-    int32_t q = act ? (c < 0 ? -(int32_t)aq : (int32_t)aq) : 0;
-    if (i == 0) q = q0;
-    if (live) mine[pos[k]] = q;
-    if constexpr (DIST) {
-      const int32_t qt = (int32_t)(CT)q;
-      const uint32_t quant = pos[k] == 0 ? qp.dc_q : qp.ac_q;
-      const int32_t off = (1 << qp.lts) - 1;
-      const int32_t r = (int32_t)(CT)((int32_t)((uint32_t)qt * quant + (uint32_t)((qt >> 31) & off)) >> qp.lts);
-      const int32_t dd = (int32_t)((uint32_t)cv[k] - (uint32_t)r);
-      // `(c * c) as u64`: i32 product (wrapping), sign-extended
-      if (live) dist += (unsigned long long)(long long)(int32_t)((uint32_t)dd * (uint32_t)dd);
-    }
-  }
+  // 2-3: scan-order gather, eob, DC, AC prefix scan (quant_common.hpp)
+  unsigned long long tail = 0;
   if constexpr (DIST) {
     if (live) {   // coefficients beyond the coded area (64-point sizes): rcoeff = 0
       const CT *src = coeffs + blk * coeff_stride;
       for (int i = area + l; i < full_area; i += G) {
         const int32_t c = (int32_t)src[i];
-        dist += (unsigned long long)(long long)(int32_t)((uint32_t)c * (uint32_t)c);
+        tail += (unsigned long long)(long long)(int32_t)((uint32_t)c * (uint32_t)c);
       }
     }
-#pragma unroll
-    for (int m = 1; m < G; m <<= 1) {
-      const uint32_t lo = __shfl_xor((uint32_t)dist, m, 64);
-      const uint32_t hi = __shfl_xor((uint32_t)(dist >> 32), m, 64);
-      dist += ((unsigned long long)hi << 32) | lo;
-    }
+  }
+  int eob = 0;
+  unsigned long long dist = 0;
+  r1q::quantize_group<CT, GL, NPL, DIST>(mine, g << GL, l, live, scan, qp, tail, eob, dist);
+  if constexpr (DIST) {
     if (live && l == 0) {
-      const int bits = 2 * (3 - qp.lts);
-      const unsigned long long d = (dist + (1ull << (bits - 1))) >> bits;
-      tx_dist[blk] = d;
-      if (est_rate) est_rate[blk] = estimate_rate(q_bin, tx_size, d);
+      tx_dist[blk] = dist;
+      if (est_rate) est_rate[blk] = r1q::estimate_rate(q_bin, tx_size, dist);
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -210,26 +108,8 @@ __global__ __launch_bounds__(256) void k_dequantize(const CT *__restrict__ q,
   r[i] = (CT)((int32_t)((uint32_t)c * quant + (uint32_t)((c >> 31) & off)) >> lts);
 }
 
-void divu_gen(uint32_t d, uint32_t *a, uint32_t *b, uint32_t *s) {
-  const unsigned m = 31 - (unsigned)__builtin_clz(d);
-  if ((d & (d - 1)) == 0) {
-    *a = 0xFFFFFFFFu; *b = 0xFFFFFFFFu;
-  } else {
-    const uint64_t t = (1ull << (m + 32)) / d;
-    const uint64_t r = (t * d + d) & 0xFFFFFFFFull;
-    if (r <= (1ull << m)) { *a = (uint32_t)t + 1; *b = 0; }
-    else { *a = (uint32_t)t; *b = (uint32_t)t; }
-  }
-  *s = m;
-}
-
-int coded_dim(int log2) { return log2 > 5 ? 32 : 1 << log2; }
-int bd_class(int bd) { int b = (bd ^ 8) >> 1; return b < 2 ? b : 2; }
-int clampq(int q) { return q < 0 ? 0 : (q > 255 ? 255 : q); }
-int log_tx_scale(int tx_size) {
-  const int area = 1 << (r1tx::kTxWLog2[tx_size] + r1tx::kTxHLog2[tx_size]);
-  return (area > 256) + (area > 1024);
-}
+using r1q::coded_dim;
+using r1q::log_tx_scale;
 
 // scan order rule (see oracle/quantize.c header; verified against the
 // reference's 42 literal tables by tests/golden/gen_quant_golden.py)
@@ -254,7 +134,7 @@ void gen_scan(int kind, int W, int H, uint16_t *scan) {
 
 template <typename CT, bool DIST>
 int launch_q(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n, int tx_size,
-             int kind, const QParams &qp, void *q, uint16_t *eobs, void *r,
+             int kind, const r1q::QParams &qp, void *q, uint16_t *eobs, void *r,
              int q_bin, uint64_t *tx_dist, uint64_t *est_rate, hipStream_t st) {
   const int full_area = 1 << (r1tx::kTxWLog2[tx_size] + r1tx::kTxHLog2[tx_size]);
   const int area = coded_dim(r1tx::kTxWLog2[tx_size]) * coded_dim(r1tx::kTxHLog2[tx_size]);
@@ -322,20 +202,7 @@ int quantize_common(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n, in
   if (n <= 0) return R1_OK;
   R1_REQUIRE(coeffs && qcoeffs && eobs);
   R1_REQUIRE(!with_dist || tx_dist);
-  QParams qp;
-  const int bc = bd_class(p->bit_depth);
-  qp.dc_q = kR1DcQLookup[bc][clampq(p->qindex + p->dc_delta_q)];
-  qp.ac_q = kR1AcQLookup[bc][clampq(p->qindex + p->ac_delta_q)];
-  divu_gen(qp.dc_q, &qp.dc_a, &qp.dc_b, &qp.dc_s);
-  divu_gen(qp.ac_q, &qp.ac_a, &qp.ac_b, &qp.ac_s);
-  const bool intra = p->is_intra != 0;
-  qp.dc_offset = qp.dc_q * (intra ? 109 : 108) / 256;
-  qp.ac_offset0 = qp.ac_q * (intra ? 98 : 97) / 256;
-  qp.ac_offset1 = qp.ac_q * (intra ? 109 : 108) / 256;
-  const uint32_t off_eob = qp.ac_q * (intra ? 88 : 44) / 256;
-  qp.lts = log_tx_scale(tx_size);
-  const uint32_t dz = (qp.ac_q - off_eob + (1u << qp.lts) - 1) >> qp.lts;
-  qp.deadzone = coeff_bytes == 2 ? (int32_t)(int16_t)dz : (int32_t)dz;
+  const r1q::QParams qp = r1q::make_qparams(*p, tx_size, coeff_bytes);
   const int kind = tx_type < 10 ? 0 : ((tx_type & 1) ? 2 : 1);
   const int q_bin = p->qindex / 32;   // RDO_QUANT_DIV
   hipStream_t st = (hipStream_t)stream;
@@ -380,9 +247,7 @@ extern "C" int r1_dequantize_batch(r1_ctx *ctx, const void *qcoeffs, int n, int 
   if (n <= 0) return R1_OK;
   R1_REQUIRE(qcoeffs && rcoeffs);
   const int area = coded_dim(r1tx::kTxWLog2[tx_size]) * coded_dim(r1tx::kTxHLog2[tx_size]);
-  const int bc = bd_class(p->bit_depth);
-  const uint32_t dcq = kR1DcQLookup[bc][clampq(p->qindex + p->dc_delta_q)];
-  const uint32_t acq = kR1AcQLookup[bc][clampq(p->qindex + p->ac_delta_q)];
+  const uint32_t dcq = r1q::dc_q(*p), acq = r1q::ac_q(*p);
   const long long total = (long long)n * area;
   const unsigned grid = (unsigned)((total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;

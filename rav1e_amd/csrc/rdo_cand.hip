@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "mc_common.hpp"
+#include "quant_common.hpp"
 #include "tx_common.hpp"
 
 namespace {
@@ -318,11 +319,25 @@ __device__ __forceinline__ uint32_t satd_column(const T *v, int lane) {
   return acc;
 }
 
-template <int BD, int WL, int HL, typename CT>
+// QUANT (the "full" candidate): the coefficients do not go to HBM
+// (unless `coeffs` is also given) but through the quantizer in place --
+// quantize + dequantize + transform-domain distortion + estimate_rate, i.e.
+// encode_tx_block's RDOType::TxDistEstRate evaluation (src/encoder.rs:1533-1650)
+// -- and only (eob, distortion, rate) leave the CU.
+struct RdoQuantArgs {
+  r1q::QParams qp;
+  const uint16_t *scan[3];   // av1_scan_orders[tx_size]: default / mrow / mcol
+  int tx_size, q_bin;
+  uint16_t *eob;
+  unsigned long long *tx_dist, *est_rate;
+  void *qcoeffs;             // optional: dense coded-area blocks
+};
+
+template <int BD, int WL, int HL, typename CT, bool QUANT>
 __global__ __launch_bounds__(64) void k_rdo_cand(
     R1Plane org, R1Plane ref, const R1RdoCand *__restrict__ cands, int n,
     uint32_t *__restrict__ sad_out, uint32_t *__restrict__ satd_out,
-    CT *__restrict__ coeffs, void *__restrict__ pred_out) {
+    CT *__restrict__ coeffs, void *__restrict__ pred_out, RdoQuantArgs qa) {
   constexpr int BPP = BD == 8 ? 1 : 2;
   // forward-transform shifts of this (size, bit depth): immediates
   constexpr int SH0 = r1tx::fwd_shift_ct(WL, HL, BD, 0), SH1 = r1tx::fwd_shift_ct(WL, HL, BD, 1),
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
     constexpr int LN = TS == 4 ? 2 : 3;
     if (live && c == 0) satd_out[cand] = (s + ((1u << LN) >> 1)) >> LN;
   }
-  if (!coeffs) return;   // wave-uniform: kernel argument
+  if (!QUANT && !coeffs) return;   // wave-uniform: kernel argument
 
   // ---- C: column transform on the residual registers ----
   __syncthreads();  // every lane is done reading the window; LDS becomes buf
@@ -427,22 +442,65 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   }
   __syncthreads();
   // ---- D: row transform, transposed store ----
-  {
-    const int cl2 = lane / P, r = lane % P;   // P lanes per candidate again
-    const long long cand2 = (long long)blockIdx.x * NC + cl2;
-    if (cand2 < n && r < H) {
-      const int tt = cands[cand2].tx_type;
-      T u[W];
+  const int cl2 = lane / P, r = lane % P;   // P lanes per candidate again
+  const long long cand2 = (long long)blockIdx.x * NC + cl2;
+  const bool live2 = cand2 < n;
+  const bool row_live = live2 && r < H;
+  const int tt = live2 ? cands[cand2].tx_type : 0;
+  constexpr int OS = H < 32 ? H : 32, WC = W < 32 ? W : 32;
+  T u[W];
+  if (row_live) {
 #pragma unroll
-      for (int k = 0; k < W; k++) u[k] = buf[r * LSTRIDE + cl2 * W + k];
-      r1tx::fwd_1d_m24<W>(u, r1tx::htx_1d(tt));
-      constexpr int OS = H < 32 ? H : 32, WC = W < 32 ? W : 32;
+    for (int k = 0; k < W; k++) u[k] = buf[r * LSTRIDE + cl2 * W + k];
+    r1tx::fwd_1d_m24<W>(u, r1tx::htx_1d(tt));
+#pragma unroll
+    for (int k = 0; k < W; k++) u[k] = (T)(CT)r1tx::shift_fwd_ct<SH2>(u[k]);   // `as T::Coeff`
+    if (coeffs) {
       CT *dst = coeffs + cand2 * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31);
 #pragma unroll
       for (int cg = 0; cg < W; cg += 32)
 #pragma unroll
-        for (int k = 0; k < WC; k++)
-          dst[H * cg + k * OS] = (CT)r1tx::shift_fwd_ct<SH2>(u[k + cg]);
+        for (int k = 0; k < WC; k++) dst[H * cg + k * OS] = (CT)u[k + cg];
+    }
+  }
+  if constexpr (QUANT) {
+    // ---- E: quantizer on the coded area, in LDS (aliases the transpose tile:
+    // every row lane has its row in registers by now) ----
+    constexpr int CODED = OS * WC;
+    constexpr int PL = WL > HL ? WL : HL;          // log2(P)
+    constexpr int NPLQ = CODED / P;
+    static_assert(CODED % P == 0 && NPLQ >= 1, "P lanes share the coded area");
+    __syncthreads();
+    int32_t *tile = (int32_t *)smem + cl2 * CODED;
+    unsigned long long tail = 0;
+    if (row_live) {
+#pragma unroll
+      for (int k = 0; k < W; k++) {
+        if (r < 32 && k < 32) {
+          tile[k * OS + r] = u[k];
+        } else {   // beyond the coded area: rcoeff = 0 (encoder.rs:1628-1634)
+          tail += (unsigned long long)(long long)(int32_t)((uint32_t)u[k] * (uint32_t)u[k]);
+        }
+      }
+    }
+    __syncthreads();
+    const int kind = tt < 10 ? 0 : ((tt & 1) ? 2 : 1);
+    int eob = 0;
+    unsigned long long dist = 0;
+    r1q::quantize_group<CT, PL, NPLQ, true>(tile, cl2 * P, r, live2, qa.scan[kind], qa.qp, tail,
+                                            eob, dist);
+    if (live2 && r == 0) {
+      qa.eob[cand2] = (uint16_t)eob;
+      qa.tx_dist[cand2] = dist;
+      if (qa.est_rate) qa.est_rate[cand2] = r1q::estimate_rate(qa.q_bin, qa.tx_size, dist);
+    }
+    if (qa.qcoeffs) {
+      __syncthreads();
+      if (live2) {
+        CT *qd = (CT *)qa.qcoeffs + cand2 * CODED;
+#pragma unroll
+        for (int k = 0; k < NPLQ; k++) qd[k * P + r] = (CT)tile[k * P + r];
+      }
     }
   }
 }
@@ -500,12 +558,17 @@ int launch_mc_fast(bool prep, const R1Plane &ref, const R1McCand *cands, int n, 
 
 template <int BD, int WL, int HL>
 int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n,
-           uint32_t *sad, uint32_t *satd, void *coeffs, void *pred, hipStream_t st) {
+           uint32_t *sad, uint32_t *satd, void *coeffs, void *pred, const RdoQuantArgs *qa,
+           hipStream_t st) {
   constexpr int W = 1 << WL, H = 1 << HL, P = W > H ? W : H, NC = 64 / P;
   typedef typename std::conditional<BD == 8, int16_t, int32_t>::type CT;
   const unsigned grid = (unsigned)((n + NC - 1) / NC);
-  hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT>), dim3(grid), dim3(64), 0, st,
-                     org, ref, cands, n, sad, satd, (CT *)coeffs, pred);
+  if (qa)
+    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, true>), dim3(grid), dim3(64), 0, st,
+                       org, ref, cands, n, sad, satd, (CT *)coeffs, pred, *qa);
+  else
+    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, false>), dim3(grid), dim3(64), 0, st,
+                       org, ref, cands, n, sad, satd, (CT *)coeffs, pred, RdoQuantArgs{});
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }
@@ -537,11 +600,10 @@ int r1_mc_fast_launch(bool prep, const R1Plane *ref, int w, int h, const R1McCan
   return 1;
 }
 
-extern "C" int r1_rdo_cand_batch(r1_ctx *ctx, const R1Plane *org,
-                                 const R1Plane *ref, int w, int h, int tx_size,
-                                 const R1RdoCand *cands, int n,
-                                 uint32_t *sad_out, uint32_t *satd_out,
-                                 void *coeffs, void *pred_out, void *stream) {
+namespace {
+int rdo_dispatch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w, int h, int tx_size,
+                 const R1RdoCand *cands, int n, uint32_t *sad_out, uint32_t *satd_out,
+                 void *coeffs, void *pred_out, const RdoQuantArgs *qa, void *stream) {
   R1_REQUIRE(ctx && org && ref);
   R1_REQUIRE(org->bytes_per_px == ref->bytes_per_px);
   R1_REQUIRE(org->bytes_per_px == 1 || org->bytes_per_px == 2);
@@ -561,11 +623,11 @@ extern "C" int r1_rdo_cand_batch(r1_ctx *ctx, const R1Plane *org,
 #define R1_RC_CASE(ID, WL, HL)                                                        \
   case ID:                                                                            \
     return bd == 8    ? launch<8, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,   \
-                                          coeffs, pred_out, st)                       \
+                                          coeffs, pred_out, qa, st)                   \
            : bd == 10 ? launch<10, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,  \
-                                           coeffs, pred_out, st)                      \
+                                           coeffs, pred_out, qa, st)                  \
                       : launch<12, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,  \
-                                           coeffs, pred_out, st);
+                                           coeffs, pred_out, qa, st);
   switch (tx_size) {
     R1_RC_CASE(0, 2, 2) R1_RC_CASE(1, 3, 3) R1_RC_CASE(2, 4, 4)
     R1_RC_CASE(3, 5, 5) R1_RC_CASE(4, 6, 6) R1_RC_CASE(5, 2, 3)
@@ -577,4 +639,36 @@ extern "C" int r1_rdo_cand_batch(r1_ctx *ctx, const R1Plane *org,
   }
 #undef R1_RC_CASE
   return R1_EINVAL;
+}
+}  // namespace
+
+extern "C" int r1_rdo_cand_batch(r1_ctx *ctx, const R1Plane *org,
+                                 const R1Plane *ref, int w, int h, int tx_size,
+                                 const R1RdoCand *cands, int n,
+                                 uint32_t *sad_out, uint32_t *satd_out,
+                                 void *coeffs, void *pred_out, void *stream) {
+  return rdo_dispatch(ctx, org, ref, w, h, tx_size, cands, n, sad_out, satd_out, coeffs, pred_out,
+                      nullptr, stream);
+}
+
+extern "C" int r1_rdo_full_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w,
+                                      int h, int tx_size, const R1RdoCand *cands, int n,
+                                      const R1QuantParams *params, uint32_t *sad_out,
+                                      uint32_t *satd_out, uint16_t *eob_out,
+                                      uint64_t *tx_dist_out, uint64_t *est_rate_out,
+                                      void *qcoeffs_out, void *coeffs, void *stream) {
+  R1_REQUIRE(ctx && org && params && eob_out && tx_dist_out);
+  R1_REQUIRE(tx_size >= 0 && tx_size < 19);
+  R1_REQUIRE(params->bit_depth == org->bit_depth);
+  RdoQuantArgs qa;
+  qa.qp = r1q::make_qparams(*params, tx_size, org->bytes_per_px == 1 ? 2 : 4);
+  for (int k = 0; k < 3; k++) qa.scan[k] = ctx->scan_dev + ctx->scan_off[tx_size][k];
+  qa.tx_size = tx_size;
+  qa.q_bin = params->qindex / 32;   // RDO_QUANT_DIV
+  qa.eob = eob_out;
+  qa.tx_dist = (unsigned long long *)tx_dist_out;
+  qa.est_rate = (unsigned long long *)est_rate_out;
+  qa.qcoeffs = qcoeffs_out;
+  return rdo_dispatch(ctx, org, ref, w, h, tx_size, cands, n, sad_out, satd_out, coeffs, nullptr,
+                      &qa, stream);
 }

@@ -102,6 +102,7 @@ def lib():
         "r1o_mc_prep_batch": (i, [vp, i, i, vp, i, vp]),
         "r1o_mc_avg_batch": (i, [vp, vp, i, i, i, i, i, vp]),
         "r1o_rdo_cand_batch": (i, [vp, vp, i, i, i, vp, i, vp, vp, vp, vp]),
+        "r1o_rdo_full_cand_batch": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         if hasattr(L, name):

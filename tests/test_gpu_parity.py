@@ -859,3 +859,73 @@ def test_quantize_rdo_vs_oracle(ctx, oracle, bd):
             assert np.array_equal(o["rcoeffs"].cpu().numpy(), r), (bd, ts, qi)
             assert np.array_equal(o["tx_dist"].cpu().numpy().view(np.uint64), dist), (bd, ts, qi)
             assert np.array_equal(o["est_rate"].cpu().numpy().view(np.uint64), rate), (bd, ts, qi)
+
+
+# ------------------------ N4: the candidate carried through the quantizer in one launch
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_rdo_full_cand_vs_oracle(ctx, oracle, bd):
+    """r1_rdo_full_cand_batch = put_8tap -> diff -> forward_transform -> quantize ->
+    dequantize -> tx-domain distortion -> estimate_rate (encode_tx_block,
+    RDOType::TxDistEstRate), per-candidate tx_type and scan order, every tx size."""
+    import ctypes as C
+    a, b = planes(bd, seed=60 + bd, pads=(88, 120))
+    # a second reference close to the source: small residuals, short eobs
+    near = planes(bd, seed=60 + bd, pads=(88, 120))[0]
+    nz = np.random.default_rng(5).integers(-3, 4, near.data.shape)
+    dtp = near.data.dtype
+    near.data[...] = np.clip(near.data.astype(np.int64) + nz, 0, (1 << bd) - 1).astype(dtp)
+    da, db, dn = dev_plane(a), dev_plane(b), dev_plane(near)
+    rng = np.random.default_rng(900 + bd)
+    ct = np.int16 if bd == 8 else np.int32
+    for ts, (w, h) in enumerate(TX_SIZES):
+        carea = min(w, 32) * min(h, 32)
+        for hp, dp, qi, intra in ((b, db, 35, 0), (b, db, 200, 1), (near, dn, 20, 0), (near, dn, 110, 0)):
+            n = 37 if w * h <= 1024 else 9
+            c = rand_rdo_cands(rng, n, a.width, a.height, w, h, 50, ts)
+            if hp is near:   # co-located, integer or fractional: residual = interpolation error
+                c["rx"], c["ry"] = c["ox"], c["oy"]
+            pa, pb = a.cstruct(), hp.cstruct()
+            wsad, wsatd = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+            weob = np.zeros(n, np.uint16)
+            wdist, wrate = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+            wq = np.zeros((n, carea), ct)
+            assert oracle.r1o_rdo_full_cand_batch(
+                C.byref(pa), C.byref(pb), w, h, ts, O.ptr(c), n, qi, intra, 0, 0, O.ptr(wsad),
+                O.ptr(wsatd), O.ptr(weob), O.ptr(wdist), O.ptr(wrate), O.ptr(wq)) == 0
+            o = ctx.rdo_full_cand_batch(da, dp, w, h, c, qi, is_intra=intra, want_qcoeffs=True)
+            key = (bd, w, h, qi)
+            assert np.array_equal(o["sad"].cpu().numpy().view(np.uint32), wsad), key
+            assert np.array_equal(o["satd"].cpu().numpy().view(np.uint32), wsatd), key
+            assert np.array_equal(o["qcoeffs"].cpu().numpy(), wq), key
+            assert np.array_equal(o["eob"].cpu().numpy().view(np.uint16), weob), key
+            assert np.array_equal(o["tx_dist"].cpu().numpy().view(np.uint64), wdist), key
+            assert np.array_equal(o["est_rate"].cpu().numpy().view(np.uint64), wrate), key
+            # scalars only (what the mode decision consumes)
+            o2 = ctx.rdo_full_cand_batch(da, dp, w, h, c, qi, is_intra=intra, want_sad=False,
+                                         want_satd=False)
+            assert np.array_equal(o2["tx_dist"].cpu().numpy().view(np.uint64), wdist), key
+            assert np.array_equal(o2["eob"].cpu().numpy().view(np.uint16), weob), key
+
+
+def test_rdo_full_cand_equals_staged_chain(ctx):
+    """Size-independent property at frame scale: the fused launch equals the staged
+    chain r1_rdo_cand_batch -> r1_quantize_rdo_batch on the GPU, per tx type."""
+    import torch
+    a, b = planes(8, w=640, h=384, seed=77)
+    da, db = dev_plane(a), dev_plane(b)
+    rng = np.random.default_rng(78)
+    for ts in (1, 2, 3, 4, 9, 17):
+        w, h = TX_SIZES[ts]
+        n = 2000
+        c = rand_rdo_cands(rng, n, a.width, a.height, w, h, 40, ts)
+        full = ctx.rdo_full_cand_batch(da, db, w, h, c, 90, want_qcoeffs=True, want_coeffs=True)
+        st = ctx.rdo_cand_batch(da, db, w, h, c)
+        assert torch.equal(full["coeffs"], st["coeffs"])
+        assert torch.equal(full["satd"], st["satd"])
+        for tt in np.unique(c["tx_type"]):
+            idx = torch.from_numpy(np.nonzero(c["tx_type"] == tt)[0]).cuda()
+            q = ctx.quantize_rdo_batch(st["coeffs"][idx].contiguous(), ts, int(tt), 90, 8, 0)
+            assert torch.equal(full["qcoeffs"][idx], q["qcoeffs"]), (ts, tt)
+            assert torch.equal(full["eob"][idx], q["eobs"]), (ts, tt)
+            assert torch.equal(full["tx_dist"][idx], q["tx_dist"]), (ts, tt)
+            assert torch.equal(full["est_rate"][idx], q["est_rate"]), (ts, tt)
