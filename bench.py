@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--single-device", action="store_true",
                     help="dry run: every rank uses cuda:0 (to exercise the N > 1 control flow on a "
                          "1-GPU box; numbers are meaningless)")
+    ap.add_argument("--chain", choices=("cand", "full"), default="cand",
+                    help="cand: the headline fused candidate (BASELINE.json north_star); full: the "
+                         "same candidate carried through quantize / tx-domain distortion / rate "
+                         "(r1_rdo_full_cand_batch, SURVEY 8f N4) -- a supplementary line")
+    ap.add_argument("--qindex", type=int, default=100)
     ap.add_argument("--no-events", action="store_true",
                     help="skip per-kernel event timing (roofline.achieved falls back to step time)")
     return ap.parse_args()
@@ -171,8 +176,25 @@ def main():
     if world > 1:
         send, gathered = tiles.make_exchange_buffers(ref.data, rank, world)
 
-    launches = {s: ctx.prepare_rdo_cand(org, ref, s, s, dcands[s], len(cands[s]), outs[s])
-                for s in cands if len(cands[s])}
+    full = args.chain == "full"
+    if full:
+        for s, c in cands.items():
+            n = len(c)
+            del outs[s]["coeffs"]
+            outs[s].update(eob=torch.empty(n, dtype=torch.int16, device="cuda"),
+                           tx_dist=torch.empty(n, dtype=torch.int64, device="cuda"),
+                           est_rate=torch.empty(n, dtype=torch.int64, device="cuda"))
+        launches = {s: ctx.prepare_rdo_full_cand(org, ref, s, s, dcands[s], len(cands[s]),
+                                                 args.qindex, outs[s])
+                    for s in cands if len(cands[s])}
+    else:
+        launches = {s: ctx.prepare_rdo_cand(org, ref, s, s, dcands[s], len(cands[s]), outs[s])
+                    for s in cands if len(cands[s])}
+
+    def abytes_per_cand(s):
+        if full:   # window + source + sad/satd/eob/tx_dist/est_rate; no coefficient store
+            return bpp * ((s + 7) * (s + 7) + s * s) + 4 + 4 + 2 + 8 + 8
+        return W.algorithmic_bytes_per_cand(s, s, bpp)
     ev = {s: [] for s in cands}
     # per-kernel events feed `roofline` (N = 1); at N > 1 they would only add
     # host work to steps that are a fraction of a millisecond long
@@ -230,18 +252,19 @@ def main():
         if per:
             dom = max(per, key=lambda s: per[s])
             n_dom = len(cands[dom])
-            abytes = W.algorithmic_bytes_per_cand(dom, dom, bpp) * n_dom
+            abytes = abytes_per_cand(dom) * n_dom
             achieved = abytes / (per[dom] * 1e-3) / 1e9
-            kname = "k_rdo_cand<bd=%d,%dx%d>" % (bd, dom, dom)
-            traffic, traffic_note = pmc_traffic(bd, dom, fw, fh, args.k)
+            kname = "k_rdo_cand<bd=%d,%dx%d%s>" % (bd, dom, dom, ",quant" if full else "")
+            traffic, traffic_note = (None, None) if full else pmc_traffic(bd, dom, fw, fh, args.k)
         else:
             dom, per = None, {}
-            abytes = sum(W.algorithmic_bytes_per_cand(s, s, bpp) * len(c) for s, c in cands.items())
+            abytes = sum(abytes_per_cand(s) * len(c) for s, c in cands.items())
             achieved = abytes / (dt / args.steps) / 1e9
             kname = "k_rdo_cand (all sizes, step time)"
             traffic, traffic_note = None, None
         res = {
-            "metric": "RDO-candidate Mpixels/s (dist+fwd_tx+mc) at 4K speed-6",
+            "metric": "RDO-candidate Mpixels/s (dist+fwd_tx+mc) at 4K speed-6" if not full else
+                      "full RDO-candidate Mpixels/s (mc+dist+fwd_tx+quantize+tx_dist+rate) at 4K speed-6",
             "value": round(total_px * args.steps / dt / 1e6, 2),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -267,7 +290,7 @@ def main():
                          "avg_launch_ms": round(per[dom], 4) if dom else None},
             "kernel_ms": {str(s): round(v, 4) for s, v in per.items()},
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and not full:
             res["cpu_baseline"] = cpu_baseline(args, host_org, host_ref, cands)
         print(json.dumps(res))
     if world > 1:

@@ -25,6 +25,11 @@ struct QParams {
   uint32_t dc_offset, ac_offset0, ac_offset1;
   int32_t deadzone;            // already cast to the coefficient type
   int32_t lts;                 // log_tx_scale
+  // i16 coefficients (8-bit pixels): |c << lts| <= 2^17, so floor(a / ac_q) is
+  // (a * ac_m24) >> ac_s24 with 24-bit multiplies (m = floor(2^s / q) + 1,
+  // s = 18 + ceil(log2 q): exact for every a < 2^18; swept over every table q in
+  // tests/test_oracle_quant.py::test_narrow_division_magic_is_exact)
+  uint32_t ac_m24, ac_s24;
 };
 
 // ---- host side -----------------------------------------------------------
@@ -53,6 +58,12 @@ inline uint32_t dc_q(const R1QuantParams &p) {
 inline uint32_t ac_q(const R1QuantParams &p) {
   return kR1AcQLookup[bd_class(p.bit_depth)][clampq(p.qindex + p.ac_delta_q)];
 }
+inline void narrow_magic(uint32_t q, uint32_t *m, uint32_t *s) {
+  unsigned L = 0;
+  while ((1u << L) < q) L++;
+  *s = 18 + L;
+  *m = (uint32_t)((1ull << *s) / q) + 1;
+}
 // QuantizationContext::update (mod.rs:219-265) for one (tx size, coefficient type)
 inline QParams make_qparams(const R1QuantParams &p, int tx_size, int coeff_bytes) {
   QParams qp;
@@ -68,6 +79,7 @@ inline QParams make_qparams(const R1QuantParams &p, int tx_size, int coeff_bytes
   qp.lts = log_tx_scale(tx_size);
   const uint32_t dz = (qp.ac_q - off_eob + (1u << qp.lts) - 1) >> qp.lts;
   qp.deadzone = coeff_bytes == 2 ? (int32_t)(int16_t)dz : (int32_t)dz;
+  narrow_magic(qp.ac_q, &qp.ac_m24, &qp.ac_s24);
   return qp;
 }
 
@@ -75,6 +87,22 @@ inline QParams make_qparams(const R1QuantParams &p, int tx_size, int coeff_bytes
 __device__ __forceinline__ uint32_t divu_pair(uint32_t x, uint32_t a, uint32_t b,
                                               uint32_t s) {
   return (uint32_t)((((uint64_t)a * x + b) >> 32) >> s);
+}
+
+// bits 32..47 of the 48-bit product of two 24-bit operands (m: wave-uniform)
+__device__ __forceinline__ uint32_t umulhi24(uint32_t m, uint32_t a) {
+  uint32_t r;
+  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(m), "v"(a));
+  return r;
+}
+
+// low 32 bits of the product of two sign-extended 24-bit operands, as the
+// hardware defines it (__mul24 promises the compiler "no signed overflow",
+// which turns the sign extension of a wrapped square into a zero extension)
+__device__ __forceinline__ int32_t mul24_wrap(int32_t a, int32_t b) {
+  int32_t r;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 // estimate_rate (src/rdo.rs:127-139): piecewise-linear lookup in RDO_RATE_TABLE
@@ -90,11 +118,44 @@ __device__ __forceinline__ unsigned long long estimate_rate(int q_bin, int tx_si
   return v < 0 ? 0ull : (unsigned long long)v;
 }
 
+// Scan positions l*NPL .. l*NPL+NPL-1 of one table, as packed u16 pairs
+// (vector loads: the run of a lane is contiguous in the table).
+template <int NPL>
+struct ScanRun {
+  uint32_t w[NPL >= 2 ? NPL / 2 : 1];
+  __device__ __forceinline__ void load(const uint16_t *__restrict__ scan, int l) {
+    const uint16_t *p = scan + l * NPL;
+    if constexpr (NPL >= 8) {
+#pragma unroll
+      for (int j = 0; j < NPL / 8; j++) {
+        const uint4 v = ((const uint4 *)p)[j];
+        w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+      }
+    } else if constexpr (NPL == 4) {
+      const uint2 v = *(const uint2 *)p;
+      w[0] = v.x; w[1] = v.y;
+    } else if constexpr (NPL == 2) {
+      w[0] = *(const uint32_t *)p;
+    } else {
+      w[0] = *p;
+    }
+  }
+  __device__ __forceinline__ uint32_t at(int k) const {
+    return (k & 1) ? w[k >> 1] >> 16 : w[k >> 1] & 0xFFFFu;
+  }
+};
+
 // G = 1 << GL lanes of a wave (the group's lane 0 is wave lane `g0`) own one
 // block whose coded coefficients sit in LDS `mine` as int32 values of CT
-// (transposed layout).  Lane l visits scan positions l, l+G, ..: gather,
-// eob-1 = max scan index with |c| >= deadzone, DC by lane 0, AC through the
-// 2-state prefix scan (see quantize.hip header).  On return `mine` holds the
+// (transposed layout).  Lane l owns the contiguous run of scan positions
+// [l*NPL, (l+1)*NPL): gather, eob-1 = max scan index with |c| >= deadzone, DC
+// by lane 0, then the AC loop of mod.rs:311-336.  Its only serial dependence
+// is level_mode (one bit), so every element is a function {0,1} -> {0,1}
+// (2 bits: what level_mode becomes for either incoming value) and both
+// candidate levels are computed up front; they differ by at most 1 (only
+// level0 == 1 makes the two offsets matter).  A lane composes its run
+// sequentially (one bfe per state), one log2(G)-step scan composes the lanes,
+// and a replay pass picks the level per element.  On return `mine` holds the
 // quantized coefficients, eob the reference's return value and -- DIST -- dist
 // the transform-domain distortion (coded part + `tail` = the caller's partial
 // sum of squares beyond the coded area), already rounded and shifted.
@@ -104,16 +165,24 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
                                                const QParams &qp, unsigned long long tail,
                                                int &eob_out, unsigned long long &dist_out) {
   constexpr int G = 1 << GL;
+  // i16 coefficients: every product below fits the 24-bit multipliers
+  // (v_mul_u32_u24 / v_mul_hi_u32_u24: full rate; v_mul_lo_u32 / v_mad_u64_u32
+  // are quarter rate).  The i16 <-> 8-bit coupling is the reference's own
+  // (T::Coeff, src/util/mod.rs) and is enforced at the entry points.
+  constexpr bool NARROW = sizeof(CT) == 2;
+  // LDS accesses are unconditional: a dead group owns its (unused) slice of
+  // the tile all the same and nothing of it reaches HBM
+  (void)live;
   int32_t cv[NPL];
-  uint16_t pos[NPL];
+  ScanRun<NPL> pos;
+  pos.load(scan, l);
   int eob_m1 = 0;
 #pragma unroll
   for (int k = 0; k < NPL; k++) {
-    pos[k] = scan[k * G + l];
-    cv[k] = live ? mine[pos[k]] : 0;
+    cv[k] = mine[pos.at(k)];
     // T::abs() wraps at T::MIN (mod.rs:296: c.abs() on T::Coeff)
     const int32_t a = (int32_t)(CT)(cv[k] < 0 ? (CT)(0 - (uint32_t)cv[k]) : (CT)cv[k]);
-    if (a >= qp.deadzone) eob_m1 = k * G + l;   // increasing in k: the max survives
+    if (a >= qp.deadzone) eob_m1 = l * NPL + k;   // increasing in k: the max survives
   }
 #pragma unroll
   for (int m = 1; m < G; m <<= 1) {
@@ -130,44 +199,85 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
   }
   q0 = __shfl(q0, g0, 64);
   const int eob = eob_m1 > 0 ? eob_m1 + 1 : (q0 != 0);
-  int carry = 1;   // level_mode starts at 1
-  unsigned long long dist = tail;
+
+  // pass 1: both candidate levels per element, the run's transition function.
+  // a + offset >= (level0 + 1) * q  <=>  a - level0 * q >= q - offset
+  const int lim = eob - l * NPL;        // elements k < lim of this run are below eob
+  const uint32_t need0 = qp.ac_q - qp.ac_offset0, need1 = qp.ac_q - qp.ac_offset1;
+  uint32_t fb[(NPL + 15) / 16] = {};    // 2 bits per element: the transition function
+  uint32_t db[(NPL + 31) / 32] = {};    // 1 bit: level_mode 1 adds one to the magnitude
+  uint32_t s0 = 0, s1 = 1;              // level_mode after the run, entering with 0 / 1
 #pragma unroll
   for (int k = 0; k < NPL; k++) {
-    const int i = k * G + l;
-    const bool act = i >= 1 && i < eob;
+    const bool act = k == 0 ? (l != 0 && lim > 0) : (k < lim);   // scan index in [1, eob)
     const int32_t c = (int32_t)((uint32_t)cv[k] << qp.lts);
     const uint32_t a = c < 0 ? 0u - (uint32_t)c : (uint32_t)c;
-    const uint32_t level0 = divu_pair(a, qp.ac_a, qp.ac_b, qp.ac_s);
-    const uint32_t thr = (level0 + 1) * qp.ac_q;
-    const uint32_t up0 = a + qp.ac_offset0 >= thr, up1 = a + qp.ac_offset1 >= thr;
+    uint32_t level0, rem;
+    if constexpr (NARROW) {
+      const uint32_t lo = __umul24(a, qp.ac_m24), hi = umulhi24(qp.ac_m24, a);
+      level0 = __builtin_amdgcn_alignbit(hi, lo, qp.ac_s24);   // (hi:lo) >> s, s < 32
+      rem = a - __umul24(level0, qp.ac_q);
+    } else {
+      level0 = divu_pair(a, qp.ac_a, qp.ac_b, qp.ac_s);
+      rem = a - level0 * qp.ac_q;
+    }
+    const uint32_t up0 = rem >= need0, up1 = rem >= need1;
     // level_mode 0: offset1 iff level0 > 1; level_mode 1: offset1 iff level0 > 0
     const uint32_t aq0 = level0 + (level0 > 1 ? up1 : up0);
     const uint32_t aq1 = level0 + (level0 > 0 ? up1 : up0);
-    // transitions (mod.rs:331-335): 0 -> (aq > 1), 1 -> (aq != 0)
-    uint32_t F = act ? ((aq0 > 1 ? 1u : 0u) | (aq1 != 0 ? 2u : 0u)) : 2u;
+    // transitions (mod.rs:331-335): 0 -> (aq > 1), 1 -> (aq != 0); identity outside [1, eob)
+    const uint32_t F = act ? ((aq0 > 1 ? 1u : 0u) | (aq1 != 0 ? 2u : 0u)) : 2u;
+    fb[k / 16] |= F << (2 * (k % 16));
+    db[k / 32] |= (act ? aq1 - aq0 : 0u) << (k % 32);
+    s0 = (F >> s0) & 1;
+    s1 = (F >> s1) & 1;
+    // keep the packing where it is written: without this the compiler carries
+    // every element's flags to the end of the loop (one VGPR each)
+    asm volatile("" : "+v"(fb[k / 16]), "+v"(db[k / 32]), "+v"(s0), "+v"(s1));
+    // signed level under level_mode 0, parked in place (this lane re-reads it in pass 2)
+    mine[pos.at(k)] = act ? (c < 0 ? -(int32_t)aq0 : (int32_t)aq0) : 0;
+  }
+  // the lanes' functions, composed in lane order (inclusive), then the
+  // level_mode entering this lane's run (level_mode starts at 1)
+  uint32_t L = s0 | (s1 << 1);
 #pragma unroll
-    for (int d = 1; d < G; d <<= 1) {
-      const uint32_t p = __shfl_up(F, d, G);
-      if (l >= d) F = ((F >> (p & 1)) & 1) | (((F >> ((p >> 1) & 1)) & 1) << 1);
-    }
-    uint32_t E = __shfl_up(F, 1, G);
-    if (l == 0) E = 2u;
-    const int mode = (E >> carry) & 1;
-    const uint32_t last = __shfl(F, g0 + G - 1, 64);
-    carry = (last >> carry) & 1;
-    const uint32_t aq = mode ? aq1 : aq0;
-    int32_t q = act ? (c < 0 ? -(int32_t)aq : (int32_t)aq) : 0;
-    if (i == 0) q = q0;
-    if (live) mine[pos[k]] = q;
+  for (int d = 1; d < G; d <<= 1) {
+    const uint32_t p = __shfl_up(L, d, G);
+    if (l >= d) L = ((L >> (p & 1)) & 1) | (((L >> ((p >> 1) & 1)) & 1) << 1);
+  }
+  uint32_t E = __shfl_up(L, 1, G);
+  if (l == 0) E = 2u;
+  uint32_t mode = (E >> 1) & 1;
+
+  // pass 2: replay
+  unsigned long long dist = tail;
+  const int32_t off = (1 << qp.lts) - 1;
+#pragma unroll
+  for (int k = 0; k < NPL; k++) {
+    const uint32_t F = (fb[k / 16] >> (2 * (k % 16))) & 3u;
+    const uint32_t bump = (db[k / 32] >> (k % 32)) & mode;   // only ever 1 -> 2
+    const uint32_t pk = pos.at(k);
+    const int32_t qs = mine[pk];
+    int32_t q = qs + (int32_t)(bump ? ((qs >> 31) | 1) : 0);
+    mode = (F >> mode) & 1;
+    if (k == 0 && l == 0) q = q0;
+    mine[pk] = q;
     if constexpr (DIST) {
       const int32_t qt = (int32_t)(CT)q;
-      const uint32_t quant = pos[k] == 0 ? qp.dc_q : qp.ac_q;
-      const int32_t off = (1 << qp.lts) - 1;
-      const int32_t r = (int32_t)(CT)((int32_t)((uint32_t)qt * quant + (uint32_t)((qt >> 31) & off)) >> qp.lts);
-      const int32_t dd = (int32_t)((uint32_t)cv[k] - (uint32_t)r);
+      // scan position 0 is coefficient 0 in every scan order
+      const uint32_t quant = (k == 0 && l == 0) ? qp.dc_q : qp.ac_q;
+      int32_t r, dd, sq;
+      if constexpr (NARROW) {
+        r = (int32_t)(CT)((__mul24(qt, (int32_t)quant) + ((qt >> 31) & off)) >> qp.lts);
+        dd = cv[k] - r;                 // both i16: 17 bits
+        sq = mul24_wrap(dd, dd);        // low 32 bits = the wrapping i32 product
+      } else {
+        r = (int32_t)((uint32_t)qt * quant + (uint32_t)((qt >> 31) & off)) >> qp.lts;
+        dd = (int32_t)((uint32_t)cv[k] - (uint32_t)r);
+        sq = (int32_t)((uint32_t)dd * (uint32_t)dd);
+      }
       // `(c * c) as u64`: i32 product (wrapping), sign-extended
-      if (live) dist += (unsigned long long)(long long)(int32_t)((uint32_t)dd * (uint32_t)dd);
+      dist += (unsigned long long)(long long)sq;
     }
   }
   eob_out = eob;

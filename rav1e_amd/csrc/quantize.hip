@@ -9,17 +9,18 @@
 // the quantized values before it (mod.rs:317-339).  `level_mode` has two
 // states, so coefficient i is a function {0,1} -> {0,1} (plus one output per
 // state) and function composition is associative: the recurrence becomes a
-// wave-level prefix scan over 2-bit function codes.
+// prefix scan over 2-bit function codes (quant_common.hpp: quantize_group).
 //
 // Mapping (wave = 64): G = min(64, coded area) lanes own one block, 64/G
 // blocks per wave, 4 waves per workgroup.
 //  1 the block's coded coefficients are staged into LDS with coalesced loads;
-//  2 lane l visits scan positions l, l+G, ..: gathers lds[scan[i]] into
-//    registers, eob-1 = max scan index with |c| >= deadzone (group max);
-//  3 DC by the group's lane 0; per chunk of G scan positions both candidate
-//    outcomes (level_mode 0 / 1) are evaluated, the 2-bit transition codes are
-//    composed by a Hillis-Steele scan inside the group, the carry-in state
-//    picks the result, which overwrites lds[scan[i]] in place;
+//  2 lane l owns the contiguous run [l*NPL, (l+1)*NPL) of scan positions:
+//    gathers lds[scan[i]] into registers, eob-1 = max scan index with
+//    |c| >= deadzone (group max);
+//  3 DC by the group's lane 0; each lane evaluates both candidate outcomes
+//    (level_mode 0 / 1) of its run and composes the run's transition function
+//    sequentially, one Hillis-Steele scan inside the group composes the lanes,
+//    a replay pass picks the results, which overwrite lds[scan[i]] in place;
 //  4 the group writes qcoeffs (and rcoeffs = dequantize(qcoeffs)) back with
 //    coalesced stores; positions >= eob are zero (the reference relies on a
 //    pre-zeroed buffer, encoder.rs:1518-1521).

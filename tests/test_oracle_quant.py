@@ -96,3 +96,20 @@ def test_tx_domain_distortion_and_rate_definition(oracle):
             b = oracle.r1o_estimate_rate(qi, ts, 5000)
             c = oracle.r1o_estimate_rate(qi, ts, 6000)
             assert min(a, c) <= b <= max(a, c)
+
+
+def test_narrow_division_magic_is_exact(oracle):
+    """The i16 fast path of the device quantizer (rav1e_amd/csrc/quant_common.hpp:
+    narrow_magic) divides by ac_q with m = floor(2^s / q) + 1, s = 18 + ceil(log2 q),
+    through 24-bit multiplies.  Sweep: every 8-bit ac_q (all qindex, delta 0), every
+    a < 2^18 (|i16| << log_tx_scale <= 2^17): floor(a / q) exactly, m and a within
+    24 bits, s < 32."""
+    a = np.arange(1 << 18, dtype=np.uint64)
+    qs = sorted({int(oracle.r1o_ac_q(qi, 0, 8)) for qi in range(256)})
+    assert qs[0] >= 4 and qs[-1] < (1 << 13)
+    for q in qs:
+        L = (q - 1).bit_length()
+        s = 18 + L
+        m = (1 << s) // q + 1
+        assert m < (1 << 24) and s < 32
+        assert np.array_equal((a * np.uint64(m)) >> np.uint64(s), a // np.uint64(q)), q
