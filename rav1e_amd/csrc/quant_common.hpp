@@ -151,10 +151,8 @@ struct ScanRun {
 // [l*NPL, (l+1)*NPL): gather, eob-1 = max scan index with |c| >= deadzone, DC
 // by lane 0, then the AC loop of mod.rs:311-336.  Its only serial dependence
 // is level_mode (one bit), so every element is a function {0,1} -> {0,1}
-// (2 bits: what level_mode becomes for either incoming value) and both
-// candidate levels are computed up front; they differ by at most 1 (only
-// level0 == 1 makes the two offsets matter).  A lane composes its run
-// sequentially (one bfe per state), one log2(G)-step scan composes the lanes,
+// (reset / keep / set, see pass 1).  A lane composes its run sequentially
+// (two adds and shifts per element), one log2(G)-step scan composes the lanes,
 // and a replay pass picks the level per element.  On return `mine` holds the
 // quantized coefficients, eob the reference's return value and -- DIST -- dist
 // the transform-domain distortion (coded part + `tail` = the caller's partial
@@ -200,16 +198,22 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
   q0 = __shfl(q0, g0, 64);
   const int eob = eob_m1 > 0 ? eob_m1 + 1 : (q0 != 0);
 
-  // pass 1: both candidate levels per element, the run's transition function.
-  // a + offset >= (level0 + 1) * q  <=>  a - level0 * q >= q - offset
+  // pass 1.  With level0 = a / q and rem = a % q the reference's two rounding
+  // candidates are A0 = level0 + (rem + offset0 >= q), A1 = level0 + (rem +
+  // offset1 >= q) (A0 <= A1 <= A0 + 1), and going through mod.rs:317-336 case
+  // by case (level0 = 0, 1, >= 2 against level_mode = 0, 1) the whole AC step
+  // collapses to
+  //     level_mode' = (min(A0, 2) + level_mode) >> 1,   |q| = level_mode' ? A1 : A0
+  // so an element is the pair (A0, A1 - A0) and its transition function is
+  // min(A0, 2): 0 = reset, 1 = keep, 2 = set.  Parked in place as
+  // A0 << 2 | (A1 - A0) << 1 | sign (A0 < 2^30: q >= 4); this lane re-reads it
+  // in pass 2.  Elements at or past eob park 0 (level 0; nothing after them
+  // reads level_mode), the DC slot parks "keep".
   const int lim = eob - l * NPL;        // elements k < lim of this run are below eob
   const uint32_t need0 = qp.ac_q - qp.ac_offset0, need1 = qp.ac_q - qp.ac_offset1;
-  uint32_t fb[(NPL + 15) / 16] = {};    // 2 bits per element: the transition function
-  uint32_t db[(NPL + 31) / 32] = {};    // 1 bit: level_mode 1 adds one to the magnitude
   uint32_t s0 = 0, s1 = 1;              // level_mode after the run, entering with 0 / 1
 #pragma unroll
   for (int k = 0; k < NPL; k++) {
-    const bool act = k == 0 ? (l != 0 && lim > 0) : (k < lim);   // scan index in [1, eob)
     const int32_t c = (int32_t)((uint32_t)cv[k] << qp.lts);
     const uint32_t a = c < 0 ? 0u - (uint32_t)c : (uint32_t)c;
     uint32_t level0, rem;
@@ -221,21 +225,15 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
       level0 = divu_pair(a, qp.ac_a, qp.ac_b, qp.ac_s);
       rem = a - level0 * qp.ac_q;
     }
-    const uint32_t up0 = rem >= need0, up1 = rem >= need1;
-    // level_mode 0: offset1 iff level0 > 1; level_mode 1: offset1 iff level0 > 0
-    const uint32_t aq0 = level0 + (level0 > 1 ? up1 : up0);
-    const uint32_t aq1 = level0 + (level0 > 0 ? up1 : up0);
-    // transitions (mod.rs:331-335): 0 -> (aq > 1), 1 -> (aq != 0); identity outside [1, eob)
-    const uint32_t F = act ? ((aq0 > 1 ? 1u : 0u) | (aq1 != 0 ? 2u : 0u)) : 2u;
-    fb[k / 16] |= F << (2 * (k % 16));
-    db[k / 32] |= (act ? aq1 - aq0 : 0u) << (k % 32);
-    s0 = (F >> s0) & 1;
-    s1 = (F >> s1) & 1;
-    // keep the packing where it is written: without this the compiler carries
-    // every element's flags to the end of the loop (one VGPR each)
-    asm volatile("" : "+v"(fb[k / 16]), "+v"(db[k / 32]), "+v"(s0), "+v"(s1));
-    // signed level under level_mode 0, parked in place (this lane re-reads it in pass 2)
-    mine[pos.at(k)] = act ? (c < 0 ? -(int32_t)aq0 : (int32_t)aq0) : 0;
+    const uint32_t A0 = level0 + (rem >= need0 ? 1u : 0u);
+    const uint32_t dA = (rem - need1 < need0 - need1) ? 2u : 0u;   // need1 <= rem < need0
+    uint32_t park = (A0 << 2) | dA | ((uint32_t)c >> 31);
+    park = (k < lim) ? park : 0u;
+    if (k == 0) park = l == 0 ? 4u : park;
+    const uint32_t t = park >> 2 < 2u ? park >> 2 : 2u;
+    s0 = (t + s0) >> 1;
+    s1 = (t + s1) >> 1;
+    mine[pos.at(k)] = (int32_t)park;
   }
   // the lanes' functions, composed in lane order (inclusive), then the
   // level_mode entering this lane's run (level_mode starts at 1)
@@ -254,12 +252,12 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
   const int32_t off = (1 << qp.lts) - 1;
 #pragma unroll
   for (int k = 0; k < NPL; k++) {
-    const uint32_t F = (fb[k / 16] >> (2 * (k % 16))) & 3u;
-    const uint32_t bump = (db[k / 32] >> (k % 32)) & mode;   // only ever 1 -> 2
     const uint32_t pk = pos.at(k);
-    const int32_t qs = mine[pk];
-    int32_t q = qs + (int32_t)(bump ? ((qs >> 31) | 1) : 0);
-    mode = (F >> mode) & 1;
+    const uint32_t park = (uint32_t)mine[pk];
+    const uint32_t A0 = park >> 2;
+    mode = ((A0 < 2u ? A0 : 2u) + mode) >> 1;
+    const uint32_t mag = A0 + ((park >> 1) & mode);
+    int32_t q = (park & 1u) ? -(int32_t)mag : (int32_t)mag;
     if (k == 0 && l == 0) q = q0;
     mine[pk] = q;
     if constexpr (DIST) {

@@ -113,3 +113,38 @@ def test_narrow_division_magic_is_exact(oracle):
         m = (1 << s) // q + 1
         assert m < (1 << 24) and s < 32
         assert np.array_equal((a * np.uint64(m)) >> np.uint64(s), a // np.uint64(q)), q
+
+
+def test_level_mode_recurrence_collapses_to_two_candidates(oracle):
+    """The device quantizer (rav1e_amd/csrc/quant_common.hpp, pass 1) replaces the
+    AC loop's rounding-offset selection (quantize/mod.rs:317-336) by
+        A0 = (a + offset0) / q,  A1 = (a + offset1) / q,
+        level_mode' = (min(A0, 2) + level_mode) >> 1,  |q| = level_mode' ? A1 : A0.
+    Host-side restatement of that form against the oracle's literal loop, golden
+    vectors (all sizes / types / bit depths) as inputs."""
+    keys = [k for k in G.files if k.endswith("_co")]
+    for k in keys[::3]:
+        _, ts, tt, bd, intra, qi, dcd, acd, _ = k.split("_")
+        ts, tt, bd, intra, qi, dcd, acd = map(int, (ts, tt, bd, intra, qi, dcd, acd))
+        co = G[k]
+        n = min(TX_W[ts], 32) * min(TX_H[ts], 32)
+        scan, iscan = np.zeros(1024, np.uint16), np.zeros(1024, np.uint16)
+        oracle.r1o_get_scan(ts, tt, O.ptr(scan), O.ptr(iscan))
+        acq = int(oracle.r1o_ac_q(qi, acd, bd))
+        lts = oracle.r1o_get_log_tx_scale(ts)
+        off0 = acq * (98 if intra else 97) // 256
+        off1 = acq * (109 if intra else 108) // 256
+        want_q, want_eob = G[k[:-3] + "_q"], G[k[:-3] + "_eob"]
+        for b in range(min(co.shape[0], 6)):
+            eob = int(want_eob[b])
+            mode = 1
+            got = np.zeros(n, np.int64)
+            got[0] = want_q[b][0]                       # DC is not part of the recurrence
+            for i in range(1, eob):
+                c = int(co[b][scan[i]]) << lts
+                a = abs(c)
+                A0, A1 = (a + off0) // acq, (a + off1) // acq
+                mode = (min(A0, 2) + mode) >> 1
+                mag = A1 if mode else A0
+                got[scan[i]] = -mag if c < 0 else mag
+            assert np.array_equal(got.astype(co.dtype), want_q[b]), (k, b)
