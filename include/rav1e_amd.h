@@ -306,6 +306,56 @@ int r1_estimate_inter_costs(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
 int r1_importance_block_difference(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
                                    uint64_t *sum_out, void *stream);
 
+/* ---- hierarchical motion estimation of whole tiles (SURVEY.md 8f "N2").
+ * Replaces estimate_tile_motion (src/me.rs:153-218) for one (tile, reference
+ * frame) pair per job: the three passes (quarter, half, full resolution) of
+ * estimate_sb_motion / refine_subsampled_sb_motion with full_pixel_me
+ * (predictor subsets, diamond search; at the first pass the thresholded
+ * subset / uneven-multi-hexagon / optional full search cascade), writing the
+ * reference's FrameMEStats.  Jobs are independent (the reference runs tiles on
+ * rayon workers, src/encoder.rs encode_tile_group, and loops the reference
+ * frames inside, me.rs:190-199) and execute concurrently; inside a job the
+ * superblocks go in anti-diagonal wavefronts -- the exact dependence order of
+ * the reference's raster walk (see rav1e_amd/csrc/me.hip).
+ *
+ * R1MeStats = MEStats (src/me.rs:31-35): mv in 1/8 pel, SAD normalised to a
+ * 128x128 block.  stats: the FrameMEStats array of this reference frame
+ * (stats_cols x stats_rows entries, one per 4x4 luma block, device memory,
+ * in/out: the first pass reads what the previous frame left there exactly as
+ * the reference does); prev: the previous frame's array for the same
+ * reference index (EPZS subset C, me.rs:477-514) or NULL.
+ * org / ref: [0] full, [1] half, [2] quarter resolution luma (FrameState
+ * input_hres / input_qres, src/encoder.rs:412-413; ReferenceFrame input_hres /
+ * input_qres): device planes with the reference's padding (>= 16 px + block
+ * at each resolution, which the MV range of me.rs:339-362 assumes).
+ * lambda[ssdec]: (fi.me_lambda * 256 / (1 << 2*ssdec) * (ssdec == 0 ? 0.5 :
+ * 0.125)) as u32, me.rs:175-177 -- f64 arithmetic, evaluated by the host.
+ * `jobs` is HOST memory (pointers inside are device pointers).  The call
+ * returns after the work has completed on `stream`. */
+typedef struct R1MeStats {
+  int16_t row, col;
+  uint32_t normalized_sad;
+} R1MeStats;
+typedef struct R1MeParams {
+  int32_t w_in_b, h_in_b;            /* fi.w_in_b, fi.h_in_b (4x4 units) */
+  int32_t stats_cols, stats_rows;    /* FrameMEStats::cols, rows */
+  int32_t bit_depth;
+  int32_t allow_hp;                  /* fi.allow_high_precision_mv */
+  int32_t allow_full_search;         /* speed_settings.motion.me_allow_full_search */
+  int32_t me_range_scale;            /* fi.me_range_scale */
+  uint32_t lambda[3];
+  int32_t reserved;
+} R1MeParams;
+typedef struct R1MeJob {
+  R1Plane org[3], ref[3];
+  R1MeStats *stats;
+  const R1MeStats *prev;
+  int32_t tile_x, tile_y;            /* luma px, multiples of 64 */
+  int32_t tile_w, tile_h;            /* luma px, multiples of 4 */
+} R1MeJob;
+int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, int n_jobs,
+                                  const R1MeParams *params, void *stream);
+
 /* ---- fused RDO candidate: the headline path.  For each candidate:
  *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)
  *   sad    = get_sad(org @ (ox,oy), pred)       if sad_out     (src/dist.rs:31)

@@ -171,6 +171,20 @@ void r1o_estimate_intra_costs(const r1o_plane *plane, int bit_depth, uint32_t *c
 uint64_t r1o_importance_block_difference(const r1o_plane *org, const r1o_plane *ref);
 void r1o_estimate_inter_costs(const r1o_plane *org, const r1o_plane *ref, const int16_t *mvs,
                               uint32_t *costs);
+/* hierarchical motion estimation of one tile against one reference
+ * (src/me.rs:153-335, see oracle/me.c).  org3 / ref3: [full, half, quarter]
+ * resolution planes; stats: FrameMEStats of this reference (in/out), prev: the
+ * previous frame's (EPZS subset C) or NULL.  PARITY UNPINNED (no reference vectors). */
+typedef struct { int16_t row, col; uint32_t normalized_sad; } r1o_me_stats;
+typedef struct {
+  int32_t w_in_b, h_in_b;                 /* fi.w_in_b / fi.h_in_b: frame size in 4x4 units */
+  int32_t stats_cols, stats_rows;         /* FrameMEStats::cols / rows */
+  int32_t tile_x, tile_y, tile_w, tile_h; /* luma px; x, y multiples of 64 */
+  int32_t bit_depth, allow_hp, allow_full_search, me_range_scale;
+  uint32_t lambda[3];                     /* by ssdec (me.rs:175-177 evaluated by the host) */
+} r1o_me_params;
+int r1o_estimate_tile_motion(const r1o_plane *org3, const r1o_plane *ref3, const r1o_me_params *p,
+                             r1o_me_stats *stats, const r1o_me_stats *prev);
 void r1o_set_threads(int n);
 int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
                    int h, const r1o_dist_cand *c, int n, uint32_t *out);

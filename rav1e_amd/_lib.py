@@ -22,6 +22,23 @@ class R1CdefParams(C.Structure):
                 ("damping", C.c_uint8), ("bit_depth", C.c_uint8), ("reserved", C.c_uint8 * 2)]
 
 
+class R1MeStats(C.Structure):
+    _fields_ = [("row", C.c_int16), ("col", C.c_int16), ("normalized_sad", C.c_uint32)]
+
+
+class R1MeParams(C.Structure):
+    _fields_ = [("w_in_b", C.c_int32), ("h_in_b", C.c_int32), ("stats_cols", C.c_int32),
+                ("stats_rows", C.c_int32), ("bit_depth", C.c_int32), ("allow_hp", C.c_int32),
+                ("allow_full_search", C.c_int32), ("me_range_scale", C.c_int32),
+                ("lambda_", C.c_uint32 * 3), ("reserved", C.c_int32)]
+
+
+class R1MeJob(C.Structure):
+    _fields_ = [("org", R1Plane * 3), ("ref", R1Plane * 3), ("stats", C.c_void_p),
+                ("prev", C.c_void_p), ("tile_x", C.c_int32), ("tile_y", C.c_int32),
+                ("tile_w", C.c_int32), ("tile_h", C.c_int32)]
+
+
 # every symbol include/rav1e_amd.h declares: name -> (restype, argtypes)
 _vp, _i, _sz, _pd = C.c_void_p, C.c_int, C.c_size_t, C.c_ssize_t
 _PP = C.POINTER(R1Plane)
@@ -55,6 +72,7 @@ SYMBOLS = {
     "r1_rdo_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "r1_rdo_full_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, C.POINTER(R1QuantParams),
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "r1_estimate_tile_motion_batch": (_i, [_vp, C.POINTER(R1MeJob), _i, C.POINTER(R1MeParams), _vp]),
     "rav1e_sad_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_satd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_sad_hbd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),

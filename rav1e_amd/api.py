@@ -71,6 +71,11 @@ class Plane:
                             self.height, self.xorigin, self.yorigin, self.bpp, self.bit_depth)
 
 
+def me_lambdas(me_lambda):
+    """lambda of the three ME passes by ssdec (src/me.rs:175-177): fi.me_lambda = sqrt(fi.lambda)."""
+    return [int(me_lambda * 256.0 / (1 << (2 * ss)) * (0.5 if ss == 0 else 0.125)) for ss in range(3)]
+
+
 def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -438,6 +443,33 @@ class Context:
             p("sad"), p("satd"), p("eob"), p("tx_dist"), p("est_rate"), p("qcoeffs"), p("coeffs"),
             _stream_ptr()), "r1_rdo_full_cand_batch")
         return o
+
+    # ---- me:: ----
+    def estimate_tile_motion(self, jobs, w_in_b, h_in_b, bit_depth, lambdas, allow_hp=True,
+                             allow_full_search=False, me_range_scale=1):
+        """estimate_tile_motion (src/me.rs:153-218) for a list of independent
+        (tile, reference frame) jobs.  Each job: dict(org=[Plane x3], ref=[Plane x3]
+        (full, half, quarter resolution), stats=int32 tensor (rows, cols, 2) viewing the
+        FrameMEStats array [(row | col << 16), normalized_sad], prev=tensor or None,
+        tile=(x, y, w, h) luma px).  lambdas: per ssdec (see me_lambdas)."""
+        n = len(jobs)
+        arr = (_lib.R1MeJob * n)()
+        rows, cols = jobs[0]["stats"].shape[:2]
+        for j, job in enumerate(jobs):
+            st = job["stats"]
+            assert st.dtype == torch.int32 and st.shape == (rows, cols, 2) and st.is_contiguous()
+            for l in range(3):
+                arr[j].org[l] = job["org"][l].cstruct()
+                arr[j].ref[l] = job["ref"][l].cstruct()
+            arr[j].stats = st.data_ptr()
+            pv = job.get("prev")
+            arr[j].prev = pv.data_ptr() if pv is not None else None
+            arr[j].tile_x, arr[j].tile_y, arr[j].tile_w, arr[j].tile_h = job["tile"]
+        p = _lib.R1MeParams(w_in_b, h_in_b, cols, rows, bit_depth, int(allow_hp),
+                            int(allow_full_search), me_range_scale,
+                            (C.c_uint32 * 3)(*[int(v) for v in lambdas]), 0)
+        self._check(self.lib.r1_estimate_tile_motion_batch(self.h, arr, n, C.byref(p), _stream_ptr()),
+                    "r1_estimate_tile_motion_batch")
 
     # ---- fused candidate ----
     def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,

@@ -37,6 +37,8 @@ extern "C" int r1_ctx_create(int device, r1_ctx **out) {
     return R1_EHIP;
   }
   c->scan_dev = nullptr;
+  c->me_jobs = nullptr;
+  c->me_jobs_bytes = 0;
   if (r1_scan_tables_create(c) != R1_OK) {
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -50,6 +52,7 @@ extern "C" void r1_ctx_destroy(r1_ctx *c) {
   if (!c) return;
   if (c->stage) (void)hipFree(c->stage);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->me_jobs) (void)hipFree(c->me_jobs);
   r1_scan_tables_destroy(c);
   (void)hipStreamDestroy(c->own_stream);
   delete c;

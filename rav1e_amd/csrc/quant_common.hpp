@@ -108,12 +108,14 @@ __device__ __forceinline__ int32_t mul24_wrap(int32_t a, int32_t b) {
 // estimate_rate (src/rdo.rs:127-139): piecewise-linear lookup in RDO_RATE_TABLE
 __device__ __forceinline__ unsigned long long estimate_rate(int q_bin, int tx_size,
                                                             unsigned long long fd) {
-  unsigned long long down = fd / 2000;
-  down = down > 48 ? 48 : down;
-  const unsigned long long up = down + 1;
-  const long long x0 = (long long)(down * 2000);
-  const long long y0 = kR1RdoRateTable[q_bin][tx_size][down], y1 = kR1RdoRateTable[q_bin][tx_size][up];
-  const long long slope = ((y1 - y0) * 256) / 2000;
+  // down = min(fd / 2000, 48): clamp first, then a 32-bit reciprocal
+  // (ceil(2^32 / 2000) = 2147484 is exact below 6.1e6)
+  const uint32_t f = fd > 97999ull ? 97999u : (uint32_t)fd;
+  const uint32_t down = __umulhi(f, 2147484u);
+  const long long x0 = (long long)(down * 2000u);
+  const int32_t y0 = (int32_t)kR1RdoRateTable[q_bin][tx_size][down],
+                y1 = (int32_t)kR1RdoRateTable[q_bin][tx_size][down + 1];
+  const int32_t slope = ((y1 - y0) * 256) / 2000;   // |y| <= 99999: 32 bits are enough
   const long long v = y0 + ((((long long)fd - x0) * slope) >> 8);
   return v < 0 ? 0ull : (unsigned long long)v;
 }

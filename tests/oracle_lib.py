@@ -102,6 +102,7 @@ def lib():
         "r1o_mc_prep_batch": (i, [vp, i, i, vp, i, vp]),
         "r1o_mc_avg_batch": (i, [vp, vp, i, i, i, i, i, vp]),
         "r1o_rdo_cand_batch": (i, [vp, vp, i, i, i, vp, i, vp, vp, vp, vp]),
+        "r1o_estimate_tile_motion": (i, [vp, vp, vp, vp, vp]),
         "r1o_rdo_full_cand_batch": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
@@ -151,3 +152,56 @@ class HostPlane:
         return Plane(data_ptr if data_ptr is not None else self.data.ctypes.data, self.stride,
                      self.alloc_height, self.width, self.height, self.xorigin, self.yorigin,
                      self.bpp, self.bit_depth)
+
+
+# ---- motion estimation (oracle/me.c) ----
+class MeParams(C.Structure):
+    """r1o_me_params"""
+    _fields_ = [("w_in_b", C.c_int32), ("h_in_b", C.c_int32), ("stats_cols", C.c_int32),
+                ("stats_rows", C.c_int32), ("tile_x", C.c_int32), ("tile_y", C.c_int32),
+                ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("bit_depth", C.c_int32),
+                ("allow_hp", C.c_int32), ("allow_full_search", C.c_int32),
+                ("me_range_scale", C.c_int32), ("lambda_", C.c_uint32 * 3)]
+
+
+ME_STATS = np.dtype([("row", "<i2"), ("col", "<i2"), ("normalized_sad", "<u4")])
+assert ME_STATS.itemsize == 8
+
+
+def plane_from_image(img, bit_depth, xpad, ypad):
+    """HostPlane whose padding replicates the edge pixels (Plane::pad)."""
+    h, w = img.shape
+    p = HostPlane(w, h, bit_depth, xpad, ypad)
+    p.data[...] = np.pad(img.astype(p.data.dtype),
+                         ((p.yorigin, p.alloc_height - p.yorigin - h),
+                          (p.xorigin, p.stride - p.xorigin - w)), mode="edge")
+    return p
+
+
+def box_down2(img):
+    """2x2 box filter with rounding (what Plane::downsampled computes inside the frame)."""
+    h, w = img.shape
+    e = np.pad(img.astype(np.int64), ((0, h & 1), (0, w & 1)), mode="edge")
+    return ((e[0::2, 0::2] + e[0::2, 1::2] + e[1::2, 0::2] + e[1::2, 1::2] + 2) >> 2)
+
+
+def me_pyramid(img, bit_depth):
+    """[full, half, quarter] HostPlanes of one luma image, padding 88 / 44 / 22."""
+    h1 = box_down2(img)
+    h2 = box_down2(h1)
+    return [plane_from_image(img, bit_depth, 88, 88), plane_from_image(h1, bit_depth, 44, 44),
+            plane_from_image(h2, bit_depth, 22, 22)]
+
+
+def me_oracle(L, org3, ref3, w_in_b, h_in_b, tile, bit_depth, lambdas, stats, prev=None,
+              allow_hp=1, allow_full_search=0, me_range_scale=1):
+    """r1o_estimate_tile_motion on HostPlane pyramids; stats: ME_STATS array (rows, cols), in place."""
+    po = (Plane * 3)(*[p.cstruct() for p in org3])
+    pr = (Plane * 3)(*[p.cstruct() for p in ref3])
+    rows, cols = stats.shape
+    prm = MeParams(w_in_b, h_in_b, cols, rows, tile[0], tile[1], tile[2], tile[3], bit_depth,
+                   allow_hp, allow_full_search, me_range_scale, (C.c_uint32 * 3)(*lambdas))
+    rc = L.r1o_estimate_tile_motion(po, pr, C.byref(prm), stats.ctypes.data,
+                                    prev.ctypes.data if prev is not None else None)
+    assert rc == 0
+    return stats

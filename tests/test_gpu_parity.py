@@ -929,3 +929,90 @@ def test_rdo_full_cand_equals_staged_chain(ctx):
             assert torch.equal(full["eob"][idx], q["eobs"]), (ts, tt)
             assert torch.equal(full["tx_dist"][idx], q["tx_dist"]), (ts, tt)
             assert torch.equal(full["est_rate"][idx], q["est_rate"]), (ts, tt)
+
+
+# ------------------------ N2: hierarchical motion estimation of whole tiles
+def _me_dev_pyr(pyr):
+    return [dev_plane(p) for p in pyr]
+
+
+def _me_stats_tensor(a):
+    import torch
+    return torch.from_numpy(a.view(np.int32).reshape(a.shape[0], a.shape[1], 2).copy()).cuda()
+
+
+def _me_stats_numpy(t):
+    return t.cpu().numpy().reshape(t.shape[0], -1).view(O.ME_STATS).reshape(t.shape[0], t.shape[1])
+
+
+def _me_images(kind, w, h, bd, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 1 << bd, (h, w)), rng.integers(0, 1 << bd, (h, w))
+    # smooth texture, the reference a shifted + noisy copy: real motion, ties in flat areas
+    f = rng.standard_normal((h + 64, w + 64))
+    for _ in range(3):
+        f = (np.roll(f, 1, 0) + 2 * f + np.roll(f, -1, 0)) / 4
+        f = (np.roll(f, 1, 1) + 2 * f + np.roll(f, -1, 1)) / 4
+    f = ((f - f.min()) / (f.max() - f.min()) * ((1 << bd) - 1)).astype(np.int64)
+    if kind == "flat":
+        f = (f >> (bd - 3)) << (bd - 3)      # 8 grey levels: many equal costs
+    org = f[32:32 + h, 32:32 + w]
+    ref = f[32 + 5:32 + 5 + h, 32 - 9:32 - 9 + w] + rng.integers(-2, 3, (h, w))
+    return org, np.clip(ref, 0, (1 << bd) - 1)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("kind", ["noise", "smooth", "flat"])
+def test_estimate_tile_motion_vs_oracle(ctx, oracle, bd, kind):
+    """r1_estimate_tile_motion_batch against oracle/me.c: frame sizes that are not
+    multiples of 64 (cropped superblocks and blocks), previous-frame predictors,
+    8- and 10-bit, with and without the full-search stage."""
+    from rav1e_amd.api import me_lambdas
+    for (w, h, full) in ((200, 136, 0), (320, 192, 0), (136, 72, 1)):
+        org, ref = _me_images(kind, w, h, bd, 7 * bd + w)
+        po, pr = O.me_pyramid(org, bd), O.me_pyramid(ref, bd)
+        rng = np.random.default_rng(w)
+        prev = np.zeros((h // 4, w // 4), O.ME_STATS)
+        prev["row"] = rng.integers(-80, 81, prev.shape)
+        prev["col"] = rng.integers(-80, 81, prev.shape)
+        prev["normalized_sad"] = rng.integers(0, 1 << 22, prev.shape)
+        init = np.zeros_like(prev)           # what the previous frame left in the array
+        init["row"] = rng.integers(-40, 41, init.shape)
+        init["col"] = rng.integers(-40, 41, init.shape)
+        init["normalized_sad"] = rng.integers(0, 1 << 22, init.shape)
+        lam = me_lambdas(30.0)
+        want = init.copy()
+        O.me_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, want, prev,
+                    allow_full_search=full)
+        st = _me_stats_tensor(init)
+        ctx.estimate_tile_motion([dict(org=_me_dev_pyr(po), ref=_me_dev_pyr(pr), stats=st,
+                                       prev=_me_stats_tensor(prev), tile=(0, 0, w, h))],
+                                 w // 4, h // 4, bd, lam, allow_full_search=bool(full))
+        got = _me_stats_numpy(st)
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, (bd, kind, w, h, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+
+
+def test_estimate_tile_motion_jobs_are_tiles_and_references(ctx, oracle):
+    """several jobs in one call: two tiles of one frame (sharing the stats array)
+    and a second reference frame with its own array; no previous-frame stats."""
+    from rav1e_amd.api import me_lambdas
+    w, h, bd = 384, 200, 8
+    org, ref1 = _me_images("smooth", w, h, bd, 11)
+    _, ref2 = _me_images("noise", w, h, bd, 12)
+    po, p1, p2 = O.me_pyramid(org, bd), O.me_pyramid(ref1, bd), O.me_pyramid(ref2, bd)
+    lam = me_lambdas(12.0)
+    tiles = [(0, 0, 192, h), (192, 0, 192, h)]
+    want1 = np.zeros((h // 4, w // 4), O.ME_STATS)
+    want2 = np.zeros_like(want1)
+    for t in tiles:
+        O.me_oracle(oracle, po, p1, w // 4, h // 4, t, bd, lam, want1)
+        O.me_oracle(oracle, po, p2, w // 4, h // 4, t, bd, lam, want2, allow_hp=1)
+    s1, s2 = _me_stats_tensor(np.zeros_like(want1)), _me_stats_tensor(np.zeros_like(want1))
+    do, d1, d2 = _me_dev_pyr(po), _me_dev_pyr(p1), _me_dev_pyr(p2)
+    jobs = [dict(org=do, ref=d1, stats=s1, tile=t) for t in tiles] + \
+           [dict(org=do, ref=d2, stats=s2, tile=t) for t in tiles]
+    ctx.estimate_tile_motion(jobs, w // 4, h // 4, bd, lam)
+    assert np.array_equal(_me_stats_numpy(s1), want1)
+    assert np.array_equal(_me_stats_numpy(s2), want2)
