@@ -356,6 +356,35 @@ typedef struct R1MeJob {
 int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, int n_jobs,
                                   const R1MeParams *params, void *stream);
 
+/* estimate_motion with a predicted MV (the RDO-time call, src/rdo.rs:1183-1196:
+ * estimate_motion(fi, ts, w, h, tile_bo, ref, Some(pmv), corner, false, 0, None),
+ * src/me.rs:536-632) over n independent blocks of one (tile, reference) pair:
+ * full_pixel_me at full resolution from the tile's MEStats (read only),
+ * get_fullpel_mv_rd with SATD when use_satd (speed_settings.motion
+ * .use_satd_subpel), then subpel_diamond_search (1/2 -> 1/4 -> 1/8 pel when
+ * allow_hp; put_8tap of fi.default_filter = filter_mode + get_satd / get_sad).
+ * tile: HOST descriptor (planes [0] are used; stats / prev as above).
+ * cands, out: DEVICE arrays.  bx, by: tile-relative position in 4x4 units;
+ * w, h: a BlockSize up to 64x64; corner: 0 = MVSamplingMode::INIT, else
+ * 1 | right << 1 | bottom << 2; pmv[k] = (row, col) in 1/8 pel.
+ * max_w, max_h: the largest block of the batch (sizes the LDS of the launch;
+ * a candidate that exceeds it, or is not a power-of-two BlockSize, returns the
+ * reference's MotionSearchResult::empty(): cost = u64::MAX, sad = u32::MAX).
+ * out[i] = MotionSearchResult { mv, rd { cost, sad } }. */
+typedef struct R1MeBlockCand {
+  int16_t bx, by;
+  uint8_t w, h, corner, reserved;
+  int16_t pmv[2][2];
+} R1MeBlockCand;
+typedef struct R1MeResult {
+  int16_t row, col;
+  uint32_t sad;
+  uint64_t cost;
+} R1MeResult;
+int r1_estimate_motion_batch(r1_ctx *ctx, const R1MeJob *tile, const R1MeParams *params,
+                             const R1MeBlockCand *cands, int n, int max_w, int max_h,
+                             int use_satd, int filter_mode, R1MeResult *out, void *stream);
+
 /* ---- fused RDO candidate: the headline path.  For each candidate:
  *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)
  *   sad    = get_sad(org @ (ox,oy), pred)       if sad_out     (src/dist.rs:31)

@@ -12,6 +12,8 @@
  *   hexagon_search 1055-1141     uneven_multi_hex_search 1170-1309
  *   get_fullpel_mv_rd 1386-1409     compute_mv_rd 1445-1462
  *   full_search 1464-1510     get_mv_rate 1512-1523
+ *   sub_pixel_me 857-882     subpel_diamond_search 1311-1383
+ *   get_subpel_mv_rd 1411-1443 (+ PredictionMode::get_mv_params src/predict.rs:284-297)
  * MotionVector arithmetic: src/mc.rs:28-100 (i16 components, 1/8 pel).
  *
  * PARITY UNPINNED: the reference holds no test vectors for me.rs (no #[test]
@@ -432,6 +434,98 @@ int r1o_estimate_tile_motion(const r1o_plane *org3, const r1o_plane *ref3, const
             store_result(&t, log2b, bx, by, r, w, h, ssdec);
           }
       }
+  }
+  return 0;
+}
+
+/* ---- estimate_motion with pmv = Some(..): the RDO-time call (src/rdo.rs:1183-1196):
+ * full_pixel_me at full resolution, then the SATD re-cost and the sub-pel
+ * diamond (me.rs:594-626).  Blocks are independent: stats are only read. ---- */
+static void pred_rd(const mectx *c, mv_t cand, const void *pred, int pstride, int use_satd,
+                    uint64_t *cost, uint32_t *sad) {
+  const void *o = px(c->org, c->po_x, c->po_y);
+  const uint32_t s = use_satd ? r1o_get_satd(o, c->org->stride, pred, pstride, c->w, c->h, c->hbd)
+                              : r1o_get_sad(o, c->org->stride, pred, pstride, c->w, c->h, c->hbd);
+  const uint32_t r1 = get_mv_rate(cand, c->pmv[0], c->allow_hp);
+  const uint32_t r2 = get_mv_rate(cand, c->pmv[1], c->allow_hp);
+  const uint32_t rate = r1 < r2 + 1 ? r1 : r2 + 1;
+  *cost = 256ull * s + (uint64_t)rate * c->lambda;
+  *sad = s;
+}
+
+static int in_range(const mectx *c, mv_t m) {
+  return !(m.col < c->mvx_min || m.col > c->mvx_max || m.row < c->mvy_min || m.row > c->mvy_max);
+}
+
+static void subpel_mv_rd(const mectx *c, mv_t cand, int use_satd, int mode, int bit_depth,
+                         uint64_t *cost, uint32_t *sad) {
+  if (!in_range(c, cand)) {
+    *cost = UINT64_MAX;
+    *sad = UINT32_MAX;
+    return;
+  }
+  int mc_w = 1;
+  while (mc_w < c->w) mc_w <<= 1; /* w.next_power_of_two() */
+  const int mc_h = (c->h + 1) & ~1;
+  uint16_t tmp[128 * 128];
+  /* get_mv_params: floor offsets, 1/16 fractions (luma: xdec = ydec = 0) */
+  const int row_off = cand.row >> 3, col_off = cand.col >> 3;
+  const int row_frac = (cand.row << 1) & 15, col_frac = (cand.col << 1) & 15;
+  r1o_put_8tap(tmp, mc_w, px(c->ref, c->po_x + col_off, c->po_y + row_off), c->ref->stride, mc_w,
+               mc_h, col_frac, row_frac, mode, mode, bit_depth, c->hbd);
+  pred_rd(c, cand, tmp, mc_w, use_satd, cost, sad);
+}
+
+int r1o_estimate_motion_batch(const r1o_plane *org3, const r1o_plane *ref3, const r1o_me_params *p,
+                              const r1o_me_stats *stats, const r1o_me_stats *prev,
+                              const r1o_me_block *blk, int n, int use_satd, int filter_mode,
+                              r1o_me_result *out) {
+  if (p->tile_x % SB || p->tile_y % SB || p->tile_w % MI || p->tile_h % MI) return -1;
+  const tilectx t = { p, (r1o_me_stats *)stats, prev, p->tile_x / MI, p->tile_y / MI,
+                      p->tile_w / MI, p->tile_h / MI };
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int i = 0; i < n; i++) {
+    mectx c;
+    int rng[4];
+    block_ctx(&t, org3, ref3, blk[i].bx, blk[i].by, blk[i].w, blk[i].h, 0, &c, rng);
+    for (int k = 0; k < 2; k++) {
+      c.pmv[k].row = blk[i].pmv[k][0];
+      c.pmv[k].col = blk[i].pmv[k][1];
+    }
+    msr_t best = full_pixel_me(&t, &c, blk[i].bx, blk[i].by, rng, blk[i].corner, 0, 0);
+    if (use_satd) { /* me.rs:596-613: get_fullpel_mv_rd(best.mv, use_satd) */
+      if (!in_range(&c, best.mv)) {
+        best.cost = UINT64_MAX;
+        best.sad = UINT32_MAX;
+      } else {
+        pred_rd(&c, best.mv, px(c.ref, c.po_x + best.mv.col / 8, c.po_y + best.mv.row / 8),
+                c.ref->stride, 1, &best.cost, &best.sad);
+      }
+    }
+    int radius_log2 = 2;
+    const int end_log2 = p->allow_hp ? 0 : 1;
+    for (;;) {
+      msr_t bc = msr_empty();
+      for (int k = 0; k < 4; k++) {
+        const mv_t cand = mv_add(best.mv, DIAMOND[k][0] << radius_log2, DIAMOND[k][1] << radius_log2);
+        uint64_t cost;
+        uint32_t sad;
+        subpel_mv_rd(&c, cand, use_satd, filter_mode, p->bit_depth, &cost, &sad);
+        if (cost < bc.cost) {
+          bc.mv = cand; bc.cost = cost; bc.sad = sad;
+        }
+      }
+      if (best.cost <= bc.cost) {
+        if (radius_log2 == end_log2) break;
+        radius_log2--;
+      } else {
+        best = bc;
+      }
+    }
+    out[i].row = best.mv.row;
+    out[i].col = best.mv.col;
+    out[i].sad = best.sad;
+    out[i].cost = best.cost;
   }
   return 0;
 }

@@ -185,6 +185,21 @@ typedef struct {
 } r1o_me_params;
 int r1o_estimate_tile_motion(const r1o_plane *org3, const r1o_plane *ref3, const r1o_me_params *p,
                              r1o_me_stats *stats, const r1o_me_stats *prev);
+/* estimate_motion(.., Some(pmv), corner, extensive = false, ssdec = 0, None) of
+ * src/rdo.rs:1183-1196 over independent blocks of one tile: full-pel search
+ * from the tile's MEStats, SATD re-cost, sub-pel diamond (me.rs:536-632).
+ * bx, by: tile-relative 4x4 units; w, h: block size in px; corner: 0 = INIT,
+ * else 1 | right << 1 | bottom << 2; pmv[k] = (row, col). */
+typedef struct {
+  int16_t bx, by;
+  uint8_t w, h, corner, reserved;
+  int16_t pmv[2][2];
+} r1o_me_block;
+typedef struct { int16_t row, col; uint32_t sad; uint64_t cost; } r1o_me_result;
+int r1o_estimate_motion_batch(const r1o_plane *org3, const r1o_plane *ref3, const r1o_me_params *p,
+                              const r1o_me_stats *stats, const r1o_me_stats *prev,
+                              const r1o_me_block *blk, int n, int use_satd, int filter_mode,
+                              r1o_me_result *out);
 void r1o_set_threads(int n);
 int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
                    int h, const r1o_dist_cand *c, int n, uint32_t *out);

@@ -73,6 +73,8 @@ SYMBOLS = {
     "r1_rdo_full_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, C.POINTER(R1QuantParams),
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "r1_estimate_tile_motion_batch": (_i, [_vp, C.POINTER(R1MeJob), _i, C.POINTER(R1MeParams), _vp]),
+    "r1_estimate_motion_batch": (_i, [_vp, C.POINTER(R1MeJob), C.POINTER(R1MeParams), _vp, _i, _i, _i,
+                                      _i, _i, _vp, _vp]),
     "rav1e_sad_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_satd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_sad_hbd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),

@@ -71,6 +71,12 @@ class Plane:
                             self.height, self.xorigin, self.yorigin, self.bpp, self.bit_depth)
 
 
+ME_BLOCK_CAND = np.dtype([("bx", "<i2"), ("by", "<i2"), ("w", "u1"), ("h", "u1"), ("corner", "u1"),
+                          ("reserved", "u1"), ("pmv", "<i2", (2, 2))])
+ME_RESULT = np.dtype([("row", "<i2"), ("col", "<i2"), ("sad", "<u4"), ("cost", "<u8")])
+assert ME_BLOCK_CAND.itemsize == 16 and ME_RESULT.itemsize == 16
+
+
 def me_lambdas(me_lambda):
     """lambda of the three ME passes by ssdec (src/me.rs:175-177): fi.me_lambda = sqrt(fi.lambda)."""
     return [int(me_lambda * 256.0 / (1 << (2 * ss)) * (0.5 if ss == 0 else 0.125)) for ss in range(3)]
@@ -470,6 +476,31 @@ class Context:
                             (C.c_uint32 * 3)(*[int(v) for v in lambdas]), 0)
         self._check(self.lib.r1_estimate_tile_motion_batch(self.h, arr, n, C.byref(p), _stream_ptr()),
                     "r1_estimate_tile_motion_batch")
+
+    def estimate_motion_batch(self, job, cands, w_in_b, h_in_b, bit_depth, lambdas, max_w=64,
+                              max_h=64, use_satd=True, filter_mode=0, allow_hp=True, n=None):
+        """estimate_motion(.., Some(pmv), ..) of src/rdo.rs:1183-1196 for independent
+        blocks (ME_BLOCK_CAND array) of one (tile, reference) job -> ME_RESULT tensor bytes."""
+        arr = (_lib.R1MeJob * 1)()
+        st = job["stats"]
+        rows, cols = st.shape[:2]
+        for l in range(3):
+            arr[0].org[l] = job["org"][l].cstruct()
+            arr[0].ref[l] = job["ref"][l].cstruct()
+        arr[0].stats = st.data_ptr()
+        pv = job.get("prev")
+        arr[0].prev = pv.data_ptr() if pv is not None else None
+        arr[0].tile_x, arr[0].tile_y, arr[0].tile_w, arr[0].tile_h = job["tile"]
+        p = _lib.R1MeParams(w_in_b, h_in_b, cols, rows, bit_depth, int(allow_hp), 0, 1,
+                            (C.c_uint32 * 3)(*[int(v) for v in lambdas]), 0)
+        dc = _dev_cands(cands, ME_BLOCK_CAND)
+        n = dc.numel() // ME_BLOCK_CAND.itemsize if n is None else n
+        out = torch.empty(n * ME_RESULT.itemsize, dtype=torch.uint8, device="cuda")
+        self._check(self.lib.r1_estimate_motion_batch(self.h, arr, C.byref(p), dc.data_ptr(), n, max_w,
+                                                      max_h, int(use_satd), filter_mode,
+                                                      out.data_ptr(), _stream_ptr()),
+                    "r1_estimate_motion_batch")
+        return out
 
     # ---- fused candidate ----
     def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,

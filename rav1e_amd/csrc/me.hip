@@ -30,6 +30,8 @@
 // best candidate), so a block's search is a chain of such steps; the chip is
 // filled by jobs x superblocks-on-the-diagonal x blocks, not by one block.
 #include "common.hpp"
+#include "dist_common.hpp"
+#include "mc_common.hpp"
 
 namespace {
 
@@ -49,6 +51,21 @@ __device__ __forceinline__ int ilog_abs(int d) {   // ILog::ilog(d.abs())
 }
 __device__ __forceinline__ int div8(int v) { return (v + ((v >> 31) & 7)) >> 3; }   // trunc
 
+// compute_mv_rd's cost (me.rs:1456-1461) from a distortion
+struct MvCost {
+  uint32_t lambda;
+  int allow_hp;
+  int pmv_row[2], pmv_col[2];
+  __device__ __forceinline__ uint32_t rate1(int row, int col, int k) const {
+    const int dr = (int16_t)(row - pmv_row[k]), dc = (int16_t)(col - pmv_col[k]);
+    return 2u * (uint32_t)(ilog_abs(allow_hp ? dr : dr >> 1) + ilog_abs(allow_hp ? dc : dc >> 1));
+  }
+  __device__ __forceinline__ unsigned long long cost(int row, int col, uint32_t dist) const {
+    const uint32_t r1 = rate1(row, col, 0), r2 = rate1(row, col, 1) + 1;
+    return 256ull * dist + (unsigned long long)(r1 < r2 ? r1 : r2) * lambda;
+  }
+};
+
 // One block of one wave.  RH = rows per candidate slot (16 or 32): the block
 // is at most RH x RH; 64 / RH candidates are evaluated per step.
 template <int BPP, int RH>
@@ -58,8 +75,7 @@ struct Block {
   long sr;               // reference stride, bytes
   int w, h, po_x, po_y;
   int mvx_min, mvx_max, mvy_min, mvy_max;
-  uint32_t lambda;
-  int allow_hp;
+  MvCost mc;
   int r, slot;               // this lane: row, candidate slot
   uint32_t o[GR * WPG];      // source row (masked)
   uint32_t m[GR * WPG];      // pixel masks of this row: 0 beyond (w, h)
@@ -113,11 +129,7 @@ struct Block {
     }
 #pragma unroll
     for (int s = 1; s < RH; s <<= 1) part += __shfl_xor(part, s, 64);
-    // pmv = [0, 0] in every caller of this path (estimate_motion with pmv = None,
-    // refine_subsampled_motion_estimate): rate1 == rate2, rate = min(r, r + 1) = r
-    const int dr = allow_hp ? row : row >> 1, dc = allow_hp ? col : col >> 1;
-    const uint32_t rate = 2u * (uint32_t)(ilog_abs((int16_t)dr) + ilog_abs((int16_t)dc));
-    cost = in ? 256ull * part + (unsigned long long)rate * lambda : COST_MAX;
+    cost = in ? mc.cost(row, col, part) : COST_MAX;
     sad = in ? part : 0xFFFFFFFFu;
   }
 
@@ -425,8 +437,10 @@ __device__ __forceinline__ void setup_block(B &b, const R1MeJob &job, const R1Me
   b.po_x = (fbx * MI) >> ssdec;
   b.po_y = (fby * MI) >> ssdec;
   b.mvx_min = rng[0]; b.mvx_max = rng[1]; b.mvy_min = rng[2]; b.mvy_max = rng[3];
-  b.lambda = p.lambda[ssdec];
-  b.allow_hp = p.allow_hp;
+  b.mc.lambda = p.lambda[ssdec];
+  b.mc.allow_hp = p.allow_hp;
+  // estimate_motion with pmv = None / refine_subsampled_motion_estimate: pmv = [0, 0]
+  b.mc.pmv_row[0] = b.mc.pmv_row[1] = b.mc.pmv_col[0] = b.mc.pmv_col[1] = 0;
   b.init(job.org[ssdec], job.ref[ssdec], lane);
 }
 
@@ -509,6 +523,251 @@ __global__ __launch_bounds__(256) void k_me_diag(const R1MeJob *__restrict__ job
   }
 }
 
+// ---------------------------------------------------------------------------
+// estimate_motion with pmv = Some(..) (the RDO-time call, src/rdo.rs:1183-1196):
+// independent blocks of any BlockSize up to 64x64, full resolution.  One
+// WORKGROUP of 4 waves per block:
+//   * the source block sits in LDS; in the full-pel steps wave v / slot s takes
+//     candidate 4-or-less * v + s of a step (rows of a candidate on max(16, h)
+//     lanes), the per-wave winners meet in LDS;
+//   * in the sub-pel diamond (me.rs:1311-1383) wave v owns candidate v of the
+//     four: it stages the (w+7) x (h+7) reference window in LDS, runs put_8tap
+//     (mc_common.hpp) into an LDS tile and takes SATD / SAD of it against the
+//     source -- the prediction never exists in HBM.
+template <int BPP>
+struct WgBlock {
+  const uint8_t *ref0;
+  long sr;
+  int w, h, po_x, po_y;
+  int mvx_min, mvx_max, mvy_min, mvy_max;
+  MvCost mc;
+  int wave, lane, RH, r, slot, ncs;
+  const uint8_t *org;             // LDS, row stride w * BPP
+  unsigned long long *red;        // LDS, 4 x 3 words: cost, (idx, sad), (row, col)
+
+  __device__ __forceinline__ void eval(int row, int col, bool valid, bool check,
+                                       unsigned long long &cost, uint32_t &sad) const {
+    bool in = valid;
+    if (check) in = in && col >= mvx_min && col <= mvx_max && row >= mvy_min && row <= mvy_max;
+    uint32_t part = 0;
+    if (in && r < h) {
+      const uint8_t *p = ref0 + (long)(div8(row) + r) * sr + (long)div8(col) * BPP;
+      const uint8_t *o = org + r * w * BPP;
+      for (int g = 0; g < w / 4; g++) {
+        if constexpr (BPP == 1) {
+          part = __builtin_amdgcn_sad_u8(*(const uint32_t *)(o + 4 * g), ld_u32(p + 4 * g), part);
+        } else {
+          const U32x2 v = ld_u32x2(p + 8 * g);
+          part = __builtin_amdgcn_sad_u16(*(const uint32_t *)(o + 8 * g), v.a, part);
+          part = __builtin_amdgcn_sad_u16(*(const uint32_t *)(o + 8 * g + 4), v.b, part);
+        }
+      }
+    }
+    for (int s = 1; s < RH; s <<= 1) part += __shfl_xor(part, s, 64);
+    cost = in ? mc.cost(row, col, part) : COST_MAX;
+    sad = in ? part : 0xFFFFFFFFu;
+  }
+
+  // workgroup-wide argmin of (cost, idx): every thread returns the winner
+  __device__ __forceinline__ void wg_min(unsigned long long &cost, int &idx, int &row, int &col,
+                                         uint32_t &sad) const {
+    if (lane == 0) {
+      red[3 * wave] = cost;
+      red[3 * wave + 1] = ((unsigned long long)(uint32_t)idx << 32) | sad;
+      red[3 * wave + 2] = ((unsigned long long)(uint32_t)row << 32) | (uint32_t)col;
+    }
+    __syncthreads();
+    int best = 0;
+    for (int v = 1; v < 4; v++) {
+      const unsigned long long c = red[3 * v], cb = red[3 * best];
+      if (c < cb || (c == cb && (int)(red[3 * v + 1] >> 32) < (int)(red[3 * best + 1] >> 32))) best = v;
+    }
+    cost = red[3 * best];
+    idx = (int)(red[3 * best + 1] >> 32);
+    sad = (uint32_t)red[3 * best + 1];
+    row = (int)(red[3 * best + 2] >> 32);
+    col = (int)(uint32_t)red[3 * best + 2];
+    __syncthreads();
+  }
+
+  template <class Gen>
+  __device__ __forceinline__ void scan(int n, Gen gen, bool check, Msr &best, int *best_idx) const {
+    for (int base = 0; base < n; base += 4 * ncs) {
+      int idx = base + wave * ncs + slot;
+      const bool valid = idx < n;
+      int row = 0, col = 0;
+      if (valid) gen(idx, row, col);
+      unsigned long long cost;
+      uint32_t sad;
+      eval(row, col, valid, check, cost, sad);
+      for (int s = RH; s < 64; s <<= 1) {
+        const unsigned long long oc =
+            ((unsigned long long)(uint32_t)__shfl_xor((int)(cost >> 32), s, 64) << 32) |
+            (uint32_t)__shfl_xor((int)(uint32_t)cost, s, 64);
+        const int oi = __shfl_xor(idx, s, 64), orow = __shfl_xor(row, s, 64),
+                  ocol = __shfl_xor(col, s, 64);
+        const uint32_t os = (uint32_t)__shfl_xor((int)sad, s, 64);
+        if (oc < cost || (oc == cost && oi < idx)) {
+          cost = oc; idx = oi; row = orow; col = ocol; sad = os;
+        }
+      }
+      wg_min(cost, idx, row, col, sad);
+      if (cost < best.cost) {
+        best = Msr{row, col, cost, sad};
+        if (best_idx) *best_idx = idx;
+      }
+    }
+  }
+
+  // this wave: put_8tap of the block at (sx, sy) + fractions into `pred`, then
+  // get_satd / get_sad against the source (compute_mv_rd's distortion)
+  __device__ __forceinline__ uint32_t predict_dist(const R1Plane &ref, uint8_t *win, uint8_t *pred,
+                                                   int sx, int sy, int col_frac, int row_frac,
+                                                   int mode, bool use_satd) const {
+    const int ws = (((w + 7) * BPP + 3) >> 2) << 2;
+    r1mc::stage_window<BPP>(win, ws, ref, sx, sy, w, h, lane, 64);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < w) {
+      if constexpr (BPP == 1)
+        r1mc::mc_column<BPP, false, 0>(win, ws, lane, w, h, col_frac, row_frac, mode, mode,
+                                       ref.bit_depth,
+                                       [&](int rr, int32_t v) { pred[rr * w + lane] = (uint8_t)v; });
+      else
+        r1mc::mc_column<BPP, false, 0>(win, ws, lane, w, h, col_frac, row_frac, mode, mode,
+                                       ref.bit_depth, [&](int rr, int32_t v) {
+                                         ((uint16_t *)pred)[rr * w + lane] = (uint16_t)v;
+                                       });
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool small = (w < h ? w : h) == 4;
+    const int ts = small ? 4 : 8, ntx = w / ts, nt = ntx * (h / ts);
+    uint32_t s = 0;
+    if (lane < nt) {
+      const int tx = lane % ntx, ty = lane / ntx;
+      const size_t off = ((size_t)ty * ts * w + (size_t)tx * ts) * BPP, st = (size_t)w * BPP;
+      if (use_satd)
+        s = small ? r1dist::tile_dist<BPP, 4, true>(org + off, st, pred + off, st)
+                  : r1dist::tile_dist<BPP, 8, true>(org + off, st, pred + off, st);
+      else
+        s = small ? r1dist::tile_dist<BPP, 4, false>(org + off, st, pred + off, st)
+                  : r1dist::tile_dist<BPP, 8, false>(org + off, st, pred + off, st);
+    }
+    for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+    const int ln = small ? 2 : 3;
+    return use_satd ? (s + ((1u << ln) >> 1)) >> ln : s;
+  }
+};
+
+template <int BPP>
+__global__ __launch_bounds__(256) void k_me_blocks(R1MeJob job, R1MeParams p,
+                                                   const R1MeBlockCand *__restrict__ cands,
+                                                   int max_w, int max_h, int use_satd,
+                                                   int filter_mode,
+                                                   R1MeResult *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int16_t sh_subsets[4][kSubsetWords];
+  __shared__ unsigned long long sh_red[12];
+  const R1MeBlockCand cd = cands[blockIdx.x];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = cd.w, h = cd.h;
+  if (w > max_w || h > max_h || w < 4 || h < 4 || (w & (w - 1)) || (h & (h - 1))) {
+    // not a block this launch was sized for: an empty MotionSearchResult
+    if (threadIdx.x == 0) out[blockIdx.x] = R1MeResult{0, 0, 0xFFFFFFFFu, COST_MAX};
+    return;
+  }
+  TileView t{job.stats, job.prev, p.stats_cols, p.stats_rows, job.tile_x / MI, job.tile_y / MI,
+             job.tile_w / MI, job.tile_h / MI};
+  // LDS: source block | 4 x (window | prediction)
+  const int ws = (((w + 7) * BPP + 3) >> 2) << 2;
+  const int org_bytes = (w * h * BPP + 15) & ~15, win_bytes = ((h + 7) * ws + 15) & ~15;
+  uint8_t *org_l = smem;
+  uint8_t *win = smem + org_bytes + wave * (win_bytes + org_bytes);
+  uint8_t *pred = win + win_bytes;
+
+  WgBlock<BPP> b;
+  int rng[4];
+  const int fbx = t.tx + cd.bx, fby = t.ty + cd.by;
+  mv_range(p, fbx, fby, w, h, 0, rng);
+  b.w = w; b.h = h;
+  b.po_x = fbx * MI; b.po_y = fby * MI;
+  b.mvx_min = rng[0]; b.mvx_max = rng[1]; b.mvy_min = rng[2]; b.mvy_max = rng[3];
+  b.mc.lambda = p.lambda[0];
+  b.mc.allow_hp = p.allow_hp;
+  for (int k = 0; k < 2; k++) { b.mc.pmv_row[k] = cd.pmv[k][0]; b.mc.pmv_col[k] = cd.pmv[k][1]; }
+  const R1Plane &org = job.org[0], &ref = job.ref[0];
+  b.sr = (long)ref.stride * BPP;
+  b.ref0 = px_addr<BPP>(ref, b.po_x, b.po_y);
+  b.wave = wave; b.lane = lane;
+  b.RH = h < 16 ? 16 : h;
+  b.r = lane % b.RH; b.slot = lane / b.RH; b.ncs = 64 / b.RH;
+  b.org = org_l;
+  b.red = sh_red;
+  {   // source block -> LDS (4-px granules)
+    const int gpr = w / 4, ng = gpr * h;
+    const uint8_t *o0 = px_addr<BPP>(org, b.po_x, b.po_y);
+    for (int i = threadIdx.x; i < ng; i += 256) {
+      const int rr = i / gpr, g = i - rr * gpr;
+      const uint8_t *src = o0 + (long)rr * org.stride * BPP + g * 4 * BPP;
+      if constexpr (BPP == 1) *(uint32_t *)(org_l + rr * w + 4 * g) = ld_u32(src);
+      else {
+        const U32x2 v = ld_u32x2(src);
+        *(uint32_t *)(org_l + (rr * w + 4 * g) * 2) = v.a;
+        *(uint32_t *)(org_l + (rr * w + 4 * g) * 2 + 4) = v.b;
+      }
+    }
+  }
+  __syncthreads();
+
+  Msr best = full_pixel_me(b, t, p, cd.bx, cd.by, rng, cd.corner, false, 0, sh_subsets[wave]);
+
+  auto in_range = [&](int row, int col) {
+    return col >= b.mvx_min && col <= b.mvx_max && row >= b.mvy_min && row <= b.mvy_max;
+  };
+  if (use_satd) {
+    // get_fullpel_mv_rd(best.mv, use_satd) (me.rs:596-613); every wave computes the same
+    if (!in_range(best.row, best.col)) {
+      best.cost = COST_MAX;
+      best.sad = 0xFFFFFFFFu;
+    } else {
+      const uint32_t d = b.predict_dist(ref, win, pred, b.po_x + div8(best.col),
+                                        b.po_y + div8(best.row), 0, 0, filter_mode, true);
+      best.sad = d;
+      best.cost = b.mc.cost(best.row, best.col, d);
+    }
+  }
+  // subpel_diamond_search: wave v <-> DIAMOND_R1_PATTERN_SUBPEL[v]
+  int radius_log2 = 2;
+  const int end_log2 = p.allow_hp ? 0 : 1;
+  for (;;) {
+    int row = (int16_t)(best.row + (kDiamond[wave][0] << radius_log2));
+    int col = (int16_t)(best.col + (kDiamond[wave][1] << radius_log2));
+    unsigned long long cost = COST_MAX;
+    uint32_t sad = 0xFFFFFFFFu;
+    if (in_range(row, col)) {
+      // get_mv_params (src/predict.rs:284-297): floor offset, 1/16 fraction
+      sad = b.predict_dist(ref, win, pred, b.po_x + (col >> 3), b.po_y + (row >> 3),
+                           (col << 1) & 15, (row << 1) & 15, filter_mode, use_satd != 0);
+      cost = b.mc.cost(row, col, sad);
+    }
+    int idx = wave;
+    b.wg_min(cost, idx, row, col, sad);
+    if (best.cost <= cost) {
+      if (radius_log2 == end_log2) break;
+      radius_log2--;
+    } else {
+      best = Msr{row, col, cost, sad};
+    }
+  }
+  if (threadIdx.x == 0) {
+    R1MeResult r;
+    r.row = (int16_t)best.row;
+    r.col = (int16_t)best.col;
+    r.sad = best.sad;
+    r.cost = best.cost;
+    out[blockIdx.x] = r;
+  }
+}
+
 }  // namespace
 
 extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, int n_jobs,
@@ -560,5 +819,41 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   R1_HIP_CHECK(hipGetLastError());
   // the descriptor buffer is reused by the next call on this context
   R1_HIP_CHECK(hipStreamSynchronize(st));
+  return R1_OK;
+}
+
+extern "C" int r1_estimate_motion_batch(r1_ctx *ctx, const R1MeJob *tile, const R1MeParams *params,
+                                        const R1MeBlockCand *cands, int n, int max_w, int max_h,
+                                        int use_satd, int filter_mode, R1MeResult *out,
+                                        void *stream) {
+  R1_REQUIRE(ctx && tile && params);
+  R1_REQUIRE(params->bit_depth == 8 || params->bit_depth == 10 || params->bit_depth == 12);
+  R1_REQUIRE(filter_mode >= 0 && filter_mode <= 3);
+  R1_REQUIRE(r1_is_pow2(max_w) && r1_is_pow2(max_h) && max_w >= 4 && max_h >= 4 && max_w <= 64 &&
+             max_h <= 64);
+  R1_REQUIRE(tile->stats && tile->org[0].data && tile->ref[0].data);
+  R1_REQUIRE(tile->tile_x % SB == 0 && tile->tile_y % SB == 0 && tile->tile_w % MI == 0 &&
+             tile->tile_h % MI == 0 && tile->tile_w > 0 && tile->tile_h > 0);
+  const int bpp = tile->org[0].bytes_per_px;
+  R1_REQUIRE((bpp == 1 || bpp == 2) && tile->ref[0].bytes_per_px == bpp);
+  if (n <= 0) return R1_OK;
+  R1_REQUIRE(cands && out);
+  hipStream_t st = (hipStream_t)stream;
+  // LDS for the largest block of the batch: source + 4 x (window + prediction)
+  const int ws = (((max_w + 7) * bpp + 3) >> 2) << 2;
+  const size_t blk = ((size_t)max_w * max_h * bpp + 15) & ~(size_t)15;
+  const size_t lds = blk + 4 * ((((size_t)(max_h + 7) * ws + 15) & ~(size_t)15) + blk);
+  if (bpp == 1) {
+    R1_HIP_CHECK(hipFuncSetAttribute((const void *)k_me_blocks<1>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_me_blocks<1>, dim3(n), dim3(256), lds, st, *tile, *params, cands, max_w,
+                       max_h, use_satd, filter_mode, out);
+  } else {
+    R1_HIP_CHECK(hipFuncSetAttribute((const void *)k_me_blocks<2>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_me_blocks<2>, dim3(n), dim3(256), lds, st, *tile, *params, cands, max_w,
+                       max_h, use_satd, filter_mode, out);
+  }
+  R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }

@@ -103,6 +103,7 @@ def lib():
         "r1o_mc_avg_batch": (i, [vp, vp, i, i, i, i, i, vp]),
         "r1o_rdo_cand_batch": (i, [vp, vp, i, i, i, vp, i, vp, vp, vp, vp]),
         "r1o_estimate_tile_motion": (i, [vp, vp, vp, vp, vp]),
+        "r1o_estimate_motion_batch": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
         "r1o_rdo_full_cand_batch": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
@@ -164,6 +165,9 @@ class MeParams(C.Structure):
                 ("me_range_scale", C.c_int32), ("lambda_", C.c_uint32 * 3)]
 
 
+ME_BLOCK_CAND = np.dtype([("bx", "<i2"), ("by", "<i2"), ("w", "u1"), ("h", "u1"), ("corner", "u1"),
+                          ("reserved", "u1"), ("pmv", "<i2", (2, 2))])
+ME_RESULT = np.dtype([("row", "<i2"), ("col", "<i2"), ("sad", "<u4"), ("cost", "<u8")])
 ME_STATS = np.dtype([("row", "<i2"), ("col", "<i2"), ("normalized_sad", "<u4")])
 assert ME_STATS.itemsize == 8
 
@@ -205,3 +209,19 @@ def me_oracle(L, org3, ref3, w_in_b, h_in_b, tile, bit_depth, lambdas, stats, pr
                                     prev.ctypes.data if prev is not None else None)
     assert rc == 0
     return stats
+
+
+def me_block_oracle(L, org3, ref3, w_in_b, h_in_b, tile, bit_depth, lambdas, stats, prev, cands,
+                    use_satd=1, filter_mode=0, allow_hp=1):
+    po = (Plane * 3)(*[p.cstruct() for p in org3])
+    pr = (Plane * 3)(*[p.cstruct() for p in ref3])
+    rows, cols = stats.shape
+    prm = MeParams(w_in_b, h_in_b, cols, rows, tile[0], tile[1], tile[2], tile[3], bit_depth,
+                   allow_hp, 0, 1, (C.c_uint32 * 3)(*lambdas))
+    out = np.zeros(len(cands), ME_RESULT)
+    rc = L.r1o_estimate_motion_batch(po, pr, C.byref(prm), stats.ctypes.data,
+                                     prev.ctypes.data if prev is not None else None,
+                                     cands.ctypes.data, len(cands), use_satd, filter_mode,
+                                     out.ctypes.data)
+    assert rc == 0
+    return out

@@ -1016,3 +1016,48 @@ def test_estimate_tile_motion_jobs_are_tiles_and_references(ctx, oracle):
     ctx.estimate_tile_motion(jobs, w // 4, h // 4, bd, lam)
     assert np.array_equal(_me_stats_numpy(s1), want1)
     assert np.array_equal(_me_stats_numpy(s2), want2)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_estimate_motion_blocks_subpel_vs_oracle(ctx, oracle, bd):
+    """r1_estimate_motion_batch (the RDO-time estimate_motion with pmv: full-pel from the
+    tile's MEStats, SATD re-cost, sub-pel diamond through put_8tap) for every BlockSize up to
+    64x64, SATD and SAD flavours, 1/8- and 1/4-pel precision, all four filters."""
+    from rav1e_amd.api import me_lambdas, ME_RESULT
+    w, h = 320, 192
+    org, ref = _me_images("smooth", w, h, bd, 21 + bd)
+    ref = np.clip(ref + np.random.default_rng(5).integers(-6, 7, ref.shape), 0, (1 << bd) - 1)
+    po, pr = O.me_pyramid(org, bd), O.me_pyramid(ref, bd)
+    lam = me_lambdas(25.0)
+    stats = np.zeros((h // 4, w // 4), O.ME_STATS)
+    O.me_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, stats)   # realistic MEStats
+    rng = np.random.default_rng(31 + bd)
+    prev = np.zeros_like(stats)
+    prev["row"] = rng.integers(-60, 61, prev.shape)
+    prev["col"] = rng.integers(-60, 61, prev.shape)
+    prev["normalized_sad"] = rng.integers(0, 1 << 20, prev.shape)
+    sizes = [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16), (32, 32),
+             (32, 64), (64, 32), (64, 64), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+    c = np.zeros(6 * len(sizes), O.ME_BLOCK_CAND)
+    for i in range(len(c)):
+        bw, bh = sizes[i % len(sizes)]
+        c["w"][i], c["h"][i] = bw, bh
+        c["bx"][i] = rng.integers(0, (w - bw) // 4 + 1)
+        c["by"][i] = rng.integers(0, (h - bh) // 4 + 1)
+        c["corner"][i] = rng.choice([0, 1, 3, 5, 7])
+        c["pmv"][i] = rng.integers(-40, 41, (2, 2))
+    job = dict(org=_me_dev_pyr(po), ref=_me_dev_pyr(pr), stats=_me_stats_tensor(stats),
+               prev=_me_stats_tensor(prev), tile=(0, 0, w, h))
+    for use_satd, mode, hp in ((1, 0, 1), (0, 0, 1), (1, 2, 0), (1, 1, 1), (0, 3, 0)):
+        want = O.me_block_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, stats, prev, c,
+                                 use_satd=use_satd, filter_mode=mode, allow_hp=hp)
+        got = ctx.estimate_motion_batch(job, c, w // 4, h // 4, bd, lam, use_satd=bool(use_satd),
+                                        filter_mode=mode, allow_hp=bool(hp)).cpu().numpy().view(ME_RESULT)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (bd, use_satd, mode, hp, c[bad[0]], got[bad[0]], want[bad[0]])
+    # a launch sized for 16x16 refuses the larger blocks (empty result), serves the rest
+    got = ctx.estimate_motion_batch(job, c, w // 4, h // 4, bd, lam, max_w=16, max_h=16).cpu().numpy().view(ME_RESULT)
+    big = (c["w"] > 16) | (c["h"] > 16)
+    assert (got["cost"][big] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    want = O.me_block_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, stats, prev, c)
+    assert np.array_equal(got[~big], want[~big])

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Whole-frame hierarchical motion estimation
+on a 4K luma frame: one JSON line per job configuration (tiles x reference frames), plus
+the CPU oracle (one thread, one tile x one reference) for scale.
+
+    python tools/bench_me.py [--width 3840 --height 2160 --bit-depth 8 --reps 5 --cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def texture(w, h, bd, seed):
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((h + 64, w + 64)).astype(np.float32)
+    for _ in range(3):
+        f = (np.roll(f, 1, 0) + 2 * f + np.roll(f, -1, 0)) / 4
+        f = (np.roll(f, 1, 1) + 2 * f + np.roll(f, -1, 1)) / 4
+    return ((f - f.min()) / (f.max() - f.min()) * ((1 << bd) - 1)).astype(np.int64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (tens of seconds)")
+    args = ap.parse_args()
+    import torch
+    import oracle_lib as O
+    from rav1e_amd.api import Context, Plane, me_lambdas
+    w, h, bd = args.width, args.height, args.bit_depth
+    f = texture(w, h, bd, 1)
+    rng = np.random.default_rng(2)
+    org = f[32:32 + h, 32:32 + w]
+    shifts = [(5, -9), (-3, 2), (12, 7), (0, -1)]
+    refs = [np.clip(f[32 + dy:32 + dy + h, 32 + dx:32 + dx + w] + rng.integers(-2, 3, (h, w)), 0,
+                    (1 << bd) - 1) for dx, dy in shifts]
+    po = O.me_pyramid(org, bd)
+    prs = [O.me_pyramid(r, bd) for r in refs]
+    dev = lambda pyr: [Plane.from_numpy(p.data, p.width, p.height, bd, p.xpad, p.ypad) for p in pyr]
+    do, drs = dev(po), [dev(p) for p in prs]
+    lam = me_lambdas(30.0)
+    ctx = Context(0)
+    rows, cols = h // 4, w // 4
+
+    def tiles_of(nx, ny):
+        tw = -(-(w // nx) // 64) * 64
+        th = -(-(h // ny) // 64) * 64
+        return [(x, y, min(tw, w - x), min(th, h - y)) for y in range(0, h, th) for x in range(0, w, tw)]
+
+    for (nx, ny, nref) in ((1, 1, 1), (1, 1, 4), (2, 2, 4), (4, 4, 4)):
+        tl = tiles_of(nx, ny)
+        stats = [torch.zeros((rows, cols, 2), dtype=torch.int32, device="cuda") for _ in range(nref)]
+        jobs = [dict(org=do, ref=drs[r], stats=stats[r], tile=t) for r in range(nref) for t in tl]
+
+        def run():
+            for s in stats:
+                s.zero_()
+            ctx.estimate_tile_motion(jobs, cols, rows, bd, lam)
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.reps * 1e3
+        print(json.dumps({"kernel": "estimate_tile_motion", "frame": "%dx%d" % (w, h), "bit_depth": bd,
+                          "tiles": len(tl), "refs": nref, "jobs": len(jobs), "ms": round(ms, 3),
+                          "Mpixels_s": round(w * h * nref / ms / 1e3, 1),
+                          "frames_refs_per_s": round(nref / ms * 1e3, 1)}), flush=True)
+    if args.cpu:
+        L = O.lib()
+        st = np.zeros((rows, cols), O.ME_STATS)
+        t0 = time.perf_counter()
+        O.me_oracle(L, po, prs[0], cols, rows, (0, 0, w, h), bd, lam, st)
+        dt = time.perf_counter() - t0
+        got = torch.zeros((rows, cols, 2), dtype=torch.int32, device="cuda")
+        ctx.estimate_tile_motion([dict(org=do, ref=drs[0], stats=got, tile=(0, 0, w, h))], cols, rows, bd, lam)
+        same = bool(np.array_equal(got.cpu().numpy().reshape(rows, -1).view(O.ME_STATS).reshape(rows, cols), st))
+        print(json.dumps({"kernel": "estimate_tile_motion (CPU oracle, 1 thread)", "ms": round(dt * 1e3, 1),
+                          "Mpixels_s": round(w * h / dt / 1e6, 1), "gpu_equals_oracle_at_4k": same}), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
