@@ -78,8 +78,48 @@ def main():
                           "tiles": len(tl), "refs": nref, "jobs": len(jobs), "ms": round(ms, 3),
                           "Mpixels_s": round(w * h * nref / ms / 1e3, 1),
                           "frames_refs_per_s": round(nref / ms * 1e3, 1)}), flush=True)
+    # ---- RDO-time estimate_motion (full-pel + SATD + sub-pel diamond) on every block of a size ----
+    from rav1e_amd.api import ME_BLOCK_CAND, ME_RESULT
+    st0 = torch.zeros((rows, cols, 2), dtype=torch.int32, device="cuda")
+    ctx.estimate_tile_motion([dict(org=do, ref=drs[0], stats=st0, tile=(0, 0, w, h))], cols, rows, bd, lam)
+    job = dict(org=do, ref=drs[0], stats=st0, tile=(0, 0, w, h))
+    blk_c = {}
+    for s in (64, 32, 16, 8):
+        nx, ny = w // s, h // s
+        c = np.zeros(nx * ny, ME_BLOCK_CAND)
+        c["bx"] = np.tile(np.arange(nx) * (s // 4), ny)
+        c["by"] = np.repeat(np.arange(ny) * (s // 4), nx)
+        c["w"] = c["h"] = s
+        c["corner"] = 7
+        c["pmv"] = rng.integers(-16, 17, (len(c), 2, 2))
+        blk_c[s] = c
+        dc = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
+        f = lambda: ctx.estimate_motion_batch(job, dc, cols, rows, bd, lam, max_w=s, max_h=s, n=len(c))
+        f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            f()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.reps * 1e3
+        print(json.dumps({"kernel": "estimate_motion (full-pel + SATD + sub-pel) %dx%d" % (s, s),
+                          "blocks": len(c), "bit_depth": bd, "ms": round(ms, 3),
+                          "Mpixels_s": round(len(c) * s * s / ms / 1e3, 1),
+                          "blocks_per_s": round(len(c) / ms * 1e3)}), flush=True)
     if args.cpu:
         L = O.lib()
+        L.r1o_set_threads(os.cpu_count() or 1)
+        hst = st0.cpu().numpy().reshape(rows, -1).view(O.ME_STATS).reshape(rows, cols)
+        for s in (16,):
+            t0 = time.perf_counter()
+            want = O.me_block_oracle(L, po, prs[0], cols, rows, (0, 0, w, h), bd, lam, hst, None, blk_c[s])
+            dt = time.perf_counter() - t0
+            got = ctx.estimate_motion_batch(job, blk_c[s], cols, rows, bd, lam, max_w=s, max_h=s)
+            same = bool(np.array_equal(got.cpu().numpy().view(ME_RESULT), want))
+            print(json.dumps({"kernel": "estimate_motion %dx%d (CPU oracle, %d threads)" % (s, s, os.cpu_count()),
+                              "ms": round(dt * 1e3, 1), "blocks_per_s": round(len(want) / dt),
+                              "gpu_equals_oracle_at_4k": same}), flush=True)
+        L.r1o_set_threads(1)
         st = np.zeros((rows, cols), O.ME_STATS)
         t0 = time.perf_counter()
         O.me_oracle(L, po, prs[0], cols, rows, (0, 0, w, h), bd, lam, st)
