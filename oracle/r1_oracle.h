@@ -200,6 +200,31 @@ int r1o_estimate_motion_batch(const r1o_plane *org3, const r1o_plane *ref3, cons
                               const r1o_me_stats *stats, const r1o_me_stats *prev,
                               const r1o_me_block *blk, int n, int use_satd, int filter_mode,
                               r1o_me_result *out);
+/* ---- deblocking filter + level search (src/deblock.rs, see oracle/deblock.c) ---- */
+typedef struct {
+  uint8_t tx_log2;   /* luma transform: log2(width_mi) | log2(height_mi) << 3 */
+  uint8_t uvtx_log2; /* bsize.largest_chroma_tx_size(xdec, ydec), same packing */
+  uint8_t n4_log2;   /* block: log2(n4_w) | log2(n4_h) << 3 */
+  uint8_t flags;     /* 1 skip, 2 ref_frames[0] == INTRA_FRAME, 4 mode_type
+                        (mode >= NEARESTMV && != GLOBALMV && != GLOBAL_GLOBALMV),
+                        bits 3-5 ref_frames[0].to_index() */
+  int8_t deltas[4];  /* deblock_deltas */
+} r1o_deblock_block;
+typedef struct {     /* DeblockState (src/encoder.rs) */
+  uint8_t levels[4];
+  uint8_t sharpness; /* carried, unused by the reference's filters (always 0) */
+  uint8_t deltas_enabled, block_deltas_enabled, block_delta_shift, block_delta_multi;
+  int8_t ref_deltas[8], mode_deltas[2];
+  uint8_t reserved[5];
+} r1o_deblock_state;
+int r1o_deblock_plane(const r1o_deblock_state *d, const r1o_plane *p, int pli, int xdec, int ydec,
+                      const r1o_deblock_block *blocks, int blocks_stride, int blocks_cols, int blocks_rows,
+                      int crop_w, int crop_h, int bd);
+int r1o_deblock_sse_plane(const r1o_plane *rec, const r1o_plane *src, int pli, int xdec, int ydec,
+                          const r1o_deblock_block *blocks, int blocks_stride, int blocks_cols,
+                          int blocks_rows, int crop_w, int crop_h, int bd, int64_t *v_tally,
+                          int64_t *h_tally);
+void r1o_deblock_pick_levels(int64_t *v_tally, int64_t *h_tally, int pli, uint8_t *out);
 void r1o_set_threads(int n);
 int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
                    int h, const r1o_dist_cand *c, int n, uint32_t *out);
