@@ -385,6 +385,51 @@ int r1_estimate_motion_batch(r1_ctx *ctx, const R1MeJob *tile, const R1MeParams 
                              const R1MeBlockCand *cands, int n, int max_w, int max_h,
                              int use_satd, int filter_mode, R1MeResult *out, void *stream);
 
+/* ---- deblocking filter and its level search (SURVEY.md 8f "N3"; reference
+ * src/deblock.rs: deblock_plane 1294-1459 / deblock_filter_frame 1544-1551,
+ * sse_plane 1461-1542, sse_optimize 1553-1617, deblock_filter_optimize 1620).
+ * R1DeblockBlock: what the filter reads from the reference's per-4x4 `Block`
+ * (src/context/block_unit.rs), one entry per 4x4 luma block of the frame,
+ * row-major with `blocks_stride` entries per row, DEVICE memory:
+ *   tx_log2   = log2(txsize.width_mi()) | log2(txsize.height_mi()) << 3
+ *   uvtx_log2 = the same for bsize.largest_chroma_tx_size(xdec, ydec)
+ *   n4_log2   = log2(n4_w) | log2(n4_h) << 3
+ *   flags     = skip | (ref_frames[0] == INTRA_FRAME) << 1
+ *               | (mode >= NEARESTMV && mode != GLOBALMV && mode != GLOBAL_GLOBALMV) << 2
+ *               | ref_frames[0].to_index() << 3
+ *   deltas    = deblock_deltas
+ * R1DeblockState = DeblockState (levels: Y vertical, Y horizontal, U, V).
+ * r1_deblock_plane filters `plane` IN PLACE (pli 0..2; luma: xdec = ydec = 0),
+ * crop_w / crop_h in luma pixels as the reference's callers pass them
+ * (fi.width, fi.height).
+ * r1_deblock_sse_plane ADDS the level-search tallies of one plane into
+ * v_tally / h_tally (device, MAX_LOOP_FILTER + 2 = 65 int64 each, zeroed by
+ * the caller); r1_deblock_pick_levels is sse_optimize's tail on HOST copies of
+ * them: luma -> levels_out[0..1] = (vertical, horizontal), chroma ->
+ * levels_out[0].  Like the reference's sse_h_edge (deblock.rs:1258) the
+ * horizontal tallies size their filters from transform WIDTHS; near the top and
+ * bottom of the frame such a line may read up to 7 rows of the planes' padding. */
+typedef struct R1DeblockBlock {
+  uint8_t tx_log2, uvtx_log2, n4_log2, flags;
+  int8_t deltas[4];
+} R1DeblockBlock;
+typedef struct R1DeblockState {
+  uint8_t levels[4];
+  uint8_t sharpness;            /* carried; the reference's filters never read it */
+  uint8_t deltas_enabled, block_deltas_enabled, block_delta_shift, block_delta_multi;
+  int8_t ref_deltas[8], mode_deltas[2];
+  uint8_t reserved[5];
+} R1DeblockState;
+int r1_deblock_plane(r1_ctx *ctx, const R1DeblockState *state, const R1Plane *plane, int pli,
+                     int xdec, int ydec, const R1DeblockBlock *blocks, int blocks_stride,
+                     int blocks_cols, int blocks_rows, int crop_w, int crop_h, void *stream);
+int r1_deblock_sse_plane(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src, int pli, int xdec,
+                         int ydec, const R1DeblockBlock *blocks, int blocks_stride, int blocks_cols,
+                         int blocks_rows, int crop_w, int crop_h, int64_t *v_tally,
+                         int64_t *h_tally, void *stream);
+int r1_deblock_pick_levels(const int64_t *v_tally, const int64_t *h_tally, int pli,
+                           uint8_t *levels_out);
+
 /* ---- fused RDO candidate: the headline path.  For each candidate:
  *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)
  *   sad    = get_sad(org @ (ox,oy), pred)       if sad_out     (src/dist.rs:31)

@@ -75,6 +75,9 @@ SYMBOLS = {
     "r1_estimate_tile_motion_batch": (_i, [_vp, C.POINTER(R1MeJob), _i, C.POINTER(R1MeParams), _vp]),
     "r1_estimate_motion_batch": (_i, [_vp, C.POINTER(R1MeJob), C.POINTER(R1MeParams), _vp, _i, _i, _i,
                                       _i, _i, _vp, _vp]),
+    "r1_deblock_plane": (_i, [_vp, _vp, _PP, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "r1_deblock_sse_plane": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "r1_deblock_pick_levels": (_i, [_vp, _vp, _i, _vp]),
     "rav1e_sad_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_satd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_sad_hbd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),

@@ -502,6 +502,38 @@ class Context:
                     "r1_estimate_motion_batch")
         return out
 
+    # ---- deblock:: ----
+    def deblock_plane(self, state, plane, pli, xdec, ydec, blocks, crop_w, crop_h):
+        """deblock_plane (src/deblock.rs:1294-1459), in place.  state: 24-byte R1DeblockState
+        (numpy, host); blocks: uint8 device tensor (mi_rows, mi_cols, 8) of R1DeblockBlock."""
+        pc = plane.cstruct()
+        st = np.ascontiguousarray(state).view(np.uint8)
+        assert st.size == 24 and blocks.dtype == torch.uint8 and blocks.shape[2] == 8
+        self._check(self.lib.r1_deblock_plane(self.h, st.ctypes.data, C.byref(pc), pli, xdec, ydec,
+                                              blocks.data_ptr(), blocks.shape[1], blocks.shape[1],
+                                              blocks.shape[0], crop_w, crop_h, _stream_ptr()),
+                    "r1_deblock_plane")
+
+    def deblock_sse_plane(self, rec, src, pli, xdec, ydec, blocks, crop_w, crop_h, tallies=None):
+        """sse_plane (src/deblock.rs:1461-1542) -> int64 device tensor (2, 65): vertical, horizontal"""
+        if tallies is None:
+            tallies = torch.zeros((2, 65), dtype=torch.int64, device="cuda")
+        pr, ps = rec.cstruct(), src.cstruct()
+        self._check(self.lib.r1_deblock_sse_plane(self.h, C.byref(pr), C.byref(ps), pli, xdec, ydec,
+                                                  blocks.data_ptr(), blocks.shape[1], blocks.shape[1],
+                                                  blocks.shape[0], crop_w, crop_h,
+                                                  tallies[0].data_ptr(), tallies[1].data_ptr(),
+                                                  _stream_ptr()), "r1_deblock_sse_plane")
+        return tallies
+
+    def deblock_pick_levels(self, tallies, pli):
+        """sse_optimize's tail on host copies of the tallies -> levels (2 for luma, 1 for chroma)"""
+        t = np.ascontiguousarray(tallies.cpu().numpy())
+        out = np.zeros(2, np.uint8)
+        self._check(self.lib.r1_deblock_pick_levels(t[0].ctypes.data, t[1].ctypes.data, pli,
+                                                    out.ctypes.data), "r1_deblock_pick_levels")
+        return out[:2] if pli == 0 else out[:1]
+
     # ---- fused candidate ----
     def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,
                        want_coeffs=True, want_pred=False, outs=None):

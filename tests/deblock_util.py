@@ -22,11 +22,13 @@ def _log2(v):
 
 
 def random_blocks(rng, mi_cols, mi_rows, xdec, ydec, p_skip=0.5, p_intra=0.2, deltas=False):
-    """Random partition of the frame into power-of-two blocks (4x4 .. 64x64, aspect <= 4),
-    each with a random transform size dividing it.  -> DEBLOCK_BLOCK array (mi_rows, mi_cols)."""
+    """Random AV1 partition trees over the frame's 64x64 superblocks, each leaf with a random
+    transform size dividing it.  -> DEBLOCK_BLOCK array (mi_rows, mi_cols)."""
     out = np.zeros((mi_rows, mi_cols), DEBLOCK_BLOCK)
 
     def leaf(x, y, w, h):       # in 4x4 units
+        if x >= mi_cols or y >= mi_rows:
+            return
         txw = 1 << rng.integers(max(0, _log2(w) - 2), min(_log2(w), 4) + 1)
         txh = 1 << rng.integers(max(0, _log2(h) - 2), min(_log2(h), 4) + 1)
         while txw > 4 * txh:
@@ -46,28 +48,49 @@ def random_blocks(rng, mi_cols, mi_rows, xdec, ydec, p_skip=0.5, p_intra=0.2, de
         if deltas:
             b["deltas"] = rng.integers(-3, 4, 4)
 
-    def split(x, y, w, h):
+    def node(x, y, n):
+        """one square of the AV1 partition tree (n in 4x4 units): the ten partition types of
+        the specification -- leaves are never split again, so the blocks sharing a chroma
+        4x4 always agree on their chroma transform size (what the in-place two-pass filter,
+        like any decoder, relies on)."""
         if x >= mi_cols or y >= mi_rows:
             return
-        r = rng.random()
-        p_leaf = {16: 0.03, 8: 0.15, 4: 0.3, 2: 0.4, 1: 0.5}[max(w, h)]
-        if (w == 1 and h == 1) or r < p_leaf:
-            leaf(x, y, w, h)
-        elif w > 1 and h > 1 and r < p_leaf + 0.5 * (1 - p_leaf):
-            for (dx, dy) in ((0, 0), (w // 2, 0), (0, h // 2), (w // 2, h // 2)):
-                split(x + dx, y + dy, w // 2, h // 2)
-        elif w > 1 and (h == 1 or r < p_leaf + 0.75 * (1 - p_leaf)) and w // 2 * 4 >= h:
-            split(x, y, w // 2, h)
-            split(x + w // 2, y, w // 2, h)
-        elif h > 1 and h // 2 * 4 >= w:
-            split(x, y, w, h // 2)
-            split(x, y + h // 2, w, h // 2)
+        h2, q = n // 2, n // 4
+        types = ["NONE"]
+        if n >= 2:
+            types += ["SPLIT"] * (6 if n >= 8 else 3) + ["HORZ", "VERT"]
+        if n >= 4:
+            types += ["HORZ_A", "HORZ_B", "VERT_A", "VERT_B", "HORZ_4", "VERT_4"]
+        if n == 16 and rng.random() < 0.9:
+            types = ["SPLIT"]
+        t = types[int(rng.integers(0, len(types)))]
+        if t == "NONE":
+            leaf(x, y, n, n)
+        elif t == "SPLIT":
+            for (dx, dy) in ((0, 0), (h2, 0), (0, h2), (h2, h2)):
+                node(x + dx, y + dy, h2)
+        elif t == "HORZ":
+            leaf(x, y, n, h2); leaf(x, y + h2, n, h2)
+        elif t == "VERT":
+            leaf(x, y, h2, n); leaf(x + h2, y, h2, n)
+        elif t == "HORZ_A":
+            leaf(x, y, h2, h2); leaf(x + h2, y, h2, h2); leaf(x, y + h2, n, h2)
+        elif t == "HORZ_B":
+            leaf(x, y, n, h2); leaf(x, y + h2, h2, h2); leaf(x + h2, y + h2, h2, h2)
+        elif t == "VERT_A":
+            leaf(x, y, h2, h2); leaf(x, y + h2, h2, h2); leaf(x + h2, y, h2, n)
+        elif t == "VERT_B":
+            leaf(x, y, h2, n); leaf(x + h2, y, h2, h2); leaf(x + h2, y + h2, h2, h2)
+        elif t == "HORZ_4":
+            for k in range(4):
+                leaf(x, y + k * q, n, q)
         else:
-            leaf(x, y, w, h)
+            for k in range(4):
+                leaf(x + k * q, y, q, n)
 
     for sy in range(0, mi_rows, 16):
         for sx in range(0, mi_cols, 16):
-            split(sx, sy, 16, 16)
+            node(sx, sy, 16)
     return out
 
 

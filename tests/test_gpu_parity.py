@@ -1061,3 +1061,83 @@ def test_estimate_motion_blocks_subpel_vs_oracle(ctx, oracle, bd):
     assert (got["cost"][big] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
     want = O.me_block_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, stats, prev, c)
     assert np.array_equal(got[~big], want[~big])
+
+
+# ------------------------ N3: deblocking filter + level search
+def _deblock_planes(rng, w, h, bd, xdec, ydec, blocks):
+    """per-plane (rec, src) images: per-8x8 DC steps + noise (what a coarse quantizer leaves)"""
+    out = []
+    for pli in range(3):
+        xd, yd = (0, 0) if pli == 0 else (xdec, ydec)
+        pw, ph = w >> xd, h >> yd
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        step = rng.integers(-6 << (bd - 8), (6 << (bd - 8)) + 1, (h // 8 + 1, w // 8 + 1))
+        rec = (1 << (bd - 1)) + 2 * step[(yy << yd) // 8, (xx << xd) // 8] + rng.integers(-2, 3, (ph, pw))
+        rec = np.clip(rec, 0, (1 << bd) - 1)
+        src = np.clip(rec + rng.integers(-3 << (bd - 8), (3 << (bd - 8)) + 1, rec.shape), 0, (1 << bd) - 1)
+        out.append((rec, src))
+    return out
+
+
+def test_deblock_golden_frames(ctx):
+    """the specification-model frames and brute-force tallies of tests/golden/deblock_golden.npz"""
+    import torch
+    import deblock_util as D
+    G = dict(np.load(os.path.join(GOLD, "deblock_golden.npz")))
+    for name in sorted(k[:-5] for k in G if k.endswith("_meta")):
+        w, h, cw, ch, bd, xdec, ydec = [int(v) for v in G[name + "_meta"]]
+        blocks = torch.from_numpy(np.ascontiguousarray(G[name + "_blocks"]).view(np.uint8).reshape(
+            G[name + "_blocks"].shape + (8,))).cuda()
+        state = np.ascontiguousarray(G[name + "_state"])
+        dt = np.uint8 if bd == 8 else np.uint16
+        for pli in range(3):
+            xd, yd = (0, 0) if pli == 0 else (xdec, ydec)
+            hp = O.plane_from_image(G["%s_p%d_rec" % (name, pli)], bd, 16, 16)
+            hs = O.plane_from_image(G["%s_p%d_src" % (name, pli)], bd, 16, 16)
+            dp, ds = dev_plane(hp), dev_plane(hs)
+            t = ctx.deblock_sse_plane(dp, ds, pli, xd, yd, blocks, cw, ch).cpu().numpy()
+            assert np.array_equal(np.cumsum(t[0])[:64], G["%s_p%d_tv" % (name, pli)]), (name, pli)
+            assert np.array_equal(np.cumsum(t[1])[:64], G["%s_p%d_th" % (name, pli)]), (name, pli)
+            ctx.deblock_plane(state, dp, pli, xd, yd, blocks, cw, ch)
+            got = dp.data.cpu().numpy().view(dt)[hp.yorigin:hp.yorigin + hp.height,
+                                                  hp.xorigin:hp.xorigin + hp.width]
+            assert np.array_equal(got, G["%s_p%d_out" % (name, pli)]), (name, pli)
+
+
+@pytest.mark.parametrize("cfg", [(8, 1, 1, False), (10, 1, 1, True), (12, 0, 0, True), (8, 1, 0, False)])
+def test_deblock_frame_vs_oracle(ctx, oracle, cfg):
+    """whole frames (720p-class, cropped width / height), three planes, against oracle/deblock.c:
+    the filter in place (padding untouched), the tallies and the picked levels."""
+    import ctypes as C
+    import torch
+    import deblock_util as D
+    bd, xdec, ydec, deltas = cfg
+    w, h, cw, ch = 1280, 720, 1276, 714
+    rng = np.random.default_rng(70 + bd + xdec)
+    blocks = D.random_blocks(rng, w // 4, h // 4, xdec, ydec, deltas=deltas)
+    state = D.make_state([int(v) for v in rng.integers(8, 50, 4)], rng, deltas, deltas)
+    dblocks = torch.from_numpy(blocks.view(np.uint8).reshape(blocks.shape + (8,)).copy()).cuda()
+    dt = np.uint8 if bd == 8 else np.uint16
+    for pli, (rec, src) in enumerate(_deblock_planes(rng, w, h, bd, xdec, ydec, blocks)):
+        xd, yd = (0, 0) if pli == 0 else (xdec, ydec)
+        hp, hs = O.plane_from_image(rec, bd, 24, 24), O.plane_from_image(src, bd, 24, 24)
+        dp, ds = dev_plane(hp), dev_plane(hs)
+        # level search on the unfiltered reconstruction
+        tv, th = np.zeros(65, np.int64), np.zeros(65, np.int64)
+        pc, sc = hp.cstruct(), hs.cstruct()
+        assert oracle.r1o_deblock_sse_plane(C.byref(pc), C.byref(sc), pli, xd, yd, blocks.ctypes.data,
+                                            blocks.shape[1], blocks.shape[1], blocks.shape[0], cw, ch, bd,
+                                            tv.ctypes.data, th.ctypes.data) == 0
+        t = ctx.deblock_sse_plane(dp, ds, pli, xd, yd, dblocks, cw, ch)
+        assert np.array_equal(t.cpu().numpy(), np.stack([tv, th])), (cfg, pli)
+        lv = np.zeros(2, np.uint8)
+        oracle.r1o_deblock_pick_levels(tv.ctypes.data, th.ctypes.data, pli, lv.ctypes.data)
+        assert np.array_equal(ctx.deblock_pick_levels(t, pli), lv[:2] if pli == 0 else lv[:1])
+        # filter
+        assert oracle.r1o_deblock_plane(state.ctypes.data, C.byref(pc), pli, xd, yd, blocks.ctypes.data,
+                                        blocks.shape[1], blocks.shape[1], blocks.shape[0], cw, ch, bd) == 0
+        ctx.deblock_plane(state, dp, pli, xd, yd, dblocks, cw, ch)
+        got = dp.data.cpu().numpy().view(dt)
+        bad = np.argwhere(got != hp.data)
+        assert len(bad) == 0, (cfg, pli, bad[:4])
+        assert (hp.view() != rec).sum() > rec.size // 20       # the filter did something
