@@ -267,16 +267,20 @@ __device__ __forceinline__ long long sse_lines(const Line &a, const Line &b, int
 
 template <int BPP>
 __global__ __launch_bounds__(256) void k_deblock_sse(R1Plane rec, R1Plane src, Geom g, int vertical_,
+                                                     long long total,
                                                      long long *__restrict__ tally_out) {
   __shared__ unsigned long long tally[MAX_LF + 2];
   for (int k = threadIdx.x; k < MAX_LF + 2; k += 256) tally[k] = 0;
   __syncthreads();
   const bool vertical = vertical_ != 0;
+  long long none_sum = 0;   // tally[0] gets every line's sse_none: one add per wave
+  // grid-stride: a workgroup flushes its tally once, however many lines it walks
+  for (long long tid = (long long)blockIdx.x * 256 + threadIdx.x; tid < total;
+       tid += (long long)gridDim.x * 256) {
   int bx, by, i;
   R1DeblockBlock b, prev;
   int size = 0;
-  if (locate(g, (long long)blockIdx.x * 256 + threadIdx.x, vertical, bx, by, i))
-    size = edge_size(g, bx, by, vertical, true, b, prev);
+  if (locate(g, tid, vertical, bx, by, i)) size = edge_size(g, bx, by, vertical, true, b, prev);
   if (size) {
     const int px = (bx >> g.xdec) * 4 + (vertical ? 0 : i), py = (by >> g.ydec) * 4 + (vertical ? i : 0);
     const long step = vertical ? BPP : (long)rec.stride * BPP;
@@ -314,9 +318,22 @@ __global__ __launch_bounds__(256) void k_deblock_sse(R1Plane rec, R1Plane src, G
       at_mask = n2 - sse_none;
       at_nhev = n4 - n2;
     }
-    atomicAdd(&tally[0], (unsigned long long)sse_none);
+    none_sum += sse_none;
     if (at_mask) atomicAdd(&tally[mask], (unsigned long long)at_mask);
     if (at_nhev) atomicAdd(&tally[nhev], (unsigned long long)at_nhev);
+  }
+  }
+  {
+    uint32_t lo = (uint32_t)none_sum, hi = (uint32_t)((unsigned long long)none_sum >> 32);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)hi, m, 64) << 32) |
+                                   (uint32_t)__shfl_xor((int)lo, m, 64);
+      const unsigned long long t = (((unsigned long long)hi << 32) | lo) + o;
+      lo = (uint32_t)t;
+      hi = (uint32_t)(t >> 32);
+    }
+    if ((threadIdx.x & 63) == 0 && (lo | hi)) atomicAdd(&tally[0], ((unsigned long long)hi << 32) | lo);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < MAX_LF + 2; k += 256)
@@ -395,12 +412,15 @@ extern "C" int r1_deblock_sse_plane(r1_ctx *ctx, const R1Plane *rec, const R1Pla
     const bool vertical = pass == 0;
     const long long n = pass_threads(g, vertical);
     if (n <= 0) continue;
-    const unsigned grid = (unsigned)((n + 255) / 256);
+    unsigned grid = (unsigned)((n + 255) / 256);
+    grid = grid > 1024 ? 1024 : grid;   // 4 workgroups per CU
     long long *out = (long long *)(vertical ? v_tally : h_tally);
     if (rec->bytes_per_px == 1)
-      hipLaunchKernelGGL(k_deblock_sse<1>, dim3(grid), dim3(256), 0, st, *rec, *src, g, (int)vertical, out);
+      hipLaunchKernelGGL(k_deblock_sse<1>, dim3(grid), dim3(256), 0, st, *rec, *src, g, (int)vertical, n,
+                         out);
     else
-      hipLaunchKernelGGL(k_deblock_sse<2>, dim3(grid), dim3(256), 0, st, *rec, *src, g, (int)vertical, out);
+      hipLaunchKernelGGL(k_deblock_sse<2>, dim3(grid), dim3(256), 0, st, *rec, *src, g, (int)vertical, n,
+                         out);
   }
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;

@@ -49,11 +49,13 @@ __global__ __launch_bounds__(256) void k_quantize(
   const long long blk = ((long long)blockIdx.x * 4 + wave) * BPW + g;
   const bool live = blk < n;
   int32_t *mine = lds[wave] + g * (G * NPL);
-  // 1: stage (coalesced)
-  if (live) {
-    const CT *src = coeffs + blk * coeff_stride;
+  // 1: stage the wave's BPW blocks (consecutive lanes = consecutive coefficients)
+  constexpr int AREA = G * NPL;
+  const long long blk0 = ((long long)blockIdx.x * 4 + wave) * BPW;
 #pragma unroll
-    for (int k = 0; k < NPL; k++) mine[k * G + l] = (int32_t)src[k * G + l];
+  for (int k = 0; k < NPL; k++) {
+    const int e = k * 64 + lane, bl = e / AREA, idx = e % AREA;
+    if (blk0 + bl < n) lds[wave][e] = (int32_t)coeffs[(blk0 + bl) * coeff_stride + idx];
   }
   __builtin_amdgcn_wave_barrier();
   // 2-3: scan-order gather, eob, DC, AC prefix scan (quant_common.hpp)
@@ -70,29 +72,28 @@ __global__ __launch_bounds__(256) void k_quantize(
   int eob = 0;
   unsigned long long dist = 0;
   r1q::quantize_group<CT, GL, NPL, DIST>(mine, g << GL, l, live, scan, qp, tail, eob, dist);
-  if constexpr (DIST) {
-    if (live && l == 0) {
+  if (live && l == 0) {
+    eobs[blk] = (uint16_t)eob;
+    if constexpr (DIST) {
       tx_dist[blk] = dist;
       if (est_rate) est_rate[blk] = r1q::estimate_rate(q_bin, tx_size, dist);
     }
   }
   __builtin_amdgcn_wave_barrier();
-  // 4: write back (coalesced), dequantize on the way (mod.rs:372-383)
-  if (live) {
-    CT *qd = qcoeffs + blk * area;
-    CT *rd = rcoeffs ? rcoeffs + blk * area : nullptr;
-    const int32_t off = (1 << qp.lts) - 1;
+  // 4: write back (coalesced, dense blocks), dequantize on the way (mod.rs:372-383)
+  const int32_t off = (1 << qp.lts) - 1;
 #pragma unroll
-    for (int k = 0; k < NPL; k++) {
-      const int idx = k * G + l;
-      const int32_t q = (int32_t)(CT)mine[idx];
-      qd[idx] = (CT)q;
-      if (rd) {
+  for (int k = 0; k < NPL; k++) {
+    const int e = k * 64 + lane, bl = e / AREA, idx = e % AREA;
+    if (blk0 + bl < n) {
+      const int32_t q = (int32_t)(CT)lds[wave][e];
+      qcoeffs[(blk0 + bl) * AREA + idx] = (CT)q;
+      if (rcoeffs) {
         const uint32_t quant = idx == 0 ? qp.dc_q : qp.ac_q;
-        rd[idx] = (CT)((int32_t)((uint32_t)q * quant + (uint32_t)((q >> 31) & off)) >> qp.lts);
+        rcoeffs[(blk0 + bl) * AREA + idx] =
+            (CT)((int32_t)((uint32_t)q * quant + (uint32_t)((q >> 31) & off)) >> qp.lts);
       }
     }
-    if (l == 0) eobs[blk] = (uint16_t)eob;
   }
 }
 
@@ -150,10 +151,12 @@ int launch_q(r1_ctx *ctx, const void *coeffs, int coeff_stride, int n, int tx_si
                        (unsigned long long *)tx_dist, (unsigned long long *)est_rate); \
   } while (0)
   switch (area) {
-    case 16: R1_Q_LAUNCH(4, 1); break;
-    case 32: R1_Q_LAUNCH(5, 1); break;
-    case 64: R1_Q_LAUNCH(6, 1); break;
-    case 128: R1_Q_LAUNCH(6, 2); break;
+    // at least 4 coefficients per lane: the per-block reductions and the cross-lane scan
+    // are paid per lane group, the run is worked off sequentially
+    case 16: R1_Q_LAUNCH(2, 4); break;
+    case 32: R1_Q_LAUNCH(3, 4); break;
+    case 64: R1_Q_LAUNCH(4, 4); break;
+    case 128: R1_Q_LAUNCH(5, 4); break;
     case 256: R1_Q_LAUNCH(6, 4); break;
     case 512: R1_Q_LAUNCH(6, 8); break;
     case 1024: R1_Q_LAUNCH(6, 16); break;

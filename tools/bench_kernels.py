@@ -165,6 +165,33 @@ def main():
     ms = timeit(lambda: ctx.cdef_filter_frame_plane(ref, ref, dst, 0, 0, 0, fw, fh, skip, ci, ystr,
                                                     ystr, 5, bd))
     report("cdef_filter_tile luma (find_dir + filter)", ms, fw * fh, 2 * fw * fh * bpp)
+    # ---- N3: deblock filter + level search, 4:2:0 frame (luma + two chroma planes) ----
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import deblock_util as D
+    blocks = D.random_blocks(rng, fw // 4, (fh + 3) // 4, 1, 1)
+    dblocks = torch.from_numpy(blocks.view(np.uint8).reshape(blocks.shape + (8,)).copy()).cuda()
+    state = D.make_state([24, 20, 16, 16])
+    planes3 = [(org, ref, 0, 0, 0), ]
+    cw_, ch_ = fw // 2, fh // 2
+    for pli in (1, 2):
+        a = Plane.from_numpy(W.random_plane_array(cw_, ch_, bd, 10 + pli, 44, 44), cw_, ch_, bd, 44, 44)
+        b = Plane.from_numpy(W.random_plane_array(cw_, ch_, bd, 20 + pli, 44, 44), cw_, ch_, bd, 44, 44)
+        planes3.append((a, b, pli, 1, 1))
+
+    def run_filter():
+        for (a, b, pli, xd, yd) in planes3:
+            ctx.deblock_plane(state, a, pli, xd, yd, dblocks, fw, fh)
+
+    tall = torch.zeros((3, 2, 65), dtype=torch.int64, device="cuda")
+
+    def run_sse():
+        for (a, b, pli, xd, yd) in planes3:
+            ctx.deblock_sse_plane(a, b, pli, xd, yd, dblocks, fw, fh, tallies=tall[pli])
+    npx = fw * fh * 3 // 2
+    ms = timeit(run_filter)
+    report("deblock_filter_frame 4:2:0 (3 planes, in place)", ms, npx, 2 * npx * bpp + blocks.size * 8)
+    ms = timeit(run_sse)
+    report("deblock sse_optimize tallies 4:2:0 (3 planes)", ms, npx, 2 * npx * bpp + blocks.size * 8)
     ctx.close()
 
 
