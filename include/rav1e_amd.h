@@ -306,6 +306,20 @@ int r1_estimate_inter_costs(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
 int r1_importance_block_difference(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
                                    uint64_t *sum_out, void *stream);
 
+/* ---- intra mode pre-screen (SURVEY.md 8f "N1"; src/rdo.rs:1434-1506): for
+ * every block the candidate modes are predicted from ONE edge set
+ * (get_intra_edges with IntraParam::None) and ranked by get_satd against the
+ * source block.  cands: n = blocks * group entries, the `group` modes of block
+ * b at [b*group, (b+1)*group); edges / lens (r1_intra_edges_batch layout) and
+ * pos_xy (x, y of the block in `src`, int16 pairs) have one entry per BLOCK.
+ * The predictions stay in LDS; satd_out[n].  The probability ordering and the
+ * final sort (rdo.rs:1424-1428, 1504) are entropy-coder state and stay with
+ * the caller. */
+int r1_intra_satd_batch(r1_ctx *ctx, const R1Plane *src, int tx_size, const R1IntraCand *cands,
+                        int n, int group, const int16_t *pos_xy, const void *edges,
+                        int edge_stride, const uint8_t *lens, const int16_t *ac,
+                        uint32_t *satd_out, void *stream);
+
 /* ---- hierarchical motion estimation of whole tiles (SURVEY.md 8f "N2").
  * Replaces estimate_tile_motion (src/me.rs:153-218) for one (tile, reference
  * frame) pair per job: the three passes (quarter, half, full resolution) of

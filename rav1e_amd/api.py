@@ -265,6 +265,20 @@ class Context:
             out.data_ptr(), _stream_ptr()), "r1_predict_intra_batch")
         return out
 
+    def intra_satd_batch(self, src, tx_size, cands, group, pos_xy, edges, lens, ac=None, n=None):
+        """the intra mode pre-screen (src/rdo.rs:1434-1506): predict `group` modes per block from
+        one edge set, get_satd against the source block at pos_xy -> (n,) int32"""
+        dc = _dev_cands(cands, INTRA_CAND)
+        n = dc.numel() // INTRA_CAND.itemsize if n is None else n
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        ps = src.cstruct()
+        self._check(self.lib.r1_intra_satd_batch(
+            self.h, C.byref(ps), int(tx_size), dc.data_ptr(), n, group, pos_xy.data_ptr(),
+            edges.data_ptr(), edges.stride(0), lens.data_ptr(),
+            ac.data_ptr() if ac is not None else None, out.data_ptr(), _stream_ptr()),
+            "r1_intra_satd_batch")
+        return out
+
     def cfl_ac_batch(self, luma, bw, bh, xdec, ydec, cands, n=None):
         """pred_cfl_ac (src/predict.rs:1020-1063) -> (n, bh*bw) int16"""
         dc = _dev_cands(cands, CFL_AC_CAND)

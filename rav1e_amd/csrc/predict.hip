@@ -19,6 +19,7 @@
 // arithmetic.  Rows are stored as W consecutive pixels per candidate
 // (coalesced).
 #include "common.hpp"
+#include "dist_common.hpp"
 
 #define R1_TABLE_QUAL __constant__
 #include "intra_tables.inc"
@@ -186,11 +187,16 @@ __device__ __forceinline__ int32_t filt5(const uint16_t *src, int i, int size, i
   return (s + 8) >> 4;
 }
 
-template <int BPP>
+// SATD_OUT: the intra mode pre-screen of src/rdo.rs:1434-1506 in one launch --
+// `group` consecutive candidates (the modes of one block) share one edge set
+// and one source position; the prediction goes to LDS and only get_satd of it
+// against the source block leaves the CU.
+template <int BPP, bool SATD_OUT>
 __global__ __launch_bounds__(64) void k_intra_predict(
     int wl, int hl, const R1IntraCand *__restrict__ cands, int n,
     const void *__restrict__ edges, int edge_stride, const uint8_t *__restrict__ lens,
-    const int16_t *__restrict__ ac, int bit_depth, void *__restrict__ dst) {
+    const int16_t *__restrict__ ac, int bit_depth, void *__restrict__ dst, R1Plane src,
+    const int16_t *__restrict__ pos_xy, int group, uint32_t *__restrict__ satd_out) {
   extern __shared__ uint16_t smem[];
   const int W = 1 << wl, H = 1 << hl;
   const int NC = 64 >> wl;
@@ -203,11 +209,12 @@ __global__ __launch_bounds__(64) void k_intra_predict(
   uint16_t *work = smem + NC * EDGE_LEN + cl * (4 * FL);   // af0 af1 lf0 lf1
   R1IntraCand cd = {};
   int left_len = 0, above_len = 0;
+  const long long ecand = SATD_OUT ? cand / group : cand;   // edge set / block of this candidate
   if (live) {
     cd = cands[cand];
-    left_len = lens[2 * cand];
-    above_len = lens[2 * cand + 1];
-    const void *e = (const uint8_t *)edges + (size_t)cand * edge_stride * BPP;
+    left_len = lens[2 * ecand];
+    above_len = lens[2 * ecand + 1];
+    const void *e = (const uint8_t *)edges + (size_t)ecand * edge_stride * BPP;
     // only [128 - left_len, 129 + above_len) is defined (and ever read)
     for (int k = 2 * MAXTX - left_len + c; k < 2 * MAXTX + 1 + above_len; k += W)
       raw[k] = (uint16_t)ldp<BPP>(e, k);
@@ -219,7 +226,9 @@ __global__ __launch_bounds__(64) void k_intra_predict(
   const int32_t top_left = raw[2 * MAXTX];
   // left pixel beside row r (left_slice[height-1-r])
   auto left_row = [&](int r) -> int32_t { return raw[2 * MAXTX - 1 - r]; };
-  void *out = (uint8_t *)dst + (size_t)cand * W * H * BPP;
+  void *out = SATD_OUT ? (void *)((uint8_t *)smem + ((NC * (EDGE_LEN + 4 * FL) * 2 + 15) & ~15) +
+                                  (size_t)cl * W * H * BPP)
+                       : (void *)((uint8_t *)dst + (size_t)cand * W * H * BPP);
 
   const bool directional = live && mode >= V_PRED && mode <= D67_PRED &&
                            !(mode == V_PRED && angle == 90) && !(mode == H_PRED && angle == 180);
@@ -343,11 +352,11 @@ __global__ __launch_bounds__(64) void k_intra_predict(
       }
       stp<BPP>(out, (size_t)i * W + j, v < 0 ? 0 : (v > smax ? smax : v));
     }
-    return;
   }
   // ---- non-directional ----
   const int ls_len = left_len < H ? left_len : H;
-  if (mode == V_PRED) {
+  if (directional) {
+  } else if (mode == V_PRED) {
     const int32_t a = above[c];
     for (int r = 0; r < H; r++) stp<BPP>(out, (size_t)r * W + c, a);
   } else if (mode == H_PRED) {
@@ -403,6 +412,25 @@ __global__ __launch_bounds__(64) void k_intra_predict(
     } else {
       for (int r = 0; r < H; r++) stp<BPP>(out, (size_t)r * W + c, (int32_t)avg);
     }
+  }
+  if constexpr (SATD_OUT) {
+    // get_satd(source block, prediction): one lane per Hadamard tile, the
+    // candidate's W lanes hold at least (W/TS)*(H/TS) tiles for every tx size
+    __builtin_amdgcn_wave_barrier();
+    const bool small = (W < H ? W : H) == 4;
+    const int ts = small ? 4 : 8, ntx = W / ts, nt = ntx * (H / ts);
+    uint32_t sum = 0;
+    if (c < nt) {
+      const int tx = c % ntx, ty = c / ntx;
+      const int bx = pos_xy[2 * ecand], by = pos_xy[2 * ecand + 1];
+      const uint8_t *po = px_addr<BPP>(src, bx + tx * ts, by + ty * ts);
+      const uint8_t *pp = (const uint8_t *)out + ((size_t)ty * ts * W + (size_t)tx * ts) * BPP;
+      sum = small ? r1dist::tile_dist<BPP, 4, true>(po, (size_t)src.stride * BPP, pp, (size_t)W * BPP)
+                  : r1dist::tile_dist<BPP, 8, true>(po, (size_t)src.stride * BPP, pp, (size_t)W * BPP);
+    }
+    for (int m = 1; m < W; m <<= 1) sum += __shfl_xor(sum, m, 64);
+    const int ln = small ? 2 : 3;
+    if (c == 0) satd_out[cand] = (sum + ((1u << ln) >> 1)) >> ln;
   }
 }
 
@@ -492,11 +520,47 @@ extern "C" int r1_predict_intra_batch(r1_ctx *ctx, int tx_size, const R1IntraCan
   const unsigned grid = (unsigned)((n + NC - 1) / NC);
   hipStream_t st = (hipStream_t)stream;
   if (bytes_per_px == 1)
-    hipLaunchKernelGGL((k_intra_predict<1>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
-                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, bit_depth, dst);
+    hipLaunchKernelGGL((k_intra_predict<1, false>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
+                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, bit_depth, dst,
+                       R1Plane{}, (const int16_t *)nullptr, 1, (uint32_t *)nullptr);
   else
-    hipLaunchKernelGGL((k_intra_predict<2>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
-                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, bit_depth, dst);
+    hipLaunchKernelGGL((k_intra_predict<2, false>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
+                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, bit_depth, dst,
+                       R1Plane{}, (const int16_t *)nullptr, 1, (uint32_t *)nullptr);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_intra_satd_batch(r1_ctx *ctx, const R1Plane *src, int tx_size,
+                                   const R1IntraCand *cands, int n, int group,
+                                   const int16_t *pos_xy, const void *edges, int edge_stride,
+                                   const uint8_t *lens, const int16_t *ac, uint32_t *satd_out,
+                                   void *stream) {
+  R1_REQUIRE(ctx && src);
+  R1_REQUIRE(tx_size >= 0 && tx_size < 19);
+  R1_REQUIRE(src->bit_depth == 8 || src->bit_depth == 10 || src->bit_depth == 12);
+  R1_REQUIRE(src->bytes_per_px == 1 || src->bytes_per_px == 2);
+  R1_REQUIRE((src->bytes_per_px == 1) == (src->bit_depth == 8));
+  R1_REQUIRE(edge_stride >= EDGE_LEN && group >= 1);
+  if (n <= 0) return R1_OK;
+  R1_REQUIRE(n % group == 0);
+  R1_REQUIRE(cands && edges && lens && pos_xy && satd_out);
+  static const uint8_t wl[19] = {2, 3, 4, 5, 6, 2, 3, 3, 4, 4, 5, 5, 6, 2, 4, 3, 5, 4, 6};
+  static const uint8_t hl[19] = {2, 3, 4, 5, 6, 3, 2, 4, 3, 5, 4, 6, 5, 4, 2, 5, 3, 6, 4};
+  const int W = 1 << wl[tx_size], H = 1 << hl[tx_size];
+  const int NC = 64 / W, FL = 2 * (W + H) + 1;
+  const size_t lds = (((size_t)NC * (EDGE_LEN + 4 * FL) * sizeof(uint16_t) + 15) & ~(size_t)15) +
+                     (size_t)NC * W * H * src->bytes_per_px;
+  const unsigned grid = (unsigned)((n + NC - 1) / NC);
+  hipStream_t st = (hipStream_t)stream;
+  if (src->bytes_per_px == 1)
+    hipLaunchKernelGGL((k_intra_predict<1, true>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
+                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, src->bit_depth,
+                       (void *)nullptr, *src, pos_xy, group, satd_out);
+  else
+    hipLaunchKernelGGL((k_intra_predict<2, true>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
+                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, src->bit_depth,
+                       (void *)nullptr, *src, pos_xy, group, satd_out);
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }

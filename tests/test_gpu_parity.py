@@ -1141,3 +1141,54 @@ def test_deblock_frame_vs_oracle(ctx, oracle, cfg):
         bad = np.argwhere(got != hp.data)
         assert len(bad) == 0, (cfg, pli, bad[:4])
         assert (hp.view() != rec).sum() > rec.size // 20       # the filter did something
+
+
+# ------------------------ N1: intra mode pre-screen in one launch
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_prescreen_vs_oracle(ctx, oracle, bd):
+    """r1_intra_satd_batch: 13 luma modes per block from one edge set (get_intra_edges with
+    IntraParam::None, as src/rdo.rs:1442-1458), SATD against the source; oracle = the reference's
+    composition get_intra_edges -> dispatch_predict_intra -> get_satd, call by call."""
+    import torch
+    from rav1e_amd.api import INTRA_EDGE_CAND
+    rng = np.random.default_rng(640 + bd)
+    rec = O.HostPlane(192, 128, bd, rng=rng)
+    srcp = O.HostPlane(192, 128, bd, rng=rng)
+    drec, dsrc = dev_plane(rec), dev_plane(srcp)
+    hbd = int(bd > 8)
+    dt = np.uint16 if hbd else np.uint8
+    MODES = list(range(13))                      # RAV1E_INTRA_MODES: DC .. PAETH
+    BASE = [0, 90, 180, 45, 135, 113, 157, 203, 67, 0, 0, 0, 0]
+    for ts in (0, 1, 2, 3, 4, 5, 8, 13, 9, 17):
+        w, h = TX_SIZES[ts]
+        nb = 40
+        gx, gy = rec.width // w, rec.height // h
+        bxs, bys = rng.integers(0, gx, nb) * w, rng.integers(0, gy, nb) * h
+        bxs[:3], bys[:3] = [0, w, 0], [0, 0, h]
+        ec = np.zeros(nb, INTRA_EDGE_CAND)
+        ec["x"], ec["y"] = bxs, bys
+        ec["mode"] = -1                           # IntraParam::None, no mode-specific trimming
+        ec["flags"] = 1 | (rng.integers(0, 4, nb) << 1)
+        edges, lens = ctx.intra_edges_batch(drec, (0, 0, rec.width, rec.height), ts, ec)
+        he, hl = edges.cpu().numpy().view(dt), lens.cpu().numpy()
+        var = np.where((bxs == 0) & (bys == 0), 0, np.where(bys == 0, 1, np.where(bxs == 0, 2, 3)))
+        pm = np.tile(MODES, nb)
+        v13 = np.repeat(var, 13)
+        # PAETH without both neighbours falls back (PredictionMode::predict_intra, predict.rs:116-140)
+        pm = np.where((pm == 12) & (v13 == 0), 0, np.where((pm == 12) & (v13 == 2), 1,
+                      np.where((pm == 12) & (v13 == 1), 2, pm)))
+        angle = np.array(BASE)[pm]
+        ief = np.where((pm >= 1) & (pm <= 8), np.tile(rng.integers(1, 3, 13), nb), 0)
+        ic = _intra_cands(pm, v13, angle, ief, [w] * len(pm), [h] * len(pm))
+        pos = torch.from_numpy(np.stack([bxs, bys], 1).astype(np.int16)).cuda()
+        got = ctx.intra_satd_batch(dsrc, ts, ic, 13, pos, edges, lens).cpu().numpy().view(np.uint32)
+        for b in range(nb):
+            for k in range(13):
+                i = b * 13 + k
+                out = np.zeros((h, w), dt)
+                assert oracle.r1o_dispatch_predict_intra(
+                    int(pm[i]), int(v13[i]), O.ptr(out), w, ts, bd, None, int(angle[i]), int(ief[i]),
+                    O.ptr(he[b]), int(hl[b, 0]), int(hl[b, 1]), w, h, hbd) == 0
+                want = oracle.r1o_get_satd(srcp.block_ptr(int(bxs[b]), int(bys[b])), srcp.stride,
+                                           O.ptr(out), w, w, h, hbd)
+                assert got[i] == want, (bd, ts, b, k, int(pm[i]))

@@ -157,6 +157,32 @@ def main():
         ms = timeit(lambda: ctx.predict_intra_batch(int(tsz), dic, edges, lens, bd, n=n))
         report("predict_intra %dx%d (mixed modes)" % (s, s), ms, n * s * s,
                n * ((2 * (2 * s) + 1) * bpp + s * s * bpp), {"blocks": n})
+    # ---- N1: intra mode pre-screen, 13 modes per block in one launch ----
+    for s, tsz in ((32, TxSize.TX_32X32), (16, TxSize.TX_16X16), (8, TxSize.TX_8X8)):
+        nx, ny = fw // s, fh // s
+        nb = nx * ny
+        ec = np.zeros(nb, api.INTRA_EDGE_CAND)
+        ec["x"] = np.tile(np.arange(nx) * s, ny)
+        ec["y"] = np.repeat(np.arange(ny) * s, nx)
+        ec["mode"] = -1
+        ec["flags"] = 7
+        edges, lens = ctx.intra_edges_batch(ref, (0, 0, fw, fh), int(tsz), ec)
+        var = np.where((ec["x"] == 0) & (ec["y"] == 0), 0, np.where(ec["y"] == 0, 1,
+                                                                     np.where(ec["x"] == 0, 2, 3)))
+        pm = np.tile(np.arange(13), nb)
+        v13 = np.repeat(var, 13)
+        pm = np.where((pm == 12) & (v13 == 0), 0, np.where((pm == 12) & (v13 == 2), 1,
+                      np.where((pm == 12) & (v13 == 1), 2, pm)))
+        ic = np.zeros(nb * 13, api.INTRA_CAND)
+        ic["mode"], ic["variant"] = pm, v13
+        ic["angle"] = np.array([0, 90, 180, 45, 135, 113, 157, 203, 67, 0, 0, 0, 0])[pm]
+        ic["ief"] = np.where((pm >= 1) & (pm <= 8), 1, 0)
+        ic["avail_w"] = ic["avail_h"] = s
+        dic = torch.from_numpy(ic.view(np.uint8).reshape(-1).copy()).cuda()
+        pos = torch.from_numpy(np.stack([ec["x"], ec["y"]], 1).astype(np.int16)).cuda()
+        ms = timeit(lambda: ctx.intra_satd_batch(org, int(tsz), dic, 13, pos, edges, lens, n=nb * 13))
+        report("intra pre-screen %dx%d (13 modes: predict + SATD, fused)" % (s, s), ms, nb * 13 * s * s,
+               nb * ((2 * (2 * s) + 1) * bpp + s * s * bpp + 13 * 4), {"blocks": nb})
     # ---- a14: whole-frame CDEF, luma ----
     dst = Plane(fw, fh, bd)
     skip = torch.zeros((fh // 4, fw // 4), dtype=torch.uint8, device="cuda")
