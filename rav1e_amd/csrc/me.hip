@@ -298,11 +298,14 @@ struct Subsets {
 };
 constexpr int kSubsetWords = 2 * (1 + 5 + 5 + 11);
 
-// one MEStats entry through the L2 (written by another wave of this workgroup
-// a barrier ago, or by another workgroup in an earlier launch)
+// one MEStats entry: written by another wave of THIS workgroup a barrier ago
+// (same CU, same L1: workgroup scope is enough -- an agent-scope fence per
+// diagonal would write back / invalidate the XCD's L2 and made the 64-job
+// launches 3.6x slower) or by another workgroup in an earlier launch (kernel
+// boundaries make that visible)
 __device__ __forceinline__ void load_stats(const R1MeStats *s, int &row, int &col, uint32_t &nsad) {
   const unsigned long long v = __hip_atomic_load((const unsigned long long *)s, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
   row = (int16_t)(v & 0xFFFF);
   col = (int16_t)((v >> 16) & 0xFFFF);
   nsad = (uint32_t)(v >> 32);
@@ -496,8 +499,7 @@ __global__ __launch_bounds__(256) void k_me_diag(const R1MeJob *__restrict__ job
                                 b.po_y + imin(div8(mvr) + 2, div8(b.mvy_max)), 1);
       store_result(t, 1 << (log2b + 1), bx, by, r, w, h, ssdec, lane);
     }
-    __threadfence();
-    __syncthreads();
+    __syncthreads();   // workgroup-scope release / acquire of the stats just written
   }
 
   // estimate_sb_motion: raster order inside the superblock = anti-diagonals
@@ -518,8 +520,7 @@ __global__ __launch_bounds__(256) void k_me_diag(const R1MeJob *__restrict__ job
       const Msr r = full_pixel_me(b, t, p, bx, by, rng, corner, init, ssdec, sh_subsets[wave]);
       store_result(t, 1 << log2b, bx, by, r, w, h, ssdec, lane);
     }
-    __threadfence();
-    __syncthreads();
+    __syncthreads();   // workgroup-scope release / acquire of the stats just written
   }
 }
 

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (tens of seconds)")
+    ap.add_argument("--only", type=int, default=-1, help="run only tile-ME configuration i (for profiling)")
     args = ap.parse_args()
     import torch
     import oracle_lib as O
@@ -58,7 +59,9 @@ def main():
         th = -(-(h // ny) // 64) * 64
         return [(x, y, min(tw, w - x), min(th, h - y)) for y in range(0, h, th) for x in range(0, w, tw)]
 
-    for (nx, ny, nref) in ((1, 1, 1), (1, 1, 4), (2, 2, 4), (4, 4, 4)):
+    for ci, (nx, ny, nref) in enumerate(((1, 1, 1), (1, 1, 4), (2, 2, 4), (4, 4, 4))):
+        if args.only >= 0 and ci != args.only:
+            continue
         tl = tiles_of(nx, ny)
         stats = [torch.zeros((rows, cols, 2), dtype=torch.int32, device="cuda") for _ in range(nref)]
         jobs = [dict(org=do, ref=drs[r], stats=stats[r], tile=t) for r in range(nref) for t in tl]
@@ -78,6 +81,9 @@ def main():
                           "tiles": len(tl), "refs": nref, "jobs": len(jobs), "ms": round(ms, 3),
                           "Mpixels_s": round(w * h * nref / ms / 1e3, 1),
                           "frames_refs_per_s": round(nref / ms * 1e3, 1)}), flush=True)
+    if args.only >= 0:
+        ctx.close()
+        return
     # ---- RDO-time estimate_motion (full-pel + SATD + sub-pel diamond) on every block of a size ----
     from rav1e_amd.api import ME_BLOCK_CAND, ME_RESULT
     st0 = torch.zeros((rows, cols, 2), dtype=torch.int32, device="cuda")
