@@ -50,3 +50,40 @@ def shard_candidates(frame_w, frame_h, k, rank, world, **kw):
         return W.speed6_ladder(frame_w, frame_h, k, **kw)
     rect = W.tile_rects(world, frame_w, frame_h)[rank]
     return W.speed6_ladder(frame_w, frame_h, k, rect=rect, **kw)
+
+
+# ---- the widened rows across GPUs --------------------------------
+def me_jobs_for_rank(n_tiles, n_refs, rank, world):
+    """(tile index, reference index) pairs rank `rank` runs in its
+    r1_estimate_tile_motion_batch call: jobs are independent (tiles are, and so
+    are the reference frames inside estimate_tile_motion, src/me.rs:190-199), dealt
+    round-robin.  No collective on the data path."""
+    jobs = [(t, r) for r in range(n_refs) for t in range(n_tiles)]
+    return jobs[rank::world]
+
+
+def merge_me_stats(stats, group=None):
+    """After every rank filled the MEStats of its own (tile, reference) jobs in a
+    ZEROED frame array (int32 view, (refs, rows, cols, 2)): one all-reduce(SUM) makes
+    the whole FrameMEStats set resident everywhere -- the tile rectangles are disjoint,
+    so the sum is a merge.  4 MB per reference at 4K."""
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    return stats
+
+
+POSTFILTER_HALO = 64   # rows.  The data dependence is 11 rows (a horizontal edge 4 rows outside a
+                       # slab still changes its first two rows and reads 7 rows further out:
+                       # 14-tap filter, src/deblock.rs:846); one SUPERBLOCK row keeps the slab's
+                       # block array aligned with the partition tree (the edge tests take 4x4
+                       # coordinates modulo the transform size, src/deblock.rs:1109,1205)
+
+
+def postfilter_slab(plane_rows, rank, world, align=64):
+    """Row slab [lo, hi) of a plane that rank `rank` deblocks / CDEFs after the
+    reconstructed-frame all-gather, and the rows [lo - halo, hi + halo) it has to read:
+    the filters are local (deblock: 7 rows, CDEF: 2 + 8-row direction blocks), so slabs
+    with POSTFILTER_HALO rows of unfiltered context reproduce the whole-frame pass."""
+    per = -(-(-(-plane_rows // world)) // align) * align
+    lo = min(rank * per, plane_rows)
+    hi = min(lo + per, plane_rows)
+    return lo, hi, max(0, lo - POSTFILTER_HALO), min(plane_rows, hi + POSTFILTER_HALO)

@@ -86,3 +86,73 @@ def test_tile_rects_match_reference_layout():
     assert (cover == 1).all()
     r1080 = W.tile_rects(8, 1920, 1080)
     assert W.tile_split(8, 1920, 1080) == (4, 2) and r1080[3][2] == 1920
+
+
+def _worker_widened(rank, world, port, q):
+    """N2 / N3 across ranks, CPU oracle as the per-rank engine: tile ME jobs merged by one
+    all-reduce; deblocking by row slabs with a 16-row halo equals the whole-frame pass."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import deblock_util as D
+    import oracle_lib as O
+    from rav1e_amd import tiles, workload as W
+    L = O.lib()
+    # ---- motion estimation: 2 tiles x 2 references dealt over the ranks ----
+    w, h, bd = 256, 128, 8
+    rng = np.random.default_rng(1)
+    org = O.me_pyramid(rng.integers(0, 256, (h, w)), bd)
+    refs = [O.me_pyramid(rng.integers(0, 256, (h, w)), bd) for _ in range(2)]
+    rects = W.tile_rects(2, w, h)
+    lam = [30, 8, 2]
+    whole = np.zeros((2, h // 4, w // 4), O.ME_STATS)
+    for r in range(2):
+        for (x0, y0, x1, y1) in rects:
+            O.me_oracle(L, org, refs[r], w // 4, h // 4, (x0, y0, x1 - x0, y1 - y0), bd, lam, whole[r])
+    mine = np.zeros_like(whole)
+    for (t, r) in tiles.me_jobs_for_rank(len(rects), 2, rank, world):
+        x0, y0, x1, y1 = rects[t]
+        O.me_oracle(L, org, refs[r], w // 4, h // 4, (x0, y0, x1 - x0, y1 - y0), bd, lam, mine[r])
+    merged = torch.from_numpy(mine.view(np.int32).reshape(2, h // 4, w // 4, 2).copy())
+    tiles.merge_me_stats(merged)
+    ok_me = np.array_equal(merged.numpy().reshape(2, h // 4, -1).view(O.ME_STATS).reshape(whole.shape), whole)
+    # ---- deblocking by row slabs ----
+    fw, fh = 192, 256
+    blocks = D.random_blocks(np.random.default_rng(2), fw // 4, fh // 4, 1, 1)
+    state = D.make_state([30, 26, 0, 0])
+    img = np.random.default_rng(3).integers(100, 140, (fh, fw))
+    ref_p = O.plane_from_image(img, bd, 16, 16)
+    pc = ref_p.cstruct()
+    assert L.r1o_deblock_plane(state.ctypes.data, C.byref(pc), 0, 0, 0, blocks.ctypes.data, fw // 4,
+                               fw // 4, fh // 4, fw, fh, bd) == 0
+    lo, hi, rlo, rhi = tiles.postfilter_slab(fh, rank, world)
+    sub = O.plane_from_image(img[rlo:rhi], bd, 16, 16)
+    sc = sub.cstruct()
+    bsub = np.ascontiguousarray(blocks[rlo // 4:rhi // 4])
+    assert L.r1o_deblock_plane(state.ctypes.data, C.byref(sc), 0, 0, 0, bsub.ctypes.data, fw // 4,
+                               fw // 4, bsub.shape[0], fw, rhi - rlo, bd) == 0
+    out = torch.zeros((fh, fw), dtype=torch.int32)
+    out[lo:hi] = torch.from_numpy(sub.view()[lo - rlo:hi - rlo].astype(np.int32))
+    dist.all_reduce(out)
+    ok_db = np.array_equal(out.numpy(), ref_p.view().astype(np.int32)) and (ref_p.view() != img).any()
+    q.put((rank, bool(ok_me), bool(ok_db)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_me_jobs_and_deblock_slabs_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_widened, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_me, ok_db in res:
+        assert ok_me and ok_db, (rank, ok_me, ok_db)
