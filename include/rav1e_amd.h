@@ -344,8 +344,9 @@ int r1_intra_satd_batch(r1_ctx *ctx, const R1Plane *src, int tx_size, const R1In
  * at each resolution, which the MV range of me.rs:339-362 assumes).
  * lambda[ssdec]: (fi.me_lambda * 256 / (1 << 2*ssdec) * (ssdec == 0 ? 0.5 :
  * 0.125)) as u32, me.rs:175-177 -- f64 arithmetic, evaluated by the host.
- * `jobs` is HOST memory (pointers inside are device pointers).  The call
- * returns after the work has completed on `stream`. */
+ * `jobs` is HOST memory (pointers inside are device pointers) and is consumed
+ * before the call returns; the work itself is only ENQUEUED on `stream`
+ * (3 x (superblock columns + rows - 1) launches). */
 typedef struct R1MeStats {
   int16_t row, col;
   uint32_t normalized_sad;

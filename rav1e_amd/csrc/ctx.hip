@@ -37,8 +37,12 @@ extern "C" int r1_ctx_create(int device, r1_ctx **out) {
     return R1_EHIP;
   }
   c->scan_dev = nullptr;
-  c->me_jobs = nullptr;
-  c->me_jobs_bytes = 0;
+  for (int k = 0; k < r1_ctx::kMeSlots; k++) {
+    c->me_jobs[k] = c->me_jobs_host[k] = nullptr;
+    c->me_jobs_bytes[k] = 0;
+    c->me_done[k] = nullptr;
+  }
+  c->me_next = 0;
   if (r1_scan_tables_create(c) != R1_OK) {
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -52,7 +56,14 @@ extern "C" void r1_ctx_destroy(r1_ctx *c) {
   if (!c) return;
   if (c->stage) (void)hipFree(c->stage);
   if (c->pinned) (void)hipHostFree(c->pinned);
-  if (c->me_jobs) (void)hipFree(c->me_jobs);
+  for (int k = 0; k < r1_ctx::kMeSlots; k++) {
+    if (c->me_done[k]) {
+      (void)hipEventSynchronize(c->me_done[k]);
+      (void)hipEventDestroy(c->me_done[k]);
+    }
+    if (c->me_jobs[k]) (void)hipFree(c->me_jobs[k]);
+    if (c->me_jobs_host[k]) (void)hipHostFree(c->me_jobs_host[k]);
+  }
   r1_scan_tables_destroy(c);
   (void)hipStreamDestroy(c->own_stream);
   delete c;

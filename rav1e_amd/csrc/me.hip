@@ -29,6 +29,8 @@
 // Every search loop of the reference is data dependent (it recentres on the
 // best candidate), so a block's search is a chain of such steps; the chip is
 // filled by jobs x superblocks-on-the-diagonal x blocks, not by one block.
+#include <string.h>
+
 #include "common.hpp"
 #include "dist_common.hpp"
 #include "mc_common.hpp"
@@ -796,30 +798,37 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
     max_sbh = sbh > max_sbh ? sbh : max_sbh;
   }
   hipStream_t st = (hipStream_t)stream;
-  // job descriptors: host -> a device copy owned by the context
+  // job descriptors: caller's array -> pinned staging -> device, one ring slot per call
   const size_t bytes = (size_t)n_jobs * sizeof(R1MeJob);
-  if (ctx->me_jobs_bytes < bytes) {
-    if (ctx->me_jobs) (void)hipFree(ctx->me_jobs);
-    ctx->me_jobs = nullptr;
-    ctx->me_jobs_bytes = 0;
-    R1_HIP_CHECK(hipMalloc(&ctx->me_jobs, bytes));
-    ctx->me_jobs_bytes = bytes;
+  const int slot = ctx->me_next;
+  ctx->me_next = (slot + 1) % r1_ctx::kMeSlots;
+  if (ctx->me_done[slot]) R1_HIP_CHECK(hipEventSynchronize(ctx->me_done[slot]));
+  else R1_HIP_CHECK(hipEventCreateWithFlags(&ctx->me_done[slot], hipEventDisableTiming));
+  if (ctx->me_jobs_bytes[slot] < bytes) {
+    if (ctx->me_jobs[slot]) (void)hipFree(ctx->me_jobs[slot]);
+    if (ctx->me_jobs_host[slot]) (void)hipHostFree(ctx->me_jobs_host[slot]);
+    ctx->me_jobs[slot] = ctx->me_jobs_host[slot] = nullptr;
+    ctx->me_jobs_bytes[slot] = 0;
+    R1_HIP_CHECK(hipMalloc(&ctx->me_jobs[slot], bytes));
+    R1_HIP_CHECK(hipHostMalloc(&ctx->me_jobs_host[slot], bytes, hipHostMallocDefault));
+    ctx->me_jobs_bytes[slot] = bytes;
   }
-  R1_HIP_CHECK(hipMemcpyAsync(ctx->me_jobs, jobs, bytes, hipMemcpyHostToDevice, st));
+  memcpy(ctx->me_jobs_host[slot], jobs, bytes);
+  R1_HIP_CHECK(hipMemcpyAsync(ctx->me_jobs[slot], ctx->me_jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
+  const R1MeJob *djobs = (const R1MeJob *)ctx->me_jobs[slot];
   const int ndiag = max_sbw + max_sbh - 1;
   const int dlen = max_sbw < max_sbh ? max_sbw : max_sbh;
   for (int log2b = 4; log2b >= 2; log2b--)
     for (int d = 0; d < ndiag; d++) {
       if (bpp == 1)
         hipLaunchKernelGGL(k_me_diag<1>, dim3(dlen, n_jobs), dim3(256), 0, st,
-                           (const R1MeJob *)ctx->me_jobs, *params, log2b, d);
+                           djobs, *params, log2b, d);
       else
         hipLaunchKernelGGL(k_me_diag<2>, dim3(dlen, n_jobs), dim3(256), 0, st,
-                           (const R1MeJob *)ctx->me_jobs, *params, log2b, d);
+                           djobs, *params, log2b, d);
     }
   R1_HIP_CHECK(hipGetLastError());
-  // the descriptor buffer is reused by the next call on this context
-  R1_HIP_CHECK(hipStreamSynchronize(st));
+  R1_HIP_CHECK(hipEventRecord(ctx->me_done[slot], st));
   return R1_OK;
 }
 
