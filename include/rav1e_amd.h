@@ -484,6 +484,28 @@ int r1_rdo_full_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, 
                            uint64_t *est_rate_out, void *qcoeffs_out, void *coeffs,
                            void *stream);
 
+/* ---- the default-configuration RDO evaluation of an inter transform block in
+ * ONE launch: what luma_chroma_mode_rdo / rdo_tx_size_type make encode_tx_block
+ * and compute_distortion do per candidate when the distortion is taken in the
+ * pixel domain (tune = Psychovisual, or need_recon_pixel; src/encoder.rs:
+ * 1533-1661, src/rdo.rs:254-340):
+ *   pred, sad, satd, resid, coeffs, eob, qcoeffs     as r1_rdo_full_cand_batch
+ *   rcoeffs = dequantize(qcoeffs)
+ *   rec     = inverse_transform_add(rcoeffs, pred)    (src/transform/inverse.rs:1633)
+ *   dist    = sse_wxh (R1_DIST_WSSE) / cdef_dist_wxh (R1_DIST_CDEF) of rec against
+ *             the source block, with the DistortionScale grid of
+ *             r1_dist_scaled_batch (same `scales` layout, xdec / ydec of the plane)
+ * Prediction, residual, coefficients and reconstruction live in registers /
+ * LDS; per candidate 10 bytes (eob, dist) + the optional outputs reach HBM.
+ * qcoeffs_out: what the entropy coder of the host needs for the real rate
+ * (RDOType::PixelDistRealRate); rec_out: dense w*h reconstructions. */
+int r1_rdo_pixel_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w, int h,
+                            int tx_size, const R1RdoCand *cands, int n,
+                            const R1QuantParams *params, int dist_kind, const uint32_t *scales,
+                            int scale_stride, int xdec, int ydec, uint32_t *sad_out,
+                            uint32_t *satd_out, uint16_t *eob_out, uint64_t *dist_out,
+                            void *qcoeffs_out, void *rec_out, void *stream);
+
 /* ---- per-call compat shims: reference asm signatures, HOST pointers ----
  * SadFn / SatdFn (src/asm/x86/dist/mod.rs:21-43): strides in BYTES. */
 uint32_t rav1e_sad_hip(const uint8_t *src, ptrdiff_t src_stride,

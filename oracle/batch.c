@@ -164,6 +164,65 @@ int r1o_rdo_full_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, i
   return bad ? -1 : 0;
 }
 
+/* The default-configuration RDO evaluation of one inter transform block
+ * (tune = Psychovisual or need_recon_pixel: encode_tx_block's pixel path,
+ * src/encoder.rs:1533-1661, + compute_distortion, src/rdo.rs:254-340):
+ * put_8tap -> diff -> forward_transform -> quantize -> dequantize ->
+ * inverse_transform_add -> sse_wxh (kind 2) / cdef_dist_wxh (kind 3) of the
+ * reconstruction against the source, with the DistortionScale grid. */
+int r1o_rdo_pixel_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, int h,
+                             int tx_size, const r1o_rdo_cand *c, int n, int qindex,
+                             int is_intra, int dc_delta_q, int ac_delta_q, int kind,
+                             const uint32_t *scales, int scale_stride, int xdec, int ydec,
+                             uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
+                             uint64_t *dist_out, void *qcoeffs_out, void *rec_out) {
+  const int hbd = org->bytes_per_px == 2, bpp = org->bytes_per_px;
+  const int cb = hbd ? 4 : 2;
+  if (r1o_tx_width(tx_size) != w || r1o_tx_height(tx_size) != h) return -1;
+  const int cw = w < 32 ? w : 32, ch = h < 32 ? h : 32;
+  const size_t carea = (size_t)cw * ch, area = (size_t)w * h;
+  int bad = 0;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    uint16_t pred16[64 * 64];
+    int16_t resid[64 * 64];
+    int32_t co[64 * 64], qc[32 * 32], rc[32 * 32];
+    void *pred = pred16;
+    r1o_put_8tap(pred, w, at(ref, c[i].rx, c[i].ry), ref->stride, w, h,
+                 c[i].col_frac, c[i].row_frac, c[i].mode_x, c[i].mode_y,
+                 ref->bit_depth, hbd);
+    const void *o = at(org, c[i].ox, c[i].oy);
+    if (sad_out) sad_out[i] = r1o_get_sad(o, org->stride, pred, w, w, h, hbd);
+    if (satd_out) satd_out[i] = r1o_get_satd(o, org->stride, pred, w, w, h, hbd);
+    r1o_diff(resid, o, org->stride, pred, w, w, h, hbd);
+    if (r1o_forward_transform(resid, co, w, tx_size, c[i].tx_type, org->bit_depth, hbd)) {
+      bad = 1;
+      continue;
+    }
+    const int eob = r1o_quantize(co, qc, tx_size, c[i].tx_type, qindex, org->bit_depth,
+                                 is_intra, dc_delta_q, ac_delta_q, hbd);
+    if (eob < 0) {
+      bad = 1;
+      continue;
+    }
+    eob_out[i] = (uint16_t)eob;
+    r1o_dequantize(qc, rc, tx_size, qindex, org->bit_depth, dc_delta_q, ac_delta_q, hbd);
+    /* the prediction buffer becomes the reconstruction */
+    if (r1o_inverse_transform_add(rc, pred, w, tx_size, c[i].tx_type, org->bit_depth, hbd, hbd)) {
+      bad = 1;
+      continue;
+    }
+    /* the reconstruction as a one-block plane for the scaled-distortion glue */
+    r1o_plane rp = { pred, w, h, w, h, 0, 0, bpp, org->bit_depth };
+    const r1o_dist_cand dc = { c[i].ox, c[i].oy, 0, 0 };
+    r1o_dist_scaled_batch(kind, org, &rp, w, h, &dc, 1, scales, scale_stride, xdec, ydec,
+                          &dist_out[i]);
+    if (qcoeffs_out) memcpy((uint8_t *)qcoeffs_out + i * carea * cb, qc, carea * cb);
+    if (rec_out) memcpy((uint8_t *)rec_out + i * area * bpp, pred, area * bpp);
+  }
+  return bad ? -1 : 0;
+}
+
 /* sse_wxh / cdef_dist_wxh (src/rdo.rs:142-224) over a candidate list, with
  * compute_bias = distortion_scale (src/rdo.rs:443-459): one Q14
  * DistortionScale per 8x8 LUMA importance block of the frame,

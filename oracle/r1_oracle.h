@@ -250,6 +250,12 @@ int r1o_rdo_full_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, i
                             uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
                             uint64_t *tx_dist_out, uint64_t *est_rate_out,
                             void *qcoeffs_out);
+int r1o_rdo_pixel_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, int h,
+                             int tx_size, const r1o_rdo_cand *c, int n, int qindex,
+                             int is_intra, int dc_delta_q, int ac_delta_q, int kind,
+                             const uint32_t *scales, int scale_stride, int xdec, int ydec,
+                             uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
+                             uint64_t *dist_out, void *qcoeffs_out, void *rec_out);
 
 #ifdef __cplusplus
 }

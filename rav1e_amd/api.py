@@ -548,6 +548,40 @@ class Context:
                                                     out.ctypes.data), "r1_deblock_pick_levels")
         return out[:2] if pli == 0 else out[:1]
 
+    def rdo_pixel_cand_batch(self, org, ref, w, h, cands, qindex, dist_kind, scales=None, xdec=0,
+                             ydec=0, is_intra=0, dc_delta_q=0, ac_delta_q=0, n=None, want_sad=True,
+                             want_satd=True, want_qcoeffs=False, want_rec=False, outs=None):
+        """mc -> sad/satd -> diff -> forward_transform -> quantize -> dequantize -> inverse
+        transform -> reconstruction -> weighted SSE / cdef_dist against the source, one launch."""
+        from .types import TxSize
+        tx_size = int(TxSize.by_dims(w, h))
+        dc = _dev_cands(cands, RDO_CAND)
+        n = dc.numel() // RDO_CAND.itemsize if n is None else n
+        ct = torch.int16 if org.bpp == 1 else torch.int32
+        o = outs if outs is not None else {}
+        o.setdefault("eob", torch.empty(n, dtype=torch.int16, device="cuda"))
+        o.setdefault("dist", torch.empty(n, dtype=torch.int64, device="cuda"))
+        if want_sad:
+            o.setdefault("sad", torch.empty(n, dtype=torch.int32, device="cuda"))
+        if want_satd:
+            o.setdefault("satd", torch.empty(n, dtype=torch.int32, device="cuda"))
+        if want_qcoeffs:
+            o.setdefault("qcoeffs", torch.empty((n, min(w, 32) * min(h, 32)), dtype=ct, device="cuda"))
+        if want_rec:
+            o.setdefault("rec", torch.empty((n, h, w), dtype=torch.uint8 if org.bpp == 1 else torch.int16,
+                                            device="cuda"))
+        po, pr = org.cstruct(), ref.cstruct()
+        qp = self._qparams(qindex, org.bit_depth, is_intra, dc_delta_q, ac_delta_q)
+
+        def p(k):
+            return o[k].data_ptr() if k in o else None
+        self._check(self.lib.r1_rdo_pixel_cand_batch(
+            self.h, C.byref(po), C.byref(pr), w, h, tx_size, dc.data_ptr(), n, C.byref(qp), dist_kind,
+            scales.data_ptr() if scales is not None else None,
+            scales.stride(0) if scales is not None else 0, xdec, ydec, p("sad"), p("satd"), p("eob"),
+            p("dist"), p("qcoeffs"), p("rec"), _stream_ptr()), "r1_rdo_pixel_cand_batch")
+        return o
+
     # ---- fused candidate ----
     def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,
                        want_coeffs=True, want_pred=False, outs=None):

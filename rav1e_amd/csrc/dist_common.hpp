@@ -1,7 +1,8 @@
 // dist_common.hpp -- the per-tile SAD / SATD arithmetic shared by dist.hip
 // (candidates from HBM) and me.hip (sub-pel candidates predicted into LDS).
 // Reference: get_sad src/dist.rs:31-52, get_satd 156-221, hadamard4_1d 61,
-// hadamard8_1d 84, hadamard2d 122.
+// hadamard8_1d 84, hadamard2d 122; get_weighted_sse 234-283, cdef_dist_kernel
+// 302-372, apply_ssim_boost src/activity.rs:109-186 (see dist_scaled.hip).
 #pragma once
 #include "common.hpp"
 
@@ -58,6 +59,113 @@ __device__ __forceinline__ uint32_t tile_dist(const uint8_t *po, size_t so,
 #pragma unroll
   for (int i = 0; i < TS * TS; i++) s += (uint32_t)iabs32(d[i]);
   return s;
+}
+
+// ---- candidate-level pixel-domain distortions with the DistortionScale bias ----
+// round(2^14 / (1 + x)): the reference's AREA_DIVISORS (dist.rs:290-297)
+__device__ __forceinline__ uint32_t area_divisor(int area) {
+  return (16384u + (uint32_t)(area >> 1)) / (uint32_t)area;
+}
+
+__device__ __forceinline__ uint32_t apply_ssim_boost(uint32_t input, uint32_t svar32,
+                                                     uint32_t dvar32, int bit_depth) {
+  const int coeff_shift = bit_depth - 8;
+  const uint64_t svar = svar32 >> (2 * coeff_shift), dvar = dvar32 >> (2 * coeff_shift);
+  const uint64_t C1 = 3355, C2 = 16128, C3 = 12338;
+  const uint64_t RATIO = (((C1 << 15) / C3) + 1) >> 1;
+  // ssim_boost_rsqrt: 1/sqrt(x) in Q(rshift) by a quadratic on the normalised mantissa
+  const uint64_t x = C1 * C1 + svar * dvar;
+  const int k = (63 - __builtin_clzll(x)) >> 1;
+  const int s = 2 * k - 14;
+  const uint16_t t = (uint16_t)(s > 0 ? x >> s : x << -s);
+  const int rshift = (uint8_t)(14 + ((s + 16) >> 1));
+  const int32_t nn = (int32_t)t - 32768;
+  const int32_t inner = -13490 + ((nn * 6711) >> 15);
+  const int32_t rsqrt = 23557 + ((nn * inner) >> 15);
+  const uint64_t norm = (uint16_t)rsqrt;
+  return (uint32_t)(((uint64_t)input * (((RATIO * (svar + dvar + C2)) * norm) >> 14)) >> rshift);
+}
+
+template <int BPP>
+__device__ __forceinline__ void load_row(const uint8_t *p, int kw, int32_t *out) {
+  if (kw == 8) {
+    load_px_row<BPP, 8>(p, out);
+  } else {
+    load_px_row<BPP, 4>(p, out);
+#pragma unroll
+    for (int i = 4; i < 8; i++) out[i] = 0;
+  }
+}
+
+
+// One 8x8 (or edge 4-wide / 4-high) tile of sse_wxh (KIND 2: four 4x4 cells,
+// each weighted by the DistortionScale of its importance block, rdo.rs:177-224
+// -> dist.rs:234-283) or of cdef_dist_wxh (KIND 3: cdef_dist_kernel + ssim
+// boost + scale, rdo.rs:142-173).  (px, py): plane position of the tile in the
+// SOURCE plane (selects the scale entries).  The weighted-SSE partials still
+// need get_weighted_sse's final (sum + 32) / 64.
+template <int BPP, int KIND>
+__device__ __forceinline__ unsigned long long tile_scaled_dist(
+    const uint8_t *po, size_t so, const uint8_t *pr, size_t sr, int kw, int kh, int px, int py,
+    const uint32_t *__restrict__ scales, int scale_stride, int xdec, int ydec, int bit_depth) {
+  unsigned long long acc = 0;
+  if constexpr (KIND == 2) {
+    // four 4x4 cells: [cy][cx]
+    uint32_t cell[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      if (r < kh) {
+        int32_t a[8], b[8];
+        load_row<BPP>(po + r * so, kw, a);
+        load_row<BPP>(pr + r * sr, kw, b);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int32_t d = a[i] - b[i];
+          cell[r >> 2][i >> 2] += (uint32_t)(d * d);
+        }
+      }
+    }
+#pragma unroll
+    for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+      for (int cx = 0; cx < 2; cx++) {
+        if (cy * 4 < kh && cx * 4 < kw) {
+          const int lx = (px + cx * 4) << xdec, ly = (py + cy * 4) << ydec;
+          const uint32_t sc =
+              scales ? scales[(size_t)(ly >> 3) * scale_stride + (lx >> 3)] : (1u << 14);
+          acc += ((unsigned long long)cell[cy][cx] * sc + 128) >> 8;
+        }
+      }
+  } else {
+    uint32_t sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      if (r < kh) {
+        int32_t a[8], b[8];
+        load_row<BPP>(po + r * so, kw, a);
+        load_row<BPP>(pr + r * sr, kw, b);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const uint32_t s = (uint32_t)a[i], d = (uint32_t)b[i];
+          sum_s += s; sum_d += d;
+          sum_s2 += s * s; sum_d2 += d * d; sum_sd += s * d;
+        }
+      }
+    }
+    const uint32_t sse = sum_d2 + sum_s2 - 2 * sum_sd;
+    const unsigned long long div = area_divisor(kw * kh);
+    const uint32_t ms = (uint32_t)(((unsigned long long)sum_s * sum_s * div + 8192) >> 14);
+    const uint32_t md = (uint32_t)(((unsigned long long)sum_d * sum_d * div + 8192) >> 14);
+    uint32_t svar = sum_s2 > ms ? sum_s2 - ms : 0;
+    uint32_t dvar = sum_d2 > md ? sum_d2 - md : 0;
+    svar = (uint32_t)(((unsigned long long)svar * div + 128) >> 8);
+    dvar = (uint32_t)(((unsigned long long)dvar * div + 128) >> 8);
+    const unsigned long long v = apply_ssim_boost(sse, svar, dvar, bit_depth);
+    const unsigned long long sc =
+        scales ? scales[(size_t)(py >> 3) * scale_stride + (px >> 3)] : (1u << 14);
+    acc = (sc * v + 8192) >> 14;
+  }
+  return acc;
 }
 
 }  // namespace r1dist

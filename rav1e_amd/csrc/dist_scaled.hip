@@ -16,43 +16,9 @@
 // Tiles of a candidate are consecutive lanes -> segmented wave reduction of
 // the u64 partials, one LDS hop for candidates with more than 64 tiles.
 #include "common.hpp"
+#include "dist_common.hpp"
 
 namespace {
-
-// round(2^14 / (1 + x)): the reference's AREA_DIVISORS (dist.rs:290-297)
-__device__ __forceinline__ uint32_t area_divisor(int area) {
-  return (16384u + (uint32_t)(area >> 1)) / (uint32_t)area;
-}
-
-__device__ __forceinline__ uint32_t apply_ssim_boost(uint32_t input, uint32_t svar32,
-                                                     uint32_t dvar32, int bit_depth) {
-  const int coeff_shift = bit_depth - 8;
-  const uint64_t svar = svar32 >> (2 * coeff_shift), dvar = dvar32 >> (2 * coeff_shift);
-  const uint64_t C1 = 3355, C2 = 16128, C3 = 12338;
-  const uint64_t RATIO = (((C1 << 15) / C3) + 1) >> 1;
-  // ssim_boost_rsqrt: 1/sqrt(x) in Q(rshift) by a quadratic on the normalised mantissa
-  const uint64_t x = C1 * C1 + svar * dvar;
-  const int k = (63 - __builtin_clzll(x)) >> 1;
-  const int s = 2 * k - 14;
-  const uint16_t t = (uint16_t)(s > 0 ? x >> s : x << -s);
-  const int rshift = (uint8_t)(14 + ((s + 16) >> 1));
-  const int32_t nn = (int32_t)t - 32768;
-  const int32_t inner = -13490 + ((nn * 6711) >> 15);
-  const int32_t rsqrt = 23557 + ((nn * inner) >> 15);
-  const uint64_t norm = (uint16_t)rsqrt;
-  return (uint32_t)(((uint64_t)input * (((RATIO * (svar + dvar + C2)) * norm) >> 14)) >> rshift);
-}
-
-template <int BPP>
-__device__ __forceinline__ void load_row(const uint8_t *p, int kw, int32_t *out) {
-  if (kw == 8) {
-    load_px_row<BPP, 8>(p, out);
-  } else {
-    load_px_row<BPP, 4>(p, out);
-#pragma unroll
-    for (int i = 4; i < 8; i++) out[i] = 0;
-  }
-}
 
 // KIND 2: weighted SSE, KIND 3: cdef_dist
 template <int BPP, int KIND>
@@ -75,63 +41,8 @@ __global__ __launch_bounds__(256) void k_dist_scaled(
     const uint8_t *po = px_addr<BPP>(org, c.ox + x0, c.oy + y0);
     const uint8_t *pr = px_addr<BPP>(ref, c.rx + x0, c.ry + y0);
     const size_t so = (size_t)org.stride * BPP, sr = (size_t)ref.stride * BPP;
-    if constexpr (KIND == 2) {
-      // four 4x4 cells: [cy][cx]
-      uint32_t cell[2][2] = {{0, 0}, {0, 0}};
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        if (r < kh) {
-          int32_t a[8], b[8];
-          load_row<BPP>(po + r * so, kw, a);
-          load_row<BPP>(pr + r * sr, kw, b);
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            const int32_t d = a[i] - b[i];
-            cell[r >> 2][i >> 2] += (uint32_t)(d * d);
-          }
-        }
-      }
-#pragma unroll
-      for (int cy = 0; cy < 2; cy++)
-#pragma unroll
-        for (int cx = 0; cx < 2; cx++) {
-          if (cy * 4 < kh && cx * 4 < kw) {
-            const int lx = (c.ox + x0 + cx * 4) << xdec, ly = (c.oy + y0 + cy * 4) << ydec;
-            const uint32_t sc =
-                scales ? scales[(size_t)(ly >> 3) * scale_stride + (lx >> 3)] : (1u << 14);
-            acc += ((unsigned long long)cell[cy][cx] * sc + 128) >> 8;
-          }
-        }
-    } else {
-      uint32_t sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        if (r < kh) {
-          int32_t a[8], b[8];
-          load_row<BPP>(po + r * so, kw, a);
-          load_row<BPP>(pr + r * sr, kw, b);
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            const uint32_t s = (uint32_t)a[i], d = (uint32_t)b[i];
-            sum_s += s; sum_d += d;
-            sum_s2 += s * s; sum_d2 += d * d; sum_sd += s * d;
-          }
-        }
-      }
-      const uint32_t sse = sum_d2 + sum_s2 - 2 * sum_sd;
-      const unsigned long long div = area_divisor(kw * kh);
-      const uint32_t ms = (uint32_t)(((unsigned long long)sum_s * sum_s * div + 8192) >> 14);
-      const uint32_t md = (uint32_t)(((unsigned long long)sum_d * sum_d * div + 8192) >> 14);
-      uint32_t svar = sum_s2 > ms ? sum_s2 - ms : 0;
-      uint32_t dvar = sum_d2 > md ? sum_d2 - md : 0;
-      svar = (uint32_t)(((unsigned long long)svar * div + 128) >> 8);
-      dvar = (uint32_t)(((unsigned long long)dvar * div + 128) >> 8);
-      const unsigned long long v = apply_ssim_boost(sse, svar, dvar, org.bit_depth);
-      const unsigned long long sc =
-          scales ? scales[(size_t)((c.oy + y0) >> 3) * scale_stride + ((c.ox + x0) >> 3)]
-                 : (1u << 14);
-      acc = (sc * v + 8192) >> 14;
-    }
+    acc = r1dist::tile_scaled_dist<BPP, KIND>(po, so, pr, sr, kw, kh, c.ox + x0, c.oy + y0, scales,
+                                              scale_stride, xdec, ydec, org.bit_depth);
   }
   // segmented u64 reduction over the candidate's tiles
   const int seg = tpc_log2 < 6 ? tpc_log2 : 6;

@@ -32,6 +32,8 @@
 //     transposed 32x32-chunk coefficient order.
 #include <type_traits>
 
+#include "dist_common.hpp"
+#include "itx_common.hpp"
 #include "mc_common.hpp"
 #include "quant_common.hpp"
 #include "tx_common.hpp"
@@ -331,9 +333,19 @@ struct RdoQuantArgs {
   uint16_t *eob;
   unsigned long long *tx_dist, *est_rate;
   void *qcoeffs;             // optional: dense coded-area blocks
+  // QM == 2 (pixel-domain leg): dequantize -> inverse transform -> reconstruct ->
+  // sse_wxh / cdef_dist_wxh against the source with the DistortionScale grid
+  // (encode_tx_block with need_recon_pixel / compute_distortion, src/rdo.rs:254-340)
+  int dist_kind, inv_shift;
+  const uint32_t *scales;
+  int scale_stride, xdec, ydec;
+  unsigned long long *pix_dist;
+  void *rec;                 // optional: dense w*h reconstructions
 };
 
-template <int BD, int WL, int HL, typename CT, bool QUANT>
+// QM: 0 = coefficients to HBM (headline), 1 = + quantizer, tx-domain distortion,
+// rate (N4), 2 = + quantizer, inverse transform, pixel-domain distortion.
+template <int BD, int WL, int HL, typename CT, int QM>
 __global__ __launch_bounds__(64) void k_rdo_cand(
     R1Plane org, R1Plane ref, const R1RdoCand *__restrict__ cands, int n,
     uint32_t *__restrict__ sad_out, uint32_t *__restrict__ satd_out,
@@ -359,6 +371,12 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   const bool live = cand < n;
   R1RdoCand cd = {};
   if (live) cd = cands[cand];
+  constexpr bool QUANT = QM != 0;
+  // QM == 2 keeps the prediction column (packed pixels) for the reconstruction
+  constexpr int PPK = QM == 2 ? (H * BPP + 3) / 4 : 1;
+  uint32_t ppk[PPK];
+#pragma unroll
+  for (int k = 0; k < PPK; k++) ppk[k] = 0;
 
   // ---- A: source column into registers, reference window into LDS ----
   T v[H];
@@ -388,6 +406,10 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
 #pragma unroll
         for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint8_t)pred[r];
       }
+      if constexpr (QM == 2) {
+#pragma unroll
+        for (int r = 0; r < H; r++) ppk[r >> 2] |= (uint32_t)pred[r] << (8 * (r & 3));
+      }
 #pragma unroll
       for (int r = 0; r < H; r++) v[r] -= pred[r];
     }
@@ -399,6 +421,10 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
         uint16_t *pp = (uint16_t *)pred_out + (size_t)cand * W * H + c;
 #pragma unroll
         for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint16_t)pred[r];
+      }
+      if constexpr (QM == 2) {
+#pragma unroll
+        for (int r = 0; r < H; r++) ppk[r >> 1] |= (uint32_t)pred[r] << (16 * (r & 1));
       }
 #pragma unroll
       for (int r = 0; r < H; r++) v[r] -= pred[r];
@@ -487,12 +513,14 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
     const int kind = tt < 10 ? 0 : ((tt & 1) ? 2 : 1);
     int eob = 0;
     unsigned long long dist = 0;
-    r1q::quantize_group<CT, PL, NPLQ, true>(tile, cl2 * P, r, live2, qa.scan[kind], qa.qp, tail,
-                                            eob, dist);
+    r1q::quantize_group<CT, PL, NPLQ, QM == 1>(tile, cl2 * P, r, live2, qa.scan[kind], qa.qp, tail,
+                                               eob, dist);
     if (live2 && r == 0) {
       qa.eob[cand2] = (uint16_t)eob;
-      qa.tx_dist[cand2] = dist;
-      if (qa.est_rate) qa.est_rate[cand2] = r1q::estimate_rate(qa.q_bin, qa.tx_size, dist);
+      if constexpr (QM == 1) {
+        qa.tx_dist[cand2] = dist;
+        if (qa.est_rate) qa.est_rate[cand2] = r1q::estimate_rate(qa.q_bin, qa.tx_size, dist);
+      }
     }
     if (qa.qcoeffs) {
       __syncthreads();
@@ -501,6 +529,108 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
 #pragma unroll
         for (int k = 0; k < NPLQ; k++) qd[k * P + r] = (CT)tile[k * P + r];
       }
+    }
+    if constexpr (QM == 2) {
+      // ---- F: dequantize (mod.rs:372-383) + inverse row transform
+      // (inverse_transform_add, src/transform/inverse.rs:1633-1705; k_inv_tx) ----
+      constexpr int HC = OS;
+      constexpr bool RECT1 = (WL > HL ? WL - HL : HL - WL) == 1;
+      __syncthreads();
+      const bool irow_live = live2 && r < HC;
+      T w_[W];
+      {
+        const int range = BD + 8;
+        const T hi = (T)((1 << (range - 1)) - 1), lo = -hi - 1;
+        const int32_t off = (1 << qa.qp.lts) - 1;
+        if (irow_live) {
+#pragma unroll
+          for (int k = 0; k < WC; k++) {
+            const int32_t q = (int32_t)(CT)tile[k * OS + r];
+            const uint32_t quant = (k == 0 && r == 0) ? qa.qp.dc_q : qa.qp.ac_q;
+            const T raw = (T)(CT)((int32_t)((uint32_t)q * quant + (uint32_t)((q >> 31) & off)) >> qa.qp.lts);
+            const T val = RECT1 ? ((T)((uint32_t)raw * 2896u + 2048u) >> 12) : raw;
+            w_[k] = r1itx::clamp3(val, lo, hi);
+          }
+#pragma unroll
+          for (int k = WC; k < W; k++) w_[k] = 0;
+          r1itx::inv_1d<W, true>(w_, r1tx::htx_1d(tt), lo, hi);
+        }
+      }
+      __syncthreads();   // every coefficient has been read: the tile becomes the row buffer
+      if (irow_live) {
+#pragma unroll
+        for (int k = 0; k < W; k++) buf[r * LSTRIDE + cl2 * W + k] = w_[k];
+      }
+      __syncthreads();
+      // ---- G: inverse column transform, reconstruction (lane = column again) ----
+      T rc[H];
+      if (col_live) {
+        const int range = BD + 6 > 16 ? BD + 6 : 16;
+        const T hi = (T)((1 << (range - 1)) - 1), lo = -hi - 1;
+        const T pmax = (T)((1 << BD) - 1);
+#pragma unroll
+        for (int rr = 0; rr < HC; rr++) {
+          const T x = buf[rr * LSTRIDE + cl * W + c];
+          rc[rr] = r1itx::clamp3((x + ((1 << qa.inv_shift) >> 1)) >> qa.inv_shift, lo, hi);
+        }
+#pragma unroll
+        for (int rr = HC; rr < H; rr++) rc[rr] = 0;
+        r1itx::inv_1d<H, true>(rc, r1tx::vtx_1d(tx_type), lo, hi);
+#pragma unroll
+        for (int rr = 0; rr < H; rr++) {
+          const T pr = BPP == 1 ? (T)((ppk[rr >> 2] >> (8 * (rr & 3))) & 0xFF)
+                                : (T)((ppk[rr >> 1] >> (16 * (rr & 1))) & 0xFFFF);
+          const T px = pr + ((rc[rr] + 8) >> 4);
+          rc[rr] = px < 0 ? 0 : (px > pmax ? pmax : px);
+        }
+      }
+      __syncthreads();   // the row buffer has been read: LDS becomes the reconstruction
+      uint8_t *rec_l = smem + cl * (W * H * BPP);
+      if (col_live) {
+#pragma unroll
+        for (int rr = 0; rr < H; rr++) {
+          if constexpr (BPP == 1) rec_l[rr * W + c] = (uint8_t)rc[rr];
+          else ((uint16_t *)rec_l)[rr * W + c] = (uint16_t)rc[rr];
+        }
+        if (qa.rec) {
+          if constexpr (BPP == 1) {
+            uint8_t *d = (uint8_t *)qa.rec + (size_t)cand * W * H + c;
+#pragma unroll
+            for (int rr = 0; rr < H; rr++) d[(size_t)rr * W] = (uint8_t)rc[rr];
+          } else {
+            uint16_t *d = (uint16_t *)qa.rec + (size_t)cand * W * H + c;
+#pragma unroll
+            for (int rr = 0; rr < H; rr++) d[(size_t)rr * W] = (uint16_t)rc[rr];
+          }
+        }
+      }
+      __syncthreads();
+      // ---- H: sse_wxh / cdef_dist_wxh of the reconstruction against the source:
+      // one lane per 8x8 tile (dist_common.hpp) ----
+      constexpr int TW8 = (W + 7) / 8, NT8 = TW8 * ((H + 7) / 8);
+      static_assert(NT8 <= P, "a candidate's lanes cover its 8x8 tiles");
+      unsigned long long acc = 0;
+      if (live && c < NT8) {
+        const int x0 = (c % TW8) * 8, y0 = (c / TW8) * 8;
+        const int kw = W - x0 < 8 ? W - x0 : 8, kh = H - y0 < 8 ? H - y0 : 8;
+        const uint8_t *po = px_addr<BPP>(org, cd.ox + x0, cd.oy + y0);
+        const uint8_t *pr = rec_l + (y0 * W + x0) * BPP;
+        if (qa.dist_kind == R1_DIST_WSSE)
+          acc = r1dist::tile_scaled_dist<BPP, 2>(po, (size_t)org.stride * BPP, pr, (size_t)W * BPP, kw, kh,
+                                                 cd.ox + x0, cd.oy + y0, qa.scales, qa.scale_stride,
+                                                 qa.xdec, qa.ydec, BD);
+        else
+          acc = r1dist::tile_scaled_dist<BPP, 3>(po, (size_t)org.stride * BPP, pr, (size_t)W * BPP, kw, kh,
+                                                 cd.ox + x0, cd.oy + y0, qa.scales, qa.scale_stride,
+                                                 qa.xdec, qa.ydec, BD);
+      }
+#pragma unroll
+      for (int m = 1; m < P; m <<= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)acc, m, 64);
+        const uint32_t hi = __shfl_xor((uint32_t)(acc >> 32), m, 64);
+        acc += ((unsigned long long)hi << 32) | lo;
+      }
+      if (live && c == 0) qa.pix_dist[cand] = qa.dist_kind == R1_DIST_WSSE ? (acc + 32) / 64 : acc;
     }
   }
 }
@@ -563,11 +693,14 @@ int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n
   constexpr int W = 1 << WL, H = 1 << HL, P = W > H ? W : H, NC = 64 / P;
   typedef typename std::conditional<BD == 8, int16_t, int32_t>::type CT;
   const unsigned grid = (unsigned)((n + NC - 1) / NC);
-  if (qa)
-    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, true>), dim3(grid), dim3(64), 0, st,
+  if (qa && qa->pix_dist)
+    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, 2>), dim3(grid), dim3(64), 0, st,
+                       org, ref, cands, n, sad, satd, (CT *)coeffs, pred, *qa);
+  else if (qa)
+    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, 1>), dim3(grid), dim3(64), 0, st,
                        org, ref, cands, n, sad, satd, (CT *)coeffs, pred, *qa);
   else
-    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, false>), dim3(grid), dim3(64), 0, st,
+    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, 0>), dim3(grid), dim3(64), 0, st,
                        org, ref, cands, n, sad, satd, (CT *)coeffs, pred, RdoQuantArgs{});
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
@@ -660,7 +793,7 @@ extern "C" int r1_rdo_full_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1P
   R1_REQUIRE(ctx && org && params && eob_out && tx_dist_out);
   R1_REQUIRE(tx_size >= 0 && tx_size < 19);
   R1_REQUIRE(params->bit_depth == org->bit_depth);
-  RdoQuantArgs qa;
+  RdoQuantArgs qa = {};
   qa.qp = r1q::make_qparams(*params, tx_size, org->bytes_per_px == 1 ? 2 : 4);
   for (int k = 0; k < 3; k++) qa.scan[k] = ctx->scan_dev + ctx->scan_off[tx_size][k];
   qa.tx_size = tx_size;
@@ -670,5 +803,38 @@ extern "C" int r1_rdo_full_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1P
   qa.est_rate = (unsigned long long *)est_rate_out;
   qa.qcoeffs = qcoeffs_out;
   return rdo_dispatch(ctx, org, ref, w, h, tx_size, cands, n, sad_out, satd_out, coeffs, nullptr,
+                      &qa, stream);
+}
+
+extern "C" int r1_rdo_pixel_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w,
+                                       int h, int tx_size, const R1RdoCand *cands, int n,
+                                       const R1QuantParams *params, int dist_kind,
+                                       const uint32_t *scales, int scale_stride, int xdec, int ydec,
+                                       uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
+                                       uint64_t *dist_out, void *qcoeffs_out, void *rec_out,
+                                       void *stream) {
+  R1_REQUIRE(ctx && org && params && eob_out && dist_out);
+  R1_REQUIRE(tx_size >= 0 && tx_size < 19);
+  R1_REQUIRE(params->bit_depth == org->bit_depth);
+  R1_REQUIRE(dist_kind == R1_DIST_WSSE || dist_kind == R1_DIST_CDEF);
+  R1_REQUIRE(xdec >= 0 && xdec <= 1 && ydec >= 0 && ydec <= 1);
+  R1_REQUIRE(dist_kind != R1_DIST_CDEF || (xdec == 0 && ydec == 0));
+  R1_REQUIRE(!scales || scale_stride > 0);
+  RdoQuantArgs qa = {};
+  qa.qp = r1q::make_qparams(*params, tx_size, org->bytes_per_px == 1 ? 2 : 4);
+  for (int k = 0; k < 3; k++) qa.scan[k] = ctx->scan_dev + ctx->scan_off[tx_size][k];
+  qa.tx_size = tx_size;
+  qa.q_bin = params->qindex / 32;
+  qa.eob = eob_out;
+  qa.qcoeffs = qcoeffs_out;
+  qa.dist_kind = dist_kind;
+  qa.inv_shift = r1itx::kInvShift[tx_size];
+  qa.scales = scales;
+  qa.scale_stride = scale_stride;
+  qa.xdec = xdec;
+  qa.ydec = ydec;
+  qa.pix_dist = (unsigned long long *)dist_out;
+  qa.rec = rec_out;
+  return rdo_dispatch(ctx, org, ref, w, h, tx_size, cands, n, sad_out, satd_out, nullptr, nullptr,
                       &qa, stream);
 }

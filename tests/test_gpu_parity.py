@@ -1192,3 +1192,49 @@ def test_intra_prescreen_vs_oracle(ctx, oracle, bd):
                 want = oracle.r1o_get_satd(srcp.block_ptr(int(bxs[b]), int(bys[b])), srcp.stride,
                                            O.ptr(out), w, w, h, hbd)
                 assert got[i] == want, (bd, ts, b, k, int(pm[i]))
+
+
+# ------------------------ pixel-domain leg of the full candidate (default-configuration RDO)
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_rdo_pixel_cand_vs_oracle(ctx, oracle, bd):
+    """r1_rdo_pixel_cand_batch = put_8tap -> diff -> forward_transform -> quantize -> dequantize
+    -> inverse_transform_add -> sse_wxh / cdef_dist_wxh with the DistortionScale grid: every tx
+    size, per-candidate tx types, both distortion kinds, with and without a scale grid."""
+    import ctypes as C
+    a, b = planes(bd, seed=80 + bd, pads=(88, 120))
+    near = planes(bd, seed=80 + bd, pads=(88, 120))[0]
+    nz = np.random.default_rng(6).integers(-4, 5, near.data.shape)
+    near.data[...] = np.clip(near.data.astype(np.int64) + nz, 0, (1 << bd) - 1).astype(near.data.dtype)
+    da, db, dn = dev_plane(a), dev_plane(b), dev_plane(near)
+    rng = np.random.default_rng(950 + bd)
+    ct = np.int16 if bd == 8 else np.int32
+    dt = np.uint8 if bd == 8 else np.uint16
+    scales = rng.integers(1 << 12, 1 << 16, ((a.height + 7) // 8, (a.width + 7) // 8)).astype(np.uint32)
+    dscales = _t(scales.view(np.int32))
+    for ts, (w, h) in enumerate(TX_SIZES):
+        carea = min(w, 32) * min(h, 32)
+        for hp, dp, qi, kind, use_sc in ((b, db, 60, 3, True), (near, dn, 25, 3, False),
+                                         (near, dn, 140, 2, True), (b, db, 220, 2, False)):
+            n = 29 if w * h <= 1024 else 7
+            c = rand_rdo_cands(rng, n, a.width, a.height, w, h, 50, ts)
+            if hp is near:
+                c["rx"], c["ry"] = c["ox"], c["oy"]
+            pa, pb = a.cstruct(), hp.cstruct()
+            wsad, wsatd = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+            weob, wdist = np.zeros(n, np.uint16), np.zeros(n, np.uint64)
+            wq, wrec = np.zeros((n, carea), ct), np.zeros((n, h, w), dt)
+            assert oracle.r1o_rdo_pixel_cand_batch(
+                C.byref(pa), C.byref(pb), w, h, ts, O.ptr(c), n, qi, 0, 0, 0, kind,
+                O.ptr(scales) if use_sc else None, scales.shape[1], 0, 0, O.ptr(wsad), O.ptr(wsatd),
+                O.ptr(weob), O.ptr(wdist), O.ptr(wq), O.ptr(wrec)) == 0
+            o = ctx.rdo_pixel_cand_batch(da, dp, w, h, c, qi, kind, scales=dscales if use_sc else None,
+                                         want_qcoeffs=True, want_rec=True)
+            key = (bd, w, h, qi, kind)
+            assert np.array_equal(o["satd"].cpu().numpy().view(np.uint32), wsatd), key
+            assert np.array_equal(o["qcoeffs"].cpu().numpy(), wq), key
+            assert np.array_equal(o["eob"].cpu().numpy().view(np.uint16), weob), key
+            assert np.array_equal(o["rec"].cpu().numpy().view(dt), wrec), key
+            assert np.array_equal(o["dist"].cpu().numpy().view(np.uint64), wdist), key
+            o2 = ctx.rdo_pixel_cand_batch(da, dp, w, h, c, qi, kind, scales=dscales if use_sc else None,
+                                          want_sad=False, want_satd=False)
+            assert np.array_equal(o2["dist"].cpu().numpy().view(np.uint64), wdist), key
