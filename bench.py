@@ -45,10 +45,11 @@ def parse():
     ap.add_argument("--single-device", action="store_true",
                     help="dry run: every rank uses cuda:0 (to exercise the N > 1 control flow on a "
                          "1-GPU box; numbers are meaningless)")
-    ap.add_argument("--chain", choices=("cand", "full"), default="cand",
+    ap.add_argument("--chain", choices=("cand", "full", "pixel"), default="cand",
                     help="cand: the headline fused candidate (BASELINE.json north_star); full: the "
                          "same candidate carried through quantize / tx-domain distortion / rate "
-                         "(r1_rdo_full_cand_batch, SURVEY 8f N4) -- a supplementary line")
+                         "(r1_rdo_full_cand_batch, SURVEY 8f N4); pixel: carried through quantize / "
+                         "inverse transform / cdef_dist (r1_rdo_pixel_cand_batch) -- supplementary lines")
     ap.add_argument("--qindex", type=int, default=100)
     ap.add_argument("--no-events", action="store_true",
                     help="skip per-kernel event timing (roofline.achieved falls back to step time)")
@@ -176,8 +177,22 @@ def main():
     if world > 1:
         send, gathered = tiles.make_exchange_buffers(ref.data, rank, world)
 
-    full = args.chain == "full"
-    if full:
+    full = args.chain != "cand"
+    pixel = args.chain == "pixel"
+    if pixel:
+        scales = torch.from_numpy(np.random.default_rng(9).integers(
+            1 << 12, 1 << 16, ((fh + 7) // 8, (fw + 7) // 8)).astype(np.int32)).cuda()
+        launches = {}
+        for s, c in cands.items():
+            n = len(c)
+            if not n:
+                continue
+            del outs[s]["coeffs"]
+            outs[s].update(eob=torch.empty(n, dtype=torch.int16, device="cuda"),
+                           dist=torch.empty(n, dtype=torch.int64, device="cuda"))
+            launches[s] = (lambda s=s, n=n: ctx.rdo_pixel_cand_batch(
+                org, ref, s, s, dcands[s], args.qindex, 3, scales=scales, n=n, outs=outs[s]))
+    elif full:
         for s, c in cands.items():
             n = len(c)
             del outs[s]["coeffs"]
@@ -192,6 +207,8 @@ def main():
                     for s in cands if len(cands[s])}
 
     def abytes_per_cand(s):
+        if pixel:  # window + source (read twice: residual, distortion) + sad/satd/eob/dist
+            return bpp * ((s + 7) * (s + 7) + 2 * s * s) + 4 + 4 + 2 + 8
         if full:   # window + source + sad/satd/eob/tx_dist/est_rate; no coefficient store
             return bpp * ((s + 7) * (s + 7) + s * s) + 4 + 4 + 2 + 8 + 8
         return W.algorithmic_bytes_per_cand(s, s, bpp)
@@ -254,7 +271,7 @@ def main():
             n_dom = len(cands[dom])
             abytes = abytes_per_cand(dom) * n_dom
             achieved = abytes / (per[dom] * 1e-3) / 1e9
-            kname = "k_rdo_cand<bd=%d,%dx%d%s>" % (bd, dom, dom, ",quant" if full else "")
+            kname = "k_rdo_cand<bd=%d,%dx%d%s>" % (bd, dom, dom, ",pixel" if pixel else (",quant" if full else ""))
             traffic, traffic_note = (None, None) if full else pmc_traffic(bd, dom, fw, fh, args.k)
         else:
             dom, per = None, {}
@@ -264,7 +281,9 @@ def main():
             traffic, traffic_note = None, None
         res = {
             "metric": "RDO-candidate Mpixels/s (dist+fwd_tx+mc) at 4K speed-6" if not full else
-                      "full RDO-candidate Mpixels/s (mc+dist+fwd_tx+quantize+tx_dist+rate) at 4K speed-6",
+                      ("full RDO-candidate Mpixels/s (mc+dist+fwd_tx+quantize+tx_dist+rate) at 4K speed-6"
+                       if not pixel else "pixel-domain RDO-candidate Mpixels/s (mc+dist+fwd_tx+quantize+"
+                       "inverse+cdef_dist) at 4K speed-6"),
             "value": round(total_px * args.steps / dt / 1e6, 2),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
