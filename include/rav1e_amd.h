@@ -506,6 +506,21 @@ int r1_rdo_pixel_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
                             uint32_t *satd_out, uint16_t *eob_out, uint64_t *dist_out,
                             void *qcoeffs_out, void *rec_out, void *stream);
 
+/* The same chains for a prediction that is NOT a single-reference put_8tap:
+ * `pred` holds n dense w*h predictions (r1_predict_intra_batch output for the
+ * intra mode / tx-type decision of src/rdo.rs:1507-1600 and rdo_tx_size_type,
+ * r1_mc_avg_batch output for compound modes); the candidates' rx / ry /
+ * fractions are ignored, (ox, oy, tx_type) are used.  dist_kind 0: dist_out =
+ * the transform-domain distortion of r1_rdo_full_cand_batch (rec_out must be
+ * NULL); R1_DIST_WSSE / R1_DIST_CDEF: the pixel-domain leg of
+ * r1_rdo_pixel_cand_batch. */
+int r1_rdo_pred_cand_batch(r1_ctx *ctx, const R1Plane *org, const void *pred, int w, int h,
+                           int tx_size, const R1RdoCand *cands, int n,
+                           const R1QuantParams *params, int dist_kind, const uint32_t *scales,
+                           int scale_stride, int xdec, int ydec, uint32_t *sad_out,
+                           uint32_t *satd_out, uint16_t *eob_out, uint64_t *dist_out,
+                           void *qcoeffs_out, void *rec_out, void *stream);
+
 /* ---- per-call compat shims: reference asm signatures, HOST pointers ----
  * SadFn / SatdFn (src/asm/x86/dist/mod.rs:21-43): strides in BYTES. */
 uint32_t rav1e_sad_hip(const uint8_t *src, ptrdiff_t src_stride,

@@ -175,7 +175,10 @@ int r1o_rdo_pixel_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, 
                              int is_intra, int dc_delta_q, int ac_delta_q, int kind,
                              const uint32_t *scales, int scale_stride, int xdec, int ydec,
                              uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
-                             uint64_t *dist_out, void *qcoeffs_out, void *rec_out) {
+                             uint64_t *dist_out, void *qcoeffs_out, void *rec_out,
+                             const void *pred_in) {
+  /* pred_in (dense n x h x w pixels) replaces put_8tap of `ref` (intra
+   * predictions, compound averages); kind 0: transform-domain distortion */
   const int hbd = org->bytes_per_px == 2, bpp = org->bytes_per_px;
   const int cb = hbd ? 4 : 2;
   if (r1o_tx_width(tx_size) != w || r1o_tx_height(tx_size) != h) return -1;
@@ -188,9 +191,12 @@ int r1o_rdo_pixel_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, 
     int16_t resid[64 * 64];
     int32_t co[64 * 64], qc[32 * 32], rc[32 * 32];
     void *pred = pred16;
-    r1o_put_8tap(pred, w, at(ref, c[i].rx, c[i].ry), ref->stride, w, h,
-                 c[i].col_frac, c[i].row_frac, c[i].mode_x, c[i].mode_y,
-                 ref->bit_depth, hbd);
+    if (pred_in)
+      memcpy(pred, (const uint8_t *)pred_in + i * area * bpp, area * bpp);
+    else
+      r1o_put_8tap(pred, w, at(ref, c[i].rx, c[i].ry), ref->stride, w, h,
+                   c[i].col_frac, c[i].row_frac, c[i].mode_x, c[i].mode_y,
+                   ref->bit_depth, hbd);
     const void *o = at(org, c[i].ox, c[i].oy);
     if (sad_out) sad_out[i] = r1o_get_sad(o, org->stride, pred, w, w, h, hbd);
     if (satd_out) satd_out[i] = r1o_get_satd(o, org->stride, pred, w, w, h, hbd);
@@ -207,6 +213,11 @@ int r1o_rdo_pixel_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, 
     }
     eob_out[i] = (uint16_t)eob;
     r1o_dequantize(qc, rc, tx_size, qindex, org->bit_depth, dc_delta_q, ac_delta_q, hbd);
+    if (qcoeffs_out) memcpy((uint8_t *)qcoeffs_out + i * carea * cb, qc, carea * cb);
+    if (kind == 0) {
+      dist_out[i] = r1o_tx_domain_distortion(co, rc, tx_size, hbd);
+      continue;
+    }
     /* the prediction buffer becomes the reconstruction */
     if (r1o_inverse_transform_add(rc, pred, w, tx_size, c[i].tx_type, org->bit_depth, hbd, hbd)) {
       bad = 1;
@@ -217,7 +228,6 @@ int r1o_rdo_pixel_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, 
     const r1o_dist_cand dc = { c[i].ox, c[i].oy, 0, 0 };
     r1o_dist_scaled_batch(kind, org, &rp, w, h, &dc, 1, scales, scale_stride, xdec, ydec,
                           &dist_out[i]);
-    if (qcoeffs_out) memcpy((uint8_t *)qcoeffs_out + i * carea * cb, qc, carea * cb);
     if (rec_out) memcpy((uint8_t *)rec_out + i * area * bpp, pred, area * bpp);
   }
   return bad ? -1 : 0;

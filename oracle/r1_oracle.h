@@ -255,7 +255,8 @@ int r1o_rdo_pixel_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, 
                              int is_intra, int dc_delta_q, int ac_delta_q, int kind,
                              const uint32_t *scales, int scale_stride, int xdec, int ydec,
                              uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
-                             uint64_t *dist_out, void *qcoeffs_out, void *rec_out);
+                             uint64_t *dist_out, void *qcoeffs_out, void *rec_out,
+                             const void *pred_in);
 
 #ifdef __cplusplus
 }

@@ -550,9 +550,11 @@ class Context:
 
     def rdo_pixel_cand_batch(self, org, ref, w, h, cands, qindex, dist_kind, scales=None, xdec=0,
                              ydec=0, is_intra=0, dc_delta_q=0, ac_delta_q=0, n=None, want_sad=True,
-                             want_satd=True, want_qcoeffs=False, want_rec=False, outs=None):
+                             want_satd=True, want_qcoeffs=False, want_rec=False, outs=None, pred=None):
         """mc -> sad/satd -> diff -> forward_transform -> quantize -> dequantize -> inverse
-        transform -> reconstruction -> weighted SSE / cdef_dist against the source, one launch."""
+        transform -> reconstruction -> weighted SSE / cdef_dist against the source, one launch.
+        pred (dense (n, h, w) device tensor): r1_rdo_pred_cand_batch -- the prediction comes
+        from that buffer instead of put_8tap(ref); dist_kind 0 = transform-domain distortion."""
         from .types import TxSize
         tx_size = int(TxSize.by_dims(w, h))
         dc = _dev_cands(cands, RDO_CAND)
@@ -570,11 +572,19 @@ class Context:
         if want_rec:
             o.setdefault("rec", torch.empty((n, h, w), dtype=torch.uint8 if org.bpp == 1 else torch.int16,
                                             device="cuda"))
-        po, pr = org.cstruct(), ref.cstruct()
+        po = org.cstruct()
         qp = self._qparams(qindex, org.bit_depth, is_intra, dc_delta_q, ac_delta_q)
 
         def p(k):
             return o[k].data_ptr() if k in o else None
+        if pred is not None:
+            self._check(self.lib.r1_rdo_pred_cand_batch(
+                self.h, C.byref(po), pred.data_ptr(), w, h, tx_size, dc.data_ptr(), n, C.byref(qp),
+                dist_kind, scales.data_ptr() if scales is not None else None,
+                scales.stride(0) if scales is not None else 0, xdec, ydec, p("sad"), p("satd"),
+                p("eob"), p("dist"), p("qcoeffs"), p("rec"), _stream_ptr()), "r1_rdo_pred_cand_batch")
+            return o
+        pr = ref.cstruct()
         self._check(self.lib.r1_rdo_pixel_cand_batch(
             self.h, C.byref(po), C.byref(pr), w, h, tx_size, dc.data_ptr(), n, C.byref(qp), dist_kind,
             scales.data_ptr() if scales is not None else None,

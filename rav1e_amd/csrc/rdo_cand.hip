@@ -341,6 +341,9 @@ struct RdoQuantArgs {
   int scale_stride, xdec, ydec;
   unsigned long long *pix_dist;
   void *rec;                 // optional: dense w*h reconstructions
+  // prediction from a dense buffer (n x h x w pixels: intra predictions, compound
+  // averages) instead of put_8tap of the reference plane
+  const void *pred_in;
 };
 
 // QM: 0 = coefficients to HBM (headline), 1 = + quantizer, tx-domain distortion,
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
     for (int r = 0; r < H; r++) v[r] = ld_px<BPP>(po + r * so);
   }
   uint8_t *win = smem + cl * (H + 7) * WS;
-  if (live)
+  if (live && !qa.pred_in)   // wave-uniform: kernel argument
     r1mc::stage_window_fast<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P>(win, WS, ref, cd.rx,
                                                                         cd.ry, c);
   __syncthreads();
@@ -400,7 +403,13 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
     const bool any_cf0 = __any(live && cd.col_frac == 0);
     if (col_live) {
       int32_t pred[H];
-      mc8_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, any_cf0, pred);
+      if (qa.pred_in) {
+        const uint8_t *pi = (const uint8_t *)qa.pred_in + (size_t)cand * W * H + c;
+#pragma unroll
+        for (int r = 0; r < H; r++) pred[r] = pi[(size_t)r * W];
+      } else {
+        mc8_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, any_cf0, pred);
+      }
       if (pred_out) {
         uint8_t *pp = (uint8_t *)pred_out + (size_t)cand * W * H + c;
 #pragma unroll
@@ -416,7 +425,13 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   } else {
     if (col_live) {
       int32_t pred[H];
-      mc16_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, BD, pred);
+      if (qa.pred_in) {
+        const uint16_t *pi = (const uint16_t *)qa.pred_in + (size_t)cand * W * H + c;
+#pragma unroll
+        for (int r = 0; r < H; r++) pred[r] = pi[(size_t)r * W];
+      } else {
+        mc16_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, BD, pred);
+      }
       if (pred_out) {
         uint16_t *pp = (uint16_t *)pred_out + (size_t)cand * W * H + c;
 #pragma unroll
@@ -737,10 +752,13 @@ namespace {
 int rdo_dispatch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w, int h, int tx_size,
                  const R1RdoCand *cands, int n, uint32_t *sad_out, uint32_t *satd_out,
                  void *coeffs, void *pred_out, const RdoQuantArgs *qa, void *stream) {
-  R1_REQUIRE(ctx && org && ref);
-  R1_REQUIRE(org->bytes_per_px == ref->bytes_per_px);
+  const bool from_pred = qa && qa->pred_in;
+  R1_REQUIRE(ctx && org && (ref || from_pred));
+  const R1Plane no_ref = {};
+  if (from_pred) ref = &no_ref;
+  R1_REQUIRE(from_pred || org->bytes_per_px == ref->bytes_per_px);
   R1_REQUIRE(org->bytes_per_px == 1 || org->bytes_per_px == 2);
-  R1_REQUIRE(org->bit_depth == ref->bit_depth);
+  R1_REQUIRE(from_pred || org->bit_depth == ref->bit_depth);
   R1_REQUIRE((org->bytes_per_px == 1) == (org->bit_depth == 8));
   R1_REQUIRE(tx_size >= 0 && tx_size < 19);
   R1_REQUIRE((1 << r1tx::kTxWLog2[tx_size]) == w &&
@@ -836,5 +854,44 @@ extern "C" int r1_rdo_pixel_cand_batch(r1_ctx *ctx, const R1Plane *org, const R1
   qa.pix_dist = (unsigned long long *)dist_out;
   qa.rec = rec_out;
   return rdo_dispatch(ctx, org, ref, w, h, tx_size, cands, n, sad_out, satd_out, nullptr, nullptr,
+                      &qa, stream);
+}
+
+extern "C" int r1_rdo_pred_cand_batch(r1_ctx *ctx, const R1Plane *org, const void *pred, int w, int h,
+                                      int tx_size, const R1RdoCand *cands, int n,
+                                      const R1QuantParams *params, int dist_kind,
+                                      const uint32_t *scales, int scale_stride, int xdec, int ydec,
+                                      uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
+                                      uint64_t *dist_out, void *qcoeffs_out, void *rec_out,
+                                      void *stream) {
+  R1_REQUIRE(ctx && org && pred && params && eob_out && dist_out);
+  R1_REQUIRE(tx_size >= 0 && tx_size < 19);
+  R1_REQUIRE(params->bit_depth == org->bit_depth);
+  R1_REQUIRE(dist_kind == 0 || dist_kind == R1_DIST_WSSE || dist_kind == R1_DIST_CDEF);
+  R1_REQUIRE(xdec >= 0 && xdec <= 1 && ydec >= 0 && ydec <= 1);
+  R1_REQUIRE(dist_kind != R1_DIST_CDEF || (xdec == 0 && ydec == 0));
+  R1_REQUIRE(!scales || scale_stride > 0);
+  R1_REQUIRE(dist_kind != 0 || !rec_out);
+  RdoQuantArgs qa = {};
+  qa.qp = r1q::make_qparams(*params, tx_size, org->bytes_per_px == 1 ? 2 : 4);
+  for (int k = 0; k < 3; k++) qa.scan[k] = ctx->scan_dev + ctx->scan_off[tx_size][k];
+  qa.tx_size = tx_size;
+  qa.q_bin = params->qindex / 32;
+  qa.eob = eob_out;
+  qa.qcoeffs = qcoeffs_out;
+  qa.pred_in = pred;
+  if (dist_kind == 0) {
+    qa.tx_dist = (unsigned long long *)dist_out;   // transform-domain distortion (QM 1)
+  } else {
+    qa.dist_kind = dist_kind;
+    qa.inv_shift = r1itx::kInvShift[tx_size];
+    qa.scales = scales;
+    qa.scale_stride = scale_stride;
+    qa.xdec = xdec;
+    qa.ydec = ydec;
+    qa.pix_dist = (unsigned long long *)dist_out;
+    qa.rec = rec_out;
+  }
+  return rdo_dispatch(ctx, org, nullptr, w, h, tx_size, cands, n, sad_out, satd_out, nullptr, nullptr,
                       &qa, stream);
 }

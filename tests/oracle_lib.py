@@ -104,7 +104,7 @@ def lib():
         "r1o_rdo_cand_batch": (i, [vp, vp, i, i, i, vp, i, vp, vp, vp, vp]),
         "r1o_estimate_tile_motion": (i, [vp, vp, vp, vp, vp]),
         "r1o_rdo_pixel_cand_batch": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i, vp, i, i, i,
-                                         vp, vp, vp, vp, vp, vp]),
+                                         vp, vp, vp, vp, vp, vp, vp]),
         "r1o_deblock_plane": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i]),
         "r1o_deblock_sse_plane": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i, vp, vp]),
         "r1o_deblock_pick_levels": (None, [vp, vp, i, vp]),

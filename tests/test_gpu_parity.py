@@ -1226,7 +1226,7 @@ def test_rdo_pixel_cand_vs_oracle(ctx, oracle, bd):
             assert oracle.r1o_rdo_pixel_cand_batch(
                 C.byref(pa), C.byref(pb), w, h, ts, O.ptr(c), n, qi, 0, 0, 0, kind,
                 O.ptr(scales) if use_sc else None, scales.shape[1], 0, 0, O.ptr(wsad), O.ptr(wsatd),
-                O.ptr(weob), O.ptr(wdist), O.ptr(wq), O.ptr(wrec)) == 0
+                O.ptr(weob), O.ptr(wdist), O.ptr(wq), O.ptr(wrec), None) == 0
             o = ctx.rdo_pixel_cand_batch(da, dp, w, h, c, qi, kind, scales=dscales if use_sc else None,
                                          want_qcoeffs=True, want_rec=True)
             key = (bd, w, h, qi, kind)
@@ -1238,3 +1238,45 @@ def test_rdo_pixel_cand_vs_oracle(ctx, oracle, bd):
             o2 = ctx.rdo_pixel_cand_batch(da, dp, w, h, c, qi, kind, scales=dscales if use_sc else None,
                                           want_sad=False, want_satd=False)
             assert np.array_equal(o2["dist"].cpu().numpy().view(np.uint64), wdist), key
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_rdo_pred_cand_vs_oracle(ctx, oracle, bd):
+    """r1_rdo_pred_cand_batch: the chains with the prediction taken from a dense buffer (intra
+    predictions / compound averages): transform-domain and both pixel-domain distortions."""
+    import ctypes as C
+    a, _ = planes(bd, seed=90 + bd)
+    da = dev_plane(a)
+    rng = np.random.default_rng(970 + bd)
+    ct = np.int16 if bd == 8 else np.int32
+    dt = np.uint8 if bd == 8 else np.uint16
+    for ts in (0, 1, 2, 3, 4, 5, 8, 9, 13, 17):
+        w, h = TX_SIZES[ts]
+        carea = min(w, 32) * min(h, 32)
+        n = 31 if w * h <= 1024 else 6
+        c = rand_rdo_cands(rng, n, a.width, a.height, w, h, 0, ts)
+        # predictions near the source (what an intra / compound predictor delivers)
+        pred = np.zeros((n, h, w), dt)
+        for i in range(n):
+            blk = a.view()[c["oy"][i]:c["oy"][i] + h, c["ox"][i]:c["ox"][i] + w].astype(np.int64)
+            pred[i] = np.clip(blk + rng.integers(-20, 21, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1)
+        dpred = _t(pred.view(np.int16) if bd > 8 else pred)
+        for kind, qi in ((0, 70), (2, 30), (3, 150)):
+            pa = a.cstruct()
+            wsad, wsatd = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+            weob, wdist = np.zeros(n, np.uint16), np.zeros(n, np.uint64)
+            wq, wrec = np.zeros((n, carea), ct), np.zeros((n, h, w), dt)
+            assert oracle.r1o_rdo_pixel_cand_batch(
+                C.byref(pa), None, w, h, ts, O.ptr(c), n, qi, 1, 0, 0, kind, None, 0, 0, 0, O.ptr(wsad),
+                O.ptr(wsatd), O.ptr(weob), O.ptr(wdist), O.ptr(wq), O.ptr(wrec) if kind else None,
+                O.ptr(pred)) == 0
+            o = ctx.rdo_pixel_cand_batch(da, None, w, h, c, qi, kind, is_intra=1, want_qcoeffs=True,
+                                         want_rec=bool(kind), pred=dpred)
+            key = (bd, w, h, kind)
+            assert np.array_equal(o["sad"].cpu().numpy().view(np.uint32), wsad), key
+            assert np.array_equal(o["satd"].cpu().numpy().view(np.uint32), wsatd), key
+            assert np.array_equal(o["eob"].cpu().numpy().view(np.uint16), weob), key
+            assert np.array_equal(o["qcoeffs"].cpu().numpy(), wq), key
+            assert np.array_equal(o["dist"].cpu().numpy().view(np.uint64), wdist), key
+            if kind:
+                assert np.array_equal(o["rec"].cpu().numpy().view(dt), wrec), key
