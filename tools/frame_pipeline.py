@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""One coded 4K frame's device-resident work, end to end, with every piece of this backend:
+
+  lookahead cost maps -> hierarchical ME (tiles x references) -> RDO-time sub-pel ME ->
+  intra pre-screen -> RDO candidates (pixel-domain chain) -> deblock level search ->
+  deblock -> CDEF
+
+Nothing returns to the host between the stages except the scalars a real encoder's control
+flow needs; the stage inputs are synthetic (the encoder's decisions are not modelled), the
+sizes are those of a 4K speed-6 frame.  Prints one JSON line with the per-stage device times.
+
+    python tools/frame_pipeline.py [--bit-depth 8] [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    import deblock_util as D
+    import oracle_lib as O
+    from rav1e_amd import api, tiles, workload as W
+    from rav1e_amd.api import Context, Plane, me_lambdas
+    from rav1e_amd.types import TxSize
+    fw, fh, bd = 3840, 2160, args.bit_depth
+    rng = np.random.default_rng(0)
+    ctx = Context(0)
+    # band-limited source, references = shifted + noisy copies
+    f = rng.standard_normal((fh + 64, fw + 64)).astype(np.float32)
+    for _ in range(3):
+        f = (np.roll(f, 1, 0) + 2 * f + np.roll(f, -1, 0)) / 4
+        f = (np.roll(f, 1, 1) + 2 * f + np.roll(f, -1, 1)) / 4
+    f = ((f - f.min()) / (f.max() - f.min()) * ((1 << bd) - 1)).astype(np.int64)
+    org_img = f[32:32 + fh, 32:32 + fw]
+    refs_img = [np.clip(f[32 + dy:32 + dy + fh, 32 + dx:32 + dx + fw] + rng.integers(-2, 3, (fh, fw)), 0,
+                        (1 << bd) - 1) for dx, dy in ((5, -9), (-3, 2), (12, 7))]
+    dev = lambda pyr: [Plane.from_numpy(p.data, p.width, p.height, bd, p.xpad, p.ypad) for p in pyr]
+    org = dev(O.me_pyramid(org_img, bd))
+    refs = [dev(O.me_pyramid(r, bd)) for r in refs_img]
+    rows, cols = fh // 4, fw // 4
+    lam = me_lambdas(30.0)
+    stages = {}
+
+    def timed(name, fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            fn()
+        torch.cuda.synchronize()
+        stages[name] = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
+
+    # 1 lookahead cost maps
+    timed("lookahead_intra_costs", lambda: ctx.estimate_intra_costs(org[0]))
+    # 2 hierarchical ME: 8 tiles x 3 references
+    rects = W.tile_rects(8, fw, fh)
+    stats = [torch.zeros((rows, cols, 2), dtype=torch.int32, device="cuda") for _ in refs]
+    jobs = [dict(org=org, ref=refs[r], stats=stats[r], tile=(x0, y0, x1 - x0, y1 - y0))
+            for r in range(len(refs)) for (x0, y0, x1, y1) in rects]
+    timed("estimate_tile_motion_8tiles_x_3refs", lambda: ctx.estimate_tile_motion(jobs, cols, rows, bd, lam))
+    # 3 RDO-time sub-pel ME on every 16x16 block, first reference
+    c = np.zeros((fw // 16) * (fh // 16), api.ME_BLOCK_CAND)
+    c["bx"] = np.tile(np.arange(fw // 16) * 4, fh // 16)
+    c["by"] = np.repeat(np.arange(fh // 16) * 4, fw // 16)
+    c["w"] = c["h"] = 16
+    c["corner"] = 7
+    dc = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
+    job0 = dict(org=org, ref=refs[0], stats=stats[0], tile=(0, 0, fw, fh))
+    timed("estimate_motion_subpel_16x16_all_blocks",
+          lambda: ctx.estimate_motion_batch(job0, dc, cols, rows, bd, lam, max_w=16, max_h=16, n=len(c)))
+    # 4 intra pre-screen, 13 modes on every 16x16 block
+    s = 16
+    nb = (fw // s) * (fh // s)
+    ec = np.zeros(nb, api.INTRA_EDGE_CAND)
+    ec["x"] = np.tile(np.arange(fw // s) * s, fh // s)
+    ec["y"] = np.repeat(np.arange(fh // s) * s, fw // s)
+    ec["mode"], ec["flags"] = -1, 7
+    var = np.where((ec["x"] == 0) & (ec["y"] == 0), 0, np.where(ec["y"] == 0, 1, np.where(ec["x"] == 0, 2, 3)))
+    pm = np.tile(np.arange(13), nb)
+    v13 = np.repeat(var, 13)
+    pm = np.where((pm == 12) & (v13 == 0), 0, np.where((pm == 12) & (v13 == 2), 1,
+                  np.where((pm == 12) & (v13 == 1), 2, pm)))
+    ic = np.zeros(nb * 13, api.INTRA_CAND)
+    ic["mode"], ic["variant"] = pm, v13
+    ic["angle"] = np.array([0, 90, 180, 45, 135, 113, 157, 203, 67, 0, 0, 0, 0])[pm]
+    ic["ief"] = np.where((pm >= 1) & (pm <= 8), 1, 0)
+    ic["avail_w"] = ic["avail_h"] = s
+    dic = torch.from_numpy(ic.view(np.uint8).reshape(-1).copy()).cuda()
+    pos = torch.from_numpy(np.stack([ec["x"], ec["y"]], 1).astype(np.int16)).cuda()
+    dec = torch.from_numpy(ec.view(np.uint8).reshape(-1).copy()).cuda()
+
+    def prescreen():
+        edges, lens = ctx.intra_edges_batch(refs[0][0], (0, 0, fw, fh), int(TxSize.TX_16X16), dec, n=nb)
+        ctx.intra_satd_batch(org[0], int(TxSize.TX_16X16), dic, 13, pos, edges, lens, n=nb * 13)
+    timed("intra_prescreen_16x16_13modes", prescreen)
+    # 5 RDO candidates, pixel-domain chain, speed-6 ladder, K = 16 per block
+    cands = tiles.shard_candidates(fw, fh, 16, 0, 1)
+    dcands = {k: torch.from_numpy(v.view(np.uint8).reshape(-1).copy()).cuda() for k, v in cands.items()}
+    scales = torch.from_numpy(rng.integers(1 << 12, 1 << 16, ((fh + 7) // 8, (fw + 7) // 8)).astype(np.int32)).cuda()
+    outs = {k: {} for k in cands}
+
+    def rdo():
+        for k in W.LADDER:
+            ctx.rdo_pixel_cand_batch(org[0], refs[0][0], k, k, dcands[k], 100, 3, scales=scales,
+                                     n=len(cands[k]), outs=outs[k])
+    timed("rdo_pixel_candidates_ladder_K16", rdo)
+    # 6-8 post filters on a 4:2:0 frame
+    blocks = D.random_blocks(rng, cols, rows, 1, 1)
+    dblocks = torch.from_numpy(blocks.view(np.uint8).reshape(blocks.shape + (8,)).copy()).cuda()
+    state = D.make_state([24, 20, 16, 16])
+    cw, ch = fw // 2, fh // 2
+    chroma = [Plane.from_numpy(W.random_plane_array(cw, ch, bd, 30 + i, 44, 44), cw, ch, bd, 44, 44) for i in range(4)]
+    planes3 = [(refs[0][0], org[0], 0, 0, 0), (chroma[0], chroma[1], 1, 1, 1), (chroma[2], chroma[3], 2, 1, 1)]
+    tall = torch.zeros((3, 2, 65), dtype=torch.int64, device="cuda")
+    timed("deblock_level_search_420", lambda: [ctx.deblock_sse_plane(a, b, p, xd, yd, dblocks, fw, fh, tallies=tall[p])
+                                               for (a, b, p, xd, yd) in planes3])
+    timed("deblock_filter_420", lambda: [ctx.deblock_plane(state, a, p, xd, yd, dblocks, fw, fh)
+                                         for (a, b, p, xd, yd) in planes3])
+    dst = Plane(fw, fh, bd)
+    skip = torch.zeros((fh // 4, fw // 4), dtype=torch.uint8, device="cuda")
+    ci = torch.zeros(((fh + 63) // 64, (fw + 63) // 64), dtype=torch.uint8, device="cuda")
+    timed("cdef_luma", lambda: ctx.cdef_filter_frame_plane(refs[0][0], refs[0][0], dst, 0, 0, 0, fw, fh, skip, ci,
+                                                           [36] * 8, [36] * 8, 5, bd))
+    total = round(sum(stages.values()), 3)
+    print(json.dumps({"frame": "%dx%d %d-bit" % (fw, fh, bd), "stage_ms": stages, "sum_ms": total,
+                      "frames_per_s_if_serial": round(1e3 / total, 1)}))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
