@@ -1,0 +1,199 @@
+/*
+ * lrf.c -- CPU oracle: loop restoration, self-guided (SGRPROJ) stripe filter
+ * (SURVEY.md 8f "N3", last stage of the post-filter chain).
+ * TEST INFRASTRUCTURE ONLY (see r1_oracle.h).
+ *
+ * Restates src/lrf.rs of the reference:
+ *   SGRPROJ_PARAMS_S 55-72, sgrproj_box_ab_internal 176-201 (+ _r1 / _r2),
+ *   sgrproj_box_f_r0 / _r1 / _r2 242-341, sgrproj_sum_finish 345-363,
+ *   get_integral_square 368-380, VertPaddedIter 402-476, HorzPaddedIter 492-524,
+ *   setup_integral_image 530-627, sgrproj_stripe_filter 630-830,
+ *   RestorationPlane::restoration_unit_index_by_stripe 1297-1307,
+ *   RestorationState::lrf_filter_frame 1482-1585 (the Sgrproj arm; the encoder
+ *   never selects Wiener: src/rdo.rs:2508 `unreachable!() // coming soon`).
+ *
+ * Pinning: the reference has no vectors for this file; the filter is a
+ * normative AV1 decoder process (spec 7.17), so tests/golden/gen_lrf_golden.py
+ * holds an independent model (direct box sums on an explicitly padded stripe,
+ * no integral images, no rolling row buffers) whose frames this file matched.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "r1_oracle.h"
+
+static const uint32_t SGR_S[16][2] = {
+  { 140, 3236 }, { 112, 2158 }, { 93, 1618 }, { 80, 1438 }, { 70, 1295 }, { 58, 1177 },
+  { 47, 1079 },  { 37, 996 },   { 30, 925 },  { 25, 863 },  { 0, 2589 },  { 0, 1618 },
+  { 0, 1177 },   { 0, 925 },    { 56, 0 },    { 22, 0 } };
+
+#define IMG_MAX (256 + 128)          /* STRIPE_IMAGE_MAX */
+#define IMG_STRIDE (IMG_MAX + 6 + 2) /* STRIPE_IMAGE_STRIDE */
+#define IMG_HEIGHT (64 + 6 + 2)
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static int imin(int a, int b) { return a < b ? a : b; }
+
+static uint32_t px(const r1o_plane *p, int x, int y) {
+  const size_t i = (size_t)(p->yorigin + y) * p->stride + p->xorigin + x;
+  return p->bytes_per_px == 1 ? ((const uint8_t *)p->data)[i] : ((const uint16_t *)p->data)[i];
+}
+
+/* setup_integral_image: (x0, y0) = the unit's origin in the plane; crop_w /
+ * crop_h are ABSOLUTE here (the reference passes them relative to the slice) */
+static void setup_integral_image(uint32_t *ii, uint32_t *sq, int crop_w, int crop_h, int stripe_w,
+                                 int stripe_h, const r1o_plane *cdeffed, const r1o_plane *deblocked,
+                                 int x0, int y0) {
+  const int left_w = 4, right_w = 3;
+  const int left_uniques = x0 == 0 ? 0 : left_w;
+  const int right_uniques = imin(right_w, (crop_w - x0) - stripe_w);
+  const int h2 = stripe_h + (stripe_h & 1);
+  const int rows_above = 4, rows_below = 2;
+  const int stripe_begin = y0, stripe_end = y0 + h2;
+  const int nrows = rows_above + h2 + rows_below, ncols = left_w + stripe_w + right_w;
+  for (int j = 0; j < nrows; j++) {
+    const int y = y0 - rows_above + j;
+    const int cy = clampi(y, 0, crop_h - 1);
+    const int ly = clampi(cy, stripe_begin - 2, stripe_end + 1);
+    const r1o_plane *src = (ly >= stripe_begin && ly < stripe_end) ? cdeffed : deblocked;
+    uint32_t sum = 0, sqs = 0;
+    for (int i = 0; i < ncols; i++) {
+      /* HorzPaddedIter over row[x0 - left_uniques ..][..row_uniques] from start_index */
+      const int idx = clampi((x0 == 0 ? -left_w : 0) + i, 0, left_uniques + stripe_w + right_uniques - 1);
+      const uint32_t cur = px(src, x0 - left_uniques + idx, ly);
+      sum += cur;
+      sqs += cur * cur;
+      ii[j * IMG_STRIDE + i] = sum + (j ? ii[(j - 1) * IMG_STRIDE + i] : 0);
+      sq[j * IMG_STRIDE + i] = sqs + (j ? sq[(j - 1) * IMG_STRIDE + i] : 0);
+    }
+  }
+}
+
+static uint32_t integral_square(const uint32_t *ii, int x, int y, int size) {
+  return ii[y * IMG_STRIDE + x] + ii[(y + size) * IMG_STRIDE + x + size] - ii[(y + size) * IMG_STRIDE + x] -
+         ii[y * IMG_STRIDE + x + size];
+}
+
+static void sum_finish(uint32_t ssq, uint32_t sum, uint32_t n, uint32_t one_over_n, uint32_t s, int bd,
+                       uint32_t *a_out, uint32_t *b_out) {
+  const int bdm8 = bd - 8;
+  const uint32_t scaled_ssq = (ssq + ((1u << (2 * bdm8)) >> 1)) >> (2 * bdm8);
+  const uint32_t scaled_sum = (sum + ((1u << bdm8) >> 1)) >> bdm8;
+  const uint32_t t = scaled_ssq * n, u = scaled_sum * scaled_sum;
+  const uint32_t p = t > u ? t - u : 0; /* saturating_sub */
+  const uint32_t z = (p * s + (1u << 19)) >> 20;
+  const uint32_t a = z >= 255 ? 256 : (z == 0 ? 1 : ((z << 8) + z / 2) / (z + 1));
+  const uint32_t b = ((1u << 8) - a) * sum * one_over_n;
+  *a_out = a;
+  *b_out = (b + (1u << 11)) >> 12;
+}
+
+/* sgrproj_box_ab_r{1,2}: one row of stripe_w + 2 (a, b) pairs at integral row y */
+static void box_ab(int r, uint32_t *af, uint32_t *bf, const uint32_t *ii, const uint32_t *sq, int y,
+                   int stripe_w, uint32_t s, int bd) {
+  const int d = 2 * r + 1;
+  for (int x = 0; x < stripe_w + 2; x++)
+    sum_finish(integral_square(sq, x, y, d), integral_square(ii, x, y, d), (uint32_t)(d * d),
+               r == 1 ? 455 : 164, s, bd, &af[x], &bf[x]);
+}
+
+static void stripe_filter(int set, const int8_t *xqd, int bd, const uint32_t *ii, const uint32_t *sq,
+                          const r1o_plane *cdeffed, const r1o_plane *out, int x0, int y0, int stripe_w,
+                          int stripe_h) {
+  static uint32_t a_r2[2][IMG_MAX + 2], b_r2[2][IMG_MAX + 2], f_r2_0[IMG_MAX], f_r2_1[IMG_MAX];
+  static uint32_t a_r1[3][IMG_MAX + 2], b_r1[3][IMG_MAX + 2], f_r1[IMG_MAX];
+#pragma omp threadprivate(a_r2, b_r2, f_r2_0, f_r2_1, a_r1, b_r1, f_r1)
+  const uint32_t s_r2 = SGR_S[set][0], s_r1 = SGR_S[set][1];
+  /* r = 1 works on the integral images moved by (1, 1) */
+  const uint32_t *ii1 = ii + IMG_STRIDE + 1, *sq1 = sq + IMG_STRIDE + 1;
+  if (s_r2 > 0) box_ab(2, a_r2[0], b_r2[0], ii, sq, 0, stripe_w, s_r2, bd);
+  if (s_r1 > 0) {
+    box_ab(1, a_r1[0], b_r1[0], ii1, sq1, 0, stripe_w, s_r1, bd);
+    box_ab(1, a_r1[1], b_r1[1], ii1, sq1, 1, stripe_w, s_r1, bd);
+  }
+  const int w0 = xqd[0], w1 = xqd[1], w2 = 128 - w0 - w1;
+  for (int y = 0; y < stripe_h; y += 2) {
+    const uint32_t *fr2[2];
+    if (s_r2 > 0) {
+      const int k0 = (y / 2) % 2, k1 = (y / 2 + 1) % 2;
+      box_ab(2, a_r2[k1], b_r2[k1], ii, sq, y + 2, stripe_w, s_r2, bd);
+      for (int x = 0; x < stripe_w; x++) {
+        const uint32_t a = 5 * (a_r2[k0][x] + a_r2[k0][x + 2]) + 6 * a_r2[k0][x + 1];
+        const uint32_t b = 5 * (b_r2[k0][x] + b_r2[k0][x + 2]) + 6 * b_r2[k0][x + 1];
+        const uint32_t ao = 5 * (a_r2[k1][x] + a_r2[k1][x + 2]) + 6 * a_r2[k1][x + 1];
+        const uint32_t bo = 5 * (b_r2[k1][x] + b_r2[k1][x + 2]) + 6 * b_r2[k1][x + 1];
+        const uint32_t v = (a + ao) * px(cdeffed, x0 + x, y0 + y) + b + bo;
+        f_r2_0[x] = (v + (1u << 8)) >> 9;
+        /* the reference reads cdeffed.row(y + 1) even when that row is past the stripe */
+        const uint32_t vo = ao * px(cdeffed, x0 + x, y0 + y + 1) + bo;
+        f_r2_1[x] = (vo + (1u << 7)) >> 8;
+      }
+      fr2[0] = f_r2_0;
+      fr2[1] = f_r2_1;
+    } else {
+      for (int x = 0; x < stripe_w; x++) f_r2_0[x] = px(cdeffed, x0 + x, y0 + y) << 4;
+      fr2[0] = fr2[1] = f_r2_0;
+    }
+    for (int dy = 0; dy < imin(2, stripe_h - y); dy++) {
+      const int yy = y + dy;
+      if (s_r1 > 0) {
+        box_ab(1, a_r1[(yy + 2) % 3], b_r1[(yy + 2) % 3], ii1, sq1, yy + 2, stripe_w, s_r1, bd);
+        const uint32_t *a0 = a_r1[yy % 3], *a1 = a_r1[(yy + 1) % 3], *a2 = a_r1[(yy + 2) % 3];
+        const uint32_t *b0 = b_r1[yy % 3], *b1 = b_r1[(yy + 1) % 3], *b2 = b_r1[(yy + 2) % 3];
+        for (int x = 0; x < stripe_w; x++) {
+          const uint32_t a = 3 * (a0[x] + a2[x] + a0[x + 2] + a2[x + 2]) +
+                             4 * (a1[x] + a0[x + 1] + a1[x + 1] + a2[x + 1] + a1[x + 2]);
+          const uint32_t b = 3 * (b0[x] + b2[x] + b0[x + 2] + b2[x + 2]) +
+                             4 * (b1[x] + b0[x + 1] + b1[x + 1] + b2[x + 1] + b1[x + 2]);
+          const uint32_t v = a * px(cdeffed, x0 + x, y0 + yy) + b;
+          f_r1[x] = (v + (1u << 8)) >> 9;
+        }
+      } else {
+        for (int x = 0; x < stripe_w; x++) f_r1[x] = px(cdeffed, x0 + x, y0 + yy) << 4;
+      }
+      for (int x = 0; x < stripe_w; x++) {
+        const int32_t u = (int32_t)px(cdeffed, x0 + x, y0 + yy) << 4;
+        const int32_t v = w0 * (int32_t)fr2[dy][x] + w1 * u + w2 * (int32_t)f_r1[x];
+        const int32_t s = (v + (1 << 10)) >> 11;
+        const int32_t o = clampi(s, 0, (1 << bd) - 1);
+        const size_t i = (size_t)(out->yorigin + y0 + yy) * out->stride + out->xorigin + x0 + x;
+        if (out->bytes_per_px == 1) ((uint8_t *)out->data)[i] = (uint8_t)o;
+        else ((uint16_t *)out->data)[i] = (uint16_t)o;
+      }
+    }
+  }
+}
+
+/* lrf_filter_frame for one plane: crop_w / crop_h in pixels of THIS plane,
+ * frame_h the luma frame height (stripe count), units: unit_rows x unit_cols */
+int r1o_lrf_filter_plane(const r1o_plane *cdeffed, const r1o_plane *deblocked, const r1o_plane *out,
+                         int ydec, int crop_w, int crop_h, int frame_h, int unit_size, int unit_cols,
+                         int unit_rows, int stripe_height, const r1o_lrf_unit *units, int bd) {
+  if (unit_size > 256 || unit_size < 32) return -1;
+  const int stripe_n = (frame_h + 7) / 64 + 1;
+  uint32_t *ii = (uint32_t *)calloc((size_t)IMG_STRIDE * IMG_HEIGHT * 2, sizeof(uint32_t));
+  uint32_t *sq = ii + IMG_STRIDE * IMG_HEIGHT;
+  for (int si = 0; si < stripe_n; si++) {
+    int y0, sz;
+    if (si == 0) {
+      y0 = 0;
+      sz = (64 - 8) >> ydec;
+    } else {
+      y0 = (si * 64 - 8) >> ydec;
+      sz = imin(64 >> ydec, crop_h - y0);
+    }
+    if (sz <= 0) continue; /* the reference's usize arithmetic never gets here on valid sizes */
+    for (int rux = 0; rux < unit_cols; rux++) {
+      const int x0 = rux * unit_size;
+      const int size = rux == unit_cols - 1 ? crop_w - x0 : unit_size;
+      const int ruy = imin(si * stripe_height / unit_size, unit_rows - 1);
+      const r1o_lrf_unit *u = &units[ruy * unit_cols + imin(rux, unit_cols - 1)];
+      if (u->filter != 3 || size <= 0) continue; /* RESTORE_SGRPROJ */
+      if (size > IMG_MAX) { free(ii); return -1; }
+      setup_integral_image(ii, sq, crop_w, crop_h, size, sz, cdeffed, deblocked, x0, y0);
+      stripe_filter(u->set, u->xqd, bd, ii, sq, cdeffed, out, x0, y0, size, sz);
+    }
+  }
+  free(ii);
+  return 0;
+}

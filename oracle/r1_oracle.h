@@ -225,6 +225,15 @@ int r1o_deblock_sse_plane(const r1o_plane *rec, const r1o_plane *src, int pli, i
                           int blocks_rows, int crop_w, int crop_h, int bd, int64_t *v_tally,
                           int64_t *h_tally);
 void r1o_deblock_pick_levels(int64_t *v_tally, int64_t *h_tally, int pli, uint8_t *out);
+/* ---- loop restoration: self-guided stripe filter (src/lrf.rs, see oracle/lrf.c) ---- */
+typedef struct {
+  uint8_t filter; /* RESTORE_NONE 0, RESTORE_SGRPROJ 3 (src/lrf.rs:34-37) */
+  uint8_t set;    /* index into SGRPROJ_PARAMS_S */
+  int8_t xqd[2];
+} r1o_lrf_unit;
+int r1o_lrf_filter_plane(const r1o_plane *cdeffed, const r1o_plane *deblocked, const r1o_plane *out,
+                         int ydec, int crop_w, int crop_h, int frame_h, int unit_size, int unit_cols,
+                         int unit_rows, int stripe_height, const r1o_lrf_unit *units, int bd);
 void r1o_set_threads(int n);
 int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
                    int h, const r1o_dist_cand *c, int n, uint32_t *out);

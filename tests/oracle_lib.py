@@ -108,6 +108,7 @@ def lib():
         "r1o_deblock_plane": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i]),
         "r1o_deblock_sse_plane": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i, vp, vp]),
         "r1o_deblock_pick_levels": (None, [vp, vp, i, vp]),
+        "r1o_lrf_filter_plane": (i, [vp, vp, vp, i, i, i, i, i, i, i, i, vp, i]),
         "r1o_estimate_motion_batch": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
         "r1o_rdo_full_cand_batch": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp]),
     }
@@ -173,6 +174,7 @@ class MeParams(C.Structure):
 ME_BLOCK_CAND = np.dtype([("bx", "<i2"), ("by", "<i2"), ("w", "u1"), ("h", "u1"), ("corner", "u1"),
                           ("reserved", "u1"), ("pmv", "<i2", (2, 2))])
 ME_RESULT = np.dtype([("row", "<i2"), ("col", "<i2"), ("sad", "<u4"), ("cost", "<u8")])
+LRF_UNIT = np.dtype([("filter", "u1"), ("set", "u1"), ("xqd", "i1", (2,))])
 ME_STATS = np.dtype([("row", "<i2"), ("col", "<i2"), ("normalized_sad", "<u4")])
 assert ME_STATS.itemsize == 8
 

@@ -1,0 +1,47 @@
+"""Pin oracle/lrf.c (self-guided loop restoration as lrf_filter_frame applies it) against the
+frames of the independent model in tests/lrf_util.py (tests/golden/gen_lrf_golden.py)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "lrf_golden.npz")))
+CASES = sorted(k[:-5] for k in G if k.endswith("_meta"))
+
+
+def run_oracle(oracle, cdef, debl, ydec, fh, us, sh, units, bd):
+    h, w = cdef.shape
+    pc, pd = O.plane_from_image(cdef, bd, 16, 16), O.plane_from_image(debl, bd, 16, 16)
+    po = O.plane_from_image(cdef, bd, 16, 16)         # out starts as a copy of the CDEF output
+    cc, cd, co = pc.cstruct(), pd.cstruct(), po.cstruct()
+    u = np.ascontiguousarray(units)
+    assert oracle.r1o_lrf_filter_plane(C.byref(cc), C.byref(cd), C.byref(co), ydec, w, h, fh, us,
+                                       u.shape[1], u.shape[0], sh, u.ctypes.data, bd) == 0
+    return po.view().copy()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sgrproj_frames_match_the_independent_model(oracle, name):
+    w, h, ydec, fh, us, sh, bd = [int(v) for v in G[name + "_meta"]]
+    got = run_oracle(oracle, G[name + "_cdef"], G[name + "_debl"], ydec, fh, us, sh, G[name + "_units"], bd)
+    bad = np.argwhere(got != G[name + "_out"])
+    assert len(bad) == 0, (name, bad[:5])
+
+
+def test_units_without_a_filter_and_flat_input_are_untouched(oracle):
+    img = np.full((80, 96), 77)
+    units = np.zeros((2, 2), O.LRF_UNIT)
+    units["filter"] = [[3, 0], [0, 3]]
+    units["set"] = 3
+    units["xqd"] = (-20, 40)
+    out = run_oracle(oracle, img, img, 0, 80, 64, 64, units, 8)
+    assert np.array_equal(out, img)                    # a flat frame is a fixed point of the filter
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:80, 0:96]
+    img = 60 + xx + yy // 2 + rng.integers(-3, 4, (80, 96))   # texture the filter acts on
+    out = run_oracle(oracle, img, img, 0, 80, 64, 64, units, 8)
+    assert np.array_equal(out[:56, 64:], img[:56, 64:])   # unit (0, 1): RESTORE_NONE, stripe 0
+    assert (out[:56, :64] != img[:56, :64]).any()
