@@ -445,6 +445,28 @@ int r1_deblock_sse_plane(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src, in
 int r1_deblock_pick_levels(const int64_t *v_tally, const int64_t *h_tally, int pli,
                            uint8_t *levels_out);
 
+/* ---- loop restoration, self-guided filter (SURVEY.md 8f "N3", last stage of
+ * the post-filter chain; reference RestorationState::lrf_filter_frame
+ * src/lrf.rs:1482-1585 -> setup_integral_image 530 + sgrproj_stripe_filter
+ * 630; the encoder never selects Wiener, src/rdo.rs:2508).  One plane per call:
+ * cdeffed = the CDEF output, deblocked = the frame before CDEF (rows outside a
+ * 64-row stripe are taken from it, as the decoder does), out = a plane that
+ * already holds a copy of the CDEF output (units without a filter are left as
+ * they are; must not alias cdeffed).  crop_w / crop_h: visible size of THIS
+ * plane ((fi.width + xdec_round) >> xdec ..), frame_height: fi.height (luma;
+ * sets the stripe count), ydec: the plane's vertical decimation, unit_size /
+ * unit_cols / unit_rows / stripe_height: RestorationPlaneConfig, units:
+ * unit_rows x unit_cols entries (DEVICE), filter = RESTORE_NONE 0 or
+ * RESTORE_SGRPROJ 3, set = index into SGRPROJ_PARAMS_S, xqd as coded. */
+typedef struct R1LrfUnit {
+  uint8_t filter, set;
+  int8_t xqd[2];
+} R1LrfUnit;
+int r1_lrf_sgrproj_plane(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *deblocked,
+                         const R1Plane *out, int ydec, int crop_w, int crop_h, int frame_height,
+                         int unit_size, int unit_cols, int unit_rows, int stripe_height,
+                         const R1LrfUnit *units, void *stream);
+
 /* ---- fused RDO candidate: the headline path.  For each candidate:
  *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)
  *   sad    = get_sad(org @ (ox,oy), pred)       if sad_out     (src/dist.rs:31)

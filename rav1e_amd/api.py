@@ -592,6 +592,19 @@ class Context:
             p("dist"), p("qcoeffs"), p("rec"), _stream_ptr()), "r1_rdo_pixel_cand_batch")
         return o
 
+    # ---- lrf:: ----
+    def lrf_sgrproj_plane(self, cdeffed, deblocked, out, ydec, crop_w, crop_h, frame_height, unit_size,
+                          units, stripe_height):
+        """lrf_filter_frame's Sgrproj arm for one plane (src/lrf.rs:1482-1585); units: uint8 device
+        tensor (unit_rows, unit_cols, 4) of R1LrfUnit; `out` must already hold the CDEF output."""
+        pc, pd, po = cdeffed.cstruct(), deblocked.cstruct(), out.cstruct()
+        assert units.dtype == torch.uint8 and units.shape[2] == 4 and units.is_contiguous()
+        self._check(self.lib.r1_lrf_sgrproj_plane(self.h, C.byref(pc), C.byref(pd), C.byref(po), ydec,
+                                                  crop_w, crop_h, frame_height, unit_size,
+                                                  units.shape[1], units.shape[0], stripe_height,
+                                                  units.data_ptr(), _stream_ptr()),
+                    "r1_lrf_sgrproj_plane")
+
     # ---- fused candidate ----
     def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,
                        want_coeffs=True, want_pred=False, outs=None):

@@ -1,0 +1,241 @@
+// lrf.hip -- loop restoration: the self-guided (SGRPROJ) stripe filter of a
+// whole plane (SURVEY.md 8f "N3", last stage of deblock -> CDEF -> LRF;
+// reference src/lrf.rs: sgrproj_sum_finish 345-363, sgrproj_box_ab_* 176-240,
+// sgrproj_box_f_r0/_r1/_r2 242-341, VertPaddedIter / HorzPaddedIter 402-524,
+// setup_integral_image 530-627, sgrproj_stripe_filter 630-830,
+// RestorationState::lrf_filter_frame 1482-1585; the encoder never selects the
+// Wiener filter, src/rdo.rs:2508).
+//
+// The reference walks stripe by stripe and restoration unit by unit, builds an
+// integral image of the padded stripe and rolls three / two rows of (a, b)
+// intermediates down the stripe.  Every output pixel, however, only depends
+// on the padded stripe within 3 pixels of it, so here:
+//   * one WORKGROUP per (stripe, 32-column chunk of a restoration unit);
+//   * the padded chunk ((32 + 7) x (stripe + 6) pixels: rows outside the
+//     stripe from the deblocked plane -- at most two -- then replicated,
+//     columns outside the unit real up to 4 / 3 pixels, replicated at the
+//     frame edge) is staged into LDS once;
+//   * the (a, b) pairs of both passes are computed for the whole chunk by
+//     direct 3x3 / 5x5 box sums from LDS (exact: the integral image's wrapping
+//     differences are these sums) and parked in LDS packed into one dword
+//     (a <= 256: 9 bits, b < 2^21);
+//   * every thread then finishes 8 pixels: the weighted (a, b) stencils, the
+//     projection with xqd, clamp, store.
+// u32 arithmetic wraps where the reference's release build wraps (p * s).
+#include "common.hpp"
+
+namespace {
+
+__constant__ uint16_t kSgrS[16][2] = {{140, 3236}, {112, 2158}, {93, 1618}, {80, 1438}, {70, 1295},
+                                      {58, 1177},  {47, 1079},  {37, 996},  {30, 925},  {25, 863},
+                                      {0, 2589},   {0, 1618},   {0, 1177},  {0, 925},   {56, 0},
+                                      {22, 0}};
+
+constexpr int TW = 32;                 // chunk width
+constexpr int SW = TW + 7;             // padded chunk width
+constexpr int SH_MAX = 64 + 6;         // padded stripe height
+constexpr int AW = TW + 2;             // (a, b) columns: centres -1 .. TW
+constexpr int A1H = 64 + 2;            // r = 1 rows: centres -1 .. 64
+constexpr int A2H = 64 / 2 + 1;        // r = 2 rows: centres -1, 1, .., 63
+
+struct LrfGeom {
+  int ydec, crop_w, crop_h, stripe_n, unit_size, unit_cols, unit_rows, stripe_height, bd;
+  int chunks;   // 32-column chunks across the plane
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// sgrproj_sum_finish -> a | b << 9
+__device__ __forceinline__ uint32_t sum_finish(uint32_t ssq, uint32_t sum, uint32_t n,
+                                               uint32_t one_over_n, uint32_t s, int bd) {
+  const int sh = bd - 8;
+  const uint32_t scaled_ssq = (ssq + ((1u << (2 * sh)) >> 1)) >> (2 * sh);
+  const uint32_t scaled_sum = (sum + ((1u << sh) >> 1)) >> sh;
+  const uint32_t t = scaled_ssq * n, u = scaled_sum * scaled_sum;
+  const uint32_t p = t > u ? t - u : 0;
+  const uint32_t z = (p * s + (1u << 19)) >> 20;
+  const uint32_t a = z >= 255 ? 256u : (z == 0 ? 1u : ((z << 8) + z / 2) / (z + 1));
+  const uint32_t b = (((1u << 8) - a) * sum * one_over_n + (1u << 11)) >> 12;
+  return a | (b << 9);
+}
+
+template <int BPP>
+__global__ __launch_bounds__(256) void k_lrf_sgr(R1Plane cdeffed, R1Plane deblocked, R1Plane out,
+                                                 LrfGeom g, const R1LrfUnit *__restrict__ units) {
+  __shared__ uint16_t S[SH_MAX][SW + 1];
+  __shared__ uint32_t ab1[A1H][AW];
+  __shared__ uint32_t ab2[A2H][AW];
+  const int si = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  // stripe geometry (lrf.rs:1507-1517)
+  int y0, sh_;
+  if (si == 0) {
+    y0 = 0;
+    sh_ = (64 - 8) >> g.ydec;
+  } else {
+    y0 = (si * 64 - 8) >> g.ydec;
+    const int rest = g.crop_h - y0;
+    sh_ = (64 >> g.ydec) < rest ? (64 >> g.ydec) : rest;
+  }
+  if (sh_ <= 0) return;
+  // unit of this chunk (the last unit stretches to the crop width)
+  const int cx0 = chunk * TW;
+  if (cx0 >= g.crop_w) return;
+  int rux = cx0 / g.unit_size;
+  rux = rux < g.unit_cols - 1 ? rux : g.unit_cols - 1;
+  const int x0 = rux * g.unit_size;
+  const int uw = rux == g.unit_cols - 1 ? g.crop_w - x0 : g.unit_size;
+  int ruy = si * g.stripe_height / g.unit_size;
+  ruy = ruy < g.unit_rows - 1 ? ruy : g.unit_rows - 1;
+  const R1LrfUnit u = units[ruy * g.unit_cols + rux];
+  if (u.filter != 3) return;   // RESTORE_NONE: `out` already holds the CDEF output
+  const int tw = (x0 + uw - cx0) < TW ? (x0 + uw - cx0) : TW;
+  const uint32_t s2 = kSgrS[u.set & 15][0], s1 = kSgrS[u.set & 15][1];
+
+  // ---- 1: padded chunk -> LDS ----
+  const int h2 = sh_ + (sh_ & 1);
+  const int lu = x0 == 0 ? 0 : 4;
+  int ru = (g.crop_w - x0) - uw;
+  ru = ru < 3 ? ru : 3;
+  const int rows = h2 + 6;
+  for (int e = tid; e < rows * SW; e += 256) {
+    const int j = e / SW, i = e - j * SW;            // S[j][i] <-> stripe pixel (cx0 - x0 + i - 4, j - 4)
+    const int cy = clampi(y0 + j - 4, 0, g.crop_h - 1);
+    const int ly = clampi(cy, y0 - 2, y0 + h2 + 1);
+    const bool inside = ly >= y0 && ly < y0 + h2;
+    const int xi = clampi(cx0 - x0 + i - 4, -lu, uw + ru - 1);
+    const R1Plane &src = inside ? cdeffed : deblocked;
+    S[j][i] = (uint16_t)ld_px<BPP>(px_addr<BPP>(src, x0 + xi, ly));
+  }
+  __syncthreads();
+
+  // ---- 2: (a, b) of both passes ----
+  if (s1 > 0) {
+    for (int e = tid; e < (sh_ + 2) * AW; e += 256) {
+      const int r = e / AW, c = e - r * AW;   // centre (c - 1, r - 1) -> S[r + 3][c + 3]
+      if (c > tw + 1) continue;
+      uint32_t sum = 0, ssq = 0;
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+          const uint32_t v = S[r + 2 + dy][c + 2 + dx];
+          sum += v;
+          ssq += v * v;
+        }
+      ab1[r][c] = sum_finish(ssq, sum, 9, 455, s1, g.bd);
+    }
+  }
+  if (s2 > 0) {
+    const int nr = h2 / 2 + 1;
+    for (int e = tid; e < nr * AW; e += 256) {
+      const int r = e / AW, c = e - r * AW;   // centre (c - 1, 2 r - 1) -> S[2 r + 3][c + 3]
+      if (c > tw + 1) continue;
+      uint32_t sum = 0, ssq = 0;
+#pragma unroll
+      for (int dy = 0; dy < 5; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 5; dx++) {
+          const uint32_t v = S[2 * r + 1 + dy][c + 1 + dx];
+          sum += v;
+          ssq += v * v;
+        }
+      ab2[r][c] = sum_finish(ssq, sum, 25, 164, s2, g.bd);
+    }
+  }
+  __syncthreads();
+
+  // ---- 3: stencils, projection, store ----
+  const int w0 = u.xqd[0], w1 = u.xqd[1], w2 = 128 - w0 - w1;
+  const int32_t pmax = (1 << g.bd) - 1;
+  for (int e = tid; e < sh_ * TW; e += 256) {
+    const int y = e / TW, x = e - y * TW;
+    if (x >= tw) continue;
+    const uint32_t p = S[y + 4][x + 4];
+    uint32_t f1, f2;
+    if (s1 > 0) {
+      uint32_t A = 0, B = 0;
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+          const uint32_t v = ab1[y + dy][x + dx];
+          const uint32_t wt = (dx != 1 && dy != 1) ? 3u : 4u;
+          A += wt * (v & 511u);
+          B += wt * (v >> 9);
+        }
+      f1 = (A * p + B + (1u << 8)) >> 9;
+    } else {
+      f1 = p << 4;
+    }
+    if (s2 > 0) {
+      uint32_t A = 0, B = 0;
+      if ((y & 1) == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+          for (int dx = 0; dx < 3; dx++) {
+            const uint32_t v = ab2[y / 2 + k][x + dx];
+            const uint32_t wt = dx == 1 ? 6u : 5u;
+            A += wt * (v & 511u);
+            B += wt * (v >> 9);
+          }
+        f2 = (A * p + B + (1u << 8)) >> 9;
+      } else {
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+          const uint32_t v = ab2[(y + 1) / 2][x + dx];
+          const uint32_t wt = dx == 1 ? 6u : 5u;
+          A += wt * (v & 511u);
+          B += wt * (v >> 9);
+        }
+        f2 = (A * p + B + (1u << 7)) >> 8;
+      }
+    } else {
+      // sgrproj_box_f_r0 once per row pair: the odd row reuses the even row's value
+      f2 = (uint32_t)S[(y & ~1) + 4][x + 4] << 4;
+    }
+    const int32_t v = w0 * (int32_t)f2 + w1 * (int32_t)(p << 4) + w2 * (int32_t)f1;
+    const int32_t s = (v + (1 << 10)) >> 11;
+    const int32_t o = s < 0 ? 0 : (s > pmax ? pmax : s);
+    uint8_t *d = (uint8_t *)px_addr<BPP>(out, cx0 + x, y0 + y);
+    if constexpr (BPP == 1) *d = (uint8_t)o;
+    else *(uint16_t *)d = (uint16_t)o;
+  }
+}
+
+}  // namespace
+
+extern "C" int r1_lrf_sgrproj_plane(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *deblocked,
+                                    const R1Plane *out, int ydec, int crop_w, int crop_h,
+                                    int frame_height, int unit_size, int unit_cols, int unit_rows,
+                                    int stripe_height, const R1LrfUnit *units, void *stream) {
+  R1_REQUIRE(ctx && cdeffed && deblocked && out && units);
+  R1_REQUIRE(cdeffed->bytes_per_px == deblocked->bytes_per_px &&
+             cdeffed->bytes_per_px == out->bytes_per_px);
+  R1_REQUIRE(cdeffed->bytes_per_px == 1 || cdeffed->bytes_per_px == 2);
+  R1_REQUIRE((cdeffed->bytes_per_px == 1) == (cdeffed->bit_depth == 8));
+  R1_REQUIRE(cdeffed->data != out->data);   // the filter reads CDEF output around what it writes
+  R1_REQUIRE(ydec >= 0 && ydec <= 1 && crop_w > 0 && crop_h > 0 && frame_height > 0);
+  R1_REQUIRE(unit_size >= 32 && unit_size <= 256 && unit_size % 32 == 0);
+  R1_REQUIRE(unit_cols > 0 && unit_rows > 0 && (stripe_height == 64 || stripe_height == 32));
+  R1_REQUIRE((unit_cols - 1) * unit_size < crop_w);
+  LrfGeom g;
+  g.ydec = ydec;
+  g.crop_w = crop_w;
+  g.crop_h = crop_h;
+  g.stripe_n = (frame_height + 7) / 64 + 1;
+  g.unit_size = unit_size;
+  g.unit_cols = unit_cols;
+  g.unit_rows = unit_rows;
+  g.stripe_height = stripe_height;
+  g.bd = cdeffed->bit_depth;
+  g.chunks = (crop_w + TW - 1) / TW;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(g.chunks, g.stripe_n);
+  if (cdeffed->bytes_per_px == 1)
+    hipLaunchKernelGGL(k_lrf_sgr<1>, grid, dim3(256), 0, st, *cdeffed, *deblocked, *out, g, units);
+  else
+    hipLaunchKernelGGL(k_lrf_sgr<2>, grid, dim3(256), 0, st, *cdeffed, *deblocked, *out, g, units);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}

@@ -1280,3 +1280,57 @@ def test_rdo_pred_cand_vs_oracle(ctx, oracle, bd):
             assert np.array_equal(o["dist"].cpu().numpy().view(np.uint64), wdist), key
             if kind:
                 assert np.array_equal(o["rec"].cpu().numpy().view(dt), wrec), key
+
+
+# ------------------------ N3: loop restoration (self-guided filter)
+def _lrf_run(ctx, cdef, debl, ydec, fh, us, sh, units, bd):
+    import torch
+    h, w = cdef.shape
+    hc, hd = O.plane_from_image(cdef, bd, 16, 16), O.plane_from_image(debl, bd, 16, 16)
+    dc, dd, do = dev_plane(hc), dev_plane(hd), dev_plane(hc)
+    du = torch.from_numpy(np.ascontiguousarray(units).view(np.uint8).reshape(units.shape + (4,)).copy()).cuda()
+    ctx.lrf_sgrproj_plane(dc, dd, do, ydec, w, h, fh, us, du, sh)
+    dt = np.uint8 if bd == 8 else np.uint16
+    return do.data.cpu().numpy().view(dt)[hc.yorigin:hc.yorigin + h, hc.xorigin:hc.xorigin + w]
+
+
+def test_lrf_golden_frames(ctx):
+    """the independent-model frames of tests/golden/lrf_golden.npz"""
+    G = dict(np.load(os.path.join(GOLD, "lrf_golden.npz")))
+    for name in sorted(k[:-5] for k in G if k.endswith("_meta")):
+        w, h, ydec, fh, us, sh, bd = [int(v) for v in G[name + "_meta"]]
+        got = _lrf_run(ctx, G[name + "_cdef"], G[name + "_debl"], ydec, fh, us, sh, G[name + "_units"], bd)
+        bad = np.argwhere(got != G[name + "_out"])
+        assert len(bad) == 0, (name, bad[:5])
+
+
+@pytest.mark.parametrize("cfg", [(8, 0, 64, 64, 1), (10, 1, 32, 32, 2), (12, 0, 128, 64, 1), (8, 0, 256, 64, 4)])
+def test_lrf_frame_vs_oracle(ctx, oracle, cfg):
+    """720p-class planes against oracle/lrf.c: every parameter set, unit sizes 32..256 (the last
+    unit of a row stretches), noisy and smooth content (the reference's wrapping p * s included)."""
+    import ctypes as C
+    bd, ydec, us, sh, noise = cfg
+    w, h = (1280 >> (1 if ydec else 0)) - 4, (720 >> ydec) - 2
+    fh = (h << ydec)
+    rng = np.random.default_rng(40 + bd + us)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (np.sin(xx / 23.0) * np.cos(yy / 17.0) + 1) / 2 * ((1 << bd) - 1)
+    debl = np.clip(base + rng.integers(-8 * noise, 8 * noise + 1, (h, w)) * (1 << (bd - 8)), 0,
+                   (1 << bd) - 1).astype(np.int64)
+    debl[: h // 3] = rng.integers(0, 1 << bd, (h // 3, w))          # pure noise band: z saturates / wraps
+    cdef = np.clip(debl + rng.integers(-2, 3, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1)
+    cols, rows = max((w + us // 2) // us, 1), max((h + us // 2) // us, 1)
+    units = np.zeros((rows, cols), O.LRF_UNIT)
+    units["filter"] = rng.choice([0, 3, 3, 3], (rows, cols))
+    units["set"] = rng.integers(0, 16, (rows, cols))
+    units["xqd"][..., 0] = rng.integers(-96, 32, (rows, cols))
+    units["xqd"][..., 1] = rng.integers(-32, 96, (rows, cols))
+    hc, hd = O.plane_from_image(cdef, bd, 16, 16), O.plane_from_image(debl, bd, 16, 16)
+    ho = O.plane_from_image(cdef, bd, 16, 16)
+    cc, cd, co = hc.cstruct(), hd.cstruct(), ho.cstruct()
+    assert oracle.r1o_lrf_filter_plane(C.byref(cc), C.byref(cd), C.byref(co), ydec, w, h, fh, us, cols,
+                                       rows, sh, units.ctypes.data, bd) == 0
+    got = _lrf_run(ctx, cdef, debl, ydec, fh, us, sh, units, bd)
+    bad = np.argwhere(got != ho.view())
+    assert len(bad) == 0, (cfg, bad[:5])
+    assert (ho.view() != cdef).sum() > cdef.size // 100      # the filter did something

@@ -218,6 +218,19 @@ def main():
     report("deblock_filter_frame 4:2:0 (3 planes, in place)", ms, npx, 2 * npx * bpp + blocks.size * 8)
     ms = timeit(run_sse)
     report("deblock sse_optimize tallies 4:2:0 (3 planes)", ms, npx, 2 * npx * bpp + blocks.size * 8)
+    # ---- N3 (last stage): self-guided loop restoration, luma plane, every unit filtered ----
+    us = 64
+    ucols, urows = max((fw + us // 2) // us, 1), max((fh + us // 2) // us, 1)
+    units = np.zeros((urows, ucols, 4), np.uint8)
+    units[..., 0] = 3
+    units[..., 1] = rng.integers(0, 16, (urows, ucols))
+    units[..., 2] = rng.integers(-96, 32, (urows, ucols)).astype(np.int8).view(np.uint8)
+    units[..., 3] = rng.integers(-32, 96, (urows, ucols)).astype(np.int8).view(np.uint8)
+    dunits = torch.from_numpy(units).cuda()
+    lrf_out = Plane(fw, fh, bd)
+    lrf_out.data.copy_(ref.data)
+    ms = timeit(lambda: ctx.lrf_sgrproj_plane(ref, org, lrf_out, 0, fw, fh, fh, us, dunits, 64))
+    report("lrf sgrproj luma (all units, mixed sets)", ms, fw * fh, 3 * fw * fh * bpp)
     ctx.close()
 
 
