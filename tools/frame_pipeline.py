@@ -3,7 +3,7 @@
 
   lookahead cost maps -> hierarchical ME (tiles x references) -> RDO-time sub-pel ME ->
   intra pre-screen -> RDO candidates (pixel-domain chain) -> deblock level search ->
-  deblock -> CDEF
+  deblock -> CDEF -> loop restoration
 
 Nothing returns to the host between the stages except the scalars a real encoder's control
 flow needs; the stage inputs are synthetic (the encoder's decisions are not modelled), the
@@ -134,6 +134,16 @@ def main():
     ci = torch.zeros(((fh + 63) // 64, (fw + 63) // 64), dtype=torch.uint8, device="cuda")
     timed("cdef_luma", lambda: ctx.cdef_filter_frame_plane(refs[0][0], refs[0][0], dst, 0, 0, 0, fw, fh, skip, ci,
                                                            [36] * 8, [36] * 8, 5, bd))
+    # 9 loop restoration (self-guided), luma, every 64x64 unit
+    us = 64
+    units = np.zeros((max((fh + 32) // us, 1), max((fw + 32) // us, 1), 4), np.uint8)
+    units[..., 0] = 3
+    units[..., 1] = rng.integers(0, 16, units.shape[:2])
+    units[..., 2] = rng.integers(-96, 32, units.shape[:2]).astype(np.int8).view(np.uint8)
+    units[..., 3] = rng.integers(-32, 96, units.shape[:2]).astype(np.int8).view(np.uint8)
+    dunits = torch.from_numpy(units).cuda()
+    lrf_out = Plane(fw, fh, bd)
+    timed("lrf_sgrproj_luma", lambda: ctx.lrf_sgrproj_plane(dst, refs[0][0], lrf_out, 0, fw, fh, fh, us, dunits, 64))
     total = round(sum(stages.values()), 3)
     print(json.dumps({"frame": "%dx%d %d-bit" % (fw, fh, bd), "stage_ms": stages, "sum_ms": total,
                       "frames_per_s_if_serial": round(1e3 / total, 1)}))
