@@ -115,8 +115,9 @@ def pmc_traffic(bd, size, fw, fh, k):
         return None, None
     d = json.load(open(files[-1]))
     lg = {64: 6, 32: 5, 16: 4, 8: 3}[size]
-    key = "k_rdo_cand<%d,%d,%d,%s>" % (bd, lg, lg, "short" if bd == 8 else "int")
-    if key not in d or "hbm_traffic_bytes" not in d[key]:
+    base = "k_rdo_cand<%d,%d,%d,%s" % (bd, lg, lg, "short" if bd == 8 else "int")
+    key = next((k for k in (base + ",0>", base + ">") if k in d), None)   # QM = 0: the headline variant
+    if key is None or "hbm_traffic_bytes" not in d[key]:
         return None, None
     return int(d[key]["hbm_traffic_bytes"]), (
         "%s: 2*FETCH_SIZE + WRITE_SIZE KiB per dispatch (gfx950 FETCH_SIZE correction, "
