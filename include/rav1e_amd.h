@@ -466,6 +466,23 @@ int r1_lrf_sgrproj_plane(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *deb
                          const R1Plane *out, int ydec, int crop_w, int crop_h, int frame_height,
                          int unit_size, int unit_cols, int unit_rows, int stripe_height,
                          const R1LrfUnit *units, void *stream);
+/* sgrproj_solve (src/lrf.rs:847-1096) as the restoration search calls it
+ * (rdo_loop_decision, src/rdo.rs:2651-2676): for each (restoration unit,
+ * parameter set) pair the least-squares projection weights xqd of the
+ * self-guided filter of `cdeffed` towards `input` (the source frame), the
+ * unit hard-clipped at its right / bottom edge, no stripes.  units (DEVICE):
+ * (x, y, w, h) in plane pixels, w <= max_w, h <= max_h (<= 384); xqd_out:
+ * 2 int8 per pair; moments_scratch: 5 int64 per pair (device; zeroed here).
+ * The moments are exact integers, the 2x2 solve is done in IEEE doubles with
+ * the reference's operation order (including its two fused multiply-adds),
+ * so the weights are bit-identical. */
+typedef struct R1SgrSolveUnit {
+  int16_t x, y, w, h;
+  uint8_t set, reserved[3];
+} R1SgrSolveUnit;
+int r1_sgrproj_solve_batch(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *input,
+                           const R1SgrSolveUnit *units, int n, int max_w, int max_h,
+                           int64_t *moments_scratch, int8_t *xqd_out, void *stream);
 
 /* ---- fused RDO candidate: the headline path.  For each candidate:
  *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)

@@ -10,13 +10,17 @@
  *   setup_integral_image 530-627, sgrproj_stripe_filter 630-830,
  *   RestorationPlane::restoration_unit_index_by_stripe 1297-1307,
  *   RestorationState::lrf_filter_frame 1482-1585 (the Sgrproj arm; the encoder
- *   never selects Wiener: src/rdo.rs:2508 `unreachable!() // coming soon`).
+ *   never selects Wiener: src/rdo.rs:2508 `unreachable!() // coming soon`),
+ *   sgrproj_solve 847-1096 with the integral image rdo_loop_decision builds
+ *   for it (src/rdo.rs:2651-2676: the unit hard-clipped at its right / bottom
+ *   edge, monolithic -- no stripes).
  *
  * Pinning: the reference has no vectors for this file; the filter is a
  * normative AV1 decoder process (spec 7.17), so tests/golden/gen_lrf_golden.py
  * holds an independent model (direct box sums on an explicitly padded stripe,
  * no integral images, no rolling row buffers) whose frames this file matched.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -196,4 +200,102 @@ int r1o_lrf_filter_plane(const r1o_plane *cdeffed, const r1o_plane *deblocked, c
   }
   free(ii);
   return 0;
+}
+
+/* sgrproj_solve for one restoration unit of the RDO (src/rdo.rs:2651-2676):
+ * integral image of the unit with crop = the unit's own right / bottom edge,
+ * cdeffed == deblocked (monolithic), then the least-squares projection
+ * weights.  input: the source plane (same coordinates). */
+void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0, int y0, int w, int h,
+                       int set, int bd, int8_t *xqd_out) {
+  const int rows = h + (h & 1) + 6;
+  uint32_t *ii = (uint32_t *)calloc((size_t)IMG_STRIDE * rows * 2, sizeof(uint32_t));
+  uint32_t *sq = ii + (size_t)IMG_STRIDE * rows;
+  setup_integral_image(ii, sq, x0 + w, y0 + h, w, h, cdeffed, cdeffed, x0, y0);
+  static uint32_t a_r2[2][IMG_MAX + 2], b_r2[2][IMG_MAX + 2], f_r2_0[IMG_MAX], f_r2_1[IMG_MAX];
+  static uint32_t a_r1[3][IMG_MAX + 2], b_r1[3][IMG_MAX + 2], f_r1[IMG_MAX];
+#pragma omp threadprivate(a_r2, b_r2, f_r2_0, f_r2_1, a_r1, b_r1, f_r1)
+  const uint32_t s_r2 = SGR_S[set][0], s_r1 = SGR_S[set][1];
+  const uint32_t *ii1 = ii + IMG_STRIDE + 1, *sq1 = sq + IMG_STRIDE + 1;
+  double hm[2][2] = { { 0, 0 }, { 0, 0 } }, c[2] = { 0, 0 };
+  if (s_r2 > 0) box_ab(2, a_r2[0], b_r2[0], ii, sq, 0, w, s_r2, bd);
+  if (s_r1 > 0) {
+    box_ab(1, a_r1[0], b_r1[0], ii1, sq1, 0, w, s_r1, bd);
+    box_ab(1, a_r1[1], b_r1[1], ii1, sq1, 1, w, s_r1, bd);
+  }
+  for (int y = 0; y < h; y += 2) {
+    const uint32_t *fr2[2];
+    if (s_r2 > 0) {
+      const int k0 = (y / 2) % 2, k1 = (y / 2 + 1) % 2;
+      box_ab(2, a_r2[k1], b_r2[k1], ii, sq, y + 2, w, s_r2, bd);
+      for (int x = 0; x < w; x++) {
+        const uint32_t a = 5 * (a_r2[k0][x] + a_r2[k0][x + 2]) + 6 * a_r2[k0][x + 1];
+        const uint32_t b = 5 * (b_r2[k0][x] + b_r2[k0][x + 2]) + 6 * b_r2[k0][x + 1];
+        const uint32_t ao = 5 * (a_r2[k1][x] + a_r2[k1][x + 2]) + 6 * a_r2[k1][x + 1];
+        const uint32_t bo = 5 * (b_r2[k1][x] + b_r2[k1][x + 2]) + 6 * b_r2[k1][x + 1];
+        f_r2_0[x] = ((a + ao) * px(cdeffed, x0 + x, y0 + y) + b + bo + (1u << 8)) >> 9;
+        f_r2_1[x] = (ao * px(cdeffed, x0 + x, y0 + y + 1) + bo + (1u << 7)) >> 8;
+      }
+      fr2[0] = f_r2_0;
+      fr2[1] = f_r2_1;
+    } else {
+      for (int x = 0; x < w; x++) f_r2_0[x] = px(cdeffed, x0 + x, y0 + y) << 4;
+      fr2[0] = fr2[1] = f_r2_0;
+    }
+    for (int dy = 0; dy < imin(2, h - y); dy++) {
+      const int yy = y + dy;
+      if (s_r1 > 0) {
+        box_ab(1, a_r1[(yy + 2) % 3], b_r1[(yy + 2) % 3], ii1, sq1, yy + 2, w, s_r1, bd);
+        const uint32_t *a0 = a_r1[yy % 3], *a1 = a_r1[(yy + 1) % 3], *a2 = a_r1[(yy + 2) % 3];
+        const uint32_t *b0 = b_r1[yy % 3], *b1 = b_r1[(yy + 1) % 3], *b2 = b_r1[(yy + 2) % 3];
+        for (int x = 0; x < w; x++) {
+          const uint32_t a = 3 * (a0[x] + a2[x] + a0[x + 2] + a2[x + 2]) +
+                             4 * (a1[x] + a0[x + 1] + a1[x + 1] + a2[x + 1] + a1[x + 2]);
+          const uint32_t b = 3 * (b0[x] + b2[x] + b0[x + 2] + b2[x + 2]) +
+                             4 * (b1[x] + b0[x + 1] + b1[x + 1] + b2[x + 1] + b1[x + 2]);
+          f_r1[x] = (a * px(cdeffed, x0 + x, y0 + yy) + b + (1u << 8)) >> 9;
+        }
+      } else {
+        for (int x = 0; x < w; x++) f_r1[x] = px(cdeffed, x0 + x, y0 + yy) << 4;
+      }
+      /* process_line: i64 sums of the line, then into the f64 accumulators */
+      int64_t l00 = 0, l11 = 0, l01 = 0, lc0 = 0, lc1 = 0;
+      for (int x = 0; x < w; x++) {
+        const int32_t u = (int32_t)px(cdeffed, x0 + x, y0 + yy) << 4;
+        const int64_t sv = ((int32_t)px(input, x0 + x, y0 + yy) << 4) - u;
+        const int64_t f2 = (int32_t)fr2[dy][x] - u, f1 = (int32_t)f_r1[x] - u;
+        l00 += f2 * f2; l11 += f1 * f1; l01 += f1 * f2; lc0 += f2 * sv; lc1 += f1 * sv;
+      }
+      hm[0][0] += (double)l00; hm[1][1] += (double)l11; hm[0][1] += (double)l01;
+      c[0] += (double)lc0; c[1] += (double)lc1;
+    }
+  }
+  free(ii);
+  const double n = (double)w * (double)h;
+  hm[0][0] /= n; hm[0][1] /= n; hm[1][1] /= n;
+  hm[1][0] = hm[0][1];
+  c[0] *= 128.0 / n;
+  c[1] *= 128.0 / n;
+  double xq0 = 0, xq1 = 0;
+  if (s_r2 == 0) {
+    if (hm[1][1] != 0.) xq1 = round(c[1] / hm[1][1]);
+  } else if (s_r1 == 0) {
+    if (hm[0][0] != 0.) xq0 = round(c[0] / hm[0][0]);
+  } else {
+    const double det = fma(hm[0][0], hm[1][1], -hm[0][1] * hm[1][0]);
+    if (det != 0.) {
+      const double div1 = fma(hm[1][1], c[0], -hm[0][1] * c[1]);
+      const double div2 = fma(hm[0][0], c[1], -hm[1][0] * c[0]);
+      xq0 = round(div1 / det);
+      xq1 = round(div2 / det);
+    }
+  }
+  /* `as i32` saturates, NaN -> 0 */
+  const int q0 = xq0 != xq0 ? 0 : (xq0 > 2147483647. ? 2147483647 : (xq0 < -2147483648. ? (-2147483647 - 1) : (int)xq0));
+  const int q1 = xq1 != xq1 ? 0 : (xq1 > 2147483647. ? 2147483647 : (xq1 < -2147483648. ? (-2147483647 - 1) : (int)xq1));
+  const int xqd0 = clampi(q0, -96, 31);
+  const int64_t t = (int64_t)128 - xqd0 - q1; /* i32 arithmetic in the reference; wraps only for absurd q1 */
+  const int xqd1 = (int)(t < -32 ? -32 : (t > 95 ? 95 : t));
+  xqd_out[0] = (int8_t)xqd0;
+  xqd_out[1] = (int8_t)xqd1;
 }

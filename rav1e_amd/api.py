@@ -77,6 +77,11 @@ ME_RESULT = np.dtype([("row", "<i2"), ("col", "<i2"), ("sad", "<u4"), ("cost", "
 assert ME_BLOCK_CAND.itemsize == 16 and ME_RESULT.itemsize == 16
 
 
+SGR_SOLVE_UNIT = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("set", "u1"),
+                           ("reserved", "u1", (3,))])
+assert SGR_SOLVE_UNIT.itemsize == 12
+
+
 def me_lambdas(me_lambda):
     """lambda of the three ME passes by ssdec (src/me.rs:175-177): fi.me_lambda = sqrt(fi.lambda)."""
     return [int(me_lambda * 256.0 / (1 << (2 * ss)) * (0.5 if ss == 0 else 0.125)) for ss in range(3)]
@@ -604,6 +609,19 @@ class Context:
                                                   units.shape[1], units.shape[0], stripe_height,
                                                   units.data_ptr(), _stream_ptr()),
                     "r1_lrf_sgrproj_plane")
+
+    def sgrproj_solve_batch(self, cdeffed, inp, units, max_w=256, max_h=256):
+        """sgrproj_solve (src/lrf.rs:847-1096) for (unit, set) pairs; units: SGR_SOLVE_UNIT array
+        -> (n, 2) int8 xqd"""
+        dc = _dev_cands(units, SGR_SOLVE_UNIT)
+        n = dc.numel() // SGR_SOLVE_UNIT.itemsize
+        scratch = torch.empty(n * 5, dtype=torch.int64, device="cuda")
+        out = torch.empty((n, 2), dtype=torch.int8, device="cuda")
+        pc, pi = cdeffed.cstruct(), inp.cstruct()
+        self._check(self.lib.r1_sgrproj_solve_batch(self.h, C.byref(pc), C.byref(pi), dc.data_ptr(), n,
+                                                    max_w, max_h, scratch.data_ptr(), out.data_ptr(),
+                                                    _stream_ptr()), "r1_sgrproj_solve_batch")
+        return out
 
     # ---- fused candidate ----
     def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,

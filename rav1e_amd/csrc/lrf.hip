@@ -59,60 +59,45 @@ __device__ __forceinline__ uint32_t sum_finish(uint32_t ssq, uint32_t sum, uint3
   return a | (b << 9);
 }
 
-template <int BPP>
-__global__ __launch_bounds__(256) void k_lrf_sgr(R1Plane cdeffed, R1Plane deblocked, R1Plane out,
-                                                 LrfGeom g, const R1LrfUnit *__restrict__ units) {
+// One tile of one unit: columns [cx0, cx0 + tw) (absolute), rows [ty0, ty0 + th)
+// relative to the unit's top (ty0 even: the radius-2 pass lives on the odd rows).
+struct SgrTile {
+  int x0, y0, uw, uh;      // the unit (restoration unit x stripe, or an RDO unit)
+  int crop_w, crop_h;      // absolute crop of the plane / of the unit
+  int cx0, ty0, tw, th;
+};
+
+// Stage the padded tile, compute the (a, b) pairs of both passes, then hand
+// every pixel of the tile to `emit(x, y, p, f1, f2)` (x, y tile-relative).
+template <int BPP, class Emit>
+__device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane &outside_p,
+                                         const SgrTile &t, int set, int bd, Emit emit) {
   __shared__ uint16_t S[SH_MAX][SW + 1];
   __shared__ uint32_t ab1[A1H][AW];
   __shared__ uint32_t ab2[A2H][AW];
-  const int si = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-  // stripe geometry (lrf.rs:1507-1517)
-  int y0, sh_;
-  if (si == 0) {
-    y0 = 0;
-    sh_ = (64 - 8) >> g.ydec;
-  } else {
-    y0 = (si * 64 - 8) >> g.ydec;
-    const int rest = g.crop_h - y0;
-    sh_ = (64 >> g.ydec) < rest ? (64 >> g.ydec) : rest;
-  }
-  if (sh_ <= 0) return;
-  // unit of this chunk (the last unit stretches to the crop width)
-  const int cx0 = chunk * TW;
-  if (cx0 >= g.crop_w) return;
-  int rux = cx0 / g.unit_size;
-  rux = rux < g.unit_cols - 1 ? rux : g.unit_cols - 1;
-  const int x0 = rux * g.unit_size;
-  const int uw = rux == g.unit_cols - 1 ? g.crop_w - x0 : g.unit_size;
-  int ruy = si * g.stripe_height / g.unit_size;
-  ruy = ruy < g.unit_rows - 1 ? ruy : g.unit_rows - 1;
-  const R1LrfUnit u = units[ruy * g.unit_cols + rux];
-  if (u.filter != 3) return;   // RESTORE_NONE: `out` already holds the CDEF output
-  const int tw = (x0 + uw - cx0) < TW ? (x0 + uw - cx0) : TW;
-  const uint32_t s2 = kSgrS[u.set & 15][0], s1 = kSgrS[u.set & 15][1];
-
-  // ---- 1: padded chunk -> LDS ----
-  const int h2 = sh_ + (sh_ & 1);
-  const int lu = x0 == 0 ? 0 : 4;
-  int ru = (g.crop_w - x0) - uw;
+  const int tid = threadIdx.x;
+  const uint32_t s2 = kSgrS[set & 15][0], s1 = kSgrS[set & 15][1];
+  // ---- 1: padded tile -> LDS (VertPaddedIter / HorzPaddedIter, lrf.rs:402-524) ----
+  const int h2 = t.uh + (t.uh & 1), th2 = t.th + (t.th & 1);
+  const int lu = t.x0 == 0 ? 0 : 4;
+  int ru = (t.crop_w - t.x0) - t.uw;
   ru = ru < 3 ? ru : 3;
-  const int rows = h2 + 6;
+  const int rows = th2 + 6;
   for (int e = tid; e < rows * SW; e += 256) {
-    const int j = e / SW, i = e - j * SW;            // S[j][i] <-> stripe pixel (cx0 - x0 + i - 4, j - 4)
-    const int cy = clampi(y0 + j - 4, 0, g.crop_h - 1);
-    const int ly = clampi(cy, y0 - 2, y0 + h2 + 1);
-    const bool inside = ly >= y0 && ly < y0 + h2;
-    const int xi = clampi(cx0 - x0 + i - 4, -lu, uw + ru - 1);
-    const R1Plane &src = inside ? cdeffed : deblocked;
-    S[j][i] = (uint16_t)ld_px<BPP>(px_addr<BPP>(src, x0 + xi, ly));
+    const int j = e / SW, i = e - j * SW;   // S[j][i] <-> unit pixel (cx0 - x0 + i - 4, ty0 + j - 4)
+    const int cy = clampi(t.y0 + t.ty0 + j - 4, 0, t.crop_h - 1);
+    const int ly = clampi(cy, t.y0 - 2, t.y0 + h2 + 1);
+    const bool inside = ly >= t.y0 && ly < t.y0 + h2;
+    const int xi = clampi(t.cx0 - t.x0 + i - 4, -lu, t.uw + ru - 1);
+    const R1Plane &src = inside ? inside_p : outside_p;
+    S[j][i] = (uint16_t)ld_px<BPP>(px_addr<BPP>(src, t.x0 + xi, ly));
   }
   __syncthreads();
-
   // ---- 2: (a, b) of both passes ----
   if (s1 > 0) {
-    for (int e = tid; e < (sh_ + 2) * AW; e += 256) {
+    for (int e = tid; e < (t.th + 2) * AW; e += 256) {
       const int r = e / AW, c = e - r * AW;   // centre (c - 1, r - 1) -> S[r + 3][c + 3]
-      if (c > tw + 1) continue;
+      if (c > t.tw + 1) continue;
       uint32_t sum = 0, ssq = 0;
 #pragma unroll
       for (int dy = 0; dy < 3; dy++)
@@ -122,14 +107,14 @@ __global__ __launch_bounds__(256) void k_lrf_sgr(R1Plane cdeffed, R1Plane debloc
           sum += v;
           ssq += v * v;
         }
-      ab1[r][c] = sum_finish(ssq, sum, 9, 455, s1, g.bd);
+      ab1[r][c] = sum_finish(ssq, sum, 9, 455, s1, bd);
     }
   }
   if (s2 > 0) {
-    const int nr = h2 / 2 + 1;
+    const int nr = th2 / 2 + 1;
     for (int e = tid; e < nr * AW; e += 256) {
       const int r = e / AW, c = e - r * AW;   // centre (c - 1, 2 r - 1) -> S[2 r + 3][c + 3]
-      if (c > tw + 1) continue;
+      if (c > t.tw + 1) continue;
       uint32_t sum = 0, ssq = 0;
 #pragma unroll
       for (int dy = 0; dy < 5; dy++)
@@ -139,17 +124,14 @@ __global__ __launch_bounds__(256) void k_lrf_sgr(R1Plane cdeffed, R1Plane debloc
           sum += v;
           ssq += v * v;
         }
-      ab2[r][c] = sum_finish(ssq, sum, 25, 164, s2, g.bd);
+      ab2[r][c] = sum_finish(ssq, sum, 25, 164, s2, bd);
     }
   }
   __syncthreads();
-
-  // ---- 3: stencils, projection, store ----
-  const int w0 = u.xqd[0], w1 = u.xqd[1], w2 = 128 - w0 - w1;
-  const int32_t pmax = (1 << g.bd) - 1;
-  for (int e = tid; e < sh_ * TW; e += 256) {
+  // ---- 3: the weighted stencils ----
+  for (int e = tid; e < t.th * TW; e += 256) {
     const int y = e / TW, x = e - y * TW;
-    if (x >= tw) continue;
+    if (x >= t.tw) continue;
     const uint32_t p = S[y + 4][x + 4];
     uint32_t f1, f2;
     if (s1 > 0) {
@@ -194,13 +176,138 @@ __global__ __launch_bounds__(256) void k_lrf_sgr(R1Plane cdeffed, R1Plane debloc
       // sgrproj_box_f_r0 once per row pair: the odd row reuses the even row's value
       f2 = (uint32_t)S[(y & ~1) + 4][x + 4] << 4;
     }
+    emit(x, y, p, f1, f2);
+  }
+}
+
+template <int BPP>
+__global__ __launch_bounds__(256) void k_lrf_sgr(R1Plane cdeffed, R1Plane deblocked, R1Plane out,
+                                                 LrfGeom g, const R1LrfUnit *__restrict__ units) {
+  const int si = blockIdx.y, chunk = blockIdx.x;
+  // stripe geometry (lrf.rs:1507-1517)
+  int y0, sh_;
+  if (si == 0) {
+    y0 = 0;
+    sh_ = (64 - 8) >> g.ydec;
+  } else {
+    y0 = (si * 64 - 8) >> g.ydec;
+    const int rest = g.crop_h - y0;
+    sh_ = (64 >> g.ydec) < rest ? (64 >> g.ydec) : rest;
+  }
+  if (sh_ <= 0) return;
+  // unit of this chunk (the last unit stretches to the crop width)
+  const int cx0 = chunk * TW;
+  if (cx0 >= g.crop_w) return;
+  int rux = cx0 / g.unit_size;
+  rux = rux < g.unit_cols - 1 ? rux : g.unit_cols - 1;
+  const int x0 = rux * g.unit_size;
+  const int uw = rux == g.unit_cols - 1 ? g.crop_w - x0 : g.unit_size;
+  int ruy = si * g.stripe_height / g.unit_size;
+  ruy = ruy < g.unit_rows - 1 ? ruy : g.unit_rows - 1;
+  const R1LrfUnit u = units[ruy * g.unit_cols + rux];
+  if (u.filter != 3) return;   // RESTORE_NONE: `out` already holds the CDEF output
+  SgrTile t;
+  t.x0 = x0; t.y0 = y0; t.uw = uw; t.uh = sh_;
+  t.crop_w = g.crop_w; t.crop_h = g.crop_h;
+  t.cx0 = cx0; t.ty0 = 0;
+  t.tw = (x0 + uw - cx0) < TW ? (x0 + uw - cx0) : TW;
+  t.th = sh_;
+  const int w0 = u.xqd[0], w1 = u.xqd[1], w2 = 128 - w0 - w1;
+  const int32_t pmax = (1 << g.bd) - 1;
+  sgr_tile<BPP>(cdeffed, deblocked, t, u.set, g.bd, [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2) {
+    // apply_filter (lrf.rs:796-815)
     const int32_t v = w0 * (int32_t)f2 + w1 * (int32_t)(p << 4) + w2 * (int32_t)f1;
     const int32_t s = (v + (1 << 10)) >> 11;
     const int32_t o = s < 0 ? 0 : (s > pmax ? pmax : s);
     uint8_t *d = (uint8_t *)px_addr<BPP>(out, cx0 + x, y0 + y);
     if constexpr (BPP == 1) *d = (uint8_t)o;
     else *(uint16_t *)d = (uint16_t)o;
+  });
+}
+
+// sgrproj_solve's moments (lrf.rs:1010-1054): grid.x = tiles of the largest
+// unit, grid.y = (unit, set) pairs; five i64 sums per pair, accumulated with
+// atomics (integer sums: exact in any order, like the reference's f64
+// accumulation of per-line i64 sums, which never leaves the exact range).
+template <int BPP>
+__global__ __launch_bounds__(256) void k_sgr_moments(R1Plane cdeffed, R1Plane input,
+                                                     const R1SgrSolveUnit *__restrict__ units,
+                                                     long long *__restrict__ acc) {
+  __shared__ long long part[4][5];
+  const R1SgrSolveUnit u = units[blockIdx.y];
+  const int ntx = (u.w + TW - 1) / TW, nty = (u.h + 63) / 64;
+  if ((int)blockIdx.x >= ntx * nty) return;   // workgroup-uniform
+  SgrTile t;
+  t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
+  t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the unit (rdo.rs:2651-2666)
+  const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+  t.cx0 = u.x + tx * TW;
+  t.ty0 = ty * 64;
+  t.tw = (u.w - tx * TW) < TW ? (u.w - tx * TW) : TW;
+  t.th = (u.h - ty * 64) < 64 ? (u.h - ty * 64) : 64;
+  long long m[5] = {0, 0, 0, 0, 0};
+  sgr_tile<BPP>(cdeffed, cdeffed, t, u.set, cdeffed.bit_depth,
+                [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2) {
+    const int32_t uu = (int32_t)(p << 4);
+    const long long sv = ((int32_t)ld_px<BPP>(px_addr<BPP>(input, t.cx0 + x, u.y + t.ty0 + y)) << 4) - uu;
+    const long long g2 = (int32_t)f2 - uu, g1 = (int32_t)f1 - uu;
+    m[0] += g2 * g2; m[1] += g1 * g1; m[2] += g1 * g2; m[3] += g2 * sv; m[4] += g1 * sv;
+  });
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    uint32_t lo = (uint32_t)m[k], hi = (uint32_t)((unsigned long long)m[k] >> 32);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)hi, s, 64) << 32) |
+                                   (uint32_t)__shfl_xor((int)lo, s, 64);
+      const unsigned long long v = (((unsigned long long)hi << 32) | lo) + o;
+      lo = (uint32_t)v;
+      hi = (uint32_t)(v >> 32);
+    }
+    if (lane == 0) part[wave][k] = (long long)(((unsigned long long)hi << 32) | lo);
   }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const long long v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
+                        part[3][threadIdx.x];
+    if (v) atomicAdd((unsigned long long *)acc + blockIdx.y * 5 + threadIdx.x, (unsigned long long)v);
+  }
+}
+
+// the 2x2 solve in IEEE doubles, operation for operation (lrf.rs:1057-1095)
+__global__ void k_sgr_solve(const R1SgrSolveUnit *__restrict__ units, const long long *__restrict__ acc,
+                            int n, int8_t *__restrict__ xqd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const R1SgrSolveUnit u = units[i];
+  const uint32_t s2 = kSgrS[u.set & 15][0], s1 = kSgrS[u.set & 15][1];
+  const double nn = __dmul_rn((double)u.w, (double)u.h);
+  const double h00 = __ddiv_rn((double)acc[i * 5 + 0], nn), h11 = __ddiv_rn((double)acc[i * 5 + 1], nn);
+  const double h01 = __ddiv_rn((double)acc[i * 5 + 2], nn);
+  const double sc = __ddiv_rn(128.0, nn);
+  const double c0 = __dmul_rn((double)acc[i * 5 + 3], sc), c1 = __dmul_rn((double)acc[i * 5 + 4], sc);
+  double xq0 = 0., xq1 = 0.;
+  if (s2 == 0) {
+    if (h11 != 0.) xq1 = round(__ddiv_rn(c1, h11));
+  } else if (s1 == 0) {
+    if (h00 != 0.) xq0 = round(__ddiv_rn(c0, h00));
+  } else {
+    const double det = __fma_rn(h00, h11, -__dmul_rn(h01, h01));
+    if (det != 0.) {
+      xq0 = round(__ddiv_rn(__fma_rn(h11, c0, -__dmul_rn(h01, c1)), det));
+      xq1 = round(__ddiv_rn(__fma_rn(h00, c1, -__dmul_rn(h01, c0)), det));
+    }
+  }
+  auto sat = [](double v) -> long long {   // `as i32`
+    if (v != v) return 0;
+    return v > 2147483647. ? 2147483647ll : (v < -2147483648. ? -2147483648ll : (long long)v);
+  };
+  const long long q0 = sat(xq0), q1 = sat(xq1);
+  const long long x0 = q0 < -96 ? -96 : (q0 > 31 ? 31 : q0);
+  const long long t = 128 - x0 - q1;
+  xqd[2 * i] = (int8_t)x0;
+  xqd[2 * i + 1] = (int8_t)(t < -32 ? -32 : (t > 95 ? 95 : t));
 }
 
 }  // namespace
@@ -236,6 +343,31 @@ extern "C" int r1_lrf_sgrproj_plane(r1_ctx *ctx, const R1Plane *cdeffed, const R
     hipLaunchKernelGGL(k_lrf_sgr<1>, grid, dim3(256), 0, st, *cdeffed, *deblocked, *out, g, units);
   else
     hipLaunchKernelGGL(k_lrf_sgr<2>, grid, dim3(256), 0, st, *cdeffed, *deblocked, *out, g, units);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_sgrproj_solve_batch(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *input,
+                                      const R1SgrSolveUnit *units, int n, int max_w, int max_h,
+                                      int64_t *moments_scratch, int8_t *xqd_out, void *stream) {
+  R1_REQUIRE(ctx && cdeffed && input);
+  R1_REQUIRE(cdeffed->bytes_per_px == input->bytes_per_px && cdeffed->bit_depth == input->bit_depth);
+  R1_REQUIRE(cdeffed->bytes_per_px == 1 || cdeffed->bytes_per_px == 2);
+  R1_REQUIRE((cdeffed->bytes_per_px == 1) == (cdeffed->bit_depth == 8));
+  R1_REQUIRE(max_w > 0 && max_h > 0 && max_w <= 384 && max_h <= 384);
+  if (n <= 0) return R1_OK;
+  R1_REQUIRE(units && moments_scratch && xqd_out);
+  hipStream_t st = (hipStream_t)stream;
+  R1_HIP_CHECK(hipMemsetAsync(moments_scratch, 0, (size_t)n * 5 * sizeof(int64_t), st));
+  const dim3 grid(((max_w + TW - 1) / TW) * ((max_h + 63) / 64), n);
+  if (cdeffed->bytes_per_px == 1)
+    hipLaunchKernelGGL(k_sgr_moments<1>, grid, dim3(256), 0, st, *cdeffed, *input, units,
+                       (long long *)moments_scratch);
+  else
+    hipLaunchKernelGGL(k_sgr_moments<2>, grid, dim3(256), 0, st, *cdeffed, *input, units,
+                       (long long *)moments_scratch);
+  hipLaunchKernelGGL(k_sgr_solve, dim3((n + 127) / 128), dim3(128), 0, st, units,
+                     (const long long *)moments_scratch, n, xqd_out);
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }

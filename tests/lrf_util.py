@@ -107,3 +107,79 @@ def lrf_plane(cdef, debl, ydec, crop_w, crop_h, frame_h, unit_size, units, strip
             if u["filter"] == 3:
                 sgr_unit(cdef, debl, out, x0, y0, size, sz, crop_w, crop_h, int(u["set"]), u["xqd"], bd)
     return out
+
+
+def solve_unit(cdef, src, x0, y0, w, h, set_, bd):
+    """sgrproj_solve (src/lrf.rs:847-1096) on the unit hard-clipped at its right / bottom edge as
+    rdo_loop_decision sets it up (src/rdo.rs:2651-2676): independent restatement -- per-pixel box
+    filters from the padded unit, exact integer moments, the 2x2 solve in IEEE doubles with the
+    reference's fused multiply-adds emulated through exact rationals."""
+    from fractions import Fraction as Fr
+    S = padded_stripe(cdef, cdef, x0, y0, w, h, x0 + w, y0 + h)
+    s2, s1 = SGR_S[set_]
+    h00 = h11 = h01 = c0 = c1 = 0
+    for y in range(h):
+        for x in range(w):
+            p = int(cdef[y0 + y, x0 + x])
+            if s1 > 0:
+                A = B = 0
+                for dy in (-1, 0, 1):
+                    for dx in (-1, 0, 1):
+                        wt = 3 if dx and dy else 4
+                        a, b = ab(S, x + dx, y + dy, 1, s1, bd)
+                        A += wt * a
+                        B += wt * b
+                f1 = (A * p + B + (1 << 8)) >> 9
+            else:
+                f1 = p << 4
+            if s2 > 0:
+                A = B = 0
+                if y % 2 == 0:
+                    for dy in (-1, 1):
+                        for dx, wt in ((-1, 5), (0, 6), (1, 5)):
+                            a, b = ab(S, x + dx, y + dy, 2, s2, bd)
+                            A += wt * a
+                            B += wt * b
+                    f2 = (A * p + B + (1 << 8)) >> 9
+                else:
+                    for dx, wt in ((-1, 5), (0, 6), (1, 5)):
+                        a, b = ab(S, x + dx, y, 2, s2, bd)
+                        A += wt * a
+                        B += wt * b
+                    f2 = (A * p + B + (1 << 7)) >> 8
+            else:
+                f2 = int(cdef[y0 + (y & ~1), x0 + x]) << 4
+            u = p << 4
+            sv = (int(src[y0 + y, x0 + x]) << 4) - u
+            f1 -= u
+            f2 -= u
+            h00 += f2 * f2
+            h11 += f1 * f1
+            h01 += f1 * f2
+            c0 += f2 * sv
+            c1 += f1 * sv
+    n = float(w) * float(h)
+    H00, H01, H11 = float(h00) / n, float(h01) / n, float(h11) / n
+    C0, C1 = float(c0) * (128.0 / n), float(c1) * (128.0 / n)
+
+    def fma(a, b, c):
+        return float(Fr(a) * Fr(b) + Fr(c))
+
+    def rnd(v):          # f64::round: half away from zero
+        import math
+        return int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
+    xq0 = xq1 = 0
+    if s2 == 0:
+        if H11 != 0.0:
+            xq1 = rnd(C1 / H11)
+    elif s1 == 0:
+        if H00 != 0.0:
+            xq0 = rnd(C0 / H00)
+    else:
+        det = fma(H00, H11, -(H01 * H01))
+        if det != 0.0:
+            xq0 = rnd(fma(H11, C0, -(H01 * C1)) / det)
+            xq1 = rnd(fma(H00, C1, -(H01 * C0)) / det)
+    xqd0 = min(max(xq0, -96), 31)
+    xqd1 = min(max(128 - xqd0 - xq1, -32), 95)
+    return xqd0, xqd1

@@ -1334,3 +1334,34 @@ def test_lrf_frame_vs_oracle(ctx, oracle, cfg):
     bad = np.argwhere(got != ho.view())
     assert len(bad) == 0, (cfg, bad[:5])
     assert (ho.view() != cdef).sum() > cdef.size // 100      # the filter did something
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_sgrproj_solve_vs_oracle(ctx, oracle, bd):
+    """r1_sgrproj_solve_batch: xqd for every parameter set on restoration units of all shapes
+    (64..256 wide / high, stretched last units, frame corner) against oracle/lrf.c."""
+    import ctypes as C
+    from rav1e_amd.api import SGR_SOLVE_UNIT
+    rng = np.random.default_rng(60 + bd)
+    h, w = 400, 600
+    yy, xx = np.mgrid[0:h, 0:w]
+    sc = 1 << (bd - 8)
+    src = np.clip(((np.sin(xx / 19.0) * np.cos(yy / 13.0) + 1) / 2 * 200 + 20 + rng.integers(-6, 7, (h, w))) * sc,
+                  0, (1 << bd) - 1).astype(np.int64)               # texture + fine detail
+    cdef = np.clip(src + rng.integers(-3, 4, (h, w)) * sc, 0, (1 << bd) - 1)   # + coding noise
+    cdef[300:, 500:] = rng.integers(0, 1 << bd, (100, 100))        # pure noise: saturated / wrapped a
+    hc, hs = O.plane_from_image(cdef, bd, 16, 16), O.plane_from_image(src, bd, 16, 16)
+    rects = [(0, 0, 64, 64), (64, 64, 64, 56), (128, 0, 256, 256), (384, 128, 216, 200),
+             (0, 256, 96, 144), (500, 300, 100, 100), (37 * 4, 200, 36, 35)]
+    u = np.zeros(len(rects) * 16, SGR_SOLVE_UNIT)
+    for i, (x, y, ww, hh) in enumerate(rects):
+        for s in range(16):
+            u[i * 16 + s] = (x, y, ww, hh, s, (0, 0, 0))
+    got = ctx.sgrproj_solve_batch(dev_plane(hc), dev_plane(hs), u).cpu().numpy()
+    cc, cs = hc.cstruct(), hs.cstruct()
+    for i in range(len(u)):
+        want = np.zeros(2, np.int8)
+        oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), int(u["x"][i]), int(u["y"][i]), int(u["w"][i]),
+                                 int(u["h"][i]), int(u["set"][i]), bd, want.ctypes.data)
+        assert np.array_equal(got[i], want), (bd, u[i], got[i], want)
+    assert len(np.unique(got, axis=0)) > 12      # the weights actually vary (not all clamped)

@@ -45,3 +45,23 @@ def test_units_without_a_filter_and_flat_input_are_untouched(oracle):
     out = run_oracle(oracle, img, img, 0, 80, 64, 64, units, 8)
     assert np.array_equal(out[:56, 64:], img[:56, 64:])   # unit (0, 1): RESTORE_NONE, stripe 0
     assert (out[:56, :64] != img[:56, :64]).any()
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_sgrproj_solve_matches_the_independent_model(oracle, bd):
+    """xqd of sgrproj_solve for every parameter set on small units (interior, frame corner,
+    odd height) against tests/lrf_util.py::solve_unit (exact moments, emulated fma)."""
+    import lrf_util as L
+    rng = np.random.default_rng(31 + bd)
+    h, w = 72, 88
+    yy, xx = np.mgrid[0:h, 0:w]
+    src = np.clip((np.sin(xx / 6.0) + np.cos(yy / 5.0) + 2) / 4 * ((1 << bd) - 1), 0, (1 << bd) - 1).astype(np.int64)
+    cdef = np.clip(src + rng.integers(-9, 10, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1)
+    pc, ps = O.plane_from_image(cdef, bd, 16, 16), O.plane_from_image(src, bd, 16, 16)
+    cc, cs = pc.cstruct(), ps.cstruct()
+    for (x0, y0, uw, uh) in ((0, 0, 24, 20), (32, 16, 28, 17), (64, 40, 24, 32)):
+        for set_ in range(16):
+            got = np.zeros(2, np.int8)
+            oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), x0, y0, uw, uh, set_, bd, got.ctypes.data)
+            want = L.solve_unit(cdef, src, x0, y0, uw, uh, set_, bd)
+            assert tuple(int(v) for v in got) == want, (bd, x0, y0, set_, got, want)
