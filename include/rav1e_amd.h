@@ -306,6 +306,15 @@ int r1_estimate_inter_costs(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
 int r1_importance_block_difference(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
                                    uint64_t *sum_out, void *stream);
 
+/* ActivityMask::from_plane + fill_scales (src/activity.rs:21-66): the spatial
+ * DistortionScale of every 8x8 luma block, ssim_boost(variance, variance) in
+ * Q14 -- the producer of the `scales` grid r1_dist_scaled_batch and
+ * r1_rdo_pixel_cand_batch consume (the encoder multiplies it with the
+ * lookahead's spatiotemporal scale, src/api/internal.rs).  ceil(w/8) x
+ * ceil(h/8) entries, row-major; either output may be NULL. */
+int r1_activity_scales(r1_ctx *ctx, const R1Plane *luma, uint32_t *variances, uint32_t *scales,
+                       void *stream);
+
 /* ---- intra mode pre-screen (SURVEY.md 8f "N1"; src/rdo.rs:1434-1506): for
  * every block the candidate modes are predicted from ONE edge set
  * (get_intra_edges with IntraParam::None) and ranked by get_satd against the

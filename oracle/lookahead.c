@@ -81,3 +81,27 @@ void r1o_estimate_inter_costs(const r1o_plane *org, const r1o_plane *ref, const 
                                        ref->stride, 8, 8, hbd);
     }
 }
+
+/* ActivityMask::from_plane + fill_scales (src/activity.rs:21-66), variance_8x8 69-99 */
+void r1o_activity_scales(const r1o_plane *luma, uint32_t *variances, uint32_t *scales) {
+  const int wb = (luma->width + 7) / 8, hb = (luma->height + 7) / 8;
+  for (int by = 0; by < hb; by++)
+    for (int bx = 0; bx < wb; bx++) {
+      uint16_t sum_cols[8] = { 0 };
+      uint32_t sum2_cols[8] = { 0 };
+      for (int j = 0; j < 8; j++)
+        for (int k = 0; k < 8; k++) {
+          const size_t i = (size_t)(luma->yorigin + by * 8 + j) * luma->stride + luma->xorigin + bx * 8 + k;
+          const uint16_t s = luma->bytes_per_px == 1 ? ((const uint8_t *)luma->data)[i]
+                                                     : ((const uint16_t *)luma->data)[i];
+          sum_cols[k] = (uint16_t)(sum_cols[k] + s);
+          sum2_cols[k] += (uint32_t)s * s;
+        }
+      uint64_t sum_s = 0, sum_s2 = 0;
+      for (int k = 0; k < 8; k++) { sum_s += sum_cols[k]; sum_s2 += sum2_cols[k]; }
+      const uint64_t v = sum_s2 - ((sum_s * sum_s + 32) >> 6);
+      const uint32_t var = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v;
+      if (variances) variances[by * wb + bx] = var;
+      if (scales) scales[by * wb + bx] = r1o_apply_ssim_boost(1u << 14, var, var, luma->bit_depth);
+    }
+}

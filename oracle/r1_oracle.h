@@ -236,6 +236,7 @@ int r1o_lrf_filter_plane(const r1o_plane *cdeffed, const r1o_plane *deblocked, c
                          int unit_rows, int stripe_height, const r1o_lrf_unit *units, int bd);
 void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0, int y0, int w, int h,
                        int set, int bd, int8_t *xqd_out);
+void r1o_activity_scales(const r1o_plane *luma, uint32_t *variances, uint32_t *scales);
 void r1o_set_threads(int n);
 int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
                    int h, const r1o_dist_cand *c, int n, uint32_t *out);

@@ -353,6 +353,17 @@ class Context:
                     "r1_estimate_inter_costs")
         return out
 
+    def activity_scales(self, luma):
+        """ActivityMask::from_plane + fill_scales (src/activity.rs:21-66) -> (variances, scales),
+        uint32-valued int32 tensors (ceil(h/8), ceil(w/8))"""
+        hb, wb = (luma.height + 7) // 8, (luma.width + 7) // 8
+        var = torch.empty((hb, wb), dtype=torch.int32, device="cuda")
+        sc = torch.empty((hb, wb), dtype=torch.int32, device="cuda")
+        pl = luma.cstruct()
+        self._check(self.lib.r1_activity_scales(self.h, C.byref(pl), var.data_ptr(), sc.data_ptr(),
+                                                _stream_ptr()), "r1_activity_scales")
+        return var, sc
+
     def importance_block_difference(self, org, ref):
         """estimate_importance_block_difference (lookahead.rs:125-180) -> f64"""
         out = torch.zeros(1, dtype=torch.int64, device="cuda")

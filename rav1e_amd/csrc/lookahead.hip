@@ -12,6 +12,7 @@
 // column: above only, else both; src/predict.rs:786-838) from the row above
 // and the column to the left, and runs the 8x8 Hadamard in registers.
 #include "common.hpp"
+#include "dist_common.hpp"
 
 namespace {
 
@@ -136,6 +137,38 @@ __global__ __launch_bounds__(256) void k_imp_diff(R1Plane org, R1Plane ref, int 
   if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
+// ActivityMask::from_plane + fill_scales (src/activity.rs:21-66): variance of
+// every 8x8 luma block (the plane padded to a multiple of 8: the last blocks
+// read the padding, as the reference's aligned rect does), then
+// ssim_boost(var, var): the spatial half of the DistortionScale grid that
+// r1_dist_scaled_batch and the pixel-domain candidate consume.
+template <int BPP>
+__global__ __launch_bounds__(256) void k_activity(R1Plane p, int wb, int hb,
+                                                  uint32_t *__restrict__ variances,
+                                                  uint32_t *__restrict__ scales) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= wb * hb) return;
+  const int bx = i % wb, by = i / wb;
+  const uint8_t *src = px_addr<BPP>(p, bx * 8, by * 8);
+  const size_t st = (size_t)p.stride * BPP;
+  unsigned long long sum_s = 0, sum_s2 = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    int32_t a[8];
+    load_px_row<BPP, 8>(src + r * st, a);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      sum_s += (uint32_t)a[k];
+      sum_s2 += (uint32_t)a[k] * (uint32_t)a[k];
+    }
+  }
+  // variance_8x8 (activity.rs:69-99): u32::try_from(..).unwrap_or(u32::MAX)
+  const unsigned long long v = sum_s2 - ((sum_s * sum_s + 32) >> 6);
+  const uint32_t var = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v;
+  if (variances) variances[i] = var;
+  if (scales) scales[i] = r1dist::apply_ssim_boost(1u << 14, var, var, p.bit_depth);
+}
+
 }  // namespace
 
 extern "C" int r1_estimate_intra_costs(r1_ctx *ctx, const R1Plane *luma, uint32_t *costs,
@@ -187,6 +220,23 @@ extern "C" int r1_importance_block_difference(r1_ctx *ctx, const R1Plane *org, c
   else
     hipLaunchKernelGGL((k_imp_diff<2>), dim3(grid), dim3(256), 0, st, *org, *ref, wb, hb,
                        (unsigned long long *)sum_out);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_activity_scales(r1_ctx *ctx, const R1Plane *luma, uint32_t *variances,
+                                  uint32_t *scales, void *stream) {
+  R1_REQUIRE(ctx && luma && (variances || scales));
+  R1_REQUIRE(luma->bytes_per_px == 1 || luma->bytes_per_px == 2);
+  R1_REQUIRE((luma->bytes_per_px == 1) == (luma->bit_depth == 8));
+  const int wb = (luma->width + 7) / 8, hb = (luma->height + 7) / 8;
+  if (wb * hb == 0) return R1_OK;
+  const unsigned grid = (unsigned)((wb * hb + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (luma->bytes_per_px == 1)
+    hipLaunchKernelGGL((k_activity<1>), dim3(grid), dim3(256), 0, st, *luma, wb, hb, variances, scales);
+  else
+    hipLaunchKernelGGL((k_activity<2>), dim3(grid), dim3(256), 0, st, *luma, wb, hb, variances, scales);
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }

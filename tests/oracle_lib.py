@@ -108,6 +108,7 @@ def lib():
         "r1o_deblock_plane": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i]),
         "r1o_deblock_sse_plane": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i, vp, vp]),
         "r1o_deblock_pick_levels": (None, [vp, vp, i, vp]),
+        "r1o_activity_scales": (None, [vp, vp, vp]),
         "r1o_lrf_filter_plane": (i, [vp, vp, vp, i, i, i, i, i, i, i, i, vp, i]),
         "r1o_sgrproj_solve": (None, [vp, vp, i, i, i, i, i, i, vp]),
         "r1o_estimate_motion_batch": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),

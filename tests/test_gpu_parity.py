@@ -1365,3 +1365,20 @@ def test_sgrproj_solve_vs_oracle(ctx, oracle, bd):
                                  int(u["h"][i]), int(u["set"][i]), bd, want.ctypes.data)
         assert np.array_equal(got[i], want), (bd, u[i], got[i], want)
     assert len(np.unique(got, axis=0)) > 12      # the weights actually vary (not all clamped)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_activity_scales_vs_oracle(ctx, oracle, bd):
+    """r1_activity_scales (ActivityMask::from_plane + fill_scales) on a frame whose size is not a
+    multiple of 8 (the last blocks read the padding, as the reference's aligned rect does)."""
+    import ctypes as C
+    hp = O.HostPlane(1284, 722, bd, rng=np.random.default_rng(3 + bd))
+    hp.view()[100:300, 200:500] = (1 << bd) // 3                       # flat area
+    hp.view()[300:400] = (hp.view()[300:400] >> (bd - 2)) << (bd - 2)  # coarse levels
+    pc = hp.cstruct()
+    hb, wb = (722 + 7) // 8, (1284 + 7) // 8
+    wvar, wsc = np.zeros((hb, wb), np.uint32), np.zeros((hb, wb), np.uint32)
+    oracle.r1o_activity_scales(C.byref(pc), O.ptr(wvar), O.ptr(wsc))
+    var, sc = ctx.activity_scales(dev_plane(hp))
+    assert np.array_equal(var.cpu().numpy().view(np.uint32), wvar)
+    assert np.array_equal(sc.cpu().numpy().view(np.uint32), wsc)

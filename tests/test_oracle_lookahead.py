@@ -62,3 +62,27 @@ def test_inter_costs_and_block_difference(oracle):
             sr = b.view()[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8].astype(np.int64).sum()
             want += abs((so + 32) // 64 - (sr + 32) // 64)
     assert tot == want
+
+
+def test_activity_scales_definition(oracle):
+    """variance_8x8 = sum(s^2) - round(sum(s)^2 / 64); scale = ssim_boost(var, var): flat blocks
+    get the largest scale, and the float formula of src/activity.rs:194-274 is met within 5 %."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    for bd in (8, 10, 12):
+        hp = O.HostPlane(100, 52, bd, rng=rng)          # not multiples of 8: the padding is read
+        hp.view()[:8, :8] = 77                          # one flat block
+        pc = hp.cstruct()
+        wb, hb = 13, 7
+        var, sc = np.zeros((hb, wb), np.uint32), np.zeros((hb, wb), np.uint32)
+        oracle.r1o_activity_scales(C.byref(pc), O.ptr(var), O.ptr(sc))
+        a = hp.data[hp.yorigin:hp.yorigin + hb * 8, hp.xorigin:hp.xorigin + wb * 8].astype(np.int64)
+        blk = a.reshape(hb, 8, wb, 8)
+        s1, s2 = blk.sum((1, 3)), (blk * blk).sum((1, 3))
+        assert np.array_equal(var, np.minimum(s2 - ((s1 * s1 + 32) >> 6), 0xFFFFFFFF))
+        assert var[0, 0] == 0 and sc[0, 0] == sc.max()
+        v = (var >> (2 * (bd - 8))).astype(np.float64)
+        # ssim_boost = (C1 / C3) * (svar + dvar + C2) / sqrt(C1^2 + svar * dvar), Q14
+        want = (1 << 14) * (3355.0 / 12338.0) * (2 * v + 16128) / np.sqrt(3355.0 ** 2 + v * v)
+        rel = np.abs(sc.astype(np.float64) - want) / want
+        assert rel.max() < 0.05, rel.max()
