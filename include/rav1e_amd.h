@@ -254,6 +254,24 @@ int r1_cfl_ac_batch(r1_ctx *ctx, const R1Plane *luma, int bw, int bh, int xdec,
                     int ydec, const R1CflAcCand *cands, int n, int16_t *ac,
                     void *stream);
 
+/* rdo_cfl_alpha (src/rdo.rs:1593-1688) for ONE chroma plane: the alpha in
+ * -16 .. 16 minimising the SSE of UV_CFL_PRED against the source over the
+ * visible part of the block, with the reference's search order and early exit.
+ * (x, y): block position in `src` (the chroma INPUT plane); variant: the
+ * PredictionVariant of the DC average (0 NONE, 1 LEFT, 2 TOP, 3 BOTH); vis_w /
+ * vis_h: clip_visible_bsize.  edges / lens: r1_intra_edges_batch of the
+ * reconstructed chroma plane (mode UV_CFL_PRED), ac: r1_cfl_ac_batch, one
+ * entry per candidate.  alpha_out: int16 per candidate; cost_out (optional):
+ * its SSE. */
+typedef struct R1CflAlphaCand {
+  int16_t x, y;
+  uint8_t variant, vis_w, vis_h, reserved;
+} R1CflAlphaCand;
+int r1_cfl_alpha_search_batch(r1_ctx *ctx, const R1Plane *src, int tx_size,
+                              const R1CflAlphaCand *cands, int n, const void *edges,
+                              int edge_stride, const uint8_t *lens, const int16_t *ac,
+                              int16_t *alpha_out, uint64_t *cost_out, void *stream);
+
 /* ---- cdef:: (reference: cdef_find_dir src/cdef.rs:84-143, cdef_filter_block
  * 198-298, cdef_filter_superblock / cdef_filter_tile 405-625; x86 dispatch
  * src/asm/x86/cdef.rs:83-110).  Edge flags = the reference's CDEF_HAVE_*. */

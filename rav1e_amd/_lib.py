@@ -86,6 +86,7 @@ SYMBOLS = {
     "r1_lrf_sgrproj_plane": (_i, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "r1_sgrproj_solve_batch": (_i, [_vp, _PP, _PP, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "r1_activity_scales": (_i, [_vp, _PP, _vp, _vp, _vp]),
+    "r1_cfl_alpha_search_batch": (_i, [_vp, _PP, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rav1e_sad_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_satd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),
     "rav1e_sad_hbd_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),

@@ -77,6 +77,8 @@ ME_RESULT = np.dtype([("row", "<i2"), ("col", "<i2"), ("sad", "<u4"), ("cost", "
 assert ME_BLOCK_CAND.itemsize == 16 and ME_RESULT.itemsize == 16
 
 
+CFL_ALPHA_CAND = np.dtype([("x", "<i2"), ("y", "<i2"), ("variant", "u1"), ("vis_w", "u1"), ("vis_h", "u1"),
+                           ("reserved", "u1")])
 SGR_SOLVE_UNIT = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("set", "u1"),
                            ("reserved", "u1", (3,))])
 assert SGR_SOLVE_UNIT.itemsize == 12
@@ -283,6 +285,19 @@ class Context:
             ac.data_ptr() if ac is not None else None, out.data_ptr(), _stream_ptr()),
             "r1_intra_satd_batch")
         return out
+
+    def cfl_alpha_search_batch(self, src, tx_size, cands, edges, lens, ac, n=None):
+        """rdo_cfl_alpha (src/rdo.rs:1593-1688) for one chroma plane -> (alpha int16, sse int64)"""
+        dc = _dev_cands(cands, CFL_ALPHA_CAND)
+        n = dc.numel() // CFL_ALPHA_CAND.itemsize if n is None else n
+        alpha = torch.empty(n, dtype=torch.int16, device="cuda")
+        cost = torch.empty(n, dtype=torch.int64, device="cuda")
+        ps = src.cstruct()
+        self._check(self.lib.r1_cfl_alpha_search_batch(
+            self.h, C.byref(ps), int(tx_size), dc.data_ptr(), n, edges.data_ptr(), edges.stride(0),
+            lens.data_ptr(), ac.data_ptr(), alpha.data_ptr(), cost.data_ptr(), _stream_ptr()),
+            "r1_cfl_alpha_search_batch")
+        return alpha, cost
 
     def cfl_ac_batch(self, luma, bw, bh, xdec, ydec, cands, n=None):
         """pred_cfl_ac (src/predict.rs:1020-1063) -> (n, bh*bw) int16"""

@@ -466,6 +466,80 @@ __global__ __launch_bounds__(64) void k_cfl_ac(R1Plane luma, int bw, int bh, int
   for (int i = threadIdx.x; i < bw * bh; i += 64) out[i] = (int16_t)(out[i] - avg);
 }
 
+// rdo_cfl_alpha (src/rdo.rs:1593-1688) for one chroma plane: one wave per block.
+// Lane a evaluates alpha = a - 16 (-16 .. 16): pred_cfl_inner (predict.rs:1064-1091)
+// of the whole block against the source, plain SSE over the visible part
+// (sse_wxh with the default scale is the plain sum); lane 0 then replays the
+// reference's sequential selection (alpha 0 first, +-1 .. +-16 with the early
+// exit `count < alpha`) on the 33 costs.
+template <int BPP>
+__global__ __launch_bounds__(64) void k_cfl_alpha(R1Plane src, int wl, int hl,
+                                                  const R1CflAlphaCand *__restrict__ cands, int n,
+                                                  const void *__restrict__ edges, int edge_stride,
+                                                  const uint8_t *__restrict__ lens,
+                                                  const int16_t *__restrict__ ac, int bit_depth,
+                                                  int16_t *__restrict__ alpha_out,
+                                                  unsigned long long *__restrict__ cost_out) {
+  __shared__ int16_t s_ac[32 * 32];
+  __shared__ uint16_t s_src[32 * 32];
+  __shared__ unsigned long long s_cost[33];
+  const int W = 1 << wl, H = 1 << hl, lane = threadIdx.x;
+  const int cand = blockIdx.x;
+  const R1CflAlphaCand cd = cands[cand];
+  const int vw = cd.vis_w, vh = cd.vis_h;
+  // DC_PRED average of the block's edges (predict.rs:885-933), by variant
+  const void *e = (const uint8_t *)edges + (size_t)cand * edge_stride * BPP;
+  const int left_len = lens[2 * cand];
+  const int ls_len = left_len < H ? left_len : H;
+  uint32_t avg;
+  if (cd.variant == 0) {
+    avg = 128u << (bit_depth - 8);
+  } else {
+    uint32_t sum = 0;
+    if (cd.variant != 2)   // LEFT or BOTH
+      for (int i = 0; i < (cd.variant == 1 ? ls_len : H); i++) sum += (uint32_t)ldp<BPP>(e, 2 * MAXTX - ls_len + i);
+    if (cd.variant != 1)   // TOP or BOTH
+      for (int i = 0; i < W; i++) sum += (uint32_t)ldp<BPP>(e, 2 * MAXTX + 1 + i);
+    const uint32_t len = cd.variant == 1 ? (uint32_t)H : (cd.variant == 2 ? (uint32_t)W : (uint32_t)(W + H));
+    avg = (sum + (len >> 1)) / len;
+  }
+  for (int i = lane; i < W * H; i += 64) {
+    s_ac[i] = ac[(size_t)cand * W * H + i];
+    const int x = i & (W - 1), y = i >> wl;
+    s_src[i] = (x < vw && y < vh) ? (uint16_t)ld_px<BPP>(px_addr<BPP>(src, cd.x + x, cd.y + y)) : 0;
+  }
+  __syncthreads();
+  if (lane < 33) {
+    const int alpha = lane - 16;
+    const int32_t smax = (1 << bit_depth) - 1;
+    unsigned long long sse = 0;
+    for (int y = 0; y < vh; y++)
+      for (int x = 0; x < vw; x++) {
+        const int i = (y << wl) + x;
+        const int32_t q6 = alpha * (int32_t)s_ac[i];
+        const int32_t q0 = ((q6 < 0 ? -q6 : q6) + 32) >> 6;
+        int32_t v = (int32_t)avg + (q6 < 0 ? -q0 : q0);
+        v = v < 0 ? 0 : (v > smax ? smax : v);
+        const int32_t d = (int32_t)s_src[i] - v;
+        sse += (unsigned long long)(uint32_t)(d * d);
+      }
+    s_cost[lane] = sse;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    unsigned long long best = s_cost[16];
+    int best_a = 0, count = 2;
+    for (int a = 1; a <= 16; a++) {
+      const unsigned long long cp = s_cost[16 + a], cm = s_cost[16 - a];
+      if (cp < best) { best = cp; best_a = a; count += 2; }
+      if (cm < best) { best = cm; best_a = -a; count += 2; }
+      if (count < a) break;
+    }
+    alpha_out[cand] = (int16_t)best_a;
+    if (cost_out) cost_out[cand] = best;
+  }
+}
+
 }  // namespace
 
 extern "C" int r1_intra_edges_batch(r1_ctx *ctx, const R1Plane *rec, int tile_x, int tile_y,
@@ -579,6 +653,33 @@ extern "C" int r1_cfl_ac_batch(r1_ctx *ctx, const R1Plane *luma, int bw, int bh,
     hipLaunchKernelGGL((k_cfl_ac<1>), dim3(n), dim3(64), 0, st, *luma, bw, bh, xdec, ydec, cands, n, ac);
   else
     hipLaunchKernelGGL((k_cfl_ac<2>), dim3(n), dim3(64), 0, st, *luma, bw, bh, xdec, ydec, cands, n, ac);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_cfl_alpha_search_batch(r1_ctx *ctx, const R1Plane *src, int tx_size,
+                                         const R1CflAlphaCand *cands, int n, const void *edges,
+                                         int edge_stride, const uint8_t *lens, const int16_t *ac,
+                                         int16_t *alpha_out, uint64_t *cost_out, void *stream) {
+  R1_REQUIRE(ctx && src);
+  R1_REQUIRE(tx_size >= 0 && tx_size < 19);
+  R1_REQUIRE(src->bytes_per_px == 1 || src->bytes_per_px == 2);
+  R1_REQUIRE((src->bytes_per_px == 1) == (src->bit_depth == 8));
+  R1_REQUIRE(edge_stride >= EDGE_LEN);
+  static const uint8_t wl[19] = {2, 3, 4, 5, 6, 2, 3, 3, 4, 4, 5, 5, 6, 2, 4, 3, 5, 4, 6};
+  static const uint8_t hl[19] = {2, 3, 4, 5, 6, 3, 2, 4, 3, 5, 4, 6, 5, 4, 2, 5, 3, 6, 4};
+  R1_REQUIRE(wl[tx_size] <= 5 && hl[tx_size] <= 5);   // CFL: chroma transforms up to 32x32
+  if (n <= 0) return R1_OK;
+  R1_REQUIRE(cands && edges && lens && ac && alpha_out);
+  hipStream_t st = (hipStream_t)stream;
+  if (src->bytes_per_px == 1)
+    hipLaunchKernelGGL((k_cfl_alpha<1>), dim3(n), dim3(64), 0, st, *src, (int)wl[tx_size],
+                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, src->bit_depth,
+                       alpha_out, (unsigned long long *)cost_out);
+  else
+    hipLaunchKernelGGL((k_cfl_alpha<2>), dim3(n), dim3(64), 0, st, *src, (int)wl[tx_size],
+                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, src->bit_depth,
+                       alpha_out, (unsigned long long *)cost_out);
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }

@@ -1382,3 +1382,62 @@ def test_activity_scales_vs_oracle(ctx, oracle, bd):
     var, sc = ctx.activity_scales(dev_plane(hp))
     assert np.array_equal(var.cpu().numpy().view(np.uint32), wvar)
     assert np.array_equal(sc.cpu().numpy().view(np.uint32), wsc)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_cfl_alpha_search_vs_oracle(ctx, oracle, bd):
+    """r1_cfl_alpha_search_batch (rdo_cfl_alpha): the oracle predicts UV_CFL_PRED for all 33
+    alphas, takes the plain SSE over the visible area and replays the reference's selection."""
+    from rav1e_amd.api import CFL_ALPHA_CAND, CFL_AC_CAND, INTRA_EDGE_CAND
+    rng = np.random.default_rng(410 + bd)
+    luma = O.HostPlane(256, 128, bd, rng=rng)
+    # chroma planes (4:2:0): reconstruction and source share structure with the luma
+    lv = luma.view().astype(np.int64)
+    sub = (lv[0::2, 0::2] + lv[0::2, 1::2] + lv[1::2, 0::2] + lv[1::2, 1::2]) // 4
+    rec = O.plane_from_image(np.clip(sub // 2 + rng.integers(0, 1 << (bd - 1), sub.shape), 0, (1 << bd) - 1), bd, 44, 44)
+    src = O.plane_from_image(np.clip(sub * 3 // 4 + rng.integers(0, 1 << (bd - 2), sub.shape), 0, (1 << bd) - 1), bd, 44, 44)
+    dl, dr, dsrc = dev_plane(luma), dev_plane(rec), dev_plane(src)
+    hbd = int(bd > 8)
+    dt = np.uint16 if hbd else np.uint8
+    for ts in (0, 1, 2, 3, 7, 8):
+        w, h = TX_SIZES[ts]
+        n = 40
+        gx, gy = rec.width // w, rec.height // h
+        bx, by = rng.integers(0, gx, n) * w, rng.integers(0, gy, n) * h
+        bx[:3], by[:3] = [0, w, 0], [0, 0, h]
+        ec = np.zeros(n, INTRA_EDGE_CAND)
+        ec["x"], ec["y"], ec["mode"], ec["flags"] = bx, by, 13, 1
+        edges, lens = ctx.intra_edges_batch(dr, (0, 0, rec.width, rec.height), ts, ec)
+        he, hl = edges.cpu().numpy().view(dt), lens.cpu().numpy()
+        ac_c = np.zeros(n, CFL_AC_CAND)
+        ac_c["x"], ac_c["y"] = bx * 2, by * 2
+        ac = ctx.cfl_ac_batch(dl, w, h, 1, 1, ac_c)
+        hac = ac.cpu().numpy()
+        var = np.where((bx == 0) & (by == 0), 0, np.where(by == 0, 1, np.where(bx == 0, 2, 3)))
+        cc = np.zeros(n, CFL_ALPHA_CAND)
+        cc["x"], cc["y"], cc["variant"] = bx, by, var
+        cc["vis_w"] = np.where(rng.random(n) < 0.2, rng.integers(1, w + 1, n), w)
+        cc["vis_h"] = np.where(rng.random(n) < 0.2, rng.integers(1, h + 1, n), h)
+        alpha, cost = ctx.cfl_alpha_search_batch(dsrc, ts, cc, edges, lens, ac)
+        alpha, cost = alpha.cpu().numpy(), cost.cpu().numpy()
+        for i in range(n):
+            vw, vh = int(cc["vis_w"][i]), int(cc["vis_h"][i])
+            s = src.view()[by[i]:by[i] + vh, bx[i]:bx[i] + vw].astype(np.int64)
+            costs = {}
+            for a in range(-16, 17):
+                out = np.zeros((h, w), dt)
+                # alpha 0 is plain DC_PRED in the reference's dispatch (predict.rs:119-123)
+                assert oracle.r1o_dispatch_predict_intra(13 if a else 0, int(var[i]), O.ptr(out), w, ts, bd,
+                                                         O.ptr(hac[i]), a, 0, O.ptr(he[i]), int(hl[i, 0]),
+                                                         int(hl[i, 1]), w, h, hbd) == 0
+                d = s - out[:vh, :vw].astype(np.int64)
+                costs[a] = int((d * d).sum())
+            best, best_a, count = costs[0], 0, 2
+            for a in range(1, 17):
+                if costs[a] < best:
+                    best, best_a, count = costs[a], a, count + 2
+                if costs[-a] < best:
+                    best, best_a, count = costs[-a], -a, count + 2
+                if count < a:
+                    break
+            assert (int(alpha[i]), int(cost[i])) == (best_a, best), (bd, ts, i, int(alpha[i]), best_a)
