@@ -1441,3 +1441,31 @@ def test_cfl_alpha_search_vs_oracle(ctx, oracle, bd):
                 if count < a:
                     break
             assert (int(alpha[i]), int(cost[i])) == (best_a, best), (bd, ts, i, int(alpha[i]), best_a)
+
+
+def test_widened_entry_points_reject_bad_arguments(ctx):
+    """where the reference would panic (asserts on geometry / bit depth / aliasing) the batch
+    calls return R1_EINVAL and say why (r1_last_error)"""
+    import torch
+    import deblock_util as D
+    from rav1e_amd.api import R1Error, Plane, me_lambdas, RDO_CAND
+    a = Plane(128, 64, 8)
+    st = torch.zeros((16, 32, 2), dtype=torch.int32, device="cuda")
+    pyr = [a, a, a]
+    with pytest.raises(R1Error):      # tile origin not superblock aligned
+        ctx.estimate_tile_motion([dict(org=pyr, ref=pyr, stats=st, tile=(32, 0, 64, 64))], 32, 16, 8,
+                                 me_lambdas(10.0))
+    with pytest.raises(R1Error):      # tile outside the stats array
+        ctx.estimate_tile_motion([dict(org=pyr, ref=pyr, stats=st, tile=(64, 0, 128, 64))], 32, 16, 8,
+                                 me_lambdas(10.0))
+    blocks = torch.zeros((16, 32, 8), dtype=torch.uint8, device="cuda")
+    with pytest.raises(R1Error):      # chroma decimation on the luma plane
+        ctx.deblock_plane(D.make_state([10, 10, 10, 10]), a, 0, 1, 1, blocks, 128, 64)
+    units = torch.zeros((1, 2, 4), dtype=torch.uint8, device="cuda")
+    with pytest.raises(R1Error):      # in-place restoration: out must not alias the CDEF output
+        ctx.lrf_sgrproj_plane(a, a, a, 0, 128, 64, 64, 64, units, 64)
+    with pytest.raises(R1Error):      # unit size not a multiple of 32
+        ctx.lrf_sgrproj_plane(a, a, Plane(128, 64, 8), 0, 128, 64, 64, 48, units, 64)
+    c = np.zeros(4, RDO_CAND)
+    with pytest.raises(R1Error):      # cdef_dist is a luma-only distortion
+        ctx.rdo_pixel_cand_batch(a, a, 16, 16, c, 100, 3, xdec=1, ydec=1)
