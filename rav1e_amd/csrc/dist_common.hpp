@@ -98,6 +98,26 @@ __device__ __forceinline__ void load_row(const uint8_t *p, int kw, int32_t *out)
 }
 
 
+// cdef_dist_kernel's fixed-point tail (dist.rs:350-372) + the ssim boost + the
+// DistortionScale of the 8x8 importance block at (px, py), from the five sums
+// of a tile of `area` pixels.
+__device__ __forceinline__ unsigned long long cdef_tile_tail(
+    uint32_t sum_s, uint32_t sum_d, uint32_t sum_s2, uint32_t sum_d2, uint32_t sum_sd, int area, int px,
+    int py, const uint32_t *__restrict__ scales, int scale_stride, int bit_depth) {
+  const uint32_t sse = sum_d2 + sum_s2 - 2 * sum_sd;
+  const unsigned long long div = area_divisor(area);
+  const uint32_t ms = (uint32_t)(((unsigned long long)sum_s * sum_s * div + 8192) >> 14);
+  const uint32_t md = (uint32_t)(((unsigned long long)sum_d * sum_d * div + 8192) >> 14);
+  uint32_t svar = sum_s2 > ms ? sum_s2 - ms : 0;
+  uint32_t dvar = sum_d2 > md ? sum_d2 - md : 0;
+  svar = (uint32_t)(((unsigned long long)svar * div + 128) >> 8);
+  dvar = (uint32_t)(((unsigned long long)dvar * div + 128) >> 8);
+  const unsigned long long v = apply_ssim_boost(sse, svar, dvar, bit_depth);
+  const unsigned long long sc =
+      scales ? scales[(size_t)(py >> 3) * scale_stride + (px >> 3)] : (1u << 14);
+  return (sc * v + 8192) >> 14;
+}
+
 // One 8x8 (or edge 4-wide / 4-high) tile of sse_wxh (KIND 2: four 4x4 cells,
 // each weighted by the DistortionScale of its importance block, rdo.rs:177-224
 // -> dist.rs:234-283) or of cdef_dist_wxh (KIND 3: cdef_dist_kernel + ssim
@@ -152,18 +172,8 @@ __device__ __forceinline__ unsigned long long tile_scaled_dist(
         }
       }
     }
-    const uint32_t sse = sum_d2 + sum_s2 - 2 * sum_sd;
-    const unsigned long long div = area_divisor(kw * kh);
-    const uint32_t ms = (uint32_t)(((unsigned long long)sum_s * sum_s * div + 8192) >> 14);
-    const uint32_t md = (uint32_t)(((unsigned long long)sum_d * sum_d * div + 8192) >> 14);
-    uint32_t svar = sum_s2 > ms ? sum_s2 - ms : 0;
-    uint32_t dvar = sum_d2 > md ? sum_d2 - md : 0;
-    svar = (uint32_t)(((unsigned long long)svar * div + 128) >> 8);
-    dvar = (uint32_t)(((unsigned long long)dvar * div + 128) >> 8);
-    const unsigned long long v = apply_ssim_boost(sse, svar, dvar, bit_depth);
-    const unsigned long long sc =
-        scales ? scales[(size_t)(py >> 3) * scale_stride + (px >> 3)] : (1u << 14);
-    acc = (sc * v + 8192) >> 14;
+    acc = cdef_tile_tail(sum_s, sum_d, sum_s2, sum_d2, sum_sd, kw * kh, px, py, scales, scale_stride,
+                         bit_depth);
   }
   return acc;
 }

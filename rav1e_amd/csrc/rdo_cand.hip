@@ -599,6 +599,72 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
           rc[rr] = px < 0 ? 0 : (px > pmax ? pmax : px);
         }
       }
+      if (col_live && qa.rec) {
+        if constexpr (BPP == 1) {
+          uint8_t *d = (uint8_t *)qa.rec + (size_t)cand * W * H + c;
+#pragma unroll
+          for (int rr = 0; rr < H; rr++) d[(size_t)rr * W] = (uint8_t)rc[rr];
+        } else {
+          uint16_t *d = (uint16_t *)qa.rec + (size_t)cand * W * H + c;
+#pragma unroll
+          for (int rr = 0; rr < H; rr++) d[(size_t)rr * W] = (uint16_t)rc[rr];
+        }
+      }
+      unsigned long long acc = 0;
+      constexpr bool COL_DIST = H <= 16;
+      if constexpr (COL_DIST) {
+        // ---- H (blocks up to 32 rows): sse_wxh / cdef_dist_wxh with lane = column.  The
+        // reconstruction column is still in registers, the source column is read
+        // again; a tile's 8 (4) lanes meet by xor-shuffles, its first lane runs the
+        // fixed-point tail (dist_common.hpp).  With one lane per 8x8 tile (the H = 64
+        // path below) an 8x8 candidate keeps 8 of the 64 lanes busy for 64 pixels each.
+        constexpr int KW = W < 8 ? W : 8, KH = H < 8 ? H : 8;
+        const uint8_t *po = px_addr<BPP>(org, cd.ox + (col_live ? c : 0), cd.oy);
+        const size_t so = (size_t)org.stride * BPP;
+        if (qa.dist_kind == R1_DIST_CDEF) {
+#pragma unroll
+          for (int y0 = 0; y0 < H; y0 += KH) {
+            uint32_t sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
+            if (col_live) {
+#pragma unroll
+              for (int rr = 0; rr < KH; rr++) {
+                const uint32_t sv = (uint32_t)ld_px<BPP>(po + (y0 + rr) * so), dv = (uint32_t)rc[y0 + rr];
+                sum_s += sv; sum_d += dv;
+                sum_s2 += sv * sv; sum_d2 += dv * dv; sum_sd += sv * dv;
+              }
+            }
+#pragma unroll
+            for (int m = 1; m < KW; m <<= 1) {
+              sum_s += __shfl_xor(sum_s, m, 64); sum_d += __shfl_xor(sum_d, m, 64);
+              sum_s2 += __shfl_xor(sum_s2, m, 64); sum_d2 += __shfl_xor(sum_d2, m, 64);
+              sum_sd += __shfl_xor(sum_sd, m, 64);
+            }
+            if (col_live && (c & (KW - 1)) == 0)
+              acc += r1dist::cdef_tile_tail(sum_s, sum_d, sum_s2, sum_d2, sum_sd, KW * KH, cd.ox + c,
+                                            cd.oy + y0, qa.scales, qa.scale_stride, BD);
+          }
+        } else {
+#pragma unroll
+          for (int y0 = 0; y0 < H; y0 += 4) {
+            uint32_t cell = 0;
+            if (col_live) {
+#pragma unroll
+              for (int rr = 0; rr < 4; rr++) {
+                const int32_t d = ld_px<BPP>(po + (y0 + rr) * so) - (int32_t)rc[y0 + rr];
+                cell += (uint32_t)(d * d);
+              }
+            }
+            cell += __shfl_xor(cell, 1, 64);
+            cell += __shfl_xor(cell, 2, 64);
+            if (col_live && (c & 3) == 0) {
+              const int lx = (cd.ox + c) << qa.xdec, ly = (cd.oy + y0) << qa.ydec;
+              const uint32_t sc =
+                  qa.scales ? qa.scales[(size_t)(ly >> 3) * qa.scale_stride + (lx >> 3)] : (1u << 14);
+              acc += ((unsigned long long)cell * sc + 128) >> 8;
+            }
+          }
+        }
+      } else {
       __syncthreads();   // the row buffer has been read: LDS becomes the reconstruction
       uint8_t *rec_l = smem + cl * (W * H * BPP);
       if (col_live) {
@@ -607,24 +673,11 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
           if constexpr (BPP == 1) rec_l[rr * W + c] = (uint8_t)rc[rr];
           else ((uint16_t *)rec_l)[rr * W + c] = (uint16_t)rc[rr];
         }
-        if (qa.rec) {
-          if constexpr (BPP == 1) {
-            uint8_t *d = (uint8_t *)qa.rec + (size_t)cand * W * H + c;
-#pragma unroll
-            for (int rr = 0; rr < H; rr++) d[(size_t)rr * W] = (uint8_t)rc[rr];
-          } else {
-            uint16_t *d = (uint16_t *)qa.rec + (size_t)cand * W * H + c;
-#pragma unroll
-            for (int rr = 0; rr < H; rr++) d[(size_t)rr * W] = (uint16_t)rc[rr];
-          }
-        }
       }
       __syncthreads();
-      // ---- H: sse_wxh / cdef_dist_wxh of the reconstruction against the source:
-      // one lane per 8x8 tile (dist_common.hpp) ----
+      // ---- H (64-row blocks): one lane per 8x8 tile (dist_common.hpp) ----
       constexpr int TW8 = (W + 7) / 8, NT8 = TW8 * ((H + 7) / 8);
       static_assert(NT8 <= P, "a candidate's lanes cover its 8x8 tiles");
-      unsigned long long acc = 0;
       if (live && c < NT8) {
         const int x0 = (c % TW8) * 8, y0 = (c / TW8) * 8;
         const int kw = W - x0 < 8 ? W - x0 : 8, kh = H - y0 < 8 ? H - y0 : 8;
@@ -638,6 +691,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
           acc = r1dist::tile_scaled_dist<BPP, 3>(po, (size_t)org.stride * BPP, pr, (size_t)W * BPP, kw, kh,
                                                  cd.ox + x0, cd.oy + y0, qa.scales, qa.scale_stride,
                                                  qa.xdec, qa.ydec, BD);
+      }
       }
 #pragma unroll
       for (int m = 1; m < P; m <<= 1) {
