@@ -21,6 +21,8 @@ CASES = [
     ("chroma420_8", 72, 76, 1, 152, 32, 32, 8),
     ("chroma422_12", 56, 140, 0, 140, 64, 64, 12),
     ("luma_8_bigunit", 150, 80, 0, 80, 128, 64, 8),
+    ("luma_8_odd", 70, 143, 0, 143, 64, 64, 8),               # odd height: the last stripe is odd
+    ("chroma420_10_odd", 53, 71, 1, 141, 32, 32, 10),
 ]
 
 
