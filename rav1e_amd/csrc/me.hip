@@ -771,6 +771,141 @@ __global__ __launch_bounds__(256) void k_me_blocks(R1MeJob job, R1MeParams p,
   }
 }
 
+// Blocks up to 16x16: ONE WAVE per block (four independent blocks per
+// workgroup, no workgroup barrier anywhere).  Full-pel steps run on the tile
+// ME's wave-level engine (source rows in registers, 4 candidates x 16 rows);
+// in the sub-pel diamond the four 16-lane groups of the wave each own one
+// candidate: window staging, put_8tap (lane = column), SATD / SAD with one lane
+// per Hadamard tile, all inside the group; the four costs meet by shuffles.
+template <int BPP>
+__global__ __launch_bounds__(256) void k_me_blocks_small(R1MeJob job, R1MeParams p,
+                                                         const R1MeBlockCand *__restrict__ cands,
+                                                         int n, int max_w, int max_h, int use_satd,
+                                                         int filter_mode,
+                                                         R1MeResult *__restrict__ out) {
+  constexpr int WS_MAX = (((16 + 7) * BPP + 3) >> 2) << 2;
+  constexpr int GROUP_BYTES = ((23 * WS_MAX + 15) & ~15) + 16 * 16 * BPP;   // window + prediction
+  __shared__ __attribute__((aligned(16))) uint8_t sh_grp[4][4][GROUP_BYTES];
+  __shared__ int16_t sh_subsets[4][kSubsetWords];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long bi = (long long)blockIdx.x * 4 + wave;
+  if (bi >= n) return;                         // wave-uniform; no barriers below
+  const R1MeBlockCand cd = cands[bi];
+  const int w = cd.w, h = cd.h;
+  if (w > max_w || h > max_h || w > 16 || h > 16 || w < 4 || h < 4 || (w & (w - 1)) || (h & (h - 1))) {
+    if (lane == 0) out[bi] = R1MeResult{0, 0, 0xFFFFFFFFu, COST_MAX};
+    return;
+  }
+  TileView t{job.stats, job.prev, p.stats_cols, p.stats_rows, job.tile_x / MI, job.tile_y / MI,
+             job.tile_w / MI, job.tile_h / MI};
+  const R1Plane &org = job.org[0], &ref = job.ref[0];
+  Block<BPP, 16> b;
+  int rng[4];
+  const int fbx = t.tx + cd.bx, fby = t.ty + cd.by;
+  mv_range(p, fbx, fby, w, h, 0, rng);
+  b.w = w; b.h = h;
+  b.po_x = fbx * MI; b.po_y = fby * MI;
+  b.mvx_min = rng[0]; b.mvx_max = rng[1]; b.mvy_min = rng[2]; b.mvy_max = rng[3];
+  b.mc.lambda = p.lambda[0];
+  b.mc.allow_hp = p.allow_hp;
+  for (int k = 0; k < 2; k++) { b.mc.pmv_row[k] = cd.pmv[k][0]; b.mc.pmv_col[k] = cd.pmv[k][1]; }
+  b.init(org, ref, lane);
+  Msr best = full_pixel_me(b, t, p, cd.bx, cd.by, rng, cd.corner, false, 0, sh_subsets[wave]);
+
+  auto in_range = [&](int row, int col) {
+    return col >= b.mvx_min && col <= b.mvx_max && row >= b.mvy_min && row <= b.mvy_max;
+  };
+  const bool small = (w < h ? w : h) == 4;
+  const int ts = small ? 4 : 8, ntx = w / ts, nt = ntx * (h / ts), ln = small ? 2 : 3;
+  const uint8_t *o0 = px_addr<BPP>(org, b.po_x, b.po_y);
+  const size_t so = (size_t)org.stride * BPP;
+  // distortion of the source block against `pp` (row stride sp), one lane per tile of lanes [0, nt)
+  auto block_dist = [&](const uint8_t *pp, size_t sp, int gl, bool satd) -> uint32_t {
+    uint32_t s = 0;
+    if (gl < nt) {
+      const int tx = gl % ntx, ty = gl / ntx;
+      const uint8_t *a = o0 + (size_t)ty * ts * so + (size_t)tx * ts * BPP;
+      const uint8_t *c = pp + (size_t)ty * ts * sp + (size_t)tx * ts * BPP;
+      if (satd) s = small ? r1dist::tile_dist<BPP, 4, true>(a, so, c, sp) : r1dist::tile_dist<BPP, 8, true>(a, so, c, sp);
+      else s = small ? r1dist::tile_dist<BPP, 4, false>(a, so, c, sp) : r1dist::tile_dist<BPP, 8, false>(a, so, c, sp);
+    }
+    return s;
+  };
+  if (use_satd) {
+    // get_fullpel_mv_rd(best.mv, use_satd) (me.rs:596-613): the block at the integer position
+    if (!in_range(best.row, best.col)) {
+      best.cost = COST_MAX;
+      best.sad = 0xFFFFFFFFu;
+    } else {
+      const uint8_t *rp = px_addr<BPP>(ref, b.po_x + div8(best.col), b.po_y + div8(best.row));
+      uint32_t s = block_dist(rp, (size_t)ref.stride * BPP, lane, true);
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+      best.sad = (s + ((1u << ln) >> 1)) >> ln;
+      best.cost = b.mc.cost(best.row, best.col, best.sad);
+    }
+  }
+  // subpel_diamond_search: 16-lane group g <-> DIAMOND_R1_PATTERN_SUBPEL[g]
+  const int g = lane >> 4, gl = lane & 15;
+  uint8_t *win = sh_grp[wave][g];
+  uint8_t *pred = win + ((23 * WS_MAX + 15) & ~15);
+  const int ws = (((w + 7) * BPP + 3) >> 2) << 2;
+  int radius_log2 = 2;
+  const int end_log2 = p.allow_hp ? 0 : 1;
+  for (;;) {
+    int row = (int16_t)(best.row + (kDiamond[g][0] << radius_log2));
+    int col = (int16_t)(best.col + (kDiamond[g][1] << radius_log2));
+    const bool ok = in_range(row, col);
+    uint32_t s = 0;
+    if (ok) {
+      // get_mv_params (src/predict.rs:284-297): floor offset, 1/16 fraction
+      r1mc::stage_window<BPP>(win, ws, ref, b.po_x + (col >> 3), b.po_y + (row >> 3), w, h, gl, 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (ok && gl < w) {
+      if constexpr (BPP == 1)
+        r1mc::mc_column<BPP, false, 0>(win, ws, gl, w, h, (col << 1) & 15, (row << 1) & 15, filter_mode,
+                                       filter_mode, ref.bit_depth,
+                                       [&](int rr, int32_t v) { pred[rr * w + gl] = (uint8_t)v; });
+      else
+        r1mc::mc_column<BPP, false, 0>(win, ws, gl, w, h, (col << 1) & 15, (row << 1) & 15, filter_mode,
+                                       filter_mode, ref.bit_depth, [&](int rr, int32_t v) {
+                                         ((uint16_t *)pred)[rr * w + gl] = (uint16_t)v;
+                                       });
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (ok) s = block_dist(pred, (size_t)w * BPP, gl, use_satd != 0);
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+    uint32_t sad = use_satd ? (s + ((1u << ln) >> 1)) >> ln : s;
+    unsigned long long cost = ok ? b.mc.cost(row, col, sad) : COST_MAX;
+    if (!ok) sad = 0xFFFFFFFFu;
+    int idx = g;
+#pragma unroll
+    for (int m = 16; m < 64; m <<= 1) {
+      const unsigned long long oc = ((unsigned long long)(uint32_t)__shfl_xor((int)(cost >> 32), m, 64) << 32) |
+                                    (uint32_t)__shfl_xor((int)(uint32_t)cost, m, 64);
+      const int oi = __shfl_xor(idx, m, 64), orow = __shfl_xor(row, m, 64), ocol = __shfl_xor(col, m, 64);
+      const uint32_t os = (uint32_t)__shfl_xor((int)sad, m, 64);
+      if (oc < cost || (oc == cost && oi < idx)) { cost = oc; idx = oi; row = orow; col = ocol; sad = os; }
+    }
+    if (best.cost <= cost) {
+      if (radius_log2 == end_log2) break;
+      radius_log2--;
+    } else {
+      best = Msr{row, col, cost, sad};
+    }
+  }
+  if (lane == 0) {
+    R1MeResult r;
+    r.row = (int16_t)best.row;
+    r.col = (int16_t)best.col;
+    r.sad = best.sad;
+    r.cost = best.cost;
+    out[bi] = r;
+  }
+}
+
 }  // namespace
 
 extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, int n_jobs,
@@ -849,6 +984,17 @@ extern "C" int r1_estimate_motion_batch(r1_ctx *ctx, const R1MeJob *tile, const 
   if (n <= 0) return R1_OK;
   R1_REQUIRE(cands && out);
   hipStream_t st = (hipStream_t)stream;
+  if (max_w <= 16 && max_h <= 16) {   // one wave per block
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    if (bpp == 1)
+      hipLaunchKernelGGL(k_me_blocks_small<1>, dim3(grid), dim3(256), 0, st, *tile, *params, cands, n,
+                         max_w, max_h, use_satd, filter_mode, out);
+    else
+      hipLaunchKernelGGL(k_me_blocks_small<2>, dim3(grid), dim3(256), 0, st, *tile, *params, cands, n,
+                         max_w, max_h, use_satd, filter_mode, out);
+    R1_HIP_CHECK(hipGetLastError());
+    return R1_OK;
+  }
   // LDS for the largest block of the batch: source + 4 x (window + prediction)
   const int ws = (((max_w + 7) * bpp + 3) >> 2) << 2;
   const size_t blk = ((size_t)max_w * max_h * bpp + 15) & ~(size_t)15;

@@ -1061,6 +1061,19 @@ def test_estimate_motion_blocks_subpel_vs_oracle(ctx, oracle, bd):
     assert (got["cost"][big] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
     want = O.me_block_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, stats, prev, c)
     assert np.array_equal(got[~big], want[~big])
+    # ... through the wave-per-block kernel: the same flavour sweep on a batch of small blocks
+    cs = np.tile(c[~big], 5)
+    cs["bx"] = rng.integers(0, (w - 16) // 4 + 1, len(cs))
+    cs["by"] = rng.integers(0, (h - 16) // 4 + 1, len(cs))
+    cs["pmv"] = rng.integers(-40, 41, (len(cs), 2, 2))
+    for use_satd, mode, hp in ((1, 0, 1), (0, 0, 1), (1, 2, 0), (1, 1, 1), (0, 3, 0)):
+        want = O.me_block_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, stats, prev, cs,
+                                 use_satd=use_satd, filter_mode=mode, allow_hp=hp)
+        got = ctx.estimate_motion_batch(job, cs, w // 4, h // 4, bd, lam, use_satd=bool(use_satd),
+                                        filter_mode=mode, allow_hp=bool(hp), max_w=16,
+                                        max_h=16).cpu().numpy().view(ME_RESULT)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (bd, use_satd, mode, hp, cs[bad[0]], got[bad[0]], want[bad[0]])
 
 
 # ------------------------ N3: deblocking filter + level search
