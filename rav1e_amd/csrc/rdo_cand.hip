@@ -54,7 +54,8 @@ __device__ __forceinline__ int32_t dpp(int32_t x) {
 // pair keeps x + p, the "upper" lane p - x.  sm = upper ? -1 : 0.
 template <int CTRL>
 __device__ __forceinline__ int32_t bfly_lanes(int32_t x, int32_t sm) {
-  return ((x ^ sm) - sm) + dpp<CTRL>(x);
+  // +-x + partner as one v_mad_i32_i24 (|x| < 2^19 for 12-bit pixels)
+  return __mul24(x, sm | 1) + dpp<CTRL>(x);
 }
 // |Hadamard across the TS lanes of a tile| of x, as this lane's share of the
 // tile's sum: the last butterfly stage is folded into the abs because
@@ -85,6 +86,45 @@ __device__ __forceinline__ uint32_t habs_lanes(int32_t x, LaneSigns sg) {
   const int32_t ax = iabs32(x);
   const int32_t ap = TS == 8 ? dpp<0x141>(ax) : dpp<0x4E>(ax);
   return (uint32_t)(ax > ap ? ax : ap);
+}
+
+// ---- the same on two i16 per register (VOP3P) ------------------------------
+// For pixels of up to 10 bits the 8x8 Hadamard fits i16 until its last stage:
+// |residual| <= 1023, five butterfly stages reach 32 * 1023 = 32736, and the
+// sixth stage is the max(|a|, |b|) fold above.  Two 8-row groups of a column
+// (or the two halves of one group after its first stage) share a register, so
+// every butterfly, abs and max works on two coefficients per lane per issue.
+typedef short v2s_t __attribute__((ext_vector_type(2)));
+typedef unsigned short v2us_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, (v2s_t)(__builtin_bit_cast(v2s_t, a) + __builtin_bit_cast(v2s_t, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, (v2s_t)(__builtin_bit_cast(v2s_t, a) - __builtin_bit_cast(v2s_t, b)));
+}
+__device__ __forceinline__ uint32_t pk_mad(uint32_t x, uint32_t s, uint32_t p) {
+  uint32_t r;
+  asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(s), "v"(p));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// both halves of (lo, hi) from the low halves of two i32
+__device__ __forceinline__ uint32_t pk_pair(int32_t lo, int32_t hi) {
+  return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+}
+// this lane's share of sum |Hadamard across the 8 lanes| for both halves of x,
+// added to acc; m1 / m2: packed +-1 of the two lane stages
+__device__ __forceinline__ uint32_t habs_lanes_pk(uint32_t x, uint32_t m1, uint32_t m2, uint32_t acc) {
+  x = pk_mad(x, m1, (uint32_t)dpp<0xB1>((int32_t)x));
+  x = pk_mad(x, m2, (uint32_t)dpp<0x4E>((int32_t)x));
+  const uint32_t ax = pk_max(x, pk_sub(0u, x));
+  const uint32_t mx = pk_max(ax, (uint32_t)dpp<0x141>((int32_t)ax));
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, mx), __builtin_bit_cast(v2us_t, 0x00010001u),
+                                acc, false);
 }
 
 // First link of a dot-product chain with a constant accumulator: the VOP3P
@@ -283,10 +323,47 @@ __device__ __forceinline__ void mc16_column(const uint8_t *win, int c, int cf, i
 }
 
 // SATD contribution of one residual column (TS rows at a time).
-template <int TS, int H>
+template <int TS, int H, int BD>
 __device__ __forceinline__ uint32_t satd_column(const T *v, int lane) {
   const LaneSigns sg = lane_signs<TS>(lane);
   uint32_t acc = 0;
+  if constexpr (TS == 8 && BD <= 10) {
+    const uint32_t m1 = (uint32_t)sg.s1 | 0x00010001u, m2 = (uint32_t)sg.s2 | 0x00010001u;
+    if constexpr (H == 8) {
+      // first vertical stage in i32, then (sum, difference) halves side by side
+      uint32_t a[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) a[k] = pk_pair(v[k] + v[k + 4], v[k] - v[k + 4]);
+      const uint32_t a0 = pk_add(a[0], a[1]), a1 = pk_sub(a[0], a[1]);
+      const uint32_t a2 = pk_add(a[2], a[3]), a3 = pk_sub(a[2], a[3]);
+      acc = habs_lanes_pk(pk_add(a0, a2), m1, m2, acc);
+      acc = habs_lanes_pk(pk_add(a1, a3), m1, m2, acc);
+      acc = habs_lanes_pk(pk_sub(a0, a2), m1, m2, acc);
+      acc = habs_lanes_pk(pk_sub(a1, a3), m1, m2, acc);
+    } else {
+#pragma unroll
+      for (int g = 0; g < H / 16; g++) {   // 8-row groups 2g and 2g+1 side by side
+        uint32_t a[8], b[8], d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = pk_pair(v[g * 16 + k], v[g * 16 + 8 + k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          b[2 * k] = pk_add(a[2 * k], a[2 * k + 1]);
+          b[2 * k + 1] = pk_sub(a[2 * k], a[2 * k + 1]);
+        }
+        d[0] = pk_add(b[0], b[2]); d[2] = pk_sub(b[0], b[2]);
+        d[1] = pk_add(b[1], b[3]); d[3] = pk_sub(b[1], b[3]);
+        d[4] = pk_add(b[4], b[6]); d[6] = pk_sub(b[4], b[6]);
+        d[5] = pk_add(b[5], b[7]); d[7] = pk_sub(b[5], b[7]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          acc = habs_lanes_pk(pk_add(d[k], d[k + 4]), m1, m2, acc);
+          acc = habs_lanes_pk(pk_sub(d[k], d[k + 4]), m1, m2, acc);
+        }
+      }
+    }
+    return acc;
+  }
 #pragma unroll
   for (int g = 0; g < H / TS; g++) {
     int32_t a[TS];
@@ -453,7 +530,7 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
     if (live && c == 0) sad_out[cand] = s;
   }
   if (satd_out) {
-    const uint32_t s = group_sum<P>(satd_column<TS, H>(v, lane));
+    const uint32_t s = group_sum<P>(satd_column<TS, H, BD>(v, lane));
     constexpr int LN = TS == 4 ? 2 : 3;
     if (live && c == 0) satd_out[cand] = (s + ((1u << LN) >> 1)) >> LN;
   }
