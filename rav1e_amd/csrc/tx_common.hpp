@@ -42,8 +42,18 @@ __device__ __forceinline__ T mul24(T a) {
   asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "n"(M), "v"(a));
   return r;
 }
-// __mul24 + add folds into one v_mad_i32_i24
-#define TX_MUL(a, m, s) ((T)((uint32_t)__mul24((a), (m)) + (uint32_t)((1 << (s)) >> 1)) >> (s))
+// (a * M + round) as ONE full-rate v_mad_i32_i24, spelled out: left to the
+// compiler (__mul24 + add) about a third of the network's multiplies came out
+// as quarter-rate v_mul_lo_u32 + v_add (the 24-bit range proof is lost in the
+// instruction selector's depth-limited known-bits walk).  Multiplier in an
+// SGPR, rounding constant in a VGPR (VOP3 has no literals on gfx9).
+template <int M, int S>
+__device__ __forceinline__ T mul_rs(T a) {
+  T r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(M), "v"((1 << S) >> 1));
+  return r >> S;
+}
+#define TX_MUL(a, m, s) (mul_rs<(m), (s)>(a))
 #include "fwd_tx_1d.inc"
 #undef TX_MUL
 }  // namespace m24
