@@ -462,10 +462,19 @@ __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, i
 }
 
 // One pass (log2b = 4, 3, 2 <-> ssdec 2, 1, 0) over the superblocks of one
-// anti-diagonal of every job.
+// anti-diagonal of every job.  The three passes run SKEWED in the same launch:
+// a superblock of pass q + 1 on diagonal d reads, besides its own area, the
+// left / top neighbours (diagonal d - 1, already pass q + 1) and the right /
+// bottom neighbours (diagonal d + 1, still pass q: get_subset_predictors samples
+// edge midpoints only, me.rs:420-452, never a diagonal neighbour), so it may
+// run as soon as pass q has finished diagonal d + 1 -- two launches behind.
+// Pass q on diagonal d + 2 meanwhile touches diagonals d + 1 .. d + 3 only.
+constexpr int kPassSkew = 2;
 template <int BPP>
 __global__ __launch_bounds__(256) void k_me_diag(const R1MeJob *__restrict__ jobs, R1MeParams p,
-                                                 int log2b, int diag) {
+                                                 int step) {
+  // blockIdx.z = pass; pass q works kPassSkew * q diagonals behind pass q - 1 (see the host loop)
+  const int log2b = 4 - (int)blockIdx.z, diag = step - kPassSkew * (int)blockIdx.z;
   const R1MeJob &job = jobs[blockIdx.y];
   const int sbw = (job.tile_w + SB - 1) / SB, sbh = (job.tile_h + SB - 1) / SB;
   const int sby = (int)blockIdx.x + imax(0, diag - (sbw - 1)), sbx = diag - sby;
@@ -953,15 +962,14 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   const R1MeJob *djobs = (const R1MeJob *)ctx->me_jobs[slot];
   const int ndiag = max_sbw + max_sbh - 1;
   const int dlen = max_sbw < max_sbh ? max_sbw : max_sbh;
-  for (int log2b = 4; log2b >= 2; log2b--)
-    for (int d = 0; d < ndiag; d++) {
-      if (bpp == 1)
-        hipLaunchKernelGGL(k_me_diag<1>, dim3(dlen, n_jobs), dim3(256), 0, st,
-                           djobs, *params, log2b, d);
-      else
-        hipLaunchKernelGGL(k_me_diag<2>, dim3(dlen, n_jobs), dim3(256), 0, st,
-                           djobs, *params, log2b, d);
-    }
+  // software pipeline over the passes: launch `step` runs diagonal step - 2 q of pass q
+  // (grid z = pass); ndiag + 4 launches instead of 3 * ndiag
+  for (int step = 0; step < ndiag + 2 * kPassSkew; step++) {
+    if (bpp == 1)
+      hipLaunchKernelGGL(k_me_diag<1>, dim3(dlen, n_jobs, 3), dim3(256), 0, st, djobs, *params, step);
+    else
+      hipLaunchKernelGGL(k_me_diag<2>, dim3(dlen, n_jobs, 3), dim3(256), 0, st, djobs, *params, step);
+  }
   R1_HIP_CHECK(hipGetLastError());
   R1_HIP_CHECK(hipEventRecord(ctx->me_done[slot], st));
   return R1_OK;

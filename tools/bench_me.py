@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (tens of seconds)")
     ap.add_argument("--only", type=int, default=-1, help="run only tile-ME configuration i (for profiling)")
+    ap.add_argument("--tile-only", action="store_true", help="stop after the tile-ME configurations")
     args = ap.parse_args()
     import torch
     import oracle_lib as O
@@ -81,7 +82,7 @@ def main():
                           "tiles": len(tl), "refs": nref, "jobs": len(jobs), "ms": round(ms, 3),
                           "Mpixels_s": round(w * h * nref / ms / 1e3, 1),
                           "frames_refs_per_s": round(nref / ms * 1e3, 1)}), flush=True)
-    if args.only >= 0:
+    if args.only >= 0 or args.tile_only:
         ctx.close()
         return
     # ---- RDO-time estimate_motion (full-pel + SATD + sub-pel diamond) on every block of a size ----
