@@ -203,13 +203,22 @@ __global__ __launch_bounds__(64) void k_intra_predict(
   const int FL = 2 * (W + H) + 1;
   const int lane = threadIdx.x;
   const int cl = lane >> wl, c = lane & (W - 1);
-  const long long cand = (long long)blockIdx.x * NC + cl;
-  const bool live = cand < n;
+  // SATD_OUT: a wave takes ONE member of the group (one mode of the pre-screen) for NC
+  // consecutive blocks, so every lane runs the same predictor; with the candidates in
+  // list order a 16x16 wave held four different modes and paid for all four branches.
+  long long cand = (long long)blockIdx.x * NC + cl;
+  bool live = cand < n;
+  long long ecand = cand;             // edge set / block of this candidate
+  if constexpr (SATD_OUT) {
+    const unsigned bg = blockIdx.x / (unsigned)group, mi = blockIdx.x - bg * (unsigned)group;
+    ecand = (long long)bg * NC + cl;
+    live = ecand < n / group;
+    cand = ecand * group + mi;
+  }
   uint16_t *raw = smem + cl * EDGE_LEN;
   uint16_t *work = smem + NC * EDGE_LEN + cl * (4 * FL);   // af0 af1 lf0 lf1
   R1IntraCand cd = {};
   int left_len = 0, above_len = 0;
-  const long long ecand = SATD_OUT ? cand / group : cand;   // edge set / block of this candidate
   if (live) {
     cd = cands[cand];
     left_len = lens[2 * ecand];
@@ -414,13 +423,49 @@ __global__ __launch_bounds__(64) void k_intra_predict(
     }
   }
   if constexpr (SATD_OUT) {
-    // get_satd(source block, prediction): one lane per Hadamard tile, the
-    // candidate's W lanes hold at least (W/TS)*(H/TS) tiles for every tx size
     __builtin_amdgcn_wave_barrier();
     const bool small = (W < H ? W : H) == 4;
     const int ts = small ? 4 : 8, ntx = W / ts, nt = ntx * (H / ts);
     uint32_t sum = 0;
-    if (c < nt) {
+    if (!small) {
+      // get_satd with 8x8 tiles, lane = column (every lane of the candidate works): the
+      // lane re-reads the column it just wrote, takes the vertical Hadamard of each 8-row
+      // group on registers and the horizontal one across its 8-lane tile by DPP (the
+      // fused candidate kernel's scheme, rdo_cand.hip) -- with one lane per tile a 16x16
+      // block kept 4 of its 16 lanes busy for 64 pixels each.
+      const int32_t s1 = -(int32_t)((lane ^ (lane >> 2)) & 1);
+      const int32_t s2 = -(int32_t)(((lane >> 1) ^ (lane >> 2)) & 1);
+      const int bx = pos_xy[2 * ecand], by = pos_xy[2 * ecand + 1];
+      const uint8_t *ps = px_addr<BPP>(src, bx + c, by);
+      const size_t ss = (size_t)src.stride * BPP;
+      for (int g = 0; g < H; g += 8) {
+        int32_t a[8], b[8], d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          a[k] = ldp<BPP>(ps + (size_t)(g + k) * ss, 0) - ldp<BPP>(out, (size_t)(g + k) * W + c);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          b[2 * k] = a[2 * k] + a[2 * k + 1];
+          b[2 * k + 1] = a[2 * k] - a[2 * k + 1];
+        }
+        d[0] = b[0] + b[2]; d[2] = b[0] - b[2];
+        d[1] = b[1] + b[3]; d[3] = b[1] - b[3];
+        d[4] = b[4] + b[6]; d[6] = b[4] - b[6];
+        d[5] = b[5] + b[7]; d[7] = b[5] - b[7];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          // masks {1, 2, 7} span (Z/2)^3: a Walsh-Hadamard transform in a relabelled lane
+          // order, same multiset of coefficients; the last stage is folded into the abs,
+          // |p + q| + |p - q| = 2 max(|p|, |q|)
+          int32_t x = k < 4 ? d[k] + d[k + 4] : d[k - 4] - d[k];
+          x = __mul24(x, s1 | 1) + __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);
+          x = __mul24(x, s2 | 1) + __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);
+          const int32_t ax = iabs(x);
+          const int32_t ap = __builtin_amdgcn_update_dpp(0, ax, 0x141, 0xf, 0xf, true);
+          sum += (uint32_t)(ax > ap ? ax : ap);
+        }
+      }
+    } else if (c < nt) {
       const int tx = c % ntx, ty = c / ntx;
       const int bx = pos_xy[2 * ecand], by = pos_xy[2 * ecand + 1];
       const uint8_t *po = px_addr<BPP>(src, bx + tx * ts, by + ty * ts);
@@ -625,7 +670,7 @@ extern "C" int r1_intra_satd_batch(r1_ctx *ctx, const R1Plane *src, int tx_size,
   const int NC = 64 / W, FL = 2 * (W + H) + 1;
   const size_t lds = (((size_t)NC * (EDGE_LEN + 4 * FL) * sizeof(uint16_t) + 15) & ~(size_t)15) +
                      (size_t)NC * W * H * src->bytes_per_px;
-  const unsigned grid = (unsigned)((n + NC - 1) / NC);
+  const unsigned grid = (unsigned)((n / group + NC - 1) / NC) * (unsigned)group;   // (block group, member)
   hipStream_t st = (hipStream_t)stream;
   if (src->bytes_per_px == 1)
     hipLaunchKernelGGL((k_intra_predict<1, true>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
