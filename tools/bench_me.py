@@ -78,10 +78,23 @@ def main():
             run()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.reps * 1e3
-        print(json.dumps({"kernel": "estimate_tile_motion", "frame": "%dx%d" % (w, h), "bit_depth": bd,
-                          "tiles": len(tl), "refs": nref, "jobs": len(jobs), "ms": round(ms, 3),
-                          "Mpixels_s": round(w * h * nref / ms / 1e3, 1),
-                          "frames_refs_per_s": round(nref / ms * 1e3, 1)}), flush=True)
+        row = {"kernel": "estimate_tile_motion", "frame": "%dx%d" % (w, h), "bit_depth": bd,
+               "tiles": len(tl), "refs": nref, "jobs": len(jobs), "ms": round(ms, 3),
+               "Mpixels_s": round(w * h * nref / ms / 1e3, 1),
+               "frames_refs_per_s": round(nref / ms * 1e3, 1)}
+        if args.cpu and len(jobs) > 1:
+            # every job of the concurrent launch against the oracle run tile by tile
+            L = O.lib()
+            L.r1o_set_threads(1)
+            same = True
+            for r in range(nref):
+                st = np.zeros((rows, cols), O.ME_STATS)
+                for t in tl:
+                    O.me_oracle(L, po, prs[r], cols, rows, t, bd, lam, st)
+                got = stats[r].cpu().numpy().reshape(rows, -1).view(O.ME_STATS).reshape(rows, cols)
+                same = same and bool(np.array_equal(got, st))
+            row["all_jobs_equal_oracle"] = same
+        print(json.dumps(row), flush=True)
     if args.only >= 0 or args.tile_only:
         ctx.close()
         return
