@@ -347,6 +347,21 @@ int r1_intra_satd_batch(r1_ctx *ctx, const R1Plane *src, int tx_size, const R1In
                         int edge_stride, const uint8_t *lens, const int16_t *ac,
                         uint32_t *satd_out, void *stream);
 
+/* The selection step of both mode pre-screens (SURVEY.md 8f "N1": "returning
+ * sorted candidate lists"): per group of `group` keys (the SATDs of one block's
+ * candidates, in the caller's order -- for the intra pre-screen that is the
+ * probability order of src/rdo.rs:1424-1428) the first `keep_head` candidates
+ * keep their places, the rest are STABLY sorted by key, and the first k of the
+ * resulting list are returned as indices into the group:
+ *   intra  modes[num_modes_rdo / 2..].sort_by_key(satd); take(num_modes_rdo)
+ *          (src/rdo.rs:1504-1509): keep_head = num_modes_rdo / 2, k = num_modes_rdo
+ *   inter  sorted.sort_by_key(satd); take(num_modes_rdo) (src/rdo.rs:1352-1357):
+ *          keep_head = 0
+ * keys: n_groups * group (device), idx_out: n_groups * k bytes (device).
+ * 1 <= k <= group <= 64, 0 <= keep_head <= k. */
+int r1_prescreen_select_batch(r1_ctx *ctx, const uint32_t *keys, int n_groups, int group,
+                              int keep_head, int k, uint8_t *idx_out, void *stream);
+
 /* ---- hierarchical motion estimation of whole tiles (SURVEY.md 8f "N2").
  * Replaces estimate_tile_motion (src/me.rs:153-218) for one (tile, reference
  * frame) pair per job: the three passes (quarter, half, full resolution) of

@@ -286,6 +286,17 @@ class Context:
             "r1_intra_satd_batch")
         return out
 
+    def prescreen_select_batch(self, keys, group, keep_head, k):
+        """the selection step of the mode pre-screens (src/rdo.rs:1352-1357, 1504-1509): keys
+        (n_groups * group,) int32 SATDs in the caller's candidate order -> (n_groups, k) uint8
+        indices: the first keep_head candidates stay, the rest stably sorted by key, take k"""
+        n_groups = keys.numel() // group
+        out = torch.empty((n_groups, k), dtype=torch.uint8, device="cuda")
+        self._check(self.lib.r1_prescreen_select_batch(self.h, keys.data_ptr(), n_groups, group,
+                                                       keep_head, k, out.data_ptr(), _stream_ptr()),
+                    "r1_prescreen_select_batch")
+        return out
+
     def cfl_alpha_search_batch(self, src, tx_size, cands, edges, lens, ac, n=None):
         """rdo_cfl_alpha (src/rdo.rs:1593-1688) for one chroma plane -> (alpha int16, sse int64)"""
         dc = _dev_cands(cands, CFL_ALPHA_CAND)

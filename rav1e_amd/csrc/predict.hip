@@ -479,6 +479,29 @@ __global__ __launch_bounds__(64) void k_intra_predict(
   }
 }
 
+// r1_prescreen_select_batch: one thread per (group, element).  An element's place in the
+// stable sort is the number of elements that precede it: smaller key, or equal key and
+// smaller index -- no sorting network, the groups have at most 64 members.
+__global__ __launch_bounds__(256) void k_prescreen_select(const uint32_t *__restrict__ keys,
+                                                          int n_groups, int group, int head, int k,
+                                                          uint8_t *__restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long g = t / group;
+  const int j = (int)(t - g * group);
+  if (g >= n_groups) return;
+  const uint32_t *kg = keys + g * group;
+  int place = j;
+  if (j >= head) {
+    const uint32_t kj = kg[j];
+    place = head;
+    for (int i = head; i < group; i++) {
+      const uint32_t ki = kg[i];
+      place += (ki < kj) || (ki == kj && i < j);
+    }
+  }
+  if (place < k) out[g * k + place] = (uint8_t)j;
+}
+
 // pred_cfl_ac (predict.rs:1020-1063): one wave per candidate
 template <int BPP>
 __global__ __launch_bounds__(64) void k_cfl_ac(R1Plane luma, int bw, int bh, int xdec, int ydec,
@@ -680,6 +703,19 @@ extern "C" int r1_intra_satd_batch(r1_ctx *ctx, const R1Plane *src, int tx_size,
     hipLaunchKernelGGL((k_intra_predict<2, true>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
                        (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, src->bit_depth,
                        (void *)nullptr, *src, pos_xy, group, satd_out);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_prescreen_select_batch(r1_ctx *ctx, const uint32_t *keys, int n_groups, int group,
+                                         int keep_head, int k, uint8_t *idx_out, void *stream) {
+  R1_REQUIRE(ctx);
+  R1_REQUIRE(group >= 1 && group <= 64 && k >= 1 && k <= group && keep_head >= 0 && keep_head <= k);
+  if (n_groups <= 0) return R1_OK;
+  R1_REQUIRE(keys && idx_out);
+  const long long total = (long long)n_groups * group;
+  hipLaunchKernelGGL(k_prescreen_select, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, keys, n_groups, group, keep_head, k, idx_out);
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }

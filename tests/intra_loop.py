@@ -99,6 +99,9 @@ class OracleBackend:
             out[k] = self.L.r1o_get_satd(src.block_ptr(x, y), src.stride, O.ptr(p), w, w, h, self.hbd)
         return out
 
+    def select(self, satds):
+        return int(np.argmin(satds))
+
     def code_block(self, src, x, y, ts, w, h, pred, qindex, kind, xdec, ydec):
         c = np.zeros(1, O.RDO_CAND)
         c["ox"], c["oy"] = x, y
@@ -158,6 +161,10 @@ class DeviceBackend:
         return self.ctx.intra_satd_batch(src, ts, self._cands(cands, w, h), len(cands), pos, edge,
                                          lens).cpu().numpy().view(np.uint32)
 
+    def select(self, satds):
+        keys = self.torch.from_numpy(np.ascontiguousarray(satds).view(np.int32)).cuda()
+        return int(self.ctx.prescreen_select_batch(keys, len(satds), 0, 1).cpu().numpy()[0, 0])
+
     def code_block(self, src, x, y, ts, w, h, pred, qindex, kind, xdec, ydec):
         c = np.zeros(1, self.api.RDO_CAND)
         c["ox"], c["oy"] = x, y
@@ -214,7 +221,7 @@ def _run_frame(be, y, u, v, qindex):
                 pm = remap_mode(m, var)
                 cands.append((pm, var, BASE_ANGLE[pm], ief if 1 <= pm <= 8 else 0))
             satds = be.satd13(src[0], bx, by, TX_32X32, 32, 32, cands, e0, l0)
-            best = int(np.argmin(satds))           # first minimum, like the stable sort of rdo.rs:1500
+            best = be.select(satds)                # first minimum = head of the stable sort of rdo.rs:1504
             modes[(bx, by)] = best
             r = dict(bx=bx, by=by, satds=np.asarray(satds).copy(), mode=best, planes=[])
             # ---- encode_tx_block per plane

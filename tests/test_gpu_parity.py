@@ -1482,3 +1482,34 @@ def test_widened_entry_points_reject_bad_arguments(ctx):
     c = np.zeros(4, RDO_CAND)
     with pytest.raises(R1Error):      # cdef_dist is a luma-only distortion
         ctx.rdo_pixel_cand_batch(a, a, 16, 16, c, 100, 3, xdec=1, ydec=1)
+
+
+# ------------------------ N1: the selection step of the mode pre-screens
+@pytest.mark.gpu
+def test_prescreen_select_matches_the_reference_sorts(ctx):
+    """r1_prescreen_select_batch against the reference's own statements run on the host:
+    intra  `modes[num_modes_rdo / 2..].sort_by_key(|&a| satds[a])` + take (src/rdo.rs:1504-1509),
+    inter  `sorted.sort_by_key(satd)` + take (src/rdo.rs:1352-1357); Rust's sort_by_key is
+    stable, like Python's sorted().  Keys with many ties, every (group, keep_head, k)."""
+    import torch
+    from rav1e_amd.api import R1Error
+    rng = np.random.default_rng(77)
+    for group in (1, 2, 3, 13, 20, 64):
+        n_groups = 257
+        for hi in (3, 1 << 20):                           # hi = 3: almost everything ties
+            keys = rng.integers(0, hi, (n_groups, group)).astype(np.uint32)
+            dk = torch.from_numpy(keys.view(np.int32).reshape(-1).copy()).cuda()
+            for k in sorted({1, min(3, group), min(7, group), group}):
+                for head in sorted({0, k // 2, k}):
+                    got = ctx.prescreen_select_batch(dk, group, head, k).cpu().numpy()
+                    for g in range(n_groups):
+                        modes = list(range(group))
+                        modes[head:] = sorted(modes[head:], key=lambda a: keys[g, a])
+                        assert list(got[g]) == modes[:k], (group, hi, k, head, g)
+    e = torch.zeros(0, dtype=torch.int32, device="cuda")
+    assert ctx.prescreen_select_batch(e, 13, 1, 3).shape == (0, 3)        # empty batch
+    one = torch.zeros(13, dtype=torch.int32, device="cuda")
+    for bad in ((65, 0, 1), (13, 0, 0), (13, 0, 14), (13, 4, 3), (13, -1, 3)):
+        with pytest.raises(R1Error):
+            ctx.prescreen_select_batch(one if bad[0] == 13 else torch.zeros(65, dtype=torch.int32, device="cuda"),
+                                       *bad)
