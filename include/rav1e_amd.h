@@ -333,6 +333,25 @@ int r1_importance_block_difference(r1_ctx *ctx, const R1Plane *org, const R1Plan
 int r1_activity_scales(r1_ctx *ctx, const R1Plane *luma, uint32_t *variances, uint32_t *scales,
                        void *stream);
 
+/* update_block_importances (SURVEY.md 8f "N1"; src/api/internal.rs:911-1068)
+ * after its SATD map, which is the map of r1_estimate_inter_costs with
+ * mvs[i] = me_stats[2y][2x].mv: every 8x8 importance block i of the current
+ * frame adds  (intra_cost + future_importance) * (1 - inter_cost / intra_cost) / len
+ * (0 when intra_cost <= inter_cost), split by overlap area, to the importance
+ * blocks of the reference frame under its motion-compensated position.  All
+ * maps are w_in_imp_b x h_in_imp_b, row-major, DEVICE; ref_importances is
+ * updated in place.  f32 throughout, one IEEE operation at a time and summed
+ * in the reference's order (source blocks in raster order): the result is
+ * bit-identical to the sequential loop.  scratch: DEVICE, 256-byte aligned,
+ * at least r1_update_block_importances_scratch_bytes(w, h) bytes (pair lists +
+ * the radix sort's workspace; < 0 on error), caller-owned like every buffer. */
+long long r1_update_block_importances_scratch_bytes(int w_in_imp_b, int h_in_imp_b);
+int r1_update_block_importances(r1_ctx *ctx, const uint32_t *intra_costs,
+                                const float *future_importances, const uint32_t *inter_costs,
+                                const int16_t *mvs, int w_in_imp_b, int h_in_imp_b, int len,
+                                float *ref_importances, void *scratch, long long scratch_bytes,
+                                void *stream);
+
 /* ---- intra mode pre-screen (SURVEY.md 8f "N1"; src/rdo.rs:1434-1506): for
  * every block the candidate modes are predicted from ONE edge set
  * (get_intra_edges with IntraParam::None) and ranked by get_satd against the

@@ -6,6 +6,8 @@
  *     (get_intra_edges -> DC_PRED predict_intra -> get_satd per 8x8 block)
  *   estimate_importance_block_difference  src/api/lookahead.rs:125-180
  *   estimate_inter_costs (the SATD map)   src/api/lookahead.rs:226-268
+ *   update_block_importances              src/api/internal.rs:911-1068
+ *     (its SATD map is estimate_inter_costs' map; the f32 propagation follows)
  *     (the motion vectors come from compute_motion_vectors -- motion search is
  *      a separate "next" row -- and are an input here)
  */
@@ -103,5 +105,48 @@ void r1o_activity_scales(const r1o_plane *luma, uint32_t *variances, uint32_t *s
       const uint32_t var = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v;
       if (variances) variances[by * wb + bx] = var;
       if (scales) scales[by * wb + bx] = r1o_apply_ssim_boost(1u << 14, var, var, luma->bit_depth);
+    }
+}
+
+/* update_block_importances (src/api/internal.rs:911-1068) after its get_satd:
+ * every 8x8 importance block of the current frame hands
+ *   (intra_cost + future_importance) * (1 - inter_cost / intra_cost) / len
+ * to the (up to) four importance blocks of the reference frame that its motion-
+ * compensated position overlaps, by overlap area.  All arithmetic is f32, one
+ * IEEE operation at a time (Rust never contracts a * b + c), and the additions
+ * into `ref_importances` happen in the raster order of the source blocks,
+ * top-left / top-right / bottom-left / bottom-right within a block.
+ * intra_costs / inter_costs / future_importances / ref_importances: w x h maps;
+ * mvs: (row, col) in 1/8 pel per block (me_stats[2y][2x].mv). */
+void r1o_update_block_importances(const uint32_t *intra_costs, const float *future_importances,
+                                  const uint32_t *inter_costs, const int16_t *mvs, int w, int h,
+                                  int len, float *ref_importances) {
+  const int64_t U = 64; /* IMP_BLOCK_SIZE_IN_MV_UNITS = 8 px * 8 units */
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const int i = y * w + x;
+      const int64_t rx = (int64_t)x * U + mvs[2 * i + 1], ry = (int64_t)y * U + mvs[2 * i];
+      const float inter = (float)inter_costs[i], intra = (float)intra_costs[i];
+      volatile float frac = 0.f; /* volatile: no re-association, no contraction */
+      if (!(intra <= inter)) {
+        volatile float q = inter / intra;
+        frac = 1.f - q;
+      }
+      volatile float sum = intra + future_importances[i];
+      volatile float prod = sum * frac;
+      const float amount = prod / (float)len;
+      const int64_t tlx = (rx - (rx < 0 ? U - 1 : 0)) / U * U, tly = (ry - (ry < 0 ? U - 1 : 0)) / U * U;
+      const int64_t bx[4] = { tlx, tlx + U, tlx, tlx + U }, by[4] = { tly, tly, tly + U, tly + U };
+      const int64_t wx[4] = { tlx + U - rx, rx + U - (tlx + U), tlx + U - rx, rx + U - (tlx + U) };
+      const int64_t wy[4] = { tly + U - ry, tly + U - ry, ry + U - (tly + U), ry + U - (tly + U) };
+      for (int c = 0; c < 4; c++) {
+        const int64_t dx = bx[c] / U, dy = by[c] / U;
+        if (dx >= 0 && dy >= 0 && dx < w && dy < h) {
+          const float fraction = (float)(wx[c] * wy[c]) / (float)(U * U);
+          volatile float add = amount * fraction;
+          volatile float acc = ref_importances[dy * w + dx] + add;
+          ref_importances[dy * w + dx] = acc;
+        }
+      }
     }
 }

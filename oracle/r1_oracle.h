@@ -171,6 +171,9 @@ void r1o_estimate_intra_costs(const r1o_plane *plane, int bit_depth, uint32_t *c
 uint64_t r1o_importance_block_difference(const r1o_plane *org, const r1o_plane *ref);
 void r1o_estimate_inter_costs(const r1o_plane *org, const r1o_plane *ref, const int16_t *mvs,
                               uint32_t *costs);
+void r1o_update_block_importances(const uint32_t *intra_costs, const float *future_importances,
+                                  const uint32_t *inter_costs, const int16_t *mvs, int w, int h,
+                                  int len, float *ref_importances);
 /* hierarchical motion estimation of one tile against one reference
  * (src/me.rs:153-335, see oracle/me.c).  org3 / ref3: [full, half, quarter]
  * resolution planes; stats: FrameMEStats of this reference (in/out), prev: the

@@ -80,6 +80,9 @@ SYMBOLS = {
     "r1_deblock_pick_levels": (_i, [_vp, _vp, _i, _vp]),
     "r1_intra_satd_batch": (_i, [_vp, _PP, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "r1_prescreen_select_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "r1_update_block_importances_scratch_bytes": (C.c_longlong, [_i, _i]),
+    "r1_update_block_importances": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, C.c_longlong,
+                                         _vp]),
     "r1_rdo_pixel_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, C.POINTER(R1QuantParams), _i,
                                      _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "r1_rdo_pred_cand_batch": (_i, [_vp, _PP, _vp, _i, _i, _i, _vp, _i, C.POINTER(R1QuantParams), _i,

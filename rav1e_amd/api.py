@@ -286,6 +286,21 @@ class Context:
             "r1_intra_satd_batch")
         return out
 
+    def update_block_importances(self, intra_costs, future_importances, inter_costs, mvs, w, h, length,
+                                 ref_importances):
+        """update_block_importances after its SATD map (src/api/internal.rs:911-1068); device
+        tensors: int32 (w*h) costs, float32 importances, int16 (w*h, 2) (row, col) motion vectors;
+        ref_importances (float32) is updated in place"""
+        need = self.lib.r1_update_block_importances_scratch_bytes(w, h) if w * h else 0
+        if need < 0:
+            raise R1Error("r1_update_block_importances_scratch_bytes failed")
+        scratch = torch.empty(max(int(need), 256), dtype=torch.uint8, device="cuda")
+        self._check(self.lib.r1_update_block_importances(
+            self.h, intra_costs.data_ptr(), future_importances.data_ptr(), inter_costs.data_ptr(),
+            mvs.data_ptr(), w, h, length, ref_importances.data_ptr(), scratch.data_ptr(),
+            scratch.numel(), _stream_ptr()), "r1_update_block_importances")
+        return ref_importances
+
     def prescreen_select_batch(self, keys, group, keep_head, k):
         """the selection step of the mode pre-screens (src/rdo.rs:1352-1357, 1504-1509): keys
         (n_groups * group,) int32 SATDs in the caller's candidate order -> (n_groups, k) uint8

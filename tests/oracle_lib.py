@@ -90,6 +90,7 @@ def lib():
         "r1o_estimate_intra_costs": (None, [vp, i, vp]),
         "r1o_importance_block_difference": (C.c_uint64, [vp, vp]),
         "r1o_estimate_inter_costs": (None, [vp, vp, vp, vp]),
+        "r1o_update_block_importances": (None, [vp, vp, vp, vp, i, i, i, vp]),
         "r1o_tx_domain_distortion": (C.c_uint64, [vp, vp, i, i]),
         "r1o_estimate_rate": (C.c_uint64, [i, i, C.c_uint64]),
         "r1o_quantize_rdo_batch": (i, [vp, i, i, i, i, i, i, i, i, i, i, vp, vp, vp, vp, vp]),

@@ -1513,3 +1513,51 @@ def test_prescreen_select_matches_the_reference_sorts(ctx):
         with pytest.raises(R1Error):
             ctx.prescreen_select_batch(one if bad[0] == 13 else torch.zeros(65, dtype=torch.int32, device="cuda"),
                                        *bad)
+
+
+# ------------------------ N1: update_block_importances (f32 scatter-add in the reference's order)
+@pytest.mark.gpu
+def test_update_block_importances_bit_exact(ctx, oracle):
+    """r1_update_block_importances against the oracle, compared as raw f32 bits: random motion
+    fields (in range, far off-frame, block-aligned), many sources per destination (all vectors
+    point at one block), 4K-sized maps; then chained over three references like the caller does."""
+    import torch
+    from test_oracle_lookahead import importance_case
+    rng = np.random.default_rng(43)
+
+    def run(w, h, length, intra, future, inter, mvs, ref_imp):
+        want = ref_imp.copy()
+        oracle.r1o_update_block_importances(O.ptr(intra), O.ptr(future), O.ptr(inter), O.ptr(mvs), w, h,
+                                            length, O.ptr(want))
+        got = ctx.update_block_importances(_t(intra.view(np.int32)), _t(future), _t(inter.view(np.int32)),
+                                           _t(mvs), w, h, length, _t(ref_imp.copy()))
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), (w, h, length)
+        return want
+
+    for (w, h, mvr, length) in ((24, 16, 300, 1), (17, 9, 2000, 3), (1, 1, 64, 2), (480, 270, 700, 4),
+                                (240, 135, 30000, 7)):
+        run(w, h, length, *importance_case(rng, w, h, mvr))
+    # every block points at (about) the same destination: long sequential chains
+    w, h = 64, 40
+    intra, future, inter, mvs, ref_imp = importance_case(rng, w, h, 20)
+    yy, xx = np.divmod(np.arange(w * h), w)
+    mvs[:, 0] += ((h // 2 - yy) * 64).astype(np.int16)
+    mvs[:, 1] += ((w // 2 - xx) * 64).astype(np.int16)
+    run(w, h, 2, intra, future, inter, mvs, ref_imp)
+    # chained like compute_block_importances: the same reference map updated from three frames
+    w, h = 120, 68
+    acc = np.zeros(w * h, np.float32)
+    dacc = _t(acc.copy())
+    for _ in range(3):
+        intra, future, inter, mvs, _unused = importance_case(rng, w, h, 500)
+        oracle.r1o_update_block_importances(O.ptr(intra), O.ptr(future), O.ptr(inter), O.ptr(mvs), w, h,
+                                            3, O.ptr(acc))
+        ctx.update_block_importances(_t(intra.view(np.int32)), _t(future), _t(inter.view(np.int32)),
+                                     _t(mvs), w, h, 3, dacc)
+    assert np.array_equal(dacc.cpu().numpy().view(np.uint32), acc.view(np.uint32))
+    # empty map and argument checks
+    from rav1e_amd.api import R1Error
+    e = torch.zeros(0, dtype=torch.int32, device="cuda")
+    ctx.update_block_importances(e, e.float(), e, e.short(), 0, 0, 1, e.float())
+    with pytest.raises(R1Error):
+        ctx.update_block_importances(e, e.float(), e, e.short(), 4, 4, 0, e.float())

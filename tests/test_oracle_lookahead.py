@@ -86,3 +86,73 @@ def test_activity_scales_definition(oracle):
         want = (1 << 14) * (3355.0 / 12338.0) * (2 * v + 16128) / np.sqrt(3355.0 ** 2 + v * v)
         rel = np.abs(sc.astype(np.float64) - want) / want
         assert rel.max() < 0.05, rel.max()
+
+
+# ---- update_block_importances (src/api/internal.rs:911-1068): the f32 propagation
+def importance_model(intra, future, inter, mvs, w, h, length, ref_imp):
+    """Independent restatement with numpy float32 scalars (one rounding per operation),
+    written from the reference text: floor-to-block of the reference position, the four
+    overlap areas, sequential += in source raster order."""
+    f32 = np.float32
+    out = ref_imp.astype(np.float32).copy()
+    for y in range(h):
+        for x in range(w):
+            i = y * w + x
+            rx, ry = x * 64 + int(mvs[i, 1]), y * 64 + int(mvs[i, 0])
+            ic, nc = f32(intra[i]), f32(inter[i])
+            frac = f32(0.0) if ic <= nc else f32(1.0) - nc / ic
+            amount = (ic + f32(future[i])) * frac / f32(length)
+            tlx, tly = (rx // 64) * 64, (ry // 64) * 64          # Python floor division
+            for (bx, by, ax, ay) in ((tlx, tly, tlx + 64 - rx, tly + 64 - ry),
+                                     (tlx + 64, tly, rx - tlx, tly + 64 - ry),
+                                     (tlx, tly + 64, tlx + 64 - rx, ry - tly),
+                                     (tlx + 64, tly + 64, rx - tlx, ry - tly)):
+                dx, dy = bx // 64, by // 64
+                if 0 <= dx < w and 0 <= dy < h:
+                    out[dy * w + dx] = out[dy * w + dx] + amount * (f32(ax * ay) / f32(4096))
+    return out
+
+
+def n_moved(a, b):
+    return int((a > b).sum())
+
+
+def importance_case(rng, w, h, mv_range):
+    n = w * h
+    intra = rng.integers(0, 5000, n).astype(np.uint32)
+    inter = np.where(rng.random(n) < 0.3, intra + rng.integers(0, 50, n),
+                     (intra * rng.random(n)).astype(np.int64)).astype(np.uint32)
+    k = min(3, n)
+    intra[:k], inter[:k] = [0, 0, 7][:k], [0, 5, 7][:k]        # 0 / 0 never divides: intra <= inter
+    future = (rng.random(n) * 3000).astype(np.float32)
+    mvs = rng.integers(-mv_range, mv_range + 1, (n, 2)).astype(np.int16)
+    mvs[::7] = (mvs[::7] // 64) * 64                           # block-aligned: zero-area neighbours
+    ref_imp = (rng.random(n) * 100).astype(np.float32)
+    return intra, future, inter, mvs, ref_imp
+
+
+def test_update_block_importances_against_the_float32_model(oracle):
+    rng = np.random.default_rng(41)
+    for (w, h, mvr, length) in ((24, 16, 300, 1), (17, 9, 2000, 3), (5, 4, 40, 7), (1, 1, 64, 2)):
+        intra, future, inter, mvs, ref_imp = importance_case(rng, w, h, mvr)
+        want = importance_model(intra, future, inter, mvs, w, h, length, ref_imp)
+        got = ref_imp.copy()
+        oracle.r1o_update_block_importances(O.ptr(intra), O.ptr(future), O.ptr(inter), O.ptr(mvs), w, h,
+                                            length, O.ptr(got))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (w, h)
+        assert (got >= ref_imp).all() and (n_moved(got, ref_imp) or w * h == 1)
+
+
+def test_update_block_importances_conserves_what_stays_in_frame(oracle):
+    """zero motion: every block keeps its own amount (one overlap of area 1, three of area 0)"""
+    rng = np.random.default_rng(42)
+    w, h = 12, 7
+    intra, future, inter, mvs, ref_imp = importance_case(rng, w, h, 0)
+    mvs[:] = 0
+    got = np.zeros(w * h, np.float32)
+    oracle.r1o_update_block_importances(O.ptr(intra), O.ptr(future), O.ptr(inter), O.ptr(mvs), w, h, 2,
+                                        O.ptr(got))
+    ic, nc = intra.astype(np.float32), inter.astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        frac = np.where(ic <= nc, np.float32(0), np.float32(1) - nc / ic).astype(np.float32)
+    assert np.array_equal(got, ((ic + future) * frac / np.float32(2)).astype(np.float32))

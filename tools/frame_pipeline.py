@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One coded 4K frame's device-resident work, end to end, with every piece of this backend:
 
-  lookahead cost maps -> hierarchical ME (tiles x references) -> RDO-time sub-pel ME ->
+  lookahead cost maps -> hierarchical ME (tiles x references) -> block importances ->
+  RDO-time sub-pel ME ->
   intra pre-screen -> RDO candidates (pixel-domain chain) -> deblock level search ->
   deblock -> CDEF -> loop restoration
 
@@ -71,6 +72,20 @@ def main():
     jobs = [dict(org=org, ref=refs[r], stats=stats[r], tile=(x0, y0, x1 - x0, y1 - y0))
             for r in range(len(refs)) for (x0, y0, x1, y1) in rects]
     timed("estimate_tile_motion_8tiles_x_3refs", lambda: ctx.estimate_tile_motion(jobs, cols, rows, bd, lam))
+    # 2b block importances: update_block_importances over the three references -- SATD map at
+    # the ME's vectors (every second MEStats entry), then the f32 propagation
+    hb, wb = fh // 8, fw // 8
+    intra_costs = ctx.estimate_intra_costs(org[0]).reshape(-1)
+    future = torch.zeros(hb * wb, dtype=torch.float32, device="cuda")
+    ref_imp = [torch.zeros(hb * wb, dtype=torch.float32, device="cuda") for _ in refs]
+
+    def importances():
+        for r in range(len(refs)):
+            mv = stats[r].view(torch.int16).reshape(rows, cols, 4)[0:2 * hb:2, 0:2 * wb:2, 0:2].contiguous()
+            inter = ctx.estimate_inter_costs(org[0], refs[r][0], mv)
+            ctx.update_block_importances(intra_costs, future, inter.reshape(-1), mv, wb, hb, len(refs),
+                                         ref_imp[r])
+    timed("update_block_importances_3refs", importances)
     # 3 RDO-time sub-pel ME on every 16x16 block, first reference
     c = np.zeros((fw // 16) * (fh // 16), api.ME_BLOCK_CAND)
     c["bx"] = np.tile(np.arange(fw // 16) * 4, fh // 16)
@@ -152,6 +167,7 @@ def main():
     def overlapped():
         with torch.cuda.stream(s_me):
             ctx.estimate_tile_motion(jobs, cols, rows, bd, lam)
+            importances()
         with torch.cuda.stream(s_rdo):
             ctx.estimate_motion_batch(job0, dc, cols, rows, bd, lam, max_w=16, max_h=16, n=len(c))
             prescreen()
