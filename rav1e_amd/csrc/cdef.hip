@@ -186,13 +186,15 @@ struct CdefFrameArgs {
 // [0, 8*floor(W/8)) x [0, 8*floor(H/8)) in luma units: that is what the
 // reference's edge flags (`bx + 1 >= xavail >> 3`, first row / column of the
 // frame; cdef.rs:441-459) say for every block at once.
-template <int BPP>
+template <int BPP, int XD, int YD>
 __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
   __shared__ int32_t part[4][128];
   __shared__ uint16_t tile[20 * 20];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int xs = 8 >> a.xdec, ys = 8 >> a.ydec;
-  const int TW = 2 * xs + 4, TH = 2 * ys + 4;
+  // the plane's decimation is a template parameter: tile geometry, the index
+  // arithmetic of the staging and the lane -> pixel map become constants
+  constexpr int xs = 8 >> XD, ys = 8 >> YD;
+  constexpr int TW = 2 * xs + 4, TH = 2 * ys + 4;
   const int gbx = blockIdx.x * 2 + (wave & 1), gby = blockIdx.y * 2 + (wave >> 1);
   const int fbx = gbx >> 3, fby = gby >> 3, bx = gbx & 7, by = gby & 7;
   const int mx = gbx * 2, my = gby * 2;
@@ -211,21 +213,31 @@ __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
   }
   // plane position of the workgroup's region (no tile offset: whole frame)
   const int rx0 = (blockIdx.x * 2) * xs, ry0 = (blockIdx.y * 2) * ys;
-  const int lim_x = ((a.luma.width >> 3) << 3) >> a.xdec, lim_y = ((a.luma.height >> 3) << 3) >> a.ydec;
+  const int lim_x = ((a.luma.width >> 3) << 3) >> XD, lim_y = ((a.luma.height >> 3) << 3) >> YD;
   {
+    // all loads of the tile first (a luma thread has two), then the LDS stores: one
+    // memory round trip instead of one per loop iteration
     const uint8_t *p0 = (const uint8_t *)a.in.data;
-    for (int t = threadIdx.x; t < TW * TH; t += 256) {
+    constexpr int NLD = (TW * TH + 255) / 256;
+    int32_t tv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const int t = threadIdx.x + 256 * k;
       const int ty = t / TW, tx = t - ty * TW;
       const int py = ry0 + ty - 2, px = rx0 + tx - 2;
-      int32_t v = VERY_LARGE;
-      if (py >= 0 && py < lim_y && px >= 0 && px < lim_x)
-        v = ldpx<BPP>(p0 + ((size_t)(a.in.yorigin + py) * a.in.stride + a.in.xorigin + px) * BPP);
-      tile[t] = (uint16_t)v;
+      tv[k] = VERY_LARGE;
+      if (t < TW * TH && py >= 0 && py < lim_y && px >= 0 && px < lim_x)
+        tv[k] = ldpx<BPP>(p0 + ((size_t)(a.in.yorigin + py) * a.in.stride + a.in.xorigin + px) * BPP);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const int t = threadIdx.x + 256 * k;
+      if (t < TW * TH) tile[t] = (uint16_t)tv[k];
     }
   }
   __syncthreads();
   if (!in_grid) return;
-  const int px = (in_xoff >> a.xdec) + bx * xs, py = (in_yoff >> a.ydec) + by * ys;
+  const int px = (in_xoff >> XD) + bx * xs, py = (in_yoff >> YD) + by * ys;
   uint8_t *dst = (uint8_t *)px_addr<BPP>(a.out, px, py);
   const size_t dstb = (size_t)a.out.stride * BPP;
   const int i = lane / xs, j = lane % xs;
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
     lpri = pri_uv << coeff_shift;
     lsec = sec_uv << coeff_shift;
     ldamp -= 1;
-    ldir = pri_uv != 0 ? (a.xdec != a.ydec ? uvdir : dir) : 0;
+    ldir = pri_uv != 0 ? (XD != YD ? uvdir : dir) : 0;
   }
   if (act) {
     auto rd = [&](int yy, int xx) -> int32_t { return t0[yy * TW + xx]; };
@@ -358,8 +370,18 @@ extern "C" int r1_cdef_filter_frame_plane(r1_ctx *ctx, const R1Plane *luma, cons
   a.nby = ((tile_h + 63) / 64) * 8;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((a.nbx + 1) / 2, (a.nby + 1) / 2);
-  if (in->bytes_per_px == 1) hipLaunchKernelGGL((k_cdef_frame<1>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_cdef_frame<2>), grid, dim3(256), 0, st, a);
+#define R1_CDEF_LAUNCH(B, X, Y) hipLaunchKernelGGL((k_cdef_frame<B, X, Y>), grid, dim3(256), 0, st, a)
+#define R1_CDEF_DEC(B)                                   \
+  do {                                                   \
+    if (xdec == 0 && ydec == 0) R1_CDEF_LAUNCH(B, 0, 0); \
+    else if (xdec == 1 && ydec == 1) R1_CDEF_LAUNCH(B, 1, 1); \
+    else if (xdec == 1) R1_CDEF_LAUNCH(B, 1, 0);         \
+    else R1_CDEF_LAUNCH(B, 0, 1);                        \
+  } while (0)
+  if (in->bytes_per_px == 1) R1_CDEF_DEC(1);
+  else R1_CDEF_DEC(2);
+#undef R1_CDEF_DEC
+#undef R1_CDEF_LAUNCH
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }
