@@ -23,6 +23,9 @@ timeout 900 python tools/bench_me.py --cpu 2>&1 | grep "^{" > $OUT/me_4k.jsonl
 echo "== rocprof stats"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-seconds 0 > /tmp/prof_$TAG.log 2>&1; tail -1 /tmp/prof_$TAG.log | cut -c1-200)
 find /tmp/prof_$TAG -name "*kernel_stats*" -exec cp {} $OUT/kernel_stats.csv \; 2>/dev/null
+echo "== rocprof stats of the frame pipeline"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profp_$TAG -o prof -- python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --reps 3 > /tmp/profp_$TAG.log 2>&1; tail -1 /tmp/profp_$TAG.log | cut -c1-120)
+find /tmp/profp_$TAG -name "*kernel_stats*" -exec cp {} $OUT/frame_pipeline_kernel_stats.csv \; 2>/dev/null
 echo "== pmc"
 bash tools/gpu_pmc.sh ${TAG}_pmc > $OUT/pmc.log 2>&1
 python tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc $OUT/pmc_summary.json 2>&1 | tail -2
