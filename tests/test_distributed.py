@@ -156,3 +156,99 @@ def test_me_jobs_and_deblock_slabs_gloo():
         assert p.exitcode == 0
     for rank, ok_me, ok_db in res:
         assert ok_me and ok_db, (rank, ok_me, ok_db)
+
+
+def _worker_halo(rank, world, port, q):
+    """N3 with the reconstruction resident per tile: 2-D tiles, point-to-point exchange of the
+    tile borders, deblock + CDEF on the expanded tile (CPU oracle as the per-rank engine), then
+    one merge of FINAL pixels -- equal to filtering the whole frame."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import deblock_util as D
+    import oracle_lib as O
+    from rav1e_amd import tiles, workload as W
+    L = O.lib()
+    fw, fh, bd = 320, 256, 8
+    rects = W.tile_rects(world, fw, fh)
+    rng = np.random.default_rng(11)                       # same on every rank
+    blocks = D.random_blocks(rng, fw // 4, fh // 4, 1, 1)
+    state = D.make_state([28, 24, 0, 0])
+    yy, xx = np.mgrid[0:fh, 0:fw]
+    img = (128 + 40 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + 6 * rng.integers(-3, 4, (fh // 8 + 1, fw // 8 + 1))[yy // 8, xx // 8]
+           + rng.integers(-2, 3, (fh, fw))).clip(0, 255).astype(np.int64)
+    skip = np.ascontiguousarray(blocks["flags"] & 1).astype(np.uint8)
+    ystr, uvstr = np.array([2 * 4 + 1] + [0] * 7, np.uint8), np.array([5] + [0] * 7, np.uint8)
+
+    def post_filter(pix, blk, sk):
+        """deblock in place, then CDEF, on a (sub-)frame given as an image"""
+        h, w = pix.shape
+        p = O.plane_from_image(pix, bd, 16, 16)
+        pc = p.cstruct()
+        assert L.r1o_deblock_plane(state.ctypes.data, C.byref(pc), 0, 0, 0, blk.ctypes.data, blk.shape[1],
+                                   blk.shape[1], blk.shape[0], w, h, bd) == 0
+        out = O.HostPlane(w, h, bd, 16, 16)
+        ci = np.zeros(((h + 63) // 64, (w + 63) // 64), np.uint8)
+        oc = out.cstruct()
+        L.r1o_cdef_filter_tile_plane(C.byref(pc), C.byref(pc), C.byref(oc), 0, 0, 0, w, h, O.ptr(sk),
+                                     sk.shape[1], sk.shape[1], sk.shape[0], O.ptr(ci), ci.shape[1],
+                                     O.ptr(ystr), O.ptr(uvstr), 4, bd)
+        return out.view().astype(np.int32)
+
+    want = post_filter(img, blocks, skip)
+    # this rank knows its own tile only
+    x0, y0, x1, y1 = rects[rank]
+    local = torch.zeros((fh, fw), dtype=torch.int32)
+    local[y0:y1, x0:x1] = torch.from_numpy(img[y0:y1, x0:x1].astype(np.int32))
+    tiles.exchange_tile_halos(local, rects, rank)
+    ex0, ey0, ex1, ey1 = tiles.expanded_rect(rects[rank], tiles.POSTFILTER_HALO, fw, fh)
+    ok_halo = np.array_equal(local.numpy()[ey0:ey1, ex0:ex1], img[ey0:ey1, ex0:ex1])
+    outside = local.numpy().copy()
+    outside[ey0:ey1, ex0:ex1] = 0
+    ok_halo = ok_halo and not outside.any()               # nothing beyond the ring was sent
+    sub = post_filter(local.numpy()[ey0:ey1, ex0:ex1].astype(np.int64),
+                      np.ascontiguousarray(blocks[ey0 // 4:ey1 // 4, ex0 // 4:ex1 // 4]),
+                      np.ascontiguousarray(skip[ey0 // 4:ey1 // 4, ex0 // 4:ex1 // 4]))
+    final = torch.zeros((fh, fw), dtype=torch.int32)
+    final[y0:y1, x0:x1] = torch.from_numpy(sub[y0 - ey0:y1 - ey0, x0 - ex0:x1 - ex0].copy())
+    dist.all_reduce(final)                                # disjoint tiles: the sum is the merge
+    ok_final = np.array_equal(final.numpy(), want) and (want != img).mean() > 0.05
+    sends, recvs = tiles.tile_halo_plan(rects, rank, tiles.POSTFILTER_HALO, fw, fh)
+    sent = sum((r[2] - r[0]) * (r[3] - r[1]) for _, r in sends)
+    q.put((rank, bool(ok_halo), bool(ok_final), sent, len(sends), len(recvs)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_halo_exchange_and_postfilter_gloo():
+    """four ranks, 2 x 2 tiles (every rank has an edge neighbour in both directions and a corner
+    neighbour)"""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_halo, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_halo, ok_final, sent, ns, nr in res:
+        assert ok_halo and ok_final, (rank, ok_halo, ok_final)
+        assert ns == 3 and nr == 3 and sent < 320 * 256 // 2, (rank, ns, nr, sent)
+
+
+def test_tile_halo_plan_is_symmetric():
+    """what a rank sends to a peer is exactly what that peer expects to receive from it (4K, 8 tiles)"""
+    from rav1e_amd import tiles, workload as W
+    rects = W.tile_rects(8, 3840, 2160)
+    plans = [tiles.tile_halo_plan(rects, r, 64, 3840, 2160) for r in range(8)]
+    for r in range(8):
+        for peer, rect in plans[r][0]:
+            assert (r, rect) in plans[peer][1]
+        for peer, rect in plans[r][1]:
+            assert (r, rect) in plans[peer][0]
+        assert sum((a[2] - a[0]) * (a[3] - a[1]) for _, a in plans[r][0]) < 400_000   # vs 8.3 M pixels
