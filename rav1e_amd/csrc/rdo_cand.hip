@@ -440,8 +440,18 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   constexpr int WS = (((W + 7) * BPP + 3) >> 2) << 2;   // window row stride
   constexpr int WIN_BYTES = NC * (H + 7) * WS;
   constexpr int LSTRIDE = NC * W + 1;
-  constexpr int TXB_BYTES = H * LSTRIDE * 4;
-  constexpr int LDS_BYTES = WIN_BYTES > TXB_BYTES ? WIN_BYTES : TXB_BYTES;
+  // 64x64: the transpose goes through LDS in two halves of 32 rows (8.3 KB instead of
+  // 16.6 KB per wave).  At 16.6 KB the CU held 9 waves where the registers allow 12, and
+  // this kernel lives on occupancy: a wave issues one instruction per ~10 cycles whatever
+  // the size, so the SIMD's throughput is proportional to the waves it holds.
+  constexpr bool SPLIT_T = W == 64 && H == 64;
+  constexpr int TXB_ROWS = SPLIT_T ? 32 : H;
+  constexpr int TXB_BYTES = TXB_ROWS * LSTRIDE * 4;
+  constexpr int QT_BYTES = QM != 0 ? NC * (W < 32 ? W : 32) * (H < 32 ? H : 32) * 4 : 0;
+  constexpr int REC_BYTES = QM == 2 ? NC * W * H * BPP : 0;
+  constexpr int LDS_A = WIN_BYTES > TXB_BYTES ? WIN_BYTES : TXB_BYTES;
+  constexpr int LDS_B = QT_BYTES > REC_BYTES ? QT_BYTES : REC_BYTES;
+  constexpr int LDS_BYTES = LDS_A > LDS_B ? LDS_A : LDS_B;
   __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
   T *buf = (T *)smem;
 
@@ -553,12 +563,14 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
 #pragma unroll
     for (int r = 0; r < H; r++) v[r] = r1tx::shift_fwd_ct<SH0>(v[r]);
     r1tx::fwd_1d_m24<H>(v, r1tx::vtx_1d(tx_type));
-    const int cc = cl * W + (r1tx::lr_flip(tx_type) ? W - 1 - c : c);
+    if constexpr (!SPLIT_T) {
+      const int cc = cl * W + (r1tx::lr_flip(tx_type) ? W - 1 - c : c);
 #pragma unroll
-    for (int r = 0; r < H; r++)
-      buf[r * LSTRIDE + cc] = r1tx::shift_fwd_ct<SH1>(v[r]);
+      for (int r = 0; r < H; r++)
+        buf[r * LSTRIDE + cc] = r1tx::shift_fwd_ct<SH1>(v[r]);
+    }
   }
-  __syncthreads();
+  if constexpr (!SPLIT_T) __syncthreads();
   // ---- D: row transform, transposed store ----
   const int cl2 = lane / P, r = lane % P;   // P lanes per candidate again
   const long long cand2 = (long long)blockIdx.x * NC + cl2;
@@ -567,9 +579,30 @@ __global__ __launch_bounds__(64) void k_rdo_cand(
   const int tt = live2 ? cands[cand2].tx_type : 0;
   constexpr int OS = H < 32 ? H : 32, WC = W < 32 ? W : 32;
   T u[W];
-  if (row_live) {
+  if constexpr (SPLIT_T) {
+    // rows 0..31 travel first and are picked up by lanes 0..31, then rows 32..63 through
+    // the same bytes for lanes 32..63 (one candidate per wave here: cl = cl2 = 0)
+    const int cc = r1tx::lr_flip(tx_type) ? W - 1 - c : c;
 #pragma unroll
-    for (int k = 0; k < W; k++) u[k] = buf[r * LSTRIDE + cl2 * W + k];
+    for (int half = 0; half < 2; half++) {
+      if (col_live) {
+#pragma unroll
+        for (int rr = 0; rr < 32; rr++)
+          buf[rr * LSTRIDE + cc] = r1tx::shift_fwd_ct<SH1>(v[half * 32 + rr]);
+      }
+      __syncthreads();
+      if (row_live && (r >> 5) == half) {
+#pragma unroll
+        for (int k = 0; k < W; k++) u[k] = buf[(r & 31) * LSTRIDE + k];
+      }
+      __syncthreads();
+    }
+  }
+  if (row_live) {
+    if constexpr (!SPLIT_T) {
+#pragma unroll
+      for (int k = 0; k < W; k++) u[k] = buf[r * LSTRIDE + cl2 * W + k];
+    }
     r1tx::fwd_1d_m24<W>(u, r1tx::htx_1d(tt));
 #pragma unroll
     for (int k = 0; k < W; k++) u[k] = (T)(CT)r1tx::shift_fwd_ct<SH2>(u[k]);   // `as T::Coeff`
