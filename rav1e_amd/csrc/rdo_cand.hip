@@ -425,8 +425,18 @@ struct RdoQuantArgs {
 
 // QM: 0 = coefficients to HBM (headline), 1 = + quantizer, tx-domain distortion,
 // rate (N4), 2 = + quantizer, inverse transform, pixel-domain distortion.
+// Waves per SIMD the register allocator is asked to make room for (0 = no request).  Only
+// where the kernel sits a few registers above an allocation step (512 / n, in eights) and
+// the step costs no spill worth mentioning -- measured, see DESIGN.md 5.1 "occupancy".
+constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm) {
+  if (wl == 5 && hl == 5 && qm == 2 && bd == 8) return 4;   // 132 VGPRs -> 128 (10-bit: 149, spills)
+  if (wl == 5 && hl == 5 && qm == 1 && bd == 8) return 5;   // 97 -> 96
+  if (wl == 6 && hl == 6 && qm == 2) return 3;              // 176 / 181 -> 168
+  return 1;
+}
+
 template <int BD, int WL, int HL, typename CT, int QM>
-__global__ __launch_bounds__(64) void k_rdo_cand(
+__global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand(
     R1Plane org, R1Plane ref, const R1RdoCand *__restrict__ cands, int n,
     uint32_t *__restrict__ sad_out, uint32_t *__restrict__ satd_out,
     CT *__restrict__ coeffs, void *__restrict__ pred_out, RdoQuantArgs qa) {
