@@ -471,7 +471,7 @@ __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, i
 // Pass q on diagonal d + 2 meanwhile touches diagonals d + 1 .. d + 3 only.
 constexpr int kPassSkew = 2;
 template <int BPP>
-__global__ __launch_bounds__(256) void k_me_diag(const R1MeJob *__restrict__ jobs, R1MeParams p,
+__global__ __launch_bounds__(256, 5) void k_me_diag(const R1MeJob *__restrict__ jobs, R1MeParams p,
                                                  int step) {
   // blockIdx.z = pass; pass q works kPassSkew * q diagonals behind pass q - 1 (see the host loop)
   const int log2b = 4 - (int)blockIdx.z, diag = step - kPassSkew * (int)blockIdx.z;
