@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void k_me_blocks(R1MeJob job, R1MeParams p,
 // candidate: window staging, put_8tap (lane = column), SATD / SAD with one lane
 // per Hadamard tile, all inside the group; the four costs meet by shuffles.
 template <int BPP>
-__global__ __launch_bounds__(256) void k_me_blocks_small(R1MeJob job, R1MeParams p,
+__global__ __launch_bounds__(256, 3) void k_me_blocks_small(R1MeJob job, R1MeParams p,
                                                          const R1MeBlockCand *__restrict__ cands,
                                                          int n, int max_w, int max_h, int use_satd,
                                                          int filter_mode,
