@@ -22,46 +22,57 @@ __global__ __launch_bounds__(64) void k_fwd_tx(const int16_t *__restrict__ in,
   constexpr int W = 1 << WL, H = 1 << HL;
   constexpr int P = W > H ? W : H, NC = 64 / P;
   constexpr int LSTRIDE = NC * W + 1;
-  __shared__ T buf[H * LSTRIDE];
+  // 64x64: the transpose goes through LDS in two halves of 32 rows (8.3 KB instead of
+  // 16.6 KB per wave: 16 waves per CU instead of 9) -- lanes 0..31 pick up rows 0..31, then
+  // rows 32..63 travel through the same bytes for lanes 32..63 (as k_rdo_cand does)
+  constexpr bool SPLIT_T = W == 64 && H == 64;
+  constexpr int HR = SPLIT_T ? H / 2 : H;
+  __shared__ T buf[HR * LSTRIDE];
   const int lane = threadIdx.x;
   const int kcol = r1tx::vtx_1d(tx_type), krow = r1tx::htx_1d(tx_type);
   const bool ud = r1tx::ud_flip(tx_type), lr = r1tx::lr_flip(tx_type);
 
   // ---- columns ----
-  if (lane < NC * W) {
-    const int cl = lane / W, c = lane % W;
-    const long long cand = (long long)blockIdx.x * NC + cl;
-    if (cand < n) {
-      const int16_t *src = in + cand * (W * H) + c;
-      T v[H];
+  const int ccl = lane / W, c = lane % W;
+  const long long ccand = (long long)blockIdx.x * NC + ccl;
+  const bool col_live = lane < NC * W && ccand < n;
+  T v[H];
+  if (col_live) {
+    const int16_t *src = in + ccand * (W * H) + c;
 #pragma unroll
-      for (int r = 0; r < H; r++)
-        v[r] = r1tx::shift_fwd((T)src[(ud ? H - 1 - r : r) * W], sh.s[0]);
-      r1tx::fwd_1d<H>(v, kcol);
-      const int cc = cl * W + (lr ? W - 1 - c : c);
-#pragma unroll
-      for (int r = 0; r < H; r++)
-        buf[r * LSTRIDE + cc] = r1tx::shift_fwd(v[r], sh.s[1]);
-    }
+    for (int r = 0; r < H; r++)
+      v[r] = r1tx::shift_fwd((T)src[(ud ? H - 1 - r : r) * W], sh.s[0]);
+    r1tx::fwd_1d<H>(v, kcol);
   }
-  __syncthreads();
+  const int cc = ccl * W + (lr ? W - 1 - c : c);
   // ---- rows ----
-  if (lane < NC * H) {
-    const int cl = lane / H, r = lane % H;
-    const long long cand = (long long)blockIdx.x * NC + cl;
-    if (cand < n) {
-      T v[W];
+  const int cl = lane / H, r = lane % H;
+  const long long cand = (long long)blockIdx.x * NC + cl;
+  const bool row_live = lane < NC * H && cand < n;
+  T u[W];
 #pragma unroll
-      for (int c = 0; c < W; c++) v[c] = buf[r * LSTRIDE + cl * W + c];
-      r1tx::fwd_1d<W>(v, krow);
-      constexpr int OS = H < 32 ? H : 32, WC = W < 32 ? W : 32;
-      CT *dst = out + cand * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31);
+  for (int half = 0; half < (SPLIT_T ? 2 : 1); half++) {
+    if (col_live) {
 #pragma unroll
-      for (int cg = 0; cg < W; cg += 32)
-#pragma unroll
-        for (int c = 0; c < WC; c++)
-          dst[H * cg + c * OS] = (CT)r1tx::shift_fwd(v[c + cg], sh.s[2]);
+      for (int rr = 0; rr < HR; rr++)
+        buf[rr * LSTRIDE + cc] = r1tx::shift_fwd(v[half * HR + rr], sh.s[1]);
     }
+    __syncthreads();
+    if (row_live && r / HR == half) {
+#pragma unroll
+      for (int k = 0; k < W; k++) u[k] = buf[(r % HR) * LSTRIDE + cl * W + k];
+    }
+    if (SPLIT_T) __syncthreads();
+  }
+  if (row_live) {
+    r1tx::fwd_1d<W>(u, krow);
+    constexpr int OS = H < 32 ? H : 32, WC = W < 32 ? W : 32;
+    CT *dst = out + cand * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31);
+#pragma unroll
+    for (int cg = 0; cg < W; cg += 32)
+#pragma unroll
+      for (int k = 0; k < WC; k++)
+        dst[H * cg + k * OS] = (CT)r1tx::shift_fwd(u[k + cg], sh.s[2]);
   }
 }
 
