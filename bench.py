@@ -51,6 +51,10 @@ def parse():
                          "(r1_rdo_full_cand_batch, SURVEY 8f N4); pixel: carried through quantize / "
                          "inverse transform / cdef_dist (r1_rdo_pixel_cand_batch) -- supplementary lines")
     ap.add_argument("--qindex", type=int, default=100)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="> 1: the launches of a step (one per block size, independent of each other) "
+                         "go to one HIP stream per size, so that a launch fills the CUs the previous "
+                         "one is draining; the steps that carry timing events stay on one stream")
     ap.add_argument("--no-events", action="store_true",
                     help="skip per-kernel event timing (roofline.achieved falls back to step time)")
     return ap.parse_args()
@@ -223,27 +227,46 @@ def main():
     EV_EVERY = 4
     nstep = [0]
 
+    fan = args.streams > 1
+    size_streams = {s: torch.cuda.Stream() for s in W.LADDER} if fan else {}
+
     def step(timed):
         mark = timed and use_events and nstep[0] % EV_EVERY == 0
         if timed:
             nstep[0] += 1
-        for s in W.LADDER:
-            n = len(cands[s])
-            if n == 0:
-                continue
-            if mark:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            launches[s]()
-            if mark:
-                e1.record()
-                ev[s].append((e0, e1))
+        main = torch.cuda.current_stream()
+        if fan and not mark:
+            # independent launches, one stream per block size (each stream is in order with the
+            # same size's launch of the previous step, which wrote the same output buffers)
+            for s in W.LADDER:
+                if len(cands[s]):
+                    with torch.cuda.stream(size_streams[s]):
+                        launches[s]()
+        else:
+            for st in size_streams.values():
+                main.wait_stream(st)
+            for s in W.LADDER:
+                n = len(cands[s])
+                if n == 0:
+                    continue
+                if mark:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                launches[s]()
+                if mark:
+                    e1.record()
+                    ev[s].append((e0, e1))
+            for st in size_streams.values():
+                st.wait_stream(main)
         if world > 1:
-            side.wait_stream(torch.cuda.current_stream())
+            for st in (size_streams.values() if fan else (main,)):
+                side.wait_stream(st)
             with torch.cuda.stream(side):
                 tiles.exchange_rows(send, gathered)
 
     def fence():
+        for st in size_streams.values():
+            torch.cuda.current_stream().wait_stream(st)
         if world > 1:
             torch.cuda.current_stream().wait_stream(side)
             dist.barrier()
