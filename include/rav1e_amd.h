@@ -15,7 +15,9 @@
  *      buffer; nothing is retained after a call returns; calls are
  *      asynchronous on `stream` (a hipStream_t passed as void*, NULL = the
  *      default stream).  Return value: 0 ok, negative R1_E* on error; results
- *      are undefined on error.  Thread-safe: no global mutable state.
+ *      are undefined on error.  Thread-safe: no global mutable state (the one
+ *      per-context resource, the job-descriptor ring of the tile ME, is
+ *      serialised internally).
  *
  *  (2) PER-CALL COMPAT SHIMS with the reference's exact asm signatures
  *      (host pointers, byte strides, values returned directly).  They stage,

@@ -31,6 +31,8 @@
 // filled by jobs x superblocks-on-the-diagonal x blocks, not by one block.
 #include <string.h>
 
+#include <mutex>
+
 #include "common.hpp"
 #include "dist_common.hpp"
 #include "mc_common.hpp"
@@ -942,7 +944,11 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
     max_sbh = sbh > max_sbh ? sbh : max_sbh;
   }
   hipStream_t st = (hipStream_t)stream;
-  // job descriptors: caller's array -> pinned staging -> device, one ring slot per call
+  // job descriptors: caller's array -> pinned staging -> device, one ring slot per call.
+  // The ring is the one piece of mutable state a context has: concurrent callers (rav1e's
+  // per-tile rayon workers share a context) take turns for the enqueue.
+  static std::mutex ring_mu;
+  std::lock_guard<std::mutex> ring_lock(ring_mu);
   const size_t bytes = (size_t)n_jobs * sizeof(R1MeJob);
   const int slot = ctx->me_next;
   ctx->me_next = (slot + 1) % r1_ctx::kMeSlots;
