@@ -1018,6 +1018,46 @@ def test_estimate_tile_motion_jobs_are_tiles_and_references(ctx, oracle):
     assert np.array_equal(_me_stats_numpy(s2), want2)
 
 
+def test_estimate_tile_motion_from_concurrent_threads(ctx, oracle):
+    """one context shared by several host threads, each enqueueing on its own stream (rav1e's
+    per-tile workers): the calls use more ring slots than the context has, results stay exact"""
+    import threading
+    import torch
+    from rav1e_amd.api import me_lambdas
+    w, h, bd = 256, 136, 8
+    lam = me_lambdas(20.0)
+    cases = []
+    for k in range(3):
+        org, ref = _me_images("smooth", w, h, bd, 50 + k)
+        po, pr = O.me_pyramid(org, bd), O.me_pyramid(ref, bd)
+        want = np.zeros((h // 4, w // 4), O.ME_STATS)
+        O.me_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, want)
+        cases.append((_me_dev_pyr(po), _me_dev_pyr(pr), want))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            do, dr, want = cases[k]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(6):
+                    st = torch.zeros((h // 4, w // 4, 2), dtype=torch.int32, device="cuda")
+                    ctx.estimate_tile_motion([dict(org=do, ref=dr, stats=st, tile=(0, 0, w, h))],
+                                             w // 4, h // 4, bd, lam)
+                    stream.synchronize()
+                    if not np.array_equal(_me_stats_numpy(st), want):
+                        errors.append(k)
+        except Exception as e:                     # noqa: BLE001 -- reported below
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("bd", [8, 10])
 def test_estimate_motion_blocks_subpel_vs_oracle(ctx, oracle, bd):
     """r1_estimate_motion_batch (the RDO-time estimate_motion with pmv: full-pel from the
