@@ -92,3 +92,88 @@ def test_full_search_never_worsens_the_first_pass(oracle):
     for s_ in (a, b):
         blk = s_.reshape(h // 16, 4, w // 16, 4)
         assert (blk == blk[:, :1, :, :1]).all()
+
+
+# ---- cross-check against the second restatement (tests/me_model.py) -----------------------
+@pytest.mark.parametrize("case", [
+    # (w, h, bd, image kind, tile, previous-frame stats, allow_hp, allow_full_search)
+    (128, 64, 8, "smooth", None, False, 1, 0),
+    (136, 72, 8, "noise", None, True, 1, 1),          # cropped superblocks, full search stage
+    (200, 136, 10, "smooth", None, True, 0, 0),       # 10-bit, quarter-pel rates
+    (192, 128, 8, "flat", (64, 0, 128, 128), True, 1, 0),   # a tile inside the frame, many ties
+])
+def test_tile_motion_equals_the_independent_model(oracle, case):
+    """oracle/me.c against tests/me_model.py: every MEStats entry (mv and normalised SAD) of the
+    three-pass search, bit for bit"""
+    import me_model
+    w, h, bd, kind, tile, use_prev, hp, full = case
+    rng = np.random.default_rng(w + h)
+    if kind == "noise":
+        org, ref = rng.integers(0, 1 << bd, (h, w)), rng.integers(0, 1 << bd, (h, w))
+    else:
+        f = rng.standard_normal((h + 64, w + 64))
+        for _ in range(3):
+            f = (np.roll(f, 1, 0) + 2 * f + np.roll(f, -1, 0)) / 4
+            f = (np.roll(f, 1, 1) + 2 * f + np.roll(f, -1, 1)) / 4
+        f = ((f - f.min()) / (f.max() - f.min()) * ((1 << bd) - 1)).astype(np.int64)
+        if kind == "flat":
+            f = (f >> (bd - 3)) << (bd - 3)
+        org = f[32:32 + h, 32:32 + w]
+        ref = np.clip(f[32 + 6:32 + 6 + h, 32 - 11:32 - 11 + w] + rng.integers(-2, 3, (h, w)), 0, (1 << bd) - 1)
+    po, pr = O.me_pyramid(org, bd), O.me_pyramid(ref, bd)
+    tile = tile or (0, 0, w, h)
+    prev = None
+    if use_prev:
+        prev = np.zeros((h // 4, w // 4), O.ME_STATS)
+        prev["row"] = rng.integers(-90, 91, prev.shape)
+        prev["col"] = rng.integers(-90, 91, prev.shape)
+        prev["normalized_sad"] = rng.integers(0, 1 << 21, prev.shape)
+    init = np.zeros((h // 4, w // 4), O.ME_STATS)
+    init["row"] = rng.integers(-30, 31, init.shape)
+    init["col"] = rng.integers(-30, 31, init.shape)
+    init["normalized_sad"] = rng.integers(0, 1 << 21, init.shape)
+    lam = [int(v) for v in rng.integers(5, 60, 3)]
+    want = init.copy()
+    O.me_oracle(oracle, po, pr, w // 4, h // 4, tile, bd, lam, want, prev, allow_hp=hp,
+                allow_full_search=full)
+    m = me_model.Model(po, pr, w // 4, h // 4, bd, lam, allow_hp=hp, allow_full_search=full)
+    got = m.estimate_tile_motion(init.copy(), tile, prev)
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, (case, len(bad), bad[:4], got[tuple(bad[0])], want[tuple(bad[0])])
+    assert (want != init).any()
+
+
+@pytest.mark.parametrize("shift", [(4, -2), (4, 2), (2, 3), (-2, 3), (-2, -3), (0, 4), (0, -4), (8, 4), (-12, 9),
+                                    (5, 0), (-7, 0), (0, 3), (0, -9), (1, 1), (-6, -2), (3, -5)])
+def test_tile_motion_pattern_entries_against_the_model(oracle, shift):
+    """delta-shaped SAD landscapes: noise, the reference an exact copy displaced by `shift`
+    quarter-resolution pixels.  In the first (extensive) pass nothing but the search patterns
+    can find the displacement -- the long cross arms, the 16-entry uneven hexagon at its six
+    scales (with its duplicated entry: (-2, -3) is not in it), the hexagon and square
+    refinements -- so a wrong entry, order or scale in either restatement changes the result."""
+    import me_model
+    w, h, bd = 320, 192, 8
+    rng = np.random.default_rng(1000 + 31 * shift[0] + shift[1])
+    big = rng.integers(0, 256, (h + 256, w + 256))
+    if (shift[0] + shift[1]) % 2:
+        # every other case on a smooth texture + noise: the SAD landscape has a slope, the
+        # searches walk it step by step (hexagon iterations, square refinement, diamond)
+        f = rng.standard_normal(big.shape)
+        for _ in range(4):
+            f = (np.roll(f, 1, 0) + 2 * f + np.roll(f, -1, 0)) / 4
+            f = (np.roll(f, 1, 1) + 2 * f + np.roll(f, -1, 1)) / 4
+        big = ((f - f.min()) / (f.max() - f.min()) * 255).astype(np.int64) + rng.integers(-3, 4, big.shape)
+        big = np.clip(big, 0, 255)
+    org = big[128:128 + h, 128:128 + w]
+    ref = big[128 + 4 * shift[0]:128 + 4 * shift[0] + h, 128 + 4 * shift[1]:128 + 4 * shift[1] + w].copy()
+    # the first superblock column is an undisplaced copy: its blocks end with SAD 0, which makes
+    # the early-exit threshold of their right-hand neighbours small (me.rs:768-769) -- those see
+    # a useless predictor (0, 0), fail the threshold and have to run the uneven multi-hexagon search
+    ref[:, :64] = org[:, :64]
+    po, pr = O.me_pyramid(org, bd), O.me_pyramid(ref, bd)
+    lam = [40, 10, 3]
+    want = np.zeros((h // 4, w // 4), O.ME_STATS)
+    O.me_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, want)
+    got = me_model.Model(po, pr, w // 4, h // 4, bd, lam).estimate_tile_motion(np.zeros_like(want), (0, 0, w, h))
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, (shift, len(bad), bad[:4], got[tuple(bad[0])], want[tuple(bad[0])])
