@@ -67,8 +67,9 @@ class Model:
         assert a.shape == (h, w) and b.shape == (h, w), "search left the padded plane"
         return int(np.abs(a - b).sum())
 
-    def mv_rd(self, blk, mv, pmv=((0, 0), (0, 0))):                # compute_mv_rd, me.rs:1445-1463
+    def mv_rd(self, blk, mv, pmv=None):                            # compute_mv_rd, me.rs:1445-1463
         ss, px, py, w, h, lam = blk["ss"], blk["px"], blk["py"], blk["w"], blk["h"], blk["lam"]
+        pmv = pmv if pmv is not None else blk.get("pmv", ((0, 0), (0, 0)))
         sad = self.sad_at(ss, px, py, px + tdiv(mv[1], 8), py + tdiv(mv[0], 8), w, h)
         rate = min(self.mv_rate(mv, pmv[0]), self.mv_rate(mv, pmv[1]) + 1)
         return (256 * sad + rate * lam, sad)
@@ -159,7 +160,7 @@ class Model:
         for y in range(y_lo, y_hi + 1, step):
             for x in range(x_lo, x_hi + 1, step):
                 mv = (8 * (y - blk["py"]), 8 * (x - blk["px"]))
-                rd = self.mv_rd(blk, mv)
+                rd = self.mv_rd(blk, mv, ((0, 0), (0, 0)))         # both callers pass zero pmv
                 if rd[0] < best[1][0]:
                     best = [mv, rd]
         return best
@@ -312,3 +313,102 @@ class Model:
                                 mv = (r[0][0] << ssdec, r[0][1] << ssdec)
                                 self.save(stats, tile, bx, by, 1 << lg, mv, r[1][1], w, h)
         return stats
+
+
+# ---- the RDO-time call: estimate_motion(.., Some(pmv), CORNER {..}, false, 0, None) ------------
+# (src/rdo.rs:1183-1196 -> me.rs:536-620: full-pel search with the predicted MVs in the rate,
+# SATD re-cost of the winner, sub-pel diamond through put_8tap)
+def _hadamard(n):
+    h = np.array([[1]], np.int64)
+    while h.shape[0] < n:
+        h = np.block([[h, h], [h, -h]])
+    return h
+
+
+def satd(a, b):
+    """get_satd (src/dist.rs:156-221) for blocks whose sides are multiples of the tile size"""
+    h, w = a.shape
+    n = min(w, h, 8)
+    H = _hadamard(n)
+    total = 0
+    for y in range(0, h, n):
+        for x in range(0, w, n):
+            d = a[y:y + n, x:x + n] - b[y:y + n, x:x + n]
+            total += int(np.abs(H @ d @ H.T).sum())
+    ln = n.bit_length() - 1
+    return (total + ((1 << ln) >> 1)) >> ln
+
+
+def _put_8tap(taps, win, w, h, cf, rf, mode, bd):
+    """put_8tap (src/mc.rs:250-352) on a (h + 7, w + 7) window whose [3, 3] is the block origin"""
+    rs = lambda v, b: (v + ((1 << b) >> 1)) >> b
+    ib = 2 if bd == 12 else 4
+    maxv = (1 << bd) - 1
+    pick = lambda frac, length: taps[mode if (mode == 3 or length > 4) else min(mode, 1) + 4][frac]
+    xf, yf = pick(cf, w), pick(rf, h)
+    blk = win[3:3 + h, 3:3 + w]
+    if cf == 0 and rf == 0:
+        return blk.copy()
+    if cf == 0:
+        return np.clip(rs(sum(int(yf[k]) * win[k:k + h, 3:3 + w] for k in range(8)), 7), 0, maxv)
+    if rf == 0:
+        s = sum(int(xf[k]) * win[3:3 + h, k:k + w] for k in range(8))
+        return np.clip(rs(rs(s, 7 - ib), ib), 0, maxv)
+    mid = rs(sum(int(xf[k]) * win[:, k:k + w] for k in range(8)), 7 - ib)
+    return np.clip(rs(sum(int(yf[k]) * mid[k:k + h, :] for k in range(8)), 7 + ib), 0, maxv)
+
+
+def estimate_motion_block(m, taps, stats, prev, tile, bx, by, w, h, corner, pmv, use_satd, filter_mode=0):
+    """m: Model; taps: SUBPEL_FILTERS (6, 16, 8); corner: (right, bottom); pmv: ((r, c), (r, c))
+    -> (row, col, sad, cost)"""
+    blk = m.block(tile, bx, by, w, h, 0)
+    blk["pmv"] = pmv
+    sub = m.subsets(stats, prev, tile, bx, by, w, h, blk["rng"], corner, 0)
+    best = m.full_pixel_me(blk, sub, False, 0)
+    px, py = blk["px"], blk["py"]
+    oy0, ox0 = m.oo[0]
+    ry0, rx0 = m.ro[0]
+    org = m.org[0][oy0 + py:oy0 + py + h, ox0 + px:ox0 + px + w]
+    x0, x1, y0, y1 = blk["rng"]
+
+    def rd_of(pred, mv):
+        d = satd(org, pred) if use_satd else int(np.abs(org - pred).sum())
+        rate = min(m.mv_rate(mv, pmv[0]), m.mv_rate(mv, pmv[1]) + 1)
+        return (256 * d + rate * blk["lam"], d)
+
+    def in_range(mv):
+        return x0 <= mv[1] <= x1 and y0 <= mv[0] <= y1
+    if use_satd:                                   # me.rs:596-613
+        mv = best[0]
+        if in_range(mv):
+            ry, rx = py + tdiv(mv[0], 8), px + tdiv(mv[1], 8)
+            best = [mv, rd_of(m.ref[0][ry0 + ry:ry0 + ry + h, rx0 + rx:rx0 + rx + w], mv)]
+        else:
+            best = [mv, (U64_MAX, U32_MAX)]
+    mc_w, mc_h = 1 << (w - 1).bit_length(), (h + 1) & ~1
+
+    def subpel_rd(mv):                             # get_subpel_mv_rd, me.rs:1412-1442
+        if not in_range(mv):
+            return (U64_MAX, U32_MAX)
+        ro, co = mv[0] >> 3, mv[1] >> 3            # get_mv_params, predict.rs:284-297 (luma)
+        rf, cf = (mv[0] << 1) & 0xF, (mv[1] << 1) & 0xF
+        wy, wx = ry0 + py + ro - 3, rx0 + px + co - 3
+        win = m.ref[0][wy:wy + mc_h + 7, wx:wx + mc_w + 7]
+        assert win.shape == (mc_h + 7, mc_w + 7), "sub-pel window left the padded plane"
+        pred = _put_8tap(taps, win, mc_w, mc_h, cf, rf, filter_mode, m.bd)
+        return rd_of(pred[:h, :w], mv)
+    log2, end = 2, 0 if m.allow_hp else 1          # subpel_diamond_search, me.rs:1310-1383
+    while True:
+        cand = [(0, 0), (U64_MAX, U32_MAX)]
+        for (dc, dr) in zip([0, 1, 0, -1], [1, 0, -1, 0]):
+            mv = (best[0][0] + (dr << log2), best[0][1] + (dc << log2))
+            rd = subpel_rd(mv)
+            if rd[0] < cand[1][0]:
+                cand = [mv, rd]
+        if best[1][0] <= cand[1][0]:
+            if log2 == end:
+                break
+            log2 -= 1
+        else:
+            best = cand
+    return (best[0][0], best[0][1], best[1][1], best[1][0])

@@ -1,6 +1,8 @@
 """Motion-estimation oracle (oracle/me.c): the reference holds no vectors for
 src/me.rs (PARITY UNPINNED, see the file header), so these tests pin what the
 algorithm must satisfy structurally, whatever the search path taken."""
+import os
+
 import numpy as np
 import pytest
 
@@ -177,3 +179,44 @@ def test_tile_motion_pattern_entries_against_the_model(oracle, shift):
     got = me_model.Model(po, pr, w // 4, h // 4, bd, lam).estimate_tile_motion(np.zeros_like(want), (0, 0, w, h))
     bad = np.argwhere(got != want)
     assert len(bad) == 0, (shift, len(bad), bad[:4], got[tuple(bad[0])], want[tuple(bad[0])])
+
+
+@pytest.mark.parametrize("cfg", [(8, 1, 1), (8, 0, 1), (10, 1, 0), (8, 1, 0)])
+def test_rdo_time_estimate_motion_equals_the_independent_model(oracle, cfg):
+    """the RDO-time estimate_motion (predicted MVs in the rate, SATD re-cost, sub-pel diamond
+    through put_8tap) of oracle/me.c against tests/me_model.py: mv, sad and cost of every block"""
+    import me_model
+    bd, use_satd, allow_hp = cfg
+    w, h = 192, 128
+    rng = np.random.default_rng(7 + bd + 2 * use_satd + allow_hp)
+    f = rng.standard_normal((h + 64, w + 64))
+    for _ in range(3):
+        f = (np.roll(f, 1, 0) + 2 * f + np.roll(f, -1, 0)) / 4
+        f = (np.roll(f, 1, 1) + 2 * f + np.roll(f, -1, 1)) / 4
+    f = ((f - f.min()) / (f.max() - f.min()) * ((1 << bd) - 1)).astype(np.int64)
+    org = f[32:32 + h, 32:32 + w]
+    ref = np.clip(f[32 - 3:32 - 3 + h, 32 + 5:32 + 5 + w] + rng.integers(-3, 4, (h, w)), 0, (1 << bd) - 1)
+    po, pr = O.me_pyramid(org, bd), O.me_pyramid(ref, bd)
+    lam = [30, 8, 2]
+    stats = np.zeros((h // 4, w // 4), O.ME_STATS)
+    O.me_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, stats, allow_hp=allow_hp)
+    cands = []
+    for (bw, bh) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16), (64, 32), (4, 4), (4, 8)):
+        for _ in range(6):
+            bx = int(rng.integers(0, (w - bw) // 4 + 1))
+            by = int(rng.integers(0, (h - bh) // 4 + 1))
+            cands.append((bx, by, bw, bh, int(rng.integers(0, 4)) * 2 + 1,
+                          [[int(v) for v in rng.integers(-40, 41, 2)] for _ in range(2)]))
+    c = np.zeros(len(cands), O.ME_BLOCK_CAND)
+    for i, (bx, by, bw, bh, corner, pmv) in enumerate(cands):
+        c[i]["bx"], c[i]["by"], c[i]["w"], c[i]["h"], c[i]["corner"], c[i]["pmv"] = bx, by, bw, bh, corner, pmv
+    want = O.me_block_oracle(oracle, po, pr, w // 4, h // 4, (0, 0, w, h), bd, lam, stats, None, c,
+                             use_satd=use_satd, filter_mode=0, allow_hp=allow_hp)
+    taps = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mc_golden.npz"))["filters"]
+    m = me_model.Model(po, pr, w // 4, h // 4, bd, lam, allow_hp=allow_hp)
+    for i, (bx, by, bw, bh, corner, pmv) in enumerate(cands):
+        got = me_model.estimate_motion_block(m, taps, stats, None, (0, 0, w, h), bx, by, bw, bh,
+                                             (bool(corner & 2), bool(corner & 4)),
+                                             (tuple(pmv[0]), tuple(pmv[1])), use_satd)
+        wnt = (int(want[i]["row"]), int(want[i]["col"]), int(want[i]["sad"]), int(want[i]["cost"]))
+        assert got == wnt, (cfg, i, cands[i], got, wnt)
