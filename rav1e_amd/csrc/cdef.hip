@@ -248,8 +248,12 @@ __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
     if (act) stpx<BPP>(dst + i * dstb + j * BPP, t0[i * TW + j]);
     return;
   }
-  uint32_t var = 0;
-  const int dir = find_dir_wave(lum, coeff_shift, part[wave], var);
+  // everything below the direction search is the same in all 64 lanes of the block: keep it in
+  // scalar registers (strengths, direction, damping, the tap offsets they select)
+  uint32_t var_v = 0;
+  const int dir = __builtin_amdgcn_readfirstlane(find_dir_wave(lum, coeff_shift, part[wave], var_v));
+  const uint32_t var = (uint32_t)__builtin_amdgcn_readfirstlane((int)var_v);
+  ci = __builtin_amdgcn_readfirstlane(ci);
   const int ysr = a.prm.y_strengths[ci], uvs = a.prm.uv_strengths[ci];
   int lpri, lsec, ldir, ldamp = a.prm.damping + coeff_shift;
   if (a.p == 0) {
