@@ -346,7 +346,7 @@ int r1_activity_scales(r1_ctx *ctx, const R1Plane *luma, uint32_t *variances, ui
  * in the reference's order (source blocks in raster order): the result is
  * bit-identical to the sequential loop.  scratch: DEVICE, 256-byte aligned,
  * at least r1_update_block_importances_scratch_bytes(w, h) bytes (pair lists,
- * per-destination counts / offsets: 52 bytes per importance block; < 0 on
+ * per-destination counts / offsets: 76 bytes per importance block; < 0 on
  * error), caller-owned like every buffer. */
 long long r1_update_block_importances_scratch_bytes(int w_in_imp_b, int h_in_imp_b);
 int r1_update_block_importances(r1_ctx *ctx, const uint32_t *intra_costs,
