@@ -508,6 +508,20 @@ int r1_deblock_sse_plane(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src, in
                          int64_t *h_tally, void *stream);
 int r1_deblock_pick_levels(const int64_t *v_tally, const int64_t *h_tally, int pli,
                            uint8_t *levels_out);
+/* The same for all three planes of a 4:x:x frame at once (deblock_filter_frame /
+ * deblock_filter_optimize, src/deblock.rs:1544-1551, 1620-1668): planes / rec /
+ * src point at THREE R1Plane structs (Y, U, V; host memory), chroma decimation
+ * xdec / ydec.  r1_deblock_frame: two launches (all vertical edges of the three
+ * planes, then all horizontal ones) instead of six.  r1_deblock_sse_frame: one
+ * launch for the six (plane, direction) tallies; `tallies` = 6 x 65 int64
+ * (DEVICE, zeroed by the caller), entry 2 * pli + (0 vertical, 1 horizontal),
+ * each as r1_deblock_sse_plane fills it. */
+int r1_deblock_frame(r1_ctx *ctx, const R1DeblockState *state, const R1Plane *planes, int xdec,
+                     int ydec, const R1DeblockBlock *blocks, int blocks_stride, int blocks_cols,
+                     int blocks_rows, int crop_w, int crop_h, void *stream);
+int r1_deblock_sse_frame(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src, int xdec, int ydec,
+                         const R1DeblockBlock *blocks, int blocks_stride, int blocks_cols,
+                         int blocks_rows, int crop_w, int crop_h, int64_t *tallies, void *stream);
 
 /* ---- loop restoration, self-guided filter (SURVEY.md 8f "N3", last stage of
  * the post-filter chain; reference RestorationState::lrf_filter_frame

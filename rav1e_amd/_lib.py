@@ -77,6 +77,8 @@ SYMBOLS = {
                                       _i, _i, _vp, _vp]),
     "r1_deblock_plane": (_i, [_vp, _vp, _PP, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "r1_deblock_sse_plane": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "r1_deblock_frame": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "r1_deblock_sse_frame": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "r1_deblock_pick_levels": (_i, [_vp, _vp, _i, _vp]),
     "r1_intra_satd_batch": (_i, [_vp, _PP, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "r1_prescreen_select_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -597,6 +597,27 @@ class Context:
                                                   _stream_ptr()), "r1_deblock_sse_plane")
         return tallies
 
+    def deblock_frame(self, state, planes, xdec, ydec, blocks, crop_w, crop_h):
+        """deblock_filter_frame (src/deblock.rs:1544-1551): the three planes in place, two launches"""
+        arr = (_lib.R1Plane * 3)(*[p.cstruct() for p in planes])
+        st = np.ascontiguousarray(state).view(np.uint8)
+        assert st.size == 24 and blocks.dtype == torch.uint8 and blocks.shape[2] == 8
+        self._check(self.lib.r1_deblock_frame(self.h, st.ctypes.data, arr, xdec, ydec, blocks.data_ptr(),
+                                              blocks.shape[1], blocks.shape[1], blocks.shape[0], crop_w,
+                                              crop_h, _stream_ptr()), "r1_deblock_frame")
+
+    def deblock_sse_frame(self, rec, src, xdec, ydec, blocks, crop_w, crop_h, tallies=None):
+        """the level search of all planes and directions in one launch -> int64 (3, 2, 65)"""
+        if tallies is None:
+            tallies = torch.zeros((3, 2, 65), dtype=torch.int64, device="cuda")
+        ra = (_lib.R1Plane * 3)(*[p.cstruct() for p in rec])
+        sa = (_lib.R1Plane * 3)(*[p.cstruct() for p in src])
+        self._check(self.lib.r1_deblock_sse_frame(self.h, ra, sa, xdec, ydec, blocks.data_ptr(),
+                                                  blocks.shape[1], blocks.shape[1], blocks.shape[0],
+                                                  crop_w, crop_h, tallies.data_ptr(), _stream_ptr()),
+                    "r1_deblock_sse_frame")
+        return tallies
+
     def deblock_pick_levels(self, tallies, pli):
         """sse_optimize's tail on host copies of the tallies -> levels (2 for luma, 1 for chroma)"""
         t = np.ascontiguousarray(tallies.cpu().numpy())

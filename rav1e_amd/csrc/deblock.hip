@@ -216,10 +216,10 @@ __device__ __forceinline__ bool locate(const Geom &g, long long tid, bool vertic
 }
 
 template <int BPP>
-__global__ __launch_bounds__(256) void k_deblock(R1Plane plane, Geom g, R1DeblockState d, int vertical_) {
-  const bool vertical = vertical_ != 0;
+__device__ __forceinline__ void deblock_line(const R1Plane &plane, const Geom &g, const R1DeblockState &d,
+                                             bool vertical, long long tid) {
   int bx, by, i;
-  if (!locate(g, (long long)blockIdx.x * 256 + threadIdx.x, vertical, bx, by, i)) return;
+  if (!locate(g, tid, vertical, bx, by, i)) return;
   R1DeblockBlock b, prev;
   const int size = edge_size(g, bx, by, vertical, vertical, b, prev);
   if (!size) return;
@@ -257,6 +257,23 @@ __global__ __launch_bounds__(256) void k_deblock(R1Plane plane, Geom g, R1Debloc
   }
 }
 
+template <int BPP>
+__global__ __launch_bounds__(256) void k_deblock(R1Plane plane, Geom g, R1DeblockState d, int vertical_) {
+  deblock_line<BPP>(plane, g, d, vertical_ != 0, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// deblock_filter_frame (deblock.rs:1544-1551): one pass of all three planes in one launch,
+// blockIdx.y = plane (the planes are independent; a chroma plane has a quarter of the lines and
+// its surplus workgroups leave at once)
+struct DeblockPlanes { R1Plane p[3]; Geom g[3]; };
+template <int BPP>
+__global__ __launch_bounds__(256) void k_deblock_frame(DeblockPlanes s, R1DeblockState d, int vertical_,
+                                                       unsigned active) {
+  const int pl = blockIdx.y;
+  if (!((active >> pl) & 1)) return;
+  deblock_line<BPP>(s.p[pl], s.g[pl], d, vertical_ != 0, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
 __device__ __forceinline__ long long sse_lines(const Line &a, const Line &b, int nw) {
   int s = 0;   // stride_sse sums in i32
 #pragma unroll
@@ -266,13 +283,12 @@ __device__ __forceinline__ long long sse_lines(const Line &a, const Line &b, int
 }
 
 template <int BPP>
-__global__ __launch_bounds__(256) void k_deblock_sse(R1Plane rec, R1Plane src, Geom g, int vertical_,
-                                                     long long total,
-                                                     long long *__restrict__ tally_out) {
+__device__ __forceinline__ void deblock_sse_walk(const R1Plane &rec, const R1Plane &src, const Geom &g,
+                                                 bool vertical, long long total,
+                                                 long long *__restrict__ tally_out) {
   __shared__ unsigned long long tally[MAX_LF + 2];
   for (int k = threadIdx.x; k < MAX_LF + 2; k += 256) tally[k] = 0;
   __syncthreads();
-  const bool vertical = vertical_ != 0;
   long long none_sum = 0;   // tally[0] gets every line's sse_none: one add per wave
   // grid-stride: a workgroup flushes its tally once, however many lines it walks
   for (long long tid = (long long)blockIdx.x * 256 + threadIdx.x; tid < total;
@@ -338,6 +354,24 @@ __global__ __launch_bounds__(256) void k_deblock_sse(R1Plane rec, R1Plane src, G
   __syncthreads();
   for (int k = threadIdx.x; k < MAX_LF + 2; k += 256)
     if (tally[k]) atomicAdd((unsigned long long *)tally_out + k, tally[k]);
+}
+
+template <int BPP>
+__global__ __launch_bounds__(256) void k_deblock_sse(R1Plane rec, R1Plane src, Geom g, int vertical_,
+                                                     long long total,
+                                                     long long *__restrict__ tally_out) {
+  deblock_sse_walk<BPP>(rec, src, g, vertical_ != 0, total, tally_out);
+}
+
+// the level search of all three planes and both edge directions in one launch:
+// blockIdx.y = 2 * plane + (0 vertical, 1 horizontal); every (plane, direction) reads the same
+// unfiltered reconstruction, so the six walks are independent
+struct DeblockSsePlanes { R1Plane rec[3], src[3]; Geom g[3]; long long total[6]; long long *out[6]; };
+template <int BPP>
+__global__ __launch_bounds__(256) void k_deblock_sse_frame(DeblockSsePlanes s) {
+  const int pl = blockIdx.y >> 1;
+  deblock_sse_walk<BPP>(s.rec[pl], s.src[pl], s.g[pl], (blockIdx.y & 1) == 0, s.total[blockIdx.y],
+                        s.out[blockIdx.y]);
 }
 
 int make_geom(Geom &g, const R1Plane *p, int pli, int xdec, int ydec, const R1DeblockBlock *blocks,
@@ -422,6 +456,77 @@ extern "C" int r1_deblock_sse_plane(r1_ctx *ctx, const R1Plane *rec, const R1Pla
       hipLaunchKernelGGL(k_deblock_sse<2>, dim3(grid), dim3(256), 0, st, *rec, *src, g, (int)vertical, n,
                          out);
   }
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_deblock_frame(r1_ctx *ctx, const R1DeblockState *state, const R1Plane *planes,
+                                int xdec, int ydec, const R1DeblockBlock *blocks, int blocks_stride,
+                                int blocks_cols, int blocks_rows, int crop_w, int crop_h,
+                                void *stream) {
+  R1_REQUIRE(ctx && state && planes);
+  DeblockPlanes s;
+  unsigned active = 0;
+  for (int pli = 0; pli < 3; pli++) {
+    const int rc = make_geom(s.g[pli], planes + pli, pli, pli ? xdec : 0, pli ? ydec : 0, blocks,
+                             blocks_stride, blocks_cols, blocks_rows, crop_w, crop_h);
+    if (rc != R1_OK) return rc;
+    R1_REQUIRE(planes[pli].bytes_per_px == planes[0].bytes_per_px);
+    s.p[pli] = planes[pli];
+    // deblock_plane's early outs (deblock.rs:1302-1319)
+    const bool off = pli == 0 ? (state->levels[0] == 0 && state->levels[1] == 0)
+                              : state->levels[pli + 1] == 0;
+    if (!off) active |= 1u << pli;
+  }
+  if (!active) return R1_OK;
+  hipStream_t st = (hipStream_t)stream;
+  for (int pass = 0; pass < 2; pass++) {
+    const bool vertical = pass == 0;
+    long long n = 0;
+    for (int pli = 0; pli < 3; pli++) {
+      const long long np = pass_threads(s.g[pli], vertical);
+      n = np > n ? np : n;
+    }
+    if (n <= 0) continue;
+    const dim3 grid((unsigned)((n + 255) / 256), 3);
+    if (planes[0].bytes_per_px == 1)
+      hipLaunchKernelGGL(k_deblock_frame<1>, grid, dim3(256), 0, st, s, *state, (int)vertical, active);
+    else
+      hipLaunchKernelGGL(k_deblock_frame<2>, grid, dim3(256), 0, st, s, *state, (int)vertical, active);
+  }
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_deblock_sse_frame(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src, int xdec,
+                                    int ydec, const R1DeblockBlock *blocks, int blocks_stride,
+                                    int blocks_cols, int blocks_rows, int crop_w, int crop_h,
+                                    int64_t *tallies, void *stream) {
+  R1_REQUIRE(ctx && rec && src && tallies);
+  DeblockSsePlanes s;
+  long long nmax = 0;
+  for (int pli = 0; pli < 3; pli++) {
+    const int rc = make_geom(s.g[pli], rec + pli, pli, pli ? xdec : 0, pli ? ydec : 0, blocks,
+                             blocks_stride, blocks_cols, blocks_rows, crop_w, crop_h);
+    if (rc != R1_OK) return rc;
+    R1_REQUIRE(src[pli].bytes_per_px == rec[pli].bytes_per_px && src[pli].bit_depth == rec[pli].bit_depth &&
+               rec[pli].bytes_per_px == rec[0].bytes_per_px);
+    s.rec[pli] = rec[pli];
+    s.src[pli] = src[pli];
+    for (int dir = 0; dir < 2; dir++) {
+      s.total[2 * pli + dir] = pass_threads(s.g[pli], dir == 0);
+      s.out[2 * pli + dir] = (long long *)tallies + (size_t)(2 * pli + dir) * (MAX_LF + 2);
+      nmax = s.total[2 * pli + dir] > nmax ? s.total[2 * pli + dir] : nmax;
+    }
+  }
+  if (nmax <= 0) return R1_OK;
+  unsigned gx = (unsigned)((nmax + 255) / 256);
+  gx = gx > 512 ? 512 : gx;   // 6 x 512 workgroups, grid-stride inside
+  hipStream_t st = (hipStream_t)stream;
+  if (rec[0].bytes_per_px == 1)
+    hipLaunchKernelGGL(k_deblock_sse_frame<1>, dim3(gx, 6), dim3(256), 0, st, s);
+  else
+    hipLaunchKernelGGL(k_deblock_sse_frame<2>, dim3(gx, 6), dim3(256), 0, st, s);
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }

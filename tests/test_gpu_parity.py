@@ -1601,3 +1601,47 @@ def test_update_block_importances_bit_exact(ctx, oracle):
     ctx.update_block_importances(e, e.float(), e, e.short(), 0, 0, 1, e.float())
     with pytest.raises(R1Error):
         ctx.update_block_importances(e, e.float(), e, e.short(), 4, 4, 0, e.float())
+
+
+# ------------------------ N3: deblocking, all three planes per launch
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(8, 1, 1, False), (10, 1, 1, True), (12, 0, 0, True), (8, 1, 0, False)])
+def test_deblock_frame_entry_points_vs_oracle(ctx, oracle, cfg):
+    """r1_deblock_sse_frame (six tallies, one launch) and r1_deblock_frame (three planes, two
+    launches) against oracle/deblock.c plane by plane; a zero chroma level switches that plane off"""
+    import ctypes as C
+    import torch
+    import deblock_util as D
+    bd, xdec, ydec, deltas = cfg
+    w, h, cw, ch = 640, 384, 636, 378
+    rng = np.random.default_rng(170 + bd + xdec)
+    blocks = D.random_blocks(rng, w // 4, h // 4, xdec, ydec, deltas=deltas)
+    dblocks = torch.from_numpy(blocks.view(np.uint8).reshape(blocks.shape + (8,)).copy()).cuda()
+    dt = np.uint8 if bd == 8 else np.uint16
+    imgs = _deblock_planes(rng, w, h, bd, xdec, ydec, blocks)
+    for levels in ([int(v) for v in rng.integers(8, 50, 4)], [20, 0, 0, 17]):
+        state = D.make_state(levels, rng, deltas, deltas)
+        hp = [O.plane_from_image(rec, bd, 24, 24) for rec, _ in imgs]
+        hs = [O.plane_from_image(src, bd, 24, 24) for _, src in imgs]
+        dp, ds = [dev_plane(p) for p in hp], [dev_plane(p) for p in hs]
+        want_t = np.zeros((3, 2, 65), np.int64)
+        for pli in range(3):
+            xd, yd = (0, 0) if pli == 0 else (xdec, ydec)
+            pc, sc = hp[pli].cstruct(), hs[pli].cstruct()
+            assert oracle.r1o_deblock_sse_plane(C.byref(pc), C.byref(sc), pli, xd, yd, blocks.ctypes.data,
+                                                blocks.shape[1], blocks.shape[1], blocks.shape[0], cw, ch, bd,
+                                                want_t[pli, 0].ctypes.data, want_t[pli, 1].ctypes.data) == 0
+        got_t = ctx.deblock_sse_frame(dp, ds, xdec, ydec, dblocks, cw, ch)
+        assert np.array_equal(got_t.cpu().numpy(), want_t), (cfg, levels)
+        for pli in range(3):
+            xd, yd = (0, 0) if pli == 0 else (xdec, ydec)
+            pc = hp[pli].cstruct()
+            assert oracle.r1o_deblock_plane(state.ctypes.data, C.byref(pc), pli, xd, yd, blocks.ctypes.data,
+                                            blocks.shape[1], blocks.shape[1], blocks.shape[0], cw, ch, bd) == 0
+        ctx.deblock_frame(state, dp, xdec, ydec, dblocks, cw, ch)
+        for pli in range(3):
+            got = dp[pli].data.cpu().numpy().view(dt)
+            assert np.array_equal(got, hp[pli].data), (cfg, levels, pli)
+        assert (hp[0].view() != imgs[0][0]).sum() > 0
+        if levels[2] == 0:
+            assert np.array_equal(hp[1].view(), imgs[1][0])     # switched off: untouched

@@ -140,10 +140,9 @@ def main():
     chroma = [Plane.from_numpy(W.random_plane_array(cw, ch, bd, 30 + i, 44, 44), cw, ch, bd, 44, 44) for i in range(4)]
     planes3 = [(refs[0][0], org[0], 0, 0, 0), (chroma[0], chroma[1], 1, 1, 1), (chroma[2], chroma[3], 2, 1, 1)]
     tall = torch.zeros((3, 2, 65), dtype=torch.int64, device="cuda")
-    timed("deblock_level_search_420", lambda: [ctx.deblock_sse_plane(a, b, p, xd, yd, dblocks, fw, fh, tallies=tall[p])
-                                               for (a, b, p, xd, yd) in planes3])
-    timed("deblock_filter_420", lambda: [ctx.deblock_plane(state, a, p, xd, yd, dblocks, fw, fh)
-                                         for (a, b, p, xd, yd) in planes3])
+    rec3, src3 = [a for (a, b, p, xd, yd) in planes3], [b for (a, b, p, xd, yd) in planes3]
+    timed("deblock_level_search_420", lambda: ctx.deblock_sse_frame(rec3, src3, 1, 1, dblocks, fw, fh, tallies=tall))
+    timed("deblock_filter_420", lambda: ctx.deblock_frame(state, rec3, 1, 1, dblocks, fw, fh))
     dst = Plane(fw, fh, bd)
     skip = torch.zeros((fh // 4, fw // 4), dtype=torch.uint8, device="cuda")
     ci = torch.zeros(((fh + 63) // 64, (fw + 63) // 64), dtype=torch.uint8, device="cuda")
@@ -172,10 +171,8 @@ def main():
             ctx.estimate_motion_batch(job0, dc, cols, rows, bd, lam, max_w=16, max_h=16, n=len(c))
             prescreen()
             rdo()
-            for (a, b, p_, xd, yd) in planes3:
-                ctx.deblock_sse_plane(a, b, p_, xd, yd, dblocks, fw, fh, tallies=tall[p_])
-            for (a, b, p_, xd, yd) in planes3:
-                ctx.deblock_plane(state, a, p_, xd, yd, dblocks, fw, fh)
+            ctx.deblock_sse_frame(rec3, src3, 1, 1, dblocks, fw, fh, tallies=tall)
+            ctx.deblock_frame(state, rec3, 1, 1, dblocks, fw, fh)
             ctx.cdef_filter_frame_plane(refs[0][0], refs[0][0], dst, 0, 0, 0, fw, fh, skip, ci, [36] * 8,
                                         [36] * 8, 5, bd)
             ctx.lrf_sgrproj_plane(dst, refs[0][0], lrf_out, 0, fw, fh, fh, us, dunits, 64)
