@@ -306,18 +306,18 @@ def _device_post(be, rec, src, blocks, fw, fh, cdef):
     torch, ctx = be.torch, be.ctx
     dblocks = torch.from_numpy(blocks.view(np.uint8).reshape(blocks.shape + (8,)).copy()).cuda()
     levels = [0, 0, 0, 0]
+    tallies = ctx.deblock_sse_frame(rec, src, 1, 1, dblocks, fw, fh)      # six tallies, one launch
     for pli in range(3):
         dec = int(pli > 0)
         t = ctx.deblock_sse_plane(rec[pli], src[pli], pli, dec, dec, dblocks, fw, fh)
+        assert torch.equal(t, tallies[pli])                                 # = the per-plane entry point
         lv = ctx.deblock_pick_levels(t, pli)
         if pli == 0:
             levels[0], levels[1] = int(lv[0]), int(lv[1])
         else:
             levels[1 + pli] = int(lv[0])
     state = D.make_state(levels)
-    for pli in range(3):
-        dec = int(pli > 0)
-        ctx.deblock_plane(state, rec[pli], pli, dec, dec, dblocks, fw, fh)
+    ctx.deblock_frame(state, rec, 1, 1, dblocks, fw, fh)                    # three planes, two launches
     deblocked = [be.pixels(p) for p in rec]
     skip = torch.from_numpy(np.ascontiguousarray(blocks["flags"] & 1).astype(np.uint8)).cuda()
     ci = torch.zeros(((fh + 63) // 64, (fw + 63) // 64), dtype=torch.uint8, device="cuda")
