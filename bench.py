@@ -55,6 +55,9 @@ def parse():
                     help="> 1: the launches of a step (one per block size, independent of each other) "
                          "go to one HIP stream per size, so that a launch fills the CUs the previous "
                          "one is draining; the steps that carry timing events stay on one stream")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed steps for this long BEFORE the W warm-up steps, so that short runs "
+                         "(small W and K) are measured at the clocks a long run settles at; 0 = off")
     ap.add_argument("--no-events", action="store_true",
                     help="skip per-kernel event timing (roofline.achieved falls back to step time)")
     return ap.parse_args()
@@ -272,6 +275,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    prewarm_steps = 0
+    if args.prewarm_ms > 0:
+        tw = time.perf_counter()
+        while (time.perf_counter() - tw) * 1e3 < args.prewarm_ms:
+            for _ in range(8):
+                step(False)
+            torch.cuda.synchronize()
+            prewarm_steps += 8
+        if world > 1:                      # every rank leaves the pre-warm before anyone warms up
+            fence()
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -339,6 +352,7 @@ def main():
                          "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": int(abytes),
                          "avg_launch_ms": round(per[dom], 4) if dom else None},
+            "prewarm_steps": prewarm_steps,
             "kernel_ms": {str(s): round(v, 4) for s, v in per.items()},
             "kernel_ms_note": "HIP events around each launch of every %dth timed step "
                               "(%d samples per size)" % (EV_EVERY, max(len(v) for v in ev.values())),
