@@ -233,7 +233,7 @@ def main():
     fan = args.streams > 1
     size_streams = {s: torch.cuda.Stream() for s in W.LADDER} if fan else {}
 
-    def step(timed):
+    def step(timed, exchange=True):
         mark = timed and use_events and nstep[0] % EV_EVERY == 0
         if timed:
             nstep[0] += 1
@@ -261,7 +261,7 @@ def main():
                     ev[s].append((e0, e1))
             for st in size_streams.values():
                 st.wait_stream(main)
-        if world > 1:
+        if world > 1 and exchange:
             for st in (size_streams.values() if fan else (main,)):
                 side.wait_stream(st)
             with torch.cuda.stream(side):
@@ -280,7 +280,7 @@ def main():
         tw = time.perf_counter()
         while (time.perf_counter() - tw) * 1e3 < args.prewarm_ms:
             for _ in range(8):
-                step(False)
+                step(False, exchange=False)    # ranks leave this loop at different counts: no collectives in it
             torch.cuda.synchronize()
             prewarm_steps += 8
         if world > 1:                      # every rank leaves the pre-warm before anyone warms up
