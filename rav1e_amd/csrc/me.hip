@@ -12,9 +12,11 @@
 // left of and above it plus the (not yet updated) ones right of and below it
 // (me.rs:417-457), so the exact dependence graph is a wavefront: SB (x, y)
 // needs (x-1, y) and (x, y-1) finished and (x+1, y), (x, y+1) untouched.
-//   * one LAUNCH per anti-diagonal of superblocks per pass (three passes:
-//     quarter, half, full resolution) -- the same-diagonal SBs of ALL jobs
-//     (tiles x reference frames) run concurrently, grid = (diag length, jobs);
+//   * one LAUNCH per anti-diagonal of superblocks; the three passes (quarter,
+//     half, full resolution) run in the SAME launches, pass q two diagonals
+//     behind pass q - 1 (k_me_diag: a pass needs its predecessor finished one
+//     diagonal ahead, nothing more) -- the same-diagonal SBs of ALL jobs (tiles
+//     x reference frames) run concurrently, grid = (diag length, jobs, passes);
 //   * one WORKGROUP (4 waves) per superblock: first the refinement of the
 //     previous pass' blocks (4x4 full search, me.rs:663-676), then the pass' own
 //     blocks along the anti-diagonals INSIDE the superblock, one wave per block;
