@@ -182,9 +182,11 @@ def test_mc_put_prep_avg_vs_oracle(ctx, oracle, bd):
         assert np.array_equal(got_avg, want_avg), (bd, w, h, "avg")
 
 
-def test_mc_golden(ctx):
-    """tests/golden/mc_golden.npz: reference tap data + independent model."""
-    G = np.load(os.path.join(GOLD, "mc_golden.npz"))
+@pytest.mark.parametrize("fixture", ["mc_ref", "mc_golden"])
+def test_mc_golden(ctx, fixture):
+    """mc_ref.npz: outputs of the reference's own source text (gen_mc_ref.py executes
+    src/mc.rs); mc_golden.npz: reference tap data + an independent model."""
+    G = np.load(os.path.join(GOLD, fixture + ".npz"))
     from rav1e_amd.api import Plane
     for k in G["cases"]:
         bd, w, h, cf, rf, mx, my, _ = map(int, k.split("_"))

@@ -1,15 +1,29 @@
-"""Pin oracle/mc.c: tap data parsed from the reference's SUBPEL_FILTERS plus an
-independent NumPy model (tests/golden/gen_mc_golden.py), and spec properties."""
+"""Pin oracle/mc.c.
+
+mc_ref.npz    put_8tap / prep_8tap / mc_avg outputs computed by the reference's own
+              source text (src/mc.rs:110-479 transpiled and executed by
+              tests/golden/gen_mc_ref.py) -- the reference-derived pin.
+mc_golden.npz the reference's tap table + an independent NumPy model
+              (tests/golden/gen_mc_golden.py) -- kept as a second opinion.
+"""
 import os
 
 import numpy as np
+import pytest
 
 import oracle_lib as O
 
-G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mc_golden.npz"))
+GOLD = {n: np.load(os.path.join(os.path.dirname(__file__), "golden", n + ".npz"))
+        for n in ("mc_ref", "mc_golden")}
+G = GOLD["mc_ref"]
 
 
-def run_case(oracle, k):
+@pytest.fixture(params=["mc_ref", "mc_golden"])
+def gold(request):
+    return GOLD[request.param]
+
+
+def run_case(oracle, k, G):
     bd, w, h, cf, rf, mx, my, _ = map(int, k.split("_"))
     win = np.ascontiguousarray(G["win_" + k])
     hbd = int(bd > 8)
@@ -22,14 +36,16 @@ def run_case(oracle, k):
     return put, prep
 
 
-def test_put_prep_match_golden(oracle):
+def test_put_prep_match_golden(oracle, gold):
+    G = gold
     for k in G["cases"]:
-        put, prep = run_case(oracle, k)
+        put, prep = run_case(oracle, k, G)
         assert np.array_equal(put, G["put_" + k]), k
         assert np.array_equal(prep, G["prep_" + k]), k
 
 
-def test_avg_matches_golden(oracle):
+def test_avg_matches_golden(oracle, gold):
+    G = gold
     for bd in (8, 10, 12):
         t1, t2 = G["avg_t1_%d" % bd], G["avg_t2_%d" % bd]
         want = G["avg_out_%d" % bd]
@@ -39,8 +55,9 @@ def test_avg_matches_golden(oracle):
         assert np.array_equal(out, want)
 
 
-def test_filter_table_properties():
-    T = G["filters"].astype(int)
+def test_filter_table_properties(gold):
+    T = gold["filters"].astype(int)
+    assert np.array_equal(T, GOLD["mc_ref"]["filters"].astype(int))
     assert (T.sum(axis=2) == 128).all()           # unity DC gain
     for s in range(6):                            # phase f and 16-f are mirror images
         for f in range(1, 16):

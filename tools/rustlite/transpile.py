@@ -307,7 +307,7 @@ class Crate:
     def pyfn(self, info):
         if not info.compiled:
             FnCompiler(self, info).compile()
-        return self.G[info.pyname]
+        return self.G.get(info.pyname)  # None while a recursive function is being compiled
 
     def get(self, name, owner=None, file=None):
         """Python callable f(_g, *args) for a reference function."""
