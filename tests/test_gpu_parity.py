@@ -663,13 +663,16 @@ def _plane_from(arr, bd, pad=16):
     return hp, Plane.from_numpy(hp.data, w, h, bd, pad, pad)
 
 
-def test_cdef_frames_spec_model(ctx):
-    """whole-frame CDEF (3 planes, 4:2:0 / 4:2:2 / 4:4:4, 8/10/12-bit) against the
-    independent spec-formulation model's vectors, plus the direction maps."""
+@pytest.mark.parametrize("fixture,ncases", [("cdef_ref", 12), ("cdef_golden", 10)])
+def test_cdef_frames_spec_model(ctx, fixture, ncases):
+    """whole-frame CDEF (3 planes, 4:2:0 / 4:2:2 / 4:4:4, 8/10/12-bit), plus the direction
+    maps.  cdef_ref.npz: frames filtered by the reference's own source text
+    (gen_cdef_ref.py executes src/cdef.rs up to cdef_filter_tile); cdef_golden.npz: the
+    independent spec-formulation model."""
     from rav1e_amd.api import CDEF_DIR_CAND
-    Z = np.load(os.path.join(GOLD, "cdef_golden.npz"))
+    Z = np.load(os.path.join(GOLD, fixture + ".npz"))
     G = {k: Z[k] for k in Z.files}
-    for c in range(10):
+    for c in range(ncases):
         k = "c%d" % c
         W, H, xdec, ydec, bd, damping = (int(v) for v in G[k + "_meta"])
         dt = np.uint16 if bd > 8 else np.uint8

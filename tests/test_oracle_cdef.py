@@ -51,11 +51,18 @@ def test_first_max_tie_break(oracle):
     assert oracle.r1o_cdef_find_dir(O.ptr(np.ascontiguousarray(hs.T)), 8, C.byref(var), 0, 0) == 6
 
 
-def test_spec_model_frames(oracle):
-    Z = np.load(os.path.join(HERE, "golden", "cdef_golden.npz"))
+import pytest
+
+
+@pytest.mark.parametrize("fixture,ncases", [("cdef_ref", 12), ("cdef_golden", 10)])
+def test_spec_model_frames(oracle, fixture, ncases):
+    """cdef_ref.npz: whole frames filtered by the reference's own source text
+    (gen_cdef_ref.py executes src/cdef.rs incl. cdef_filter_tile); cdef_golden.npz: an
+    independent AV1-spec-formulation model."""
+    Z = np.load(os.path.join(HERE, "golden", fixture + ".npz"))
     G = {k: Z[k] for k in Z.files}
     ncase = len([k for k in G if k.endswith("_meta")])
-    assert ncase == 10
+    assert ncase == ncases
     for c in range(ncase):
         k = "c%d" % c
         W, H, xdec, ydec, bd, damping = (int(v) for v in G[k + "_meta"])

@@ -485,6 +485,24 @@ def copy_if_array(v):
     return v
 
 
+class Aligned:
+    """util::Aligned<T> { data: T }"""
+    __slots__ = ("data",)
+
+    def __init__(self, data):
+        self.data = data
+
+
+def augop(cur, name, rv, fallback):
+    """`cur op= rv` where cur may be a struct implementing the *Assign trait"""
+    if isinstance(cur, RStruct):
+        if cur._crate.find_method(cur._rname, name + "_assign") is not None:
+            cur._crate.call_method(cur, name + "_assign", (rv,))
+            return cur
+        return cur._binop(name, rv)
+    return fallback(cur, rv)
+
+
 class MaybeUninitSlot:
     """Element reference of a `[MaybeUninit<T>]` (r.write(v))."""
     __slots__ = ("c", "k")
@@ -1353,6 +1371,24 @@ class PlaneRegion(RStruct):
         n = max(0, self.rw - w + 1)
         return RIter(PlaneRegion(self.data, self.base + k, self.plane_cfg, self.rx + k, self.ry, w, self.rh)
                      for k in range(n))
+
+    def to_frame_block_offset(self, tile_bo):
+        # plane_region.rs:349-361
+        xdec, ydec = self.plane_cfg.xdec, self.plane_cfg.ydec
+        G = self._crate.G
+        if "S_PlaneBlockOffset" not in G:
+            self._crate.autoload("PlaneBlockOffset")
+        bx = self.rx >> (2 - xdec)
+        by = self.ry >> (2 - ydec)
+        return G["S_PlaneBlockOffset"](G["S_BlockOffset"](x=bx + tile_bo._0.x, y=by + tile_bo._0.y))
+
+    def frame_block_offset(self):
+        G = self._crate.G
+        if "S_BlockOffset" not in G:
+            self._crate.autoload("BlockOffset")
+        zero = type("TBO", (), {})()
+        zero._0 = G["S_BlockOffset"](x=0, y=0)
+        return self.to_frame_block_offset(zero)
 
     def scratch_copy(self):
         raise Panic("scratch_copy unsupported")

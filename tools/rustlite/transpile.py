@@ -207,6 +207,9 @@ class Crate:
         if t is tuple:
             return R.tuple_method(recv, name, args)
         if t is R.Cell or t is R.RRef:
+            if name == "write" and len(args) == 1:
+                recv.set(args[0])
+                return None
             return self._mc(g, recv.get(), hint, name, args)
         rn = getattr(t, "_rname", None)
         if rn is not None:
@@ -364,6 +367,13 @@ class Crate:
                     self.enum_vals[(ename, vn)] = (None, d, kind, fields)
                 d += 1
         return self.enum_vals[key]
+
+    def define_enum(self, name, variants):
+        """an enum of a third-party crate (e.g. v_frame's ChromaSampling): unit variants"""
+        node = N("enum", name=name, variants=[(v, "unit", [], None) for v in variants], attrs=[])
+        self.enums[name] = node
+        for v in variants:
+            self.variants.setdefault(v, []).append(name)
 
     def uniq(self, base):
         self._uniq += 1
@@ -2016,8 +2026,15 @@ class FnCompiler:
             return "%s.to_vec()" % self.args(argn)[0]
         if a in WRAPPERS and name in ("new", "from", "uninit", "uninit_array", "uninitialized", "zeroed"):
             if name in ("new", "from"):
-                return self.args(argn)[0]
+                v = self.args(argn)[0]
+                return "R.Aligned(%s)" % v if a == "Aligned" else v
+            if gen0:
+                t = self.norm(gen0[0]) if gen0[0].k != "gconst" else None
+                if self.is_scalar_ty(t) or t in self.type_params:
+                    return "0"
             exp = self.strip(self.expected)
+            if exp is None:
+                return "None"
             return self.default_for(exp, uninit=True)
         if name == "default" and (a == "Default" or a is None):
             return self.default_for(self.strip(self.expected))
@@ -2126,7 +2143,15 @@ class FnCompiler:
         lt = self.strip(self.ty(l))
         rnode = N("bin", op=bop, l=N("_raw", s="{L}"), r=e.r)
 
+        OPN = {"+": "add", "-": "sub", "*": "mul", "/": "div", "%": "rem", "<<": "shl", ">>": "shr",
+               "&": "bitand", "|": "bitor", "^": "bitxor"}
+
         def combine(cur, rv):
+            if not self.is_scalar_ty(lt) and not (isinstance(lt, str) and lt in self.type_params) and \
+                    (lt is None and self.strip(self.ty(e.r)) is None or
+                     (isinstance(lt, str) and lt in self.c.structs)):
+                pyop = {"/": "_div(a, b)", "%": "_rem(a, b)"}.get(bop, "a %s b" % bop)
+                return "R.augop(%s, %r, %s, lambda a, b: %s)" % (cur, OPN[bop], rv, pyop)
             if bop in ("/", "%"):
                 if isinstance(lt, str) and lt in INT and lt[0] == "u":
                     s = "(%s %s %s)" % (cur, "//" if bop == "/" else "%", rv)
