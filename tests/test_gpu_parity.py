@@ -395,10 +395,13 @@ def test_fwd_inv_roundtrip_on_device(ctx):
 
 
 # ------------------------------------------------------------------ quantize
-def test_quantize_golden_vectors(ctx):
-    G = np.load(os.path.join(GOLD, "quant_golden.npz"))
+@pytest.mark.parametrize("fixture,ncases", [("quant_ref", 894), ("quant_golden", 570)])
+def test_quantize_golden_vectors(ctx, fixture, ncases):
+    """quant_ref.npz: outputs of the reference's own source text (gen_quant_ref.py executes
+    src/quantize/mod.rs + tables.rs + scan_order.rs); quant_golden.npz: independent model."""
+    G = np.load(os.path.join(GOLD, fixture + ".npz"))
     keys = [k for k in G.files if k.endswith("_co")]
-    assert len(keys) == 570
+    assert len(keys) == ncases
     for k in keys:
         _, ts, tt, bd, intra, qi, dcd, acd, _ = k.split("_")
         ts, tt, bd, intra, qi, dcd, acd = map(int, (ts, tt, bd, intra, qi, dcd, acd))

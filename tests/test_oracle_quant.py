@@ -1,6 +1,12 @@
-"""Pin the quantizer oracle: scan-order rule vs the reference's literal tables
-(SHA-256 committed by tests/golden/gen_quant_golden.py), quantize/dequantize vs
-an independent model's vectors, divu exactness (src/quantize/mod.rs:169-178)."""
+"""Pin the quantizer oracle.
+
+quant_ref.npz     quantize / dequantize outputs and the scan orders computed by the
+                  reference's own source text (gen_quant_ref.py executes
+                  src/quantize/mod.rs, tables.rs and scan_order.rs) -- the
+                  reference-derived pin.
+quant_golden.npz  an independent model's vectors (gen_quant_golden.py); scan-order
+                  SHA-256s of the reference's literal tables.
+divu exactness mirrors src/quantize/mod.rs:169-178."""
 import hashlib
 import json
 import os
@@ -10,7 +16,10 @@ import numpy as np
 import oracle_lib as O
 
 HERE = os.path.dirname(__file__)
+import pytest
+
 G = np.load(os.path.join(HERE, "golden", "quant_golden.npz"))
+GREF = np.load(os.path.join(HERE, "golden", "quant_ref.npz"))
 SHA = json.load(open(os.path.join(HERE, "golden", "scan_sha256.json")))
 TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
 TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
@@ -34,9 +43,21 @@ def test_divu_pair_is_exact_division(oracle):
             assert oracle.r1o_divu(x, d) == x // d, (x, d)
 
 
-def test_quantize_dequantize_vectors(oracle):
+def test_scan_rule_matches_reference_scan_orders(oracle):
+    """av1_scan_orders[tx_size][tx_type].scan as the reference's text evaluates it"""
+    for ts in range(19):
+        n = min(TX_W[ts], 32) * min(TX_H[ts], 32)
+        for tt in range(16):
+            scan, iscan = np.zeros(1024, np.uint16), np.zeros(1024, np.uint16)
+            assert oracle.r1o_get_scan(ts, tt, O.ptr(scan), O.ptr(iscan)) == n
+            assert np.array_equal(scan[:n], GREF["scan_%d_%d" % (ts, tt)]), (ts, tt)
+
+
+@pytest.mark.parametrize("fixture,ncases", [("ref", 894), ("golden", 570)])
+def test_quantize_dequantize_vectors(oracle, fixture, ncases):
+    G = GREF if fixture == "ref" else globals()["G"]
     keys = [k for k in G.files if k.endswith("_co")]
-    assert len(keys) == 570
+    assert len(keys) == ncases
     for k in keys:
         _, ts, tt, bd, intra, qi, dcd, acd, _ = k.split("_")
         ts, tt, bd, intra, qi, dcd, acd = map(int, (ts, tt, bd, intra, qi, dcd, acd))
