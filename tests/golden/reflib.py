@@ -74,7 +74,15 @@ def plane_to_array(p, dtype):
 
 
 def enum(c, ename, vname):
+    if ename not in c.enums:
+        c.autoload(ename)
     return c.G[c.enum_value(ename, vname)[0]]
+
+
+def struct(c, name):
+    if "S_" + name not in c.G:
+        c.autoload(name)
+    return c.G["S_" + name]
 
 
 def save(name, out):

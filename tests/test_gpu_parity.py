@@ -534,13 +534,15 @@ def test_predict_reference_known_answers(ctx):
     assert np.array_equal(got, want)
 
 
-def test_predict_spec_model_vectors(ctx):
-    """4272 vectors of the AV1-spec-formulation model (every size, angle delta,
-    edge filter / upsample path; tests/golden/gen_predict_golden.py)."""
-    Z = np.load(os.path.join(GOLD, "predict_golden.npz"))
-    G = {k: Z[k] for k in Z.files}
+@pytest.mark.parametrize("fixture", ["predict_ref", "predict_golden"])
+def test_predict_spec_model_vectors(ctx, fixture):
+    """predict_ref.npz: 4992 outputs of the reference's own source text (gen_predict_ref.py
+    executes src/predict.rs); predict_golden.npz: 4272 vectors of the AV1-spec-formulation
+    model.  Every size, angle delta, edge filter / upsample path."""
+    Z = np.load(os.path.join(GOLD, fixture + ".npz"))
+    G = {k: Z[k] for k in Z.files if not k.startswith(("e_", "a_"))}
     for ts, (w, h) in enumerate(TX_SIZES):
-        for bd in (8, 10):
+        for bd in (8, 10, 12):
             idx = np.nonzero((G["ts"] == ts) & (G["bd"] == bd))[0]
             if not len(idx):
                 continue

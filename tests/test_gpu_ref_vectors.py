@@ -69,3 +69,54 @@ def test_dist_ref_wxh_glue_on_planes(ctx):
         c["ox"], c["oy"], c["rx"], c["ry"] = cands.T
         got = ctx.dist_scaled_batch(kind, da, db, w, h, c, sc if use_grid else None, xdec, xdec)
         assert np.array_equal(got.cpu().numpy().view(np.uint64), G["f_out_" + k]), k
+
+
+def test_predict_ref_intra_edges(ctx):
+    """get_intra_edges vectors of the reference's own text (src/partition.rs:639-898)."""
+    from rav1e_amd.api import INTRA_EDGE_CAND, Plane
+    Z = np.load(os.path.join(GOLD, "predict_ref.npz"))
+    G = {k: Z[k] for k in Z.files if k.startswith("e_")}
+    cases = np.unique(G["e_case"])
+    for cs in cases:
+        idx = np.nonzero(G["e_case"] == cs)[0]
+        bd = int(G["e_bd"][idx[0]])
+        rect_w, rect_h = int(G["e_rect_w"][idx[0]]), int(G["e_rect_h"][idx[0]])
+        tile = G["e_tile_%d" % cs]
+        th, tw = tile.shape
+        dt = np.uint16 if bd > 8 else np.uint8
+        # plane whose visible size is the tile's visible rectangle; the rest of the tile
+        # array (pixels past the frame edge) lands in the padding
+        hp = O.HostPlane(rect_w, rect_h, bd, 96, 48)
+        hp.data[hp.yorigin:hp.yorigin + th, hp.xorigin:hp.xorigin + tw] = tile.astype(dt)
+        dp = Plane.from_numpy(hp.data, rect_w, rect_h, bd, 96, 48)
+        for ts in np.unique(G["e_ts"][idx]):
+            sub = idx[G["e_ts"][idx] == ts]
+            ec = np.zeros(len(sub), INTRA_EDGE_CAND)
+            ec["x"], ec["y"] = G["e_x"][sub], G["e_y"][sub]
+            ec["mode"], ec["angle_delta"] = G["e_mode"][sub], G["e_angle_delta"][sub]
+            ec["flags"] = G["e_enable_ief"][sub] | (G["e_has_tr"][sub] << 1) | (G["e_has_bl"][sub] << 2)
+            edges, lens = ctx.intra_edges_batch(dp, (0, 0, tw, th), int(ts), ec)
+            ge, gl = edges.cpu().numpy().view(dt), lens.cpu().numpy()
+            for k, i in enumerate(sub):
+                ll, al = int(G["e_left_len"][i]), int(G["e_above_len"][i])
+                assert tuple(gl[k]) == (ll, al), (cs, i)
+                assert np.array_equal(ge[k, 128 - ll:129 + al].astype(np.uint16),
+                                      G["e_edges"][i][128 - ll:129 + al]), (cs, i)
+
+
+def test_predict_ref_cfl_ac(ctx):
+    """pred_cfl_ac vectors of the reference's own text (src/predict.rs:1020-1063)."""
+    from rav1e_amd.api import CFL_AC_CAND
+    Z = np.load(os.path.join(GOLD, "predict_ref.npz"))
+    G = {k: Z[k] for k in Z.files if k.startswith("a_")}
+    for i in range(len(G["a_bd"])):
+        bd, bw, bh = int(G["a_bd"][i]), int(G["a_bw"][i]), int(G["a_bh"][i])
+        xdec, ydec = int(G["a_xdec"][i]), int(G["a_ydec"][i])
+        lw, lh = max(bw << xdec, 8), max(bh << ydec, 8)
+        luma = G["a_luma"][G["a_luma_off"][i]:G["a_luma_off"][i + 1]].reshape(lh, lw)
+        hp = block_plane(luma.astype(np.uint16 if bd > 8 else np.uint8), bd, 16)
+        c = np.zeros(1, CFL_AC_CAND)
+        c["w_pad"], c["h_pad"] = int(G["a_w_pad"][i]), int(G["a_h_pad"][i])
+        got = ctx.cfl_ac_batch(dev_plane(hp), bw, bh, xdec, ydec, c).cpu().numpy()[0]
+        off = int(G["a_off"][i])
+        assert np.array_equal(got.ravel(), G["a_out"][off:off + bw * bh]), i

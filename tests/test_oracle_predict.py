@@ -79,8 +79,12 @@ def test_reference_pred_max(oracle):
         assert (run(oracle, mode, 3, angle, edge, bd=12) == 4095).all()
 
 
-def test_spec_model_vectors(oracle):
-    Z = np.load(os.path.join(HERE, "golden", "predict_golden.npz"))
+@pytest.mark.parametrize("fixture", ["predict_ref", "predict_golden"])
+def test_spec_model_vectors(oracle, fixture):
+    """predict_ref.npz: outputs of the reference's own source text (gen_predict_ref.py executes
+    src/predict.rs dispatch_predict_intra and every kernel below it); predict_golden.npz: the
+    independent AV1-spec-formulation model."""
+    Z = np.load(os.path.join(HERE, "golden", fixture + ".npz"))
     G = {k: Z[k] for k in Z.files}      # decompress once
     n = len(G["ts"])
     assert n > 2000
@@ -143,3 +147,46 @@ def test_get_intra_edges_geometry(oracle):
         oracle.r1o_get_intra_edges(O.ptr(edge), lens, O.ptr(tile), 96, 0, 24, 96, 64, 1, bd, 0, 0, 0,
                                    0, 0, hbd)
         assert list(lens) == [0, 8]
+
+
+def test_get_intra_edges_reference_vectors(oracle):
+    """get_intra_edges as the reference's own text computes it (src/partition.rs:639-898
+    executed by gen_predict_ref.py), with the reference's has_top_right / has_bottom_left
+    answers passed in as flags."""
+    Z = np.load(os.path.join(HERE, "golden", "predict_ref.npz"))
+    G = {k: Z[k] for k in Z.files if k.startswith("e_")}
+    n = len(G["e_x"])
+    assert n > 400
+    for i in range(n):
+        bd = int(G["e_bd"][i])
+        hbd = int(bd > 8)
+        tile = np.ascontiguousarray(G["e_tile_%d" % G["e_case"][i]].astype(np.uint16 if hbd else np.uint8))
+        edge = np.full(257, 0xFFFF if hbd else 0xFF, tile.dtype)
+        lens = (O.C.c_int * 2)()
+        oracle.r1o_get_intra_edges(O.ptr(edge), lens, O.ptr(tile), tile.shape[1], int(G["e_x"][i]),
+                                   int(G["e_y"][i]), int(G["e_rect_w"][i]), int(G["e_rect_h"][i]),
+                                   int(G["e_ts"][i]), bd, int(G["e_mode"][i]), int(G["e_enable_ief"][i]),
+                                   int(G["e_angle_delta"][i]), int(G["e_has_tr"][i]), int(G["e_has_bl"][i]),
+                                   hbd)
+        ll, al = int(G["e_left_len"][i]), int(G["e_above_len"][i])
+        assert list(lens) == [ll, al], i
+        want = G["e_edges"][i]
+        assert np.array_equal(edge[128 - ll:129 + al].astype(np.uint16), want[128 - ll:129 + al]), \
+            (i, int(G["e_mode"][i]), int(G["e_x"][i]), int(G["e_y"][i]))
+
+
+def test_pred_cfl_ac_reference_vectors(oracle):
+    """pred_cfl_ac::<T, XDEC, YDEC> of the reference's text (src/predict.rs:1020-1063)."""
+    Z = np.load(os.path.join(HERE, "golden", "predict_ref.npz"))
+    G = {k: Z[k] for k in Z.files if k.startswith("a_")}
+    for i in range(len(G["a_bd"])):
+        bd, bw, bh = int(G["a_bd"][i]), int(G["a_bw"][i]), int(G["a_bh"][i])
+        xdec, ydec = int(G["a_xdec"][i]), int(G["a_ydec"][i])
+        lw, lh = max(bw << xdec, 8), max(bh << ydec, 8)
+        luma = G["a_luma"][G["a_luma_off"][i]:G["a_luma_off"][i + 1]].reshape(lh, lw)
+        luma = np.ascontiguousarray(luma.astype(np.uint16 if bd > 8 else np.uint8))
+        ac = np.zeros(bw * bh, np.int16)
+        oracle.r1o_pred_cfl_ac(O.ptr(ac), O.ptr(luma), lw, bw, bh, int(G["a_w_pad"][i]),
+                               int(G["a_h_pad"][i]), xdec, ydec, int(bd > 8))
+        off = int(G["a_off"][i])
+        assert np.array_equal(ac, G["a_out"][off:off + bw * bh]), i

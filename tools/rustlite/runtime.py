@@ -503,6 +503,11 @@ def augop(cur, name, rv, fallback):
     return fallback(cur, rv)
 
 
+def mwrite(c, i, v):
+    c[i] = v
+    return RRef(c, i)
+
+
 class MaybeUninitSlot:
     """Element reference of a `[MaybeUninit<T>]` (r.write(v))."""
     __slots__ = ("c", "k")
@@ -1051,9 +1056,14 @@ def int_method(v, t, name, a):
         return (v > 0) - (v < 0)
     if name == "pow":
         return v ** a[0]
-    if name in ("get", "into", "clone", "to_owned", "as_", "to_usize", "to_i32", "to_u32", "to_u16", "to_i16",
-                "borrow", "to_asm_stride"):
+    if name in ("get", "into", "clone", "to_owned", "as_", "borrow", "to_asm_stride"):
         return v
+    if name in ("to_usize", "to_i32", "to_u32", "to_u16", "to_i16", "to_u8", "to_u64", "to_i64", "to_isize"):
+        t2 = name[3:]          # num_traits::ToPrimitive
+        return Some(v) if int_min(t2) <= v <= int_max(t2) else NONE
+    if name == "try_into":
+        # the target type is inferred in Rust; every use in the reference goes to an unsigned type
+        return Ok(v) if v >= 0 else Err(None)
     if name == "is_power_of_two":
         return v > 0 and (v & (v - 1)) == 0
     if name == "next_power_of_two":

@@ -496,7 +496,7 @@ class FnCompiler:
         k = t.k
         if k == "tref":
             inner = self.norm(t.inner)
-            return ("ref", inner)
+            return ("ref", inner, bool(t.mut))
         if k == "tptr":
             return ("ptr", self.norm(t.inner))
         if k in ("tarray", "tslice"):
@@ -721,6 +721,14 @@ class FnCompiler:
                 params.append(a)
                 pre.append((pat, a, nt))
         self.ret_ty = self.norm(node.ret)
+        for i, (pat, ty) in enumerate(node.params):
+            t = ty
+            while t.k == "tref":
+                t = t.inner
+            if t.k == "tarray" and t.n.k == "pathx" and len(t.n.path.segs) == 1 and \
+                    t.n.path.segs[0] in self.const_params:
+                # a const generic that is inferred from an array argument's length
+                self.emit("_g = {**_g, %r: len(%s)}" % (t.n.path.segs[0], params[i + 1 + int(node.has_self)]))
         for p in pre:
             if isinstance(p, str):
                 self.emit(p)
@@ -1078,7 +1086,11 @@ class FnCompiler:
             elif it.k == "ref" and it.mut:
                 src = "_ii(%s, True)" % self.ex(it.e)
             else:
-                src = "_ii(%s)" % self.ex(it)
+                itt = self.ty(it)
+                # `for x in s` with s: &mut [T] iterates by mutable reference
+                mutit = isinstance(itt, tuple) and itt[0] == "ref" and len(itt) > 2 and itt[2] and \
+                    isinstance(itt[1], tuple) and itt[1][0] == "arr"
+                src = "_ii(%s%s)" % (self.ex(it), ", True" if mutit else "")
             simple_pat = e.pat.k == "pident" and not self._is_const_pat(e.pat.name) and e.pat.name not in self.boxed
             self.push()
             if simple_pat:
@@ -2042,6 +2054,10 @@ class FnCompiler:
             f = self.args(argn)[0]
             exp = self.strip(self.expected)
             self.err("Aligned::from_fn")
+        if name == "transmute" and len(argn) == 1:
+            return self.args(argn)[0]
+        if name == "new_unchecked" and a in NONZERO:
+            return self.args(argn)[0]
         if name == "drop" and len(segs) == 1:
             self.args(argn)
             return "None"
@@ -2093,6 +2109,13 @@ class FnCompiler:
             return "_mc(_g, %s, None, 'zip', (%s, True))" % (r, a)
         if name in ("sum", "product", "collect", "into", "try_into", "unwrap", "cast") and not e.args:
             pass
+        rn = e.recv
+        while rn.k == "paren":
+            rn = rn.e
+        if name == "write" and len(e.args) == 1 and rn.k == "index" and rn.i.k != "range":
+            # MaybeUninit<T>::write on an element: store, and hand back a reference to it
+            cc, ii, vv = self.seq([rn.e, rn.i, e.args[0]])
+            return "R.mwrite(%s, %s, %s)" % (cc, ii, vv)
         recv = self.ex(e.recv) if e.recv.k != "ref" else self.ex(e.recv)
         hint = self.tyname(recv_t) if isinstance(recv_t, str) else None
         if name == "write" and len(e.args) == 1:
