@@ -1343,6 +1343,14 @@ class PlaneRegion(RStruct):
     def rect(self):
         return Rect(self.rx, self.ry, self.rw, self.rh)
 
+    @staticmethod
+    def new(plane, rect):
+        return plane._region(rect.x, rect.y, rect.width, rect.height)
+
+    @staticmethod
+    def new_from_plane(plane):
+        return plane.as_region()
+
     def __getitem__(self, r):
         if not (0 <= r < self.rh):
             raise Panic("PlaneRegion row %d out of %d" % (r, self.rh))
