@@ -124,3 +124,14 @@ def test_predict_ref_cfl_ac(ctx):
         got = ctx.cfl_ac_batch(dev_plane(hp), bw, bh, xdec, ydec, c).cpu().numpy()[0]
         off = int(G["a_off"][i])
         assert np.array_equal(got.ravel(), G["a_out"][off:off + bw * bh]), i
+
+
+def test_activity_ref_scales(ctx):
+    """ActivityMask::from_plane + fill_scales vectors of the reference's own text."""
+    A = np.load(os.path.join(GOLD, "activity_ref.npz"))
+    for k in A["keys"]:
+        bd, w, h = map(int, k.split("_"))
+        hp = O.plane_from_image(A["img_" + k], bd, 16, 16)
+        var, sc = ctx.activity_scales(dev_plane(hp))
+        assert np.array_equal(var.cpu().numpy().view(np.uint32), A["var_" + k]), k
+        assert np.array_equal(sc.cpu().numpy().view(np.uint32), A["scale_" + k]), k

@@ -91,3 +91,18 @@ def test_wxh_glue_on_planes(oracle):
                                             O.ptr(scales) if use_grid else None, scales.shape[1],
                                             xdec, xdec, O.ptr(want)) == 0
         assert np.array_equal(want, G["f_out_" + k]), k
+
+
+def test_activity_scales_reference_vectors(oracle):
+    """ActivityMask::from_plane + fill_scales as the reference's text computes them
+    (tests/golden/activity_ref.npz, gen_activity_ref.py executes src/activity.rs:21-186)."""
+    A = np.load(os.path.join(os.path.dirname(__file__), "golden", "activity_ref.npz"))
+    for k in A["keys"]:
+        bd, w, h = map(int, k.split("_"))
+        hp = O.plane_from_image(A["img_" + k], bd, 16, 16)       # edge-replicated padding (Frame::pad)
+        hb, wb = (h + 7) // 8, (w + 7) // 8
+        var, sc = np.zeros((hb, wb), np.uint32), np.zeros((hb, wb), np.uint32)
+        pc = hp.cstruct()
+        oracle.r1o_activity_scales(C.byref(pc), O.ptr(var), O.ptr(sc))
+        assert np.array_equal(var, A["var_" + k]), k
+        assert np.array_equal(sc, A["scale_" + k]), k

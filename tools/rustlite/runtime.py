@@ -128,6 +128,16 @@ class RRef:
         else:
             self.c[self.k] = v
 
+    # a reference to a struct element: field access goes through to the struct
+    def __getattr__(self, name):
+        return getattr(self.get(), name)
+
+    def __setattr__(self, name, v):
+        if name in ("c", "k", "attr"):
+            object.__setattr__(self, name, v)
+        else:
+            setattr(self.get(), name, v)
+
 
 _REFS = (Cell, RRef)
 
@@ -290,7 +300,7 @@ class RSlice:
         def gen():
             for i in range(self.n):
                 v = self.b[self.o + i]
-                yield RRef(self, i) if is_scalar(v) or isinstance(v, tuple) else v
+                yield RRef(self, i) if is_scalar(v) or isinstance(v, (tuple, RStruct, REnum)) else v
         return RIter(gen())
 
     def as_ptr(self):

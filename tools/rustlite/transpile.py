@@ -1831,6 +1831,10 @@ class FnCompiler:
                 return repr(sys.float_info.epsilon if a == "f64" else 1.1920929e-07)
             if b == "INFINITY":
                 return "float('inf')"
+        if (a in INT or a in ("f64", "f32")) and b in ("from", "cast_from"):
+            return "(lambda _x: _cast(_x, %r))" % a
+        if a in self.type_params and b in ("from", "cast_from"):
+            return "(lambda _x: _cast(_x, _g[%r]))" % a
         if a in self.type_params:
             self.err("associated item %s::%s of a type parameter" % (a, b))
         key = a + "::" + b
