@@ -1142,11 +1142,13 @@ def _deblock_planes(rng, w, h, bd, xdec, ydec, blocks):
     return out
 
 
-def test_deblock_golden_frames(ctx):
-    """the specification-model frames and brute-force tallies of tests/golden/deblock_golden.npz"""
+@pytest.mark.parametrize("fixture", ["deblock_ref", "deblock_golden"])
+def test_deblock_golden_frames(ctx, fixture):
+    """deblock_ref.npz: frames filtered and tallies summed by the reference's own source text
+    (gen_deblock_ref.py executes src/deblock.rs); deblock_golden.npz: the specification-model
+    frames and brute-force tallies."""
     import torch
-    import deblock_util as D
-    G = dict(np.load(os.path.join(GOLD, "deblock_golden.npz")))
+    G = dict(np.load(os.path.join(GOLD, fixture + ".npz")))
     for name in sorted(k[:-5] for k in G if k.endswith("_meta")):
         w, h, cw, ch, bd, xdec, ydec = [int(v) for v in G[name + "_meta"]]
         blocks = torch.from_numpy(np.ascontiguousarray(G[name + "_blocks"]).view(np.uint8).reshape(

@@ -10,8 +10,12 @@ import deblock_util as D
 import oracle_lib as O
 
 HERE = os.path.dirname(__file__)
-G = dict(np.load(os.path.join(HERE, "golden", "deblock_golden.npz")))
-CASES = sorted(k[:-5] for k in G if k.endswith("_meta"))
+# deblock_ref.npz: frames filtered / tallies summed by the reference's own source text
+# (gen_deblock_ref.py executes src/deblock.rs); deblock_golden.npz: the independent
+# specification-formulation model + brute force.
+GS = {n: dict(np.load(os.path.join(HERE, "golden", n + ".npz"))) for n in ("deblock_ref", "deblock_golden")}
+G = GS["deblock_golden"]
+CASES = [(n, k[:-5]) for n in GS for k in sorted(GS[n]) if k.endswith("_meta")]
 
 
 def run_filter(oracle, img, pli, xd, yd, blocks, state, cw, ch, bd):
@@ -34,8 +38,9 @@ def run_sse(oracle, rec, src, pli, xd, yd, blocks, cw, ch, bd):
     return tv, th
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_filter_matches_the_specification_model(oracle, name):
+@pytest.mark.parametrize("fixture,name", CASES)
+def test_filter_matches_the_specification_model(oracle, fixture, name):
+    G = GS[fixture]
     w, h, cw, ch, bd, xdec, ydec = [int(v) for v in G[name + "_meta"]]
     blocks = np.ascontiguousarray(G[name + "_blocks"])
     state = np.ascontiguousarray(G[name + "_state"])
@@ -47,9 +52,10 @@ def test_filter_matches_the_specification_model(oracle, name):
         assert len(bad) == 0, (name, pli, bad[:4])
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_level_search_tallies_are_the_per_level_sse(oracle, name):
+@pytest.mark.parametrize("fixture,name", CASES)
+def test_level_search_tallies_are_the_per_level_sse(oracle, fixture, name):
     """after sse_optimize's prefix sum, tally[L] = SSE of filtering every edge at level L"""
+    G = GS[fixture]
     w, h, cw, ch, bd, xdec, ydec = [int(v) for v in G[name + "_meta"]]
     blocks = np.ascontiguousarray(G[name + "_blocks"])
     for pli in range(3):
@@ -65,6 +71,9 @@ def test_level_search_tallies_are_the_per_level_sse(oracle, name):
             assert (lv[0], lv[1]) == (int(np.argmin(gv)), int(np.argmin(gh)))   # first minimum
         else:
             assert lv[0] == int(np.argmin(gv + gh))
+        if name + "_levels" in G:      # what the reference's sse_optimize picked
+            want = G[name + "_levels"]
+            assert (lv[0], lv[1]) == (want[0], want[1]) if pli == 0 else lv[0] == want[pli + 1]
 
 
 def test_level_zero_and_skipped_inter_interiors_are_untouched(oracle):

@@ -1078,9 +1078,18 @@ def int_method(v, t, name, a):
         return v > 0 and (v & (v - 1)) == 0
     if name == "next_power_of_two":
         return 1 if v <= 1 else 1 << (v - 1).bit_length()
+    if name == "ilog" and not a:
+        # v_frame::math::ILog: floor(log2(x)) + 1, and 0 for x <= 0
+        return v.bit_length() if v > 0 else 0
     if name == "ilog2" or name == "ilog":
         if v <= 0:
             raise Panic("ilog2 of %d" % v)
+        if name == "ilog":
+            r, b = 0, a[0]
+            while v >= b:
+                v //= b
+                r += 1
+            return r
         return v.bit_length() - 1
     if name == "trailing_zeros":
         if v == 0:

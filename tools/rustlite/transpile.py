@@ -2058,6 +2058,8 @@ class FnCompiler:
             f = self.args(argn)[0]
             exp = self.strip(self.expected)
             self.err("Aligned::from_fn")
+        if full == "ILog::ilog" and len(argn) == 1:
+            return "_im(%s, None, 'ilog', ())" % self.args(argn)[0]
         if name == "transmute" and len(argn) == 1:
             return self.args(argn)[0]
         if name == "new_unchecked" and a in NONZERO:
