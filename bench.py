@@ -77,12 +77,15 @@ def cpu_baseline(args, host_org, host_ref, cands):
     pa, pb = ho.cstruct(), hr.cstruct()
     ct = np.int16 if ho.bpp == 1 else np.int32
 
+    check = {}
+
     def run(frac_n):
         px = 0
         t0 = time.perf_counter()
         for s, c in cands.items():
             n = max(1, int(len(c) * frac_n))
-            sub = np.ascontiguousarray(c[:: max(1, len(c) // n)][:n])
+            idx = np.arange(0, len(c), max(1, len(c) // n))[:n]
+            sub = np.ascontiguousarray(c[idx])
             sad = np.zeros(len(sub), np.uint32)
             satd = np.zeros(len(sub), np.uint32)
             co = np.zeros((len(sub), s * s), ct)
@@ -91,6 +94,7 @@ def cpu_baseline(args, host_org, host_ref, cands):
                                       O.ptr(sad), O.ptr(satd), O.ptr(co), None)
             assert rc == 0
             px += len(sub) * s * s
+            check[s] = (idx, sad, satd, co)      # what the oracle says about these candidates
         return px, time.perf_counter() - t0
     frac, px, dt = 0.002, 0, 0.0
     while True:                               # grow the sample until it is measurable
@@ -104,7 +108,24 @@ def cpu_baseline(args, host_org, host_ref, cands):
     return {"value": round(px / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores,
             "kind": "port",
             "sample": "%.3f%% of the step's candidates (every ladder size, strided), %.1f s, "
-                      "OpenMP over candidates" % (100 * frac, dt)}
+                      "OpenMP over candidates" % (100 * frac, dt)}, check
+
+
+def parity_check(check, outs):
+    """Compare the buffers the timed GPU steps wrote with the oracle's results for the
+    candidates of the CPU-baseline sample (same planes, same descriptors)."""
+    import torch
+    n_checked, bad = 0, []
+    for s, (idx, sad, satd, co) in check.items():
+        ix = torch.from_numpy(idx.astype(np.int64)).cuda()
+        g_sad = outs[s]["sad"].index_select(0, ix).cpu().numpy().view(np.uint32)
+        g_satd = outs[s]["satd"].index_select(0, ix).cpu().numpy().view(np.uint32)
+        g_co = outs[s]["coeffs"].index_select(0, ix).cpu().numpy()
+        ok = np.array_equal(g_sad, sad) and np.array_equal(g_satd, satd) and np.array_equal(g_co, co)
+        if not ok:
+            bad.append(s)
+        n_checked += len(idx)
+    return n_checked, bad
 
 
 def pmc_traffic(bd, size, fw, fh, k):
@@ -357,9 +378,18 @@ def main():
             "kernel_ms_note": "HIP events around each launch of every %dth timed step "
                               "(%d samples per size)" % (EV_EVERY, max(len(v) for v in ev.values())),
         }
+        bad = []
         if world == 1 and args.cpu_seconds > 0 and not full:
-            res["cpu_baseline"] = cpu_baseline(args, host_org, host_ref, cands)
+            res["cpu_baseline"], check = cpu_baseline(args, host_org, host_ref, cands)
+            # the oracle just evaluated a strided sample of this very step at 4K: compare it
+            # with what the timed launches left in HBM (sad, satd and every coefficient)
+            n_checked, bad = parity_check(check, outs)
+            res["parity_checked"] = n_checked
+            res["parity_ok"] = not bad
         print(json.dumps(res))
+        if bad:
+            print("PARITY FAILURE at block sizes %s" % bad, file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
