@@ -199,6 +199,13 @@ int r1_mc_prep_batch(r1_ctx *ctx, const R1Plane *ref, int w, int h,
 int r1_mc_avg_batch(r1_ctx *ctx, const int16_t *tmp1, const int16_t *tmp2,
                     int w, int h, int n, int bit_depth, int bytes_per_px,
                     void *dst, void *stream);
+/* The same put_8tap / prep_8tap (prep != 0) with the horizontal 8-tap pass on the matrix
+ * cores (banded-Toeplitz v_mfma_i32_16x16x32_i8; csrc/mc_mfma.hip): 8-bit planes, square
+ * blocks 8 / 16 / 32 / 64.  Bit-identical to r1_mc_put_batch / r1_mc_prep_batch; kept as a
+ * separate entry point so that both formulations can be timed side by side
+ * (tools/bench_mc_mfma.py).  Other sizes / bit depths: R1_EINVAL. */
+int r1_mc_batch_mfma(r1_ctx *ctx, int prep, const R1Plane *ref, int w, int h,
+                     const R1McCand *cands, int n, void *dst, void *stream);
 
 /* ---- predict:: (reference: get_intra_edges src/partition.rs:639-898,
  * PredictionMode::predict_intra src/predict.rs:205-249, dispatch_predict_intra

@@ -437,6 +437,17 @@ class Context:
                                               out.data_ptr(), _stream_ptr()), "r1_mc_prep_batch")
         return out
 
+    def mc_batch_mfma(self, ref, w, h, cands, prep=False, n=None, out=None):
+        """put_8tap / prep_8tap with the horizontal pass on the matrix cores (csrc/mc_mfma.hip)"""
+        dc = _dev_cands(cands, MC_CAND)
+        n = dc.numel() // MC_CAND.itemsize if n is None else n
+        if out is None:
+            out = torch.empty((n, h, w), dtype=torch.int16 if prep else torch.uint8, device="cuda")
+        pr = ref.cstruct()
+        self._check(self.lib.r1_mc_batch_mfma(self.h, int(prep), C.byref(pr), w, h, dc.data_ptr(), n,
+                                              out.data_ptr(), _stream_ptr()), "r1_mc_batch_mfma")
+        return out
+
     def mc_avg_batch(self, tmp1, tmp2, w, h, bit_depth, out=None):
         n = tmp1.numel() // (w * h)
         bpp = 1 if bit_depth == 8 else 2

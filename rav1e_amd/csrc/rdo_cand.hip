@@ -30,6 +30,7 @@
 //     transpose through LDS (odd stride, aliasing the dead window).
 //  D  lane = (candidate, row): row transform, stores in the reference's
 //     transposed 32x32-chunk coefficient order.
+#include <cstdlib>
 #include <type_traits>
 
 #include "dist_common.hpp"
@@ -37,6 +38,33 @@
 #include "mc_common.hpp"
 #include "quant_common.hpp"
 #include "tx_common.hpp"
+
+#ifdef R1_PHASE_PROF
+// experiment build only (make prof): wall-clock cycles a wave spends in each phase of the
+// headline kernel, summed over all waves; read back by r1_debug_phase_prof().
+// every 64th workgroup writes its own row: no atomics, so the probes do not queue up
+__device__ unsigned long long g_phase[4096][8];
+#define R1_PROF(i)                                                          \
+  do {                                                                      \
+    const unsigned long long t_ = __builtin_readcyclecounter();             \
+    if (QM == 0 && threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 4096) \
+      g_phase[blockIdx.x >> 6][i] = t_ - tprev_;                            \
+    tprev_ = t_;                                                            \
+  } while (0)
+#define R1_PROF_INIT unsigned long long tprev_ = __builtin_readcyclecounter()
+#else
+#define R1_PROF(i) do {} while (0)
+#define R1_PROF_INIT do {} while (0)
+#endif
+
+// which instantiations stage the source block in LDS (see k_rdo_cand); overridable for A/B builds
+#ifndef R1_SRC_LDS_POLICY
+#define R1_SRC_LDS_POLICY(BPP, P) ((BPP) == 1 || (P) <= 32)
+#endif
+// which instantiations send the coefficients through LDS for 16-byte stores
+#ifndef R1_WIDE_STORE_POLICY
+#define R1_WIDE_STORE_POLICY(P) ((P) <= 16)
+#endif
 
 namespace {
 using r1tx::T;
@@ -86,6 +114,12 @@ __device__ __forceinline__ uint32_t habs_lanes(int32_t x, LaneSigns sg) {
   const int32_t ax = iabs32(x);
   const int32_t ap = TS == 8 ? dpp<0x141>(ax) : dpp<0x4E>(ax);
   return (uint32_t)(ax > ap ? ax : ap);
+}
+
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc) {
+  uint32_t r;
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+  return r;
 }
 
 // ---- the same on two i16 per register (VOP3P) ------------------------------
@@ -166,15 +200,51 @@ __device__ __forceinline__ int32_t dot4_seed(uint32_t a, uint32_t b, int32_t c_u
 // (sum u*mid + 64) >> 7 without clamp; the same algebra makes the one path
 // exact for its four cases too (mid = 16 p when col_frac == 0, u = 128 picks
 // mid when row_frac == 0).
+// the taps of one candidate, loaded ahead of their use (the pipelined kernel fetches the
+// next group's taps while the current group computes)
+struct Taps8 { uint32_t fx0, fx1, ty[4]; };
+template <int W, int H>
+__device__ __forceinline__ Taps8 load_taps8(int cf, int rf, int mx, int my) {
+  const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
+  const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
+  Taps8 t;
+  t.fx0 = kTapI8[fxi][cf][0];
+  t.fx1 = kTapI8[fxi][cf][1];
+#pragma unroll
+  for (int j = 0; j < 4; j++) t.ty[j] = kTapI16[fyi][rf][j];
+  return t;
+}
+struct Taps16 { uint32_t tx[4], ty[4]; };
+template <int W, int H>
+__device__ __forceinline__ Taps16 load_taps16(int cf, int rf, int mx, int my) {
+  const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
+  const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
+  Taps16 t;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    t.tx[j] = kTapI16[fxi][cf][j];
+    t.ty[j] = kTapI16[fyi][rf][j];
+  }
+  return t;
+}
+
+template <int W, int H, int WS, bool PREP = false>
+__device__ __forceinline__ void mc8_column_t(const uint8_t *win, int c, const Taps8 &tp, int32_t *pred);
+
 template <int W, int H, int WS, bool PREP = false>
 __device__ __forceinline__ void mc8_column(const uint8_t *win, int c, int cf, int rf, int mx,
                                            int my, bool any_cf0, int32_t *pred) {
-  const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
-  const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
-  const uint32_t fx0 = kTapI8[fxi][cf][0], fx1 = kTapI8[fxi][cf][1];
+  (void)any_cf0;
+  const Taps8 tp = load_taps8<W, H>(cf, rf, mx, my);
+  mc8_column_t<W, H, WS, PREP>(win, c, tp, pred);
+}
+
+template <int W, int H, int WS, bool PREP>
+__device__ __forceinline__ void mc8_column_t(const uint8_t *win, int c, const Taps8 &tp, int32_t *pred) {
+  const uint32_t fx0 = tp.fx0, fx1 = tp.fx1;
   uint32_t ty[4], tz[5];
 #pragma unroll
-  for (int j = 0; j < 4; j++) ty[j] = kTapI16[fyi][rf][j];
+  for (int j = 0; j < 4; j++) ty[j] = tp.ty[j];
   tz[0] = ty[0] << 16;
 #pragma unroll
   for (int j = 1; j < 4; j++) tz[j] = __builtin_amdgcn_alignbit(ty[j], ty[j - 1], 16);
@@ -189,7 +259,6 @@ __device__ __forceinline__ void mc8_column(const uint8_t *win, int c, int cf, in
   const uint32_t *wrow = (const uint32_t *)win + (c >> 2);
   const uint32_t sh = (uint32_t)(c & 3);
   typedef short v2s __attribute__((ext_vector_type(2)));
-  (void)any_cf0;
   // the window holds pixels already biased by -128 (staged with xor 0x80)
   auto hrow = [&](int r) -> int32_t {
     const uint32_t d0 = wrow[r * WSD], d1 = wrow[r * WSD + 1], d2 = wrow[r * WSD + 2];
@@ -253,16 +322,25 @@ __device__ __forceinline__ void mc8_column(const uint8_t *win, int c, int cf, in
 // 2^(6+ib) = 128 * 2^(ib-1) and every tap row sums to 128.
 // PREP: (sum u*mid + 64) >> 7 - PREP_BIAS (8192), no clamp (mc.rs:355-451).
 template <int W, int H, int WS, bool PREP = false>
+__device__ __forceinline__ void mc16_column_t(const uint8_t *win, int c, const Taps16 &tp, int bit_depth,
+                                              int32_t *pred);
+
+template <int W, int H, int WS, bool PREP = false>
 __device__ __forceinline__ void mc16_column(const uint8_t *win, int c, int cf, int rf, int mx,
                                             int my, int bit_depth, int32_t *pred) {
+  const Taps16 tp = load_taps16<W, H>(cf, rf, mx, my);
+  mc16_column_t<W, H, WS, PREP>(win, c, tp, bit_depth, pred);
+}
+
+template <int W, int H, int WS, bool PREP>
+__device__ __forceinline__ void mc16_column_t(const uint8_t *win, int c, const Taps16 &tp, int bit_depth,
+                                              int32_t *pred) {
   typedef short v2s __attribute__((ext_vector_type(2)));
-  const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
-  const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
   uint32_t tx[4], ty[4], tz[5];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    tx[j] = kTapI16[fxi][cf][j];
-    ty[j] = kTapI16[fyi][rf][j];
+    tx[j] = tp.tx[j];
+    ty[j] = tp.ty[j];
   }
   tz[0] = ty[0] << 16;
 #pragma unroll
@@ -459,18 +537,31 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   constexpr int TXB_BYTES = TXB_ROWS * LSTRIDE * 4;
   constexpr int QT_BYTES = QM != 0 ? NC * (W < 32 ? W : 32) * (H < 32 ? H : 32) * 4 : 0;
   constexpr int REC_BYTES = QM == 2 ? NC * W * H * BPP : 0;
-  constexpr int LDS_A = WIN_BYTES > TXB_BYTES ? WIN_BYTES : TXB_BYTES;
+  // The source block is staged in LDS next to the window (16-byte row chunks: H*W*BPP/1024
+  // load instructions per wave instead of H one-pixel-per-lane loads) and read back column by
+  // column AFTER the motion compensation: the H source registers are not live across the
+  // filter any more.  Not for 64-wide 16-bit blocks: + 8 KB of LDS would cost a wave per SIMD.
+  constexpr bool SRC_LDS = R1_SRC_LDS_POLICY(BPP, P);
+  constexpr int SRC_ROW = W * BPP;
+  constexpr int WIN_PAD = (WIN_BYTES + 15) & ~15;
+  constexpr int SRC_BYTES = SRC_LDS ? NC * H * SRC_ROW : 0;
+  constexpr int LDS_A = WIN_PAD + SRC_BYTES > TXB_BYTES ? WIN_PAD + SRC_BYTES : TXB_BYTES;
   constexpr int LDS_B = QT_BYTES > REC_BYTES ? QT_BYTES : REC_BYTES;
   constexpr int LDS_BYTES = LDS_A > LDS_B ? LDS_A : LDS_B;
   __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
   T *buf = (T *)smem;
 
+  R1_PROF_INIT;
   const int lane = threadIdx.x;
   const int cl = lane / P, c = lane % P;
   const long long cand = (long long)blockIdx.x * NC + cl;
   const bool live = cand < n;
   R1RdoCand cd = {};
   if (live) cd = cands[cand];
+#ifdef R1_PHASE_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  R1_PROF(5);   // A0: descriptor round trip
+#endif
   constexpr bool QUANT = QM != 0;
   // QM == 2 keeps the prediction column (packed pixels) for the reconstruction
   constexpr int PPK = QM == 2 ? (H * BPP + 3) / 4 : 1;
@@ -478,12 +569,44 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
   for (int k = 0; k < PPK; k++) ppk[k] = 0;
 
-  // ---- A: source column into registers, reference window into LDS ----
+  // ---- A: source block (registers, or LDS in wide chunks), reference window into LDS ----
   T v[H];
 #pragma unroll
   for (int r = 0; r < H; r++) v[r] = 0;
   const bool col_live = live && c < W;
-  if (col_live) {
+  const uint8_t *src_l = smem + WIN_PAD + cl * (H * SRC_ROW) + c * BPP;
+  if constexpr (SRC_LDS) {
+    constexpr int CHS = SRC_ROW >= 16 ? 16 : SRC_ROW;      // bytes per lane per pass
+    constexpr int CPR = SRC_ROW / CHS;                      // chunks per source row
+    constexpr int RPP = P / CPR;                            // rows per pass (P lanes per candidate)
+    constexpr int SPASS = (H + RPP - 1) / RPP;
+    const int srow = c / CPR, sch = c - srow * CPR;
+    if (live) {
+      const uint8_t *po = px_addr<BPP>(org, cd.ox, cd.oy) + sch * CHS;
+      const size_t so = (size_t)org.stride * BPP;
+      uint8_t *sd = smem + WIN_PAD + cl * (H * SRC_ROW) + sch * CHS;
+      U32x4 q[SPASS];
+#pragma unroll
+      for (int u = 0; u < SPASS; u++) {
+        const int rr = srow + u * RPP;
+        q[u] = U32x4{0, 0, 0, 0};
+        if (rr < H) {
+          if constexpr (CHS == 16) q[u] = ld_u32x4(po + rr * so);
+          else if constexpr (CHS == 8) { const U32x2 t = ld_u32x2(po + rr * so); q[u].a = t.a; q[u].b = t.b; }
+          else q[u].a = ld_u32(po + rr * so);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SPASS; u++) {
+        const int rr = srow + u * RPP;
+        if (rr < H) {
+          if constexpr (CHS == 16) *(uint4 *)(sd + rr * SRC_ROW) = make_uint4(q[u].a, q[u].b, q[u].c, q[u].d);
+          else if constexpr (CHS == 8) *(uint2 *)(sd + rr * SRC_ROW) = make_uint2(q[u].a, q[u].b);
+          else *(uint32_t *)(sd + rr * SRC_ROW) = q[u].a;
+        }
+      }
+    }
+  } else if (col_live) {
     const uint8_t *po = px_addr<BPP>(org, cd.ox + c, cd.oy);
     const size_t so = (size_t)org.stride * BPP;
 #pragma unroll
@@ -493,9 +616,15 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   if (live && !qa.pred_in)   // wave-uniform: kernel argument
     r1mc::stage_window_fast<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P>(win, WS, ref, cd.rx,
                                                                         cd.ry, c);
+#ifdef R1_PHASE_PROF
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  R1_PROF(6);   // A1: source column + window round trip (+ LDS writes issued)
+#endif
   __syncthreads();
+  R1_PROF(0);   // A: descriptor, source column, window staged
 
   // ---- B: prediction column, residual, SAD / SATD ----
+  uint32_t sad_acc = 0;
   if constexpr (BPP == 1) {
     const bool any_cf0 = __any(live && cd.col_frac == 0);
     if (col_live) {
@@ -516,8 +645,17 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
         for (int r = 0; r < H; r++) ppk[r >> 2] |= (uint32_t)pred[r] << (8 * (r & 3));
       }
+      if constexpr (SRC_LDS) {
 #pragma unroll
-      for (int r = 0; r < H; r++) v[r] -= pred[r];
+        for (int r = 0; r < H; r++) {
+          const uint32_t sp = src_l[r * SRC_ROW];
+          sad_acc = sad_u32(sp, (uint32_t)pred[r], sad_acc);   // |source - prediction| summed in one op
+          v[r] = (T)sp - pred[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < H; r++) v[r] -= pred[r];
+      }
     }
   } else {
     if (col_live) {
@@ -538,14 +676,26 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
         for (int r = 0; r < H; r++) ppk[r >> 1] |= (uint32_t)pred[r] << (16 * (r & 1));
       }
+      if constexpr (SRC_LDS) {
 #pragma unroll
-      for (int r = 0; r < H; r++) v[r] -= pred[r];
+        for (int r = 0; r < H; r++) {
+          const uint32_t sp = *(const uint16_t *)(src_l + r * SRC_ROW);
+          sad_acc = sad_u32(sp, (uint32_t)pred[r], sad_acc);
+          v[r] = (T)sp - pred[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < H; r++) v[r] -= pred[r];
+      }
     }
   }
+  R1_PROF(1);   // B1: motion compensation + residual
   if (sad_out) {
-    uint32_t sad = 0;
+    uint32_t sad = sad_acc;
+    if constexpr (!SRC_LDS) {
 #pragma unroll
-    for (int r = 0; r < H; r++) sad += (uint32_t)iabs32(v[r]);
+      for (int r = 0; r < H; r++) sad += (uint32_t)iabs32(v[r]);
+    }
     const uint32_t s = group_sum<P>(sad);
     if (live && c == 0) sad_out[cand] = s;
   }
@@ -554,6 +704,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     constexpr int LN = TS == 4 ? 2 : 3;
     if (live && c == 0) satd_out[cand] = (s + ((1u << LN) >> 1)) >> LN;
   }
+  R1_PROF(2);   // B2: SAD + SATD
   if (!QUANT && !coeffs) return;   // wave-uniform: kernel argument
 
   // ---- C: column transform on the residual registers ----
@@ -581,6 +732,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     }
   }
   if constexpr (!SPLIT_T) __syncthreads();
+  R1_PROF(3);   // C: column transform, transpose written
   // ---- D: row transform, transposed store ----
   const int cl2 = lane / P, r = lane % P;   // P lanes per candidate again
   const long long cand2 = (long long)blockIdx.x * NC + cl2;
@@ -616,14 +768,63 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     r1tx::fwd_1d_m24<W>(u, r1tx::htx_1d(tt));
 #pragma unroll
     for (int k = 0; k < W; k++) u[k] = (T)(CT)r1tx::shift_fwd_ct<SH2>(u[k]);   // `as T::Coeff`
-    if (coeffs) {
+  }
+  if constexpr (!R1_WIDE_STORE_POLICY(P)) {
+    // large blocks: direct element stores (measured: the LDS detour costs more than the
+    // 16-byte stores save at 32x32 and 64x64, profiles/r02_wide_store_ab.log)
+    if (coeffs && row_live) {
       CT *dst = coeffs + cand2 * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31);
 #pragma unroll
       for (int cg = 0; cg < W; cg += 32)
 #pragma unroll
         for (int k = 0; k < WC; k++) dst[H * cg + k * OS] = (CT)u[k + cg];
     }
+  } else
+  if (coeffs) {   // wave-uniform: kernel argument
+    // The reference's transposed coefficient order (forward.rs:135-159) puts the rows r of a
+    // column k next to each other: with lane = row a direct store is one 2- or 4-byte element
+    // per lane per instruction -- W (64x64: 128) scattered store instructions per wave, and
+    // this kernel runs at the texture-address unit's ~16 cycles per vector-memory instruction
+    // (DESIGN.md 5.1).  So the block is assembled in LDS in its final order (the transpose
+    // tile is dead: every lane holds its row) and leaves as 16-byte stores, W*sizeof(CT)/16
+    // per wave.  64x64 32-bit coefficients (16 KB) go in two halves (k < 32, k >= 32), which
+    // are contiguous halves of the output.
+    constexpr int ESZ = (int)sizeof(CT);
+    constexpr int NP = NC * W * H * ESZ > LDS_BYTES ? 2 : 1;
+    static_assert(NP == 1 || W == 64, "only the 64-wide blocks are split");
+    static_assert(NC * W * H * ESZ / NP <= LDS_BYTES, "a pass fits the LDS of the kernel");
+    constexpr int EPP = W * H / NP;                 // elements of one candidate per pass
+    constexpr int CBY = EPP * ESZ;                  // bytes of one candidate per pass
+    constexpr int CH = CBY / P >= 16 ? 16 : CBY / P;   // bytes a lane moves per step
+    constexpr int NCH = CBY / P / CH;
+    static_assert(CH * NCH * P == CBY && (CH == 16 || CH == 8 || CH == 4), "whole chunks");
+    CT *tile = (CT *)smem + cl2 * EPP;
+    uint8_t *gdst = (uint8_t *)(coeffs + cand2 * (W * H));
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      __syncthreads();   // rows are in registers (pass 0) / the previous half has been copied out
+      if (row_live) {
+        constexpr int KP = W / NP;
+#pragma unroll
+        for (int k = p * KP; k < (p + 1) * KP; k++) {
+          const int e = (r >= 32 ? OS * WC : 0) + (r & 31) + H * (k & ~31) + (k & 31) * OS - p * EPP;
+          tile[e] = (CT)u[k];
+        }
+      }
+      __syncthreads();
+      if (live2) {
+        const uint8_t *src = (const uint8_t *)tile + r * CH;
+        uint8_t *dst = gdst + p * CBY + r * CH;
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+          if constexpr (CH == 16) *(uint4 *)(dst + j * P * CH) = *(const uint4 *)(src + j * P * CH);
+          else if constexpr (CH == 8) *(uint2 *)(dst + j * P * CH) = *(const uint2 *)(src + j * P * CH);
+          else *(uint32_t *)(dst + j * P * CH) = *(const uint32_t *)(src + j * P * CH);
+        }
+      }
+    }
   }
+  R1_PROF(4);   // D: row transform + stores issued
   if constexpr (QUANT) {
     // ---- E: quantizer on the coded area, in LDS (aliases the transpose tile:
     // every row lane has its row in registers by now) ----
@@ -896,6 +1097,18 @@ int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n
 }
 
 }  // namespace
+
+#ifdef R1_PHASE_PROF
+extern "C" int r1_debug_phase_prof(unsigned long long *out, int reset) {   /* out[4096][8] */
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 4096 * 64) != hipSuccess) return -1;
+  if (reset) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase)) != hipSuccess) return -1;
+    if (hipMemset(p, 0, 4096 * 64) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 // Used by r1_mc_put_batch / r1_mc_prep_batch (mc.hip) for block sizes that are
 // transform sizes; returns 1 when (w, h) is not one of them.

@@ -1657,3 +1657,31 @@ def test_deblock_frame_entry_points_vs_oracle(ctx, oracle, cfg):
         assert (hp[0].view() != imgs[0][0]).sum() > 0
         if levels[2] == 0:
             assert np.array_equal(hp[1].view(), imgs[1][0])     # switched off: untouched
+
+
+@pytest.mark.parametrize("prep", [False, True])
+def test_mc_mfma_variant_equals_dot4_path(ctx, oracle, prep):
+    """r1_mc_batch_mfma (horizontal 8-tap pass as a banded-Toeplitz v_mfma_i32_16x16x32_i8,
+    csrc/mc_mfma.hip) against the oracle and against r1_mc_put_batch / r1_mc_prep_batch."""
+    import ctypes as C
+    a, _ = planes(8, seed=77)
+    da = dev_plane(a)
+    rng = np.random.default_rng(1234 + int(prep))
+    for s in (8, 16, 32, 64):
+        n = 203 if s <= 16 else 37      # ragged: partial waves
+        c = rand_mc_cands(rng, n, a.width, a.height, s, s, 60)
+        c["mode_x"] = rng.integers(0, 4, n)
+        c["mode_y"] = rng.integers(0, 4, n)
+        pa = a.cstruct()
+        if prep:
+            want = np.zeros((n, s, s), np.int16)
+            assert oracle.r1o_mc_prep_batch(C.byref(pa), s, s, O.ptr(c), n, O.ptr(want)) == 0
+            ref = ctx.prep_8tap_batch(da, s, s, c).cpu().numpy()
+        else:
+            want = np.zeros((n, s, s), np.uint8)
+            assert oracle.r1o_mc_put_batch(C.byref(pa), s, s, O.ptr(c), n, O.ptr(want)) == 0
+            ref = ctx.put_8tap_batch(da, s, s, c).cpu().numpy()
+        got = ctx.mc_batch_mfma(da, s, s, c, prep=prep).cpu().numpy()
+        assert np.array_equal(ref, want), (s, "dot4 path")
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, (s, prep, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
