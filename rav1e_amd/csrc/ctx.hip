@@ -388,3 +388,136 @@ extern "C" int rav1e_ipred_hip(void *dst, ptrdiff_t dst_stride, const void *topl
   SHIM_HIP(hipStreamSynchronize(st));
   return R1_OK;
 }
+
+// ---------------------------------------------------------------------------
+// per-table-entry dispatch symbols (include/rav1e_amd_dispatch.h, generated by
+// tools/gen_dispatch.py): the reference's exact asm argument lists.  They sit on the
+// generic shims above plus the few below.
+// ---------------------------------------------------------------------------
+int r1_internal_wsse_raw(const R1Plane *a, const R1Plane *b, int w, int h, const R1DistCand *cand,
+                         const uint32_t *scale, int scale_stride, uint64_t *out, hipStream_t st);
+int r1_internal_cdef_dist_raw(const R1Plane *a, const R1Plane *b, int w, int h, const R1DistCand *cand,
+                              uint32_t *out3, hipStream_t st);
+namespace {
+#define SHIM_OK(expr)                                                  \
+  do {                                                                 \
+    if ((expr) != R1_OK) {                                             \
+      fprintf(stderr, "rav1e_amd shim: %s -> %s\n", #expr, g_err);     \
+      abort();                                                         \
+    }                                                                  \
+  } while (0)
+
+void inv_shim_abort(void *dst, ptrdiff_t ds, const void *coeff, int tx_size, int tx_type, int bpp, int bd) {
+  SHIM_OK(inv_shim(dst, ds, coeff, tx_size, tx_type, bpp, bd));
+}
+
+// two host blocks -> device, as planes with the block at (0, 0)
+struct TwoBlocks { uint8_t *d; size_t blk; R1Plane a, b; };
+TwoBlocks upload_pair(r1_ctx *c, const void *src, ptrdiff_t ss, const void *dst, ptrdiff_t ds, int w, int h,
+                      int bpp, int bd, size_t extra, hipStream_t st) {
+  const size_t row = (size_t)w * bpp, blk = align256(row * h);
+  uint8_t *d = (uint8_t *)stage(c, 2 * blk + 512 + extra);
+  SHIM_HIP(hipMemcpy2DAsync(d, row, src, ss, row, h, hipMemcpyHostToDevice, st));
+  SHIM_HIP(hipMemcpy2DAsync(d + blk, row, dst, ds, row, h, hipMemcpyHostToDevice, st));
+  R1DistCand cand = {0, 0, 0, 0};
+  SHIM_HIP(hipMemcpyAsync(d + 2 * blk, &cand, sizeof(cand), hipMemcpyHostToDevice, st));
+  TwoBlocks t = {d, blk, {d, w, h, w, h, 0, 0, bpp, bd}, {d + blk, w, h, w, h, 0, 0, bpp, bd}};
+  return t;
+}
+
+// WeightedSseFn (src/asm/x86/dist/sse.rs:18-34): the raw sum over 4x4 cells of
+// (cell_sse * scale + 128) >> 8; `scale_stride` in BYTES like every asm stride (sse.rs:113)
+uint64_t wsse_shim(const void *src, ptrdiff_t ss, const void *dst, ptrdiff_t ds, const uint32_t *scale,
+                   ptrdiff_t scale_stride_bytes, int w, int h, int bpp) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  hipStream_t st = c->own_stream;
+  const int cw = w / 4, chh = h / 4;
+  const size_t sbytes = align256((size_t)cw * chh * 4);
+  TwoBlocks t = upload_pair(c, src, ss, dst, ds, w, h, bpp, bpp == 1 ? 8 : 10, sbytes, st);
+  uint8_t *sd = t.d + 2 * t.blk + 512;
+  SHIM_HIP(hipMemcpy2DAsync(sd, (size_t)cw * 4, scale, scale_stride_bytes, (size_t)cw * 4, chh,
+                            hipMemcpyHostToDevice, st));
+  uint64_t *res = (uint64_t *)(t.d + 2 * t.blk + 256);
+  SHIM_OK(r1_internal_wsse_raw(&t.a, &t.b, w, h, (const R1DistCand *)(t.d + 2 * t.blk), (const uint32_t *)sd,
+                               cw, res, st));
+  uint64_t out = 0;
+  SHIM_HIP(hipMemcpyAsync(&out, res, 8, hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+  return out;
+}
+
+// CdefDistKernelFn (src/asm/x86/dist/cdef_dist.rs:18-24): ret_ptr[3] = {svar, dvar, sse}
+void cdef_dist_kernel_shim(const void *src, ptrdiff_t ss, const void *dst, ptrdiff_t ds, int w, int h, int bpp,
+                           uint32_t *ret) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  hipStream_t st = c->own_stream;
+  TwoBlocks t = upload_pair(c, src, ss, dst, ds, w, h, bpp, bpp == 1 ? 8 : 10, 0, st);
+  uint32_t *res = (uint32_t *)(t.d + 2 * t.blk + 256);
+  SHIM_OK(r1_internal_cdef_dist_raw(&t.a, &t.b, w, h, (const R1DistCand *)(t.d + 2 * t.blk), res, st));
+  SHIM_HIP(hipMemcpyAsync(ret, res, 12, hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+}
+
+// PrepFn / PrepHBDFn (src/asm/x86/mc.rs:40-59): tmp = dense w*h int16
+void prep_shim(int16_t *tmp, const void *src, ptrdiff_t ss, int w, int h, int mx, int my, int mode_x, int mode_y,
+               int bpp, int bd) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  const int ww = w + 7, wh = h + 7;
+  const size_t wrow = (size_t)ww * bpp, wblk = align256(wrow * wh);
+  const size_t oblk = align256((size_t)w * h * 2);
+  uint8_t *d = (uint8_t *)stage(c, wblk + oblk + 256);
+  hipStream_t st = c->own_stream;
+  const uint8_t *s0 = (const uint8_t *)src - 3 * ss - 3 * bpp;
+  SHIM_HIP(hipMemcpy2DAsync(d, wrow, s0, ss, wrow, wh, hipMemcpyHostToDevice, st));
+  R1McCand cand = {0, 0, (uint8_t)mx, (uint8_t)my, (uint8_t)mode_x, (uint8_t)mode_y};
+  SHIM_HIP(hipMemcpyAsync(d + wblk + oblk, &cand, sizeof(cand), hipMemcpyHostToDevice, st));
+  R1Plane p = {d, ww, wh, w, h, 3, 3, bpp, bd};
+  SHIM_OK(r1_mc_prep_batch(c, &p, w, h, (const R1McCand *)(d + wblk + oblk), 1, (int16_t *)(d + wblk), st));
+  SHIM_HIP(hipMemcpyAsync(tmp, d + wblk, (size_t)w * h * 2, hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+}
+
+// AvgFn / AvgHBDFn (src/asm/x86/mc.rs:61-78)
+void avg_shim(void *dst, ptrdiff_t ds, const int16_t *t1, const int16_t *t2, int w, int h, int bpp, int bd) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  const size_t tb = align256((size_t)w * h * 2), ob = align256((size_t)w * h * bpp);
+  uint8_t *d = (uint8_t *)stage(c, 2 * tb + ob);
+  hipStream_t st = c->own_stream;
+  SHIM_HIP(hipMemcpyAsync(d, t1, (size_t)w * h * 2, hipMemcpyHostToDevice, st));
+  SHIM_HIP(hipMemcpyAsync(d + tb, t2, (size_t)w * h * 2, hipMemcpyHostToDevice, st));
+  SHIM_OK(r1_mc_avg_batch(c, (const int16_t *)d, (const int16_t *)(d + tb), w, h, 1, bd, bpp, d + 2 * tb, st));
+  SHIM_HIP(hipMemcpy2DAsync(dst, ds, d + 2 * tb, (size_t)w * bpp, (size_t)w * bpp, h, hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+}
+
+// DequantizeFn (src/asm/x86/quantize.rs:22-31): i16 coefficients, coded area of tx_size
+void dequant_shim(int qindex, const int16_t *coeffs, int16_t *rcoeffs, int tx_size, int bit_depth, int dc_delta_q,
+                  int ac_delta_q) {
+  static const uint8_t wl[19] = {2, 3, 4, 5, 6, 2, 3, 3, 4, 4, 5, 5, 6, 2, 4, 3, 5, 4, 6};
+  static const uint8_t hl[19] = {2, 3, 4, 5, 6, 3, 2, 4, 3, 5, 4, 6, 5, 4, 2, 5, 3, 6, 4};
+  if (tx_size < 0 || tx_size >= 19) abort();
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  const int w = 1 << wl[tx_size], h = 1 << hl[tx_size];
+  const int area = (w < 32 ? w : 32) * (h < 32 ? h : 32);
+  const size_t cb = align256((size_t)area * 2);
+  uint8_t *d = (uint8_t *)stage(c, 2 * cb);
+  hipStream_t st = c->own_stream;
+  SHIM_HIP(hipMemcpyAsync(d, coeffs, (size_t)area * 2, hipMemcpyHostToDevice, st));
+  R1QuantParams qp = {};
+  qp.qindex = qindex;
+  qp.bit_depth = bit_depth;
+  qp.is_intra = 0;
+  qp.dc_delta_q = dc_delta_q;
+  qp.ac_delta_q = ac_delta_q;
+  SHIM_OK(r1_dequantize_batch(c, d, 1, tx_size, &qp, 2, d + cb, st));
+  SHIM_HIP(hipMemcpyAsync(rcoeffs, d + cb, (size_t)area * 2, hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+}
+}  // namespace
+
+#include "dispatch_gen.inc"

@@ -21,7 +21,7 @@
 namespace {
 
 // KIND 2: weighted SSE, KIND 3: cdef_dist
-template <int BPP, int KIND>
+template <int BPP, int KIND, bool RAW = false>
 __global__ __launch_bounds__(256) void k_dist_scaled(
     R1Plane org, R1Plane ref, int w, int h, int tw, int tiles, int tpc_log2,
     const R1DistCand *__restrict__ cands, int n, const uint32_t *__restrict__ scales,
@@ -61,11 +61,72 @@ __global__ __launch_bounds__(256) void k_dist_scaled(
   }
   if (cand < n && t == 0) {
     // get_weighted_sse's tail: den = DistortionScale::new(1, 256).0 = 64
-    out[cand] = KIND == 2 ? (acc + 32) / 64 : acc;
+    // RAW: what the reference's WeightedSseFn asm returns (the caller divides, sse.rs:123-131)
+    out[cand] = (KIND == 2 && !RAW) ? (acc + 32) / 64 : acc;
   }
 }
 
+// cdef_dist_kernel's three values as the reference's CdefDistKernelFn asm returns them
+// (src/asm/x86/dist/cdef_dist.rs:18-24,100-118: [svar, dvar, sse] before apply_ssim_boost):
+// one lane per candidate, a single tile of w x h <= 8 x 8.
+template <int BPP>
+__global__ __launch_bounds__(64) void k_cdef_dist_raw(R1Plane org, R1Plane ref, int w, int h,
+                                                      const R1DistCand *__restrict__ cands, int n,
+                                                      uint32_t *__restrict__ out3) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const R1DistCand c = cands[i];
+  const uint8_t *po = px_addr<BPP>(org, c.ox, c.oy);
+  const uint8_t *pr = px_addr<BPP>(ref, c.rx, c.ry);
+  const size_t so = (size_t)org.stride * BPP, sr = (size_t)ref.stride * BPP;
+  uint32_t sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
+  for (int r = 0; r < h; r++)
+    for (int x = 0; x < w; x++) {
+      const uint32_t s = (uint32_t)ld_px<BPP>(po + r * so + x * BPP), d = (uint32_t)ld_px<BPP>(pr + r * sr + x * BPP);
+      sum_s += s; sum_d += d;
+      sum_s2 += s * s; sum_d2 += d * d; sum_sd += s * d;
+    }
+  const uint32_t sse = sum_d2 + sum_s2 - 2 * sum_sd;
+  const unsigned long long div = r1dist::area_divisor(w * h);
+  const uint32_t ms = (uint32_t)(((unsigned long long)sum_s * sum_s * div + 8192) >> 14);
+  const uint32_t md = (uint32_t)(((unsigned long long)sum_d * sum_d * div + 8192) >> 14);
+  uint32_t svar = sum_s2 > ms ? sum_s2 - ms : 0;
+  uint32_t dvar = sum_d2 > md ? sum_d2 - md : 0;
+  svar = (uint32_t)(((unsigned long long)svar * div + 128) >> 8);
+  dvar = (uint32_t)(((unsigned long long)dvar * div + 128) >> 8);
+  out3[3 * i] = svar;
+  out3[3 * i + 1] = dvar;
+  out3[3 * i + 2] = sse;
+}
+
 }  // namespace
+
+// internal (ctx.hip's per-table-entry shims): raw weighted SSE with one scale per 4x4 CELL of
+// the block (get_weighted_sse's own indexing), and cdef_dist_kernel's raw triple
+int r1_internal_wsse_raw(const R1Plane *a, const R1Plane *b, int w, int h, const R1DistCand *cand,
+                         const uint32_t *scale, int scale_stride, uint64_t *out, hipStream_t st) {
+  const int tw = (w + 7) / 8, th = (h + 7) / 8, tiles = tw * th;
+  const int tpc_log2 = r1_ilog2(tiles);
+  const unsigned grid = (unsigned)(((1ll << tpc_log2) + 255) / 256);
+  // xdec = ydec = 1 makes the scale lookup (x << 1) >> 3 = x >> 2: per 4x4 cell of the block at (0, 0)
+  if (a->bytes_per_px == 1)
+    hipLaunchKernelGGL((k_dist_scaled<1, 2, true>), dim3(grid), dim3(256), 0, st, *a, *b, w, h, tw, tiles,
+                       tpc_log2, cand, 1, scale, scale_stride, 1, 1, (unsigned long long *)out);
+  else
+    hipLaunchKernelGGL((k_dist_scaled<2, 2, true>), dim3(grid), dim3(256), 0, st, *a, *b, w, h, tw, tiles,
+                       tpc_log2, cand, 1, scale, scale_stride, 1, 1, (unsigned long long *)out);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+int r1_internal_cdef_dist_raw(const R1Plane *a, const R1Plane *b, int w, int h, const R1DistCand *cand,
+                              uint32_t *out3, hipStream_t st) {
+  if (a->bytes_per_px == 1)
+    hipLaunchKernelGGL((k_cdef_dist_raw<1>), dim3(1), dim3(64), 0, st, *a, *b, w, h, cand, 1, out3);
+  else
+    hipLaunchKernelGGL((k_cdef_dist_raw<2>), dim3(1), dim3(64), 0, st, *a, *b, w, h, cand, 1, out3);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
 
 extern "C" int r1_dist_scaled_batch(r1_ctx *ctx, int kind, const R1Plane *org,
                                     const R1Plane *ref, int w, int h,
