@@ -200,11 +200,20 @@ def main():
                                          device="cuda")}
     my_px = sum(len(c) * s * s for s, c in cands.items())
 
-    # ---- exchange step for N > 1: all-gather of the tile-row slabs of the
-    # reconstructed plane (stand-in payload: this rank's rows of `ref`) ----
-    side = torch.cuda.Stream() if world > 1 else None
+    # ---- exchange step for N > 1: the tile-boundary rectangles the neighbours'
+    # post filters read (point to point), then every rank's tile of the reference plane to
+    # everybody (all-gather) -- through the C ABI (csrc/comm.hip links RCCL), on the SAME
+    # stream as the launches: the next step's motion compensation reads the plane the
+    # all-gather writes, so the exchange is on the critical path, not hidden behind it ----
+    comm, exch_note, rects = None, None, None
     if world > 1:
-        send, gathered = tiles.make_exchange_buffers(ref.data, rank, world)
+        rects = W.tile_rects(world, fw, fh)
+        try:
+            comm = tiles.Comm(ctx, rank, world)
+            exch_note = "r1_comm_exchange_halos (64 px) + r1_comm_allgather_tiles per step, in stream order"
+        except Exception as e:   # keep the scaling run alive; the JSON says which path ran
+            exch_note = "torch.distributed all_gather_into_tensor (C-ABI comm failed: %s)" % (str(e)[:80],)
+            send, gathered = tiles.make_exchange_buffers(ref.data, rank, world)
 
     full = args.chain != "cand"
     pixel = args.chain == "pixel"
@@ -283,16 +292,23 @@ def main():
             for st in size_streams.values():
                 st.wait_stream(main)
         if world > 1 and exchange:
-            for st in (size_streams.values() if fan else (main,)):
-                side.wait_stream(st)
-            with torch.cuda.stream(side):
+            for st in size_streams.values():
+                main.wait_stream(st)
+            if comm is not None:
+                comm.exchange_tile_halos(ref, rects)
+                comm.allgather_tiles(ref, rects)
+            else:
                 tiles.exchange_rows(send, gathered)
+            for st in size_streams.values():
+                st.wait_stream(main)
 
     def fence():
         for st in size_streams.values():
             torch.cuda.current_stream().wait_stream(st)
         if world > 1:
-            torch.cuda.current_stream().wait_stream(side)
+            # drain this rank's stream (the C-ABI communicator's collectives included) before
+            # torch's own communicator runs its barrier: the two never have work in flight together
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -365,7 +381,7 @@ def main():
                                    % (fw, fh, bd, args.k),
                        "candidates_per_step": int(sum(len(c) for c in cands.values())) if world == 1
                        else None,
-                       "tiles": world,
+                       "tiles": world, "exchange": exch_note,
                        "parallelism": "tile-per-gpu x%d" % world if world > 1 else "single-gpu"},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -390,6 +406,8 @@ def main():
         if bad:
             print("PARITY FAILURE at block sizes %s" % bad, file=sys.stderr)
             sys.exit(3)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -41,6 +41,7 @@ extern "C" {
 #define R1_OK 0
 #define R1_EINVAL (-1)   /* bad argument / descriptor (reference: assert! panic) */
 #define R1_EHIP (-2)     /* HIP runtime error; see r1_last_error() */
+#define R1_ECOMM (-3)    /* RCCL error; see r1_last_error() */
 #define R1_ENOMEM (-3)
 
 /* ---- Plane<T> view (v_frame 0.3.9 PlaneConfig layout; reference use:
@@ -644,6 +645,36 @@ int r1_rdo_pred_cand_batch(r1_ctx *ctx, const R1Plane *org, const void *pred, in
                            int scale_stride, int xdec, int ydec, uint32_t *sad_out,
                            uint32_t *satd_out, uint16_t *eob_out, uint64_t *dist_out,
                            void *qcoeffs_out, void *rec_out, void *stream);
+
+/* ---- multi-GPU: the tile-boundary exchange and the reference-frame all-gather (RCCL over
+ * xGMI), SURVEY.md 8(e).  One process (or host thread) per GPU, tile r on rank r.  Rendezvous:
+ * rank 0 calls r1_comm_unique_id and hands the 128 bytes to the other ranks by any channel the
+ * host has; every rank then calls r1_comm_create with the device of its context current.
+ * All calls enqueue on `stream`; planes / buffers are device memory. */
+typedef struct r1_comm r1_comm;
+typedef struct R1HaloXfer {
+  int32_t peer;            /* rank on the other side */
+  int32_t dir;             /* 0: send this rectangle of my plane, 1: receive into it */
+  int32_t x0, y0, x1, y1;  /* plane pixels, visible-area coordinates, half-open */
+} R1HaloXfer;
+int r1_comm_unique_id(uint8_t *id128);
+int r1_comm_create(r1_ctx *ctx, int rank, int world, const uint8_t *id128, r1_comm **out);
+void r1_comm_destroy(r1_comm *comm);
+int r1_comm_rank(const r1_comm *comm);
+int r1_comm_world(const r1_comm *comm);
+/* every rank contributes bytes_per_rank bytes; recv = the contributions in rank order
+ * (a plane: each rank's slab of whole rows -> the whole allocation on every rank) */
+int r1_comm_allgather(r1_comm *comm, const void *send, void *recv, size_t bytes_per_rank,
+                      void *stream);
+/* rank r owns rects4[4r .. 4r+3] = (x0, y0, x1, y1) of `plane`; afterwards every rank holds
+ * every tile (pack, one all-gather of equal slots, unpack): the whole reconstructed frame as
+ * the next reference */
+int r1_comm_allgather_tiles(r1_comm *comm, const R1Plane *plane, const int32_t *rects4, void *stream);
+/* rectangles of `plane` to / from neighbouring ranks in one grouped send / receive; the two
+ * sides derive matching rectangles from the tile grid (rav1e_amd.tiles.tile_halo_plan =
+ * (my tile) ^ (peer's tile + halo)), so nothing is negotiated */
+int r1_comm_exchange_halos(r1_comm *comm, const R1Plane *plane, const R1HaloXfer *xfers, int n,
+                           void *stream);
 
 /* ---- per-call compat shims: reference asm signatures, HOST pointers ----
  * SadFn / SatdFn (src/asm/x86/dist/mod.rs:21-43): strides in BYTES. */

@@ -70,6 +70,14 @@ SYMBOLS = {
     "r1_mc_prep_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_avg_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "r1_mc_batch_mfma": (_i, [_vp, _i, _PP, _i, _i, _vp, _i, _vp, _vp]),
+    "r1_comm_unique_id": (_i, [_vp]),
+    "r1_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "r1_comm_destroy": (None, [_vp]),
+    "r1_comm_rank": (_i, [_vp]),
+    "r1_comm_world": (_i, [_vp]),
+    "r1_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "r1_comm_exchange_halos": (_i, [_vp, _PP, _vp, _i, _vp]),
+    "r1_comm_allgather_tiles": (_i, [_vp, _PP, _vp, _vp]),
     "r1_rdo_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "r1_rdo_full_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, C.POINTER(R1QuantParams),
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -10,10 +10,99 @@ filters the tile borders travel point to point first (exchange_tile_halos), so
 that the all-gather carries final pixels.  Everything here works on any
 torch.distributed backend: RCCL ("nccl") on the GPUs, gloo on CPU for the tests.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import workload as W
+
+HALO_XFER = np.dtype([("peer", "<i4"), ("dir", "<i4"), ("x0", "<i4"), ("y0", "<i4"), ("x1", "<i4"), ("y1", "<i4")])
+
+
+class Comm:
+    """The exchange behind the C ABI (csrc/comm.hip: RCCL linked into librav1e_hip.so): what a
+    Rust host would bind.  torch.distributed is used ONLY to carry the 128-byte unique id from
+    rank 0 to the others (any channel would do)."""
+
+    def __init__(self, ctx, rank, world, group=None):
+        from . import _lib
+        self.lib = _lib.load()
+        self.rank, self.world = rank, world
+        # every rank goes through the same collectives whatever fails locally: a rank that
+        # raised before the broadcast (or created alone) would leave the others waiting
+        idb, err = bytearray(128), None
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            if self.lib.r1_comm_unique_id(buf) != 0:
+                err = "r1_comm_unique_id: " + self.lib.r1_last_error().decode()
+            idb = bytearray(buf)
+        if world > 1:
+            box = [None if err else bytes(idb)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            if box[0] is None:
+                raise RuntimeError(err or "rank 0 could not make an RCCL unique id")
+            idb = bytearray(box[0])
+        elif err:
+            raise RuntimeError(err)
+        h = C.c_void_p()
+        arr = (C.c_uint8 * 128).from_buffer(idb)
+        rc = self.lib.r1_comm_create(ctx.h, rank, world, arr, C.byref(h))
+        if rc != 0:
+            err = "r1_comm_create: " + self.lib.r1_last_error().decode()
+        if world > 1:
+            oks = [None] * world
+            dist.all_gather_object(oks, err is None, group=group)
+            if not all(oks):
+                if rc == 0:
+                    self.lib.r1_comm_destroy(h)
+                raise RuntimeError(err or "r1_comm_create failed on rank(s) %s"
+                                   % [i for i, o in enumerate(oks) if not o])
+        elif err:
+            raise RuntimeError(err)
+        self.h = h
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.r1_last_error().decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.r1_comm_destroy(self.h)
+            self.h = None
+
+    def allgather(self, send, recv):
+        """tensors: every rank's `send` (same byte size) lands in recv in rank order"""
+        nbytes = send.numel() * send.element_size()
+        assert recv.numel() * recv.element_size() == nbytes * self.world
+        self._check(self.lib.r1_comm_allgather(self.h, send.data_ptr(), recv.data_ptr(), nbytes,
+                                               torch.cuda.current_stream().cuda_stream), "r1_comm_allgather")
+        return recv
+
+    def allgather_tiles(self, plane, rects):
+        """plane: rav1e_amd.api.Plane; rects[r] = (x0, y0, x1, y1) owned by rank r"""
+        assert len(rects) == self.world
+        r4 = np.ascontiguousarray(np.array(rects, np.int32).reshape(-1))
+        p = plane.cstruct()
+        self._check(self.lib.r1_comm_allgather_tiles(self.h, C.byref(p), r4.ctypes.data,
+                                                     torch.cuda.current_stream().cuda_stream),
+                    "r1_comm_allgather_tiles")
+
+    def exchange_tile_halos(self, plane, rects, halo=None):
+        """the tile-boundary rectangles of tile_halo_plan, in one grouped send / receive"""
+        halo = POSTFILTER_HALO if halo is None else halo
+        sends, recvs = tile_halo_plan(rects, self.rank, halo, plane.width, plane.height)
+        x = np.zeros(len(sends) + len(recvs), HALO_XFER)
+        for i, (peer, r) in enumerate(sends + recvs):
+            x[i] = (peer, int(i >= len(sends)), r[0], r[1], r[2], r[3])
+        if not len(x):
+            return 0
+        p = plane.cstruct()
+        self._check(self.lib.r1_comm_exchange_halos(self.h, C.byref(p), x.ctypes.data, len(x),
+                                                    torch.cuda.current_stream().cuda_stream),
+                    "r1_comm_exchange_halos")
+        return len(x)
 
 
 def owned_rows(alloc_height, rank, world):

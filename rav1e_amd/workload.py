@@ -42,6 +42,12 @@ def tile_rects(n_tiles, frame_w, frame_h):
     cols, rows = tile_split(n_tiles, frame_w, frame_h)
     sb_w, sb_h = -(-frame_w // SB), -(-frame_h // SB)
     tw, th = -(-sb_w // cols), -(-sb_h // rows)   # tile size in SBs (uniform spacing)
+    # like TilingInfo::from_target_tiles (tiler.rs:86-104): once the tile size is rounded up to
+    # whole superblocks the grid is recomputed from it -- a small frame yields fewer tiles
+    cols, rows = -(-sb_w // tw), -(-sb_h // th)
+    if cols * rows != n_tiles:
+        raise ValueError("a %dx%d frame splits into %d x %d superblock-aligned tiles, not %d"
+                         % (frame_w, frame_h, cols, rows, n_tiles))
     rects = []
     for r in range(rows):
         for c in range(cols):

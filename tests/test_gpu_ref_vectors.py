@@ -135,3 +135,25 @@ def test_activity_ref_scales(ctx):
         var, sc = ctx.activity_scales(dev_plane(hp))
         assert np.array_equal(var.cpu().numpy().view(np.uint32), A["var_" + k]), k
         assert np.array_equal(sc.cpu().numpy().view(np.uint32), A["scale_" + k]), k
+
+
+def test_comm_c_abi_single_rank(ctx):
+    """csrc/comm.hip through the C ABI on one GPU: RCCL initialises (world 1), the tile
+    all-gather packs / gathers / leaves the plane intact, a halo plan without neighbours is a
+    no-op.  (Multi-rank geometry: tests/test_distributed.py on gloo; the 8-GPU run is the driver's.)"""
+    import torch
+    from rav1e_amd import tiles
+    from rav1e_amd import workload as W
+    hp = O.HostPlane(640, 384, 8, rng=np.random.default_rng(5))
+    dp = dev_plane(hp)
+    comm = tiles.Comm(ctx, 0, 1)
+    rects = W.tile_rects(1, 640, 384)
+    before = dp.data.clone()
+    comm.allgather_tiles(dp, rects)
+    assert comm.exchange_tile_halos(dp, rects) == 0
+    send = torch.arange(4096, dtype=torch.uint8, device="cuda")
+    recv = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    comm.allgather(send, recv)
+    torch.cuda.synchronize()
+    assert torch.equal(before, dp.data) and torch.equal(send, recv)
+    comm.close()
