@@ -135,6 +135,8 @@ static const int16_t *get_filter(int mode, int frac, int length) {
   return FILTERS[idx][frac];
 }
 
+const int16_t *r1o_get_filter(int mode, int frac, int length) { return get_filter(mode, frac, length); }
+
 static inline int32_t run_filter_px(const void *src, int hbd, ptrdiff_t base,
                                     ptrdiff_t step, const int16_t *f) {
   int32_t s = 0;

@@ -241,6 +241,12 @@ void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0,
                        int set, int bd, int8_t *xqd_out);
 void r1o_activity_scales(const r1o_plane *luma, uint32_t *variances, uint32_t *scales);
 void r1o_set_threads(int n);
+/* mc.c: get_filter (src/mc.rs:238-247) for fast_cand.c */
+const int16_t *r1o_get_filter(int mode, int frac, int length);
+/* fast_cand.c: the compiler-vectorised CPU-baseline leg of bench.py (square blocks, DCT_DCT) */
+int r1o_fast_rdo_cand_batch(const r1o_plane *org, const r1o_plane *ref, int n_px, int tx_size,
+                            const r1o_rdo_cand *c, int n, int threads, uint32_t *sad_out,
+                            uint32_t *satd_out, void *coeffs);
 int r1o_dist_batch(int kind, const r1o_plane *org, const r1o_plane *ref, int w,
                    int h, const r1o_dist_cand *c, int n, uint32_t *out);
 int r1o_dist_scaled_batch(int kind, const r1o_plane *org, const r1o_plane *ref,

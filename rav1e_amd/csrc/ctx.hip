@@ -43,7 +43,8 @@ extern "C" int r1_ctx_create(int device, r1_ctx **out) {
     c->me_done[k] = nullptr;
   }
   c->me_next = 0;
-  if (r1_scan_tables_create(c) != R1_OK) {
+  if (r1_scan_tables_create(c) != R1_OK || r1_me_kernel_attrs() != R1_OK) {
+    r1_scan_tables_destroy(c);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
     return R1_EHIP;

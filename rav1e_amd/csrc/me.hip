@@ -949,8 +949,8 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   // job descriptors: caller's array -> pinned staging -> device, one ring slot per call.
   // The ring is the one piece of mutable state a context has: concurrent callers (rav1e's
   // per-tile rayon workers share a context) take turns for the enqueue.
-  static std::mutex ring_mu;
-  std::lock_guard<std::mutex> ring_lock(ring_mu);
+  std::lock_guard<std::mutex> ring_lock(ctx->me_mu);
+  R1DeviceGuard dev_guard(ctx);
   const size_t bytes = (size_t)n_jobs * sizeof(R1MeJob);
   const int slot = ctx->me_next;
   ctx->me_next = (slot + 1) % r1_ctx::kMeSlots;
@@ -980,6 +980,19 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   }
   R1_HIP_CHECK(hipGetLastError());
   R1_HIP_CHECK(hipEventRecord(ctx->me_done[slot], st));
+  return R1_OK;
+}
+
+// k_me_blocks' dynamic LDS at 64x64, 16-bit: source + 4 x (window + prediction) -- above the
+// 64 KB default, so the limit is raised ONCE per context (ctx.hip) to this worst case; a
+// per-launch setting would race between threads sharing a context.
+static constexpr size_t kMeBlocksMaxLds = 8192 + 4 * ((((size_t)(64 + 7) * 144 + 15) & ~(size_t)15) + 8192);
+
+int r1_me_kernel_attrs() {
+  R1_HIP_CHECK(hipFuncSetAttribute((const void *)k_me_blocks<1>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMeBlocksMaxLds));
+  R1_HIP_CHECK(hipFuncSetAttribute((const void *)k_me_blocks<2>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMeBlocksMaxLds));
   return R1_OK;
 }
 
@@ -1015,14 +1028,11 @@ extern "C" int r1_estimate_motion_batch(r1_ctx *ctx, const R1MeJob *tile, const 
   const int ws = (((max_w + 7) * bpp + 3) >> 2) << 2;
   const size_t blk = ((size_t)max_w * max_h * bpp + 15) & ~(size_t)15;
   const size_t lds = blk + 4 * ((((size_t)(max_h + 7) * ws + 15) & ~(size_t)15) + blk);
+  R1_REQUIRE(lds <= kMeBlocksMaxLds);
   if (bpp == 1) {
-    R1_HIP_CHECK(hipFuncSetAttribute((const void *)k_me_blocks<1>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_me_blocks<1>, dim3(n), dim3(256), lds, st, *tile, *params, cands, max_w,
                        max_h, use_satd, filter_mode, out);
   } else {
-    R1_HIP_CHECK(hipFuncSetAttribute((const void *)k_me_blocks<2>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_me_blocks<2>, dim3(n), dim3(256), lds, st, *tile, *params, cands, max_w,
                        max_h, use_satd, filter_mode, out);
   }

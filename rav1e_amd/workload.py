@@ -57,13 +57,28 @@ def tile_rects(n_tiles, frame_w, frame_h):
     return rects
 
 
-def speed6_ladder(frame_w, frame_h, k, seed=3, mv_range=32, rect=None, tx_type=0):
+# the seven transform types rav1e's RDO searches (RAV1E_TX_TYPES, src/transform/mod.rs:28-44):
+# DCT_DCT, ADST_DCT, DCT_ADST, ADST_ADST, IDTX, V_DCT, H_DCT -- by TxType discriminant
+RDO_TX_TYPES = (0, 1, 2, 3, 9, 10, 11)
+
+
+def rdo_tx_types_for(size):
+    """the subset of RDO_TX_TYPES that valid_av1_transform (src/transform/mod.rs:405-417) admits
+    for a square transform of this size: all seven up to 16x16, DCT_DCT / IDTX at 32, DCT_DCT at 64"""
+    return RDO_TX_TYPES if size <= 16 else ((0, 9) if size == 32 else (0,))
+
+
+def speed6_ladder(frame_w, frame_h, k, seed=3, mv_range=32, rect=None, tx_type=0, sizes=LADDER,
+                  mix_filters=False, mix_tx_types=False):
     """-> {size: structured array of RDO_CAND}; blocks restricted to `rect`
     (a tile) when given.  Deterministic per (seed, size): a tile's list is the
     subset of the whole-frame list, so sharded and unsharded runs evaluate the
-    same candidates."""
+    same candidates.  sizes: the block ladder (chroma planes of 4:2:0 use 32/16/8/4);
+    mix_filters: one of the 9 8-tap filter pairs per candidate (REGULAR / SMOOTH / SHARP in
+    each direction) instead of REGULAR/REGULAR; mix_tx_types: one of rdo_tx_types_for(size) per
+    candidate instead of `tx_type`."""
     out = {}
-    for lvl, s in enumerate(LADDER):
+    for lvl, s in enumerate(sizes):
         rng = np.random.default_rng([seed, lvl])
         nx, ny = frame_w // s, frame_h // s
         n = nx * ny * k
@@ -76,6 +91,12 @@ def speed6_ladder(frame_w, frame_h, k, seed=3, mv_range=32, rect=None, tx_type=0
         c["col_frac"] = rng.integers(0, 16, n)
         c["row_frac"] = rng.integers(0, 16, n)
         c["tx_type"] = tx_type
+        # drawn after everything else, so the default lists do not depend on these options
+        if mix_filters:
+            c["mode_x"] = rng.integers(0, 3, n)
+            c["mode_y"] = rng.integers(0, 3, n)
+        if mix_tx_types:
+            c["tx_type"] = np.array(rdo_tx_types_for(s), np.uint8)[rng.integers(0, len(rdo_tx_types_for(s)), n)]
         if rect is not None:
             x0, y0, x1, y1 = rect
             keep = (bx >= x0) & (bx < x1) & (by >= y0) & (by < y1)

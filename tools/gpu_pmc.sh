@@ -8,7 +8,7 @@ cd /tmp
 run() { # name counters...
   n=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$TAG/$n -o p -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-events $BENCH_ARGS > /tmp/pmc_$TAG.$n.log 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-events --no-extra $BENCH_ARGS > /tmp/pmc_$TAG.$n.log 2>&1
   f=$(find /tmp/pmc_$TAG/$n -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/$n.csv || (echo "no counters for $n"; tail -5 /tmp/pmc_$TAG.$n.log)
 }

@@ -21,7 +21,7 @@ for bd in 8 10; do
 done
 timeout 900 python tools/bench_me.py --cpu 2>&1 | grep "^{" > $OUT/me_4k.jsonl
 echo "== rocprof stats"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-seconds 0 > /tmp/prof_$TAG.log 2>&1; tail -1 /tmp/prof_$TAG.log | cut -c1-200)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --no-extra > /tmp/prof_$TAG.log 2>&1; tail -1 /tmp/prof_$TAG.log | cut -c1-200)
 find /tmp/prof_$TAG -name "*kernel_stats*" -exec cp {} $OUT/kernel_stats.csv \; 2>/dev/null
 echo "== rocprof stats of the frame pipeline"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profp_$TAG -o prof -- python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --reps 3 > /tmp/profp_$TAG.log 2>&1; tail -1 /tmp/profp_$TAG.log | cut -c1-120)

@@ -2,6 +2,8 @@
 """Instruction histogram of the gfx950 code of one .hip file, per kernel.
 
   python tools/isa_hist.py rav1e_amd/csrc/rdo_cand.hip [kernel-name-substring ...]
+  python tools/isa_hist.py --json profiles/r02_isa_mix.json rav1e_amd/csrc/rdo_cand.hip k_rdo_cand
+      (the per-kernel VALU mix bench.py's `roofline` prices the VALU-issue roof with)
 
 Compiles the file to device assembly (hipcc -S --cuda-device-only) and counts, per kernel,
 VALU / SALU / LDS / VMEM instructions.  VALU is weighted with the issue costs measured by
@@ -22,8 +24,15 @@ COST_FAST, COST_SLOW = 2.6, 4.4
 
 
 def main():
-    src = sys.argv[1]
-    pats = sys.argv[2:]
+    argv = sys.argv[1:]
+    jpath = None
+    if argv and argv[0] == "--json":
+        jpath, argv = argv[1], argv[2:]
+    src = argv[0]
+    pats = argv[1:]
+    jout = {"_model": {"fast_cycles": COST_FAST, "slow_cycles": COST_SLOW,
+                       "source": "tools/ubench/valu_rate.hip on MI355X; cycles of the 2.4 GHz nominal clock "
+                                 "per wave64 instruction per SIMD; static counts of the unrolled kernel"}}
     here = os.path.dirname(os.path.abspath(src))
     out = "/tmp/isa_hist_%d.s" % os.getpid()
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S",
@@ -64,11 +73,18 @@ def main():
         lds = sum(n for o, n in c.items() if o.startswith("ds_"))
         vmem = sum(n for o, n in c.items() if o.startswith(("global_", "buffer_", "flat_", "scratch_")))
         salu = sum(n for o, n in c.items() if o.startswith("s_"))
+        short = re.sub(r"^void \(anonymous namespace\)::", "", name).split("(")[0].replace(" ", "")
+        jout[short] = {"valu": fast + slow, "fast": fast, "slow": slow, "mfma": mfma, "lds": lds, "vmem": vmem,
+                       "salu": salu, "issue_cycles_per_valu": round((fast * COST_FAST + slow * COST_SLOW) /
+                                                                    max(1, fast + slow), 4)}
         print("%s\n  VALU %d (fast %d, slow %d) -> %.0f issue cycles; MFMA %d, LDS %d, VMEM %d, SALU %d; %s"
               % (name[:150], fast + slow, fast, slow, fast * COST_FAST + slow * COST_SLOW, mfma, lds, vmem, salu,
                  meta.get(k, {})))
         top = sorted(valu.items(), key=lambda kv: -kv[1])[:14]
         print("  top VALU: " + ", ".join("%s %d" % kv for kv in top))
+    if jpath:
+        import json
+        json.dump(jout, open(jpath, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
