@@ -334,6 +334,22 @@ int r1_estimate_inter_costs(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
 int r1_importance_block_difference(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref,
                                    uint64_t *sum_out, void *stream);
 
+/* ---- frame glue: planes stay resident in HBM between the block stages ----
+ * r1_plane_pad: Plane::pad(w, h) (v_frame 0.3.9) as FramePad::pad calls it per plane
+ * (src/frame/mod.rs:76-86) on the reconstruction before it becomes a reference
+ * (src/api/internal.rs:1436): the visible area of (w + xdec) >> xdec by (h + ydec) >> ydec
+ * pixels is replicated over the whole allocation (left / right to the stride, above / below to
+ * alloc_height).  w, h: FRAME size in luma pixels; xdec, ydec: the plane's decimation.
+ * r1_plane_downsample: Plane::downsampled(frame_w, frame_h) (v_frame 0.3.9), the call that
+ * makes FrameState::input_hres / input_qres (src/encoder.rs:476-477): dst (caller-allocated,
+ * visible size ((src.width + 1) / 2, (src.height + 1) / 2), half the padding) receives the
+ * rounded 2x2 box average, then dst.pad(frame_w, frame_h) with dst's decimation (1 for the
+ * half-, 2 for the quarter-resolution plane) -- one launch for both.  src must be padded (odd
+ * sizes read one pixel into its border), as in the reference. */
+int r1_plane_pad(r1_ctx *ctx, const R1Plane *plane, int w, int h, int xdec, int ydec, void *stream);
+int r1_plane_downsample(r1_ctx *ctx, const R1Plane *src, const R1Plane *dst, int frame_w, int frame_h,
+                        int dst_xdec, int dst_ydec, void *stream);
+
 /* ActivityMask::from_plane + fill_scales (src/activity.rs:21-66): the spatial
  * DistortionScale of every 8x8 luma block, ssim_boost(variance, variance) in
  * Q14 -- the producer of the `scales` grid r1_dist_scaled_batch and

@@ -240,6 +240,10 @@ int r1o_lrf_filter_plane(const r1o_plane *cdeffed, const r1o_plane *deblocked, c
 void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0, int y0, int w, int h,
                        int set, int bd, int8_t *xqd_out);
 void r1o_activity_scales(const r1o_plane *luma, uint32_t *variances, uint32_t *scales);
+/* plane.c: v_frame 0.3.9 Plane::pad / Plane::downsampled (see the header of plane.c) */
+void r1o_plane_pad(const r1o_plane *p, int w, int h, int xdec, int ydec);
+int r1o_plane_downsample(const r1o_plane *src, const r1o_plane *dst, int frame_w, int frame_h,
+                         int dst_xdec, int dst_ydec);
 void r1o_set_threads(int n);
 /* mc.c: get_filter (src/mc.rs:238-247) for fast_cand.c */
 const int16_t *r1o_get_filter(int mode, int frac, int length);

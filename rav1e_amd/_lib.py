@@ -48,6 +48,8 @@ SYMBOLS = {
     "r1_last_error": (C.c_char_p, []),
     "r1_abi_version": (_i, []),
     "r1_dist_batch": (_i, [_vp, _i, _PP, _PP, _i, _i, _vp, _i, _vp, _vp]),
+    "r1_plane_pad": (_i, [_vp, _PP, _i, _i, _i, _i, _vp]),
+    "r1_plane_downsample": (_i, [_vp, _PP, _PP, _i, _i, _i, _i, _vp]),
     "r1_dist_scaled_batch": (_i, [_vp, _i, _PP, _PP, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "r1_fwd_txfm_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "r1_inv_txfm_add_batch": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

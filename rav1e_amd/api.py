@@ -373,6 +373,23 @@ class Context:
             cdef_index_sb.data_ptr(), cdef_index_sb.stride(0), C.byref(prm), _stream_ptr()),
             "r1_cdef_filter_frame_plane")
 
+    # ---- frame glue ----
+    def plane_pad(self, plane, w, h, xdec=0, ydec=0):
+        """Plane::pad(w, h) in place (FramePad::pad, src/frame/mod.rs:76-86); w, h: frame size"""
+        pl = plane.cstruct()
+        self._check(self.lib.r1_plane_pad(self.h, C.byref(pl), w, h, xdec, ydec, _stream_ptr()),
+                    "r1_plane_pad")
+        return plane
+
+    def plane_downsample(self, src, frame_w, frame_h, dec):
+        """Plane::downsampled(frame_w, frame_h) (src/encoder.rs:476-477) -> new padded Plane of
+        half the size and half the padding; dec: the NEW plane's decimation (1 half, 2 quarter)"""
+        dst = Plane((src.width + 1) // 2, (src.height + 1) // 2, src.bit_depth, src.xpad // 2, src.ypad // 2)
+        a, b = src.cstruct(), dst.cstruct()
+        self._check(self.lib.r1_plane_downsample(self.h, C.byref(a), C.byref(b), frame_w, frame_h, dec, dec,
+                                                 _stream_ptr()), "r1_plane_downsample")
+        return dst
+
     # ---- lookahead cost maps ----
     def estimate_intra_costs(self, luma):
         """estimate_intra_costs (src/api/lookahead.rs:30-123) -> (h/8, w/8) int32"""

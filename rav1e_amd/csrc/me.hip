@@ -31,6 +31,7 @@
 // Every search loop of the reference is data dependent (it recentres on the
 // best candidate), so a block's search is a chain of such steps; the chip is
 // filled by jobs x superblocks-on-the-diagonal x blocks, not by one block.
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -475,8 +476,10 @@ __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, i
 // Pass q on diagonal d + 2 meanwhile touches diagonals d + 1 .. d + 3 only.
 constexpr int kPassSkew = 2;
 template <int BPP>
-__global__ __launch_bounds__(256, 5) void k_me_diag(const R1MeJob *__restrict__ jobs, R1MeParams p,
-                                                 int step) {
+__global__ __launch_bounds__(256, 5) void k_me_diag(const R1MeJob *__restrict__ jobs,
+                                                 const R1MeParams *__restrict__ pp, int step) {
+  const R1MeParams p = *pp;   // uniform: lives in SGPRs; in device memory so that the launch
+                              // arguments (and with them the captured graph) do not depend on it
   // blockIdx.z = pass; pass q works kPassSkew * q diagonals behind pass q - 1 (see the host loop)
   const int log2b = 4 - (int)blockIdx.z, diag = step - kPassSkew * (int)blockIdx.z;
   const R1MeJob &job = jobs[blockIdx.y];
@@ -946,17 +949,20 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
     max_sbh = sbh > max_sbh ? sbh : max_sbh;
   }
   hipStream_t st = (hipStream_t)stream;
-  // job descriptors: caller's array -> pinned staging -> device, one ring slot per call.
-  // The ring is the one piece of mutable state a context has: concurrent callers (rav1e's
+  // job descriptors + parameters: caller's memory -> pinned staging -> device, one ring slot per
+  // call.  The ring is the one piece of mutable state a context has: concurrent callers (rav1e's
   // per-tile rayon workers share a context) take turns for the enqueue.
   std::lock_guard<std::mutex> ring_lock(ctx->me_mu);
   R1DeviceGuard dev_guard(ctx);
-  const size_t bytes = (size_t)n_jobs * sizeof(R1MeJob);
+  const size_t jobs_bytes = ((size_t)n_jobs * sizeof(R1MeJob) + 15) & ~(size_t)15;
+  const size_t bytes = jobs_bytes + sizeof(R1MeParams);
   const int slot = ctx->me_next;
   ctx->me_next = (slot + 1) % r1_ctx::kMeSlots;
   if (ctx->me_done[slot]) R1_HIP_CHECK(hipEventSynchronize(ctx->me_done[slot]));
   else R1_HIP_CHECK(hipEventCreateWithFlags(&ctx->me_done[slot], hipEventDisableTiming));
   if (ctx->me_jobs_bytes[slot] < bytes) {
+    if (ctx->me_graph[slot]) (void)hipGraphExecDestroy(ctx->me_graph[slot]);   // it holds the old pointers
+    ctx->me_graph[slot] = nullptr;
     if (ctx->me_jobs[slot]) (void)hipFree(ctx->me_jobs[slot]);
     if (ctx->me_jobs_host[slot]) (void)hipHostFree(ctx->me_jobs_host[slot]);
     ctx->me_jobs[slot] = ctx->me_jobs_host[slot] = nullptr;
@@ -965,20 +971,63 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
     R1_HIP_CHECK(hipHostMalloc(&ctx->me_jobs_host[slot], bytes, hipHostMallocDefault));
     ctx->me_jobs_bytes[slot] = bytes;
   }
-  memcpy(ctx->me_jobs_host[slot], jobs, bytes);
-  R1_HIP_CHECK(hipMemcpyAsync(ctx->me_jobs[slot], ctx->me_jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
+  memcpy(ctx->me_jobs_host[slot], jobs, (size_t)n_jobs * sizeof(R1MeJob));
+  memcpy((uint8_t *)ctx->me_jobs_host[slot] + jobs_bytes, params, sizeof(R1MeParams));
   const R1MeJob *djobs = (const R1MeJob *)ctx->me_jobs[slot];
+  const R1MeParams *dparams = (const R1MeParams *)((const uint8_t *)ctx->me_jobs[slot] + jobs_bytes);
   const int ndiag = max_sbw + max_sbh - 1;
   const int dlen = max_sbw < max_sbh ? max_sbw : max_sbh;
   // software pipeline over the passes: launch `step` runs diagonal step - 2 q of pass q
   // (grid z = pass); ndiag + 4 launches instead of 3 * ndiag
-  for (int step = 0; step < ndiag + 2 * kPassSkew; step++) {
-    if (bpp == 1)
-      hipLaunchKernelGGL(k_me_diag<1>, dim3(dlen, n_jobs, 3), dim3(256), 0, st, djobs, *params, step);
-    else
-      hipLaunchKernelGGL(k_me_diag<2>, dim3(dlen, n_jobs, 3), dim3(256), 0, st, djobs, *params, step);
+  const int nsteps = ndiag + 2 * kPassSkew;
+  const void *fn = bpp == 1 ? (const void *)k_me_diag<1> : (const void *)k_me_diag<2>;
+  static const bool use_graph = !getenv("R1_ME_NO_GRAPH");   // A/B switch for tools/bench_me.py
+  if (!use_graph) {
+    R1_HIP_CHECK(hipMemcpyAsync(ctx->me_jobs[slot], ctx->me_jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
+    for (int step = 0; step < nsteps; step++) {
+      if (bpp == 1) hipLaunchKernelGGL(k_me_diag<1>, dim3(dlen, n_jobs, 3), dim3(256), 0, st, djobs, dparams, step);
+      else hipLaunchKernelGGL(k_me_diag<2>, dim3(dlen, n_jobs, 3), dim3(256), 0, st, djobs, dparams, step);
+    }
+    R1_HIP_CHECK(hipGetLastError());
+    R1_HIP_CHECK(hipEventRecord(ctx->me_done[slot], st));
+    return R1_OK;
   }
-  R1_HIP_CHECK(hipGetLastError());
+  // The sequence (upload, then one launch per diagonal step, each depending on the one before)
+  // is a function of (pixel size, jobs, diagonal length, steps) and of the slot's buffers only --
+  // the job contents and the parameters travel through the upload.  It is built once as an
+  // explicit hipGraph and replayed with a single hipGraphLaunch per call.
+  const long long sig[4] = {bpp, n_jobs, dlen, nsteps};
+  if (!ctx->me_graph[slot] || memcmp(sig, ctx->me_graph_sig[slot], sizeof(sig)) != 0) {
+    if (ctx->me_graph[slot]) (void)hipGraphExecDestroy(ctx->me_graph[slot]);
+    ctx->me_graph[slot] = nullptr;
+    hipGraph_t g;
+    R1_HIP_CHECK(hipGraphCreate(&g, 0));
+    hipGraphNode_t prev;
+    hipError_t e = hipGraphAddMemcpyNode1D(&prev, g, nullptr, 0, ctx->me_jobs[slot], ctx->me_jobs_host[slot],
+                                           bytes, hipMemcpyHostToDevice);
+    for (int step = 0; step < nsteps && e == hipSuccess; step++) {
+      int step_arg = step;
+      void *args[3] = {(void *)&djobs, (void *)&dparams, (void *)&step_arg};
+      hipKernelNodeParams kp;
+      memset(&kp, 0, sizeof(kp));
+      kp.func = (void *)fn;
+      kp.gridDim = dim3(dlen, n_jobs, 3);
+      kp.blockDim = dim3(256);
+      kp.sharedMemBytes = 0;
+      kp.kernelParams = args;   // copied at node creation
+      hipGraphNode_t node;
+      e = hipGraphAddKernelNode(&node, g, &prev, 1, &kp);
+      prev = node;
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&ctx->me_graph[slot], g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {
+      ctx->me_graph[slot] = nullptr;
+      R1_HIP_CHECK(e);
+    }
+    memcpy(ctx->me_graph_sig[slot], sig, sizeof(sig));
+  }
+  R1_HIP_CHECK(hipGraphLaunch(ctx->me_graph[slot], st));
   R1_HIP_CHECK(hipEventRecord(ctx->me_done[slot], st));
   return R1_OK;
 }

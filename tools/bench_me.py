@@ -80,6 +80,8 @@ def main():
         ms = (time.perf_counter() - t0) / args.reps * 1e3
         row = {"kernel": "estimate_tile_motion", "frame": "%dx%d" % (w, h), "bit_depth": bd,
                "tiles": len(tl), "refs": nref, "jobs": len(jobs), "ms": round(ms, 3),
+               "launch": "per-call launches (R1_ME_NO_GRAPH)" if os.environ.get("R1_ME_NO_GRAPH")
+               else "hipGraph replay",
                "Mpixels_s": round(w * h * nref / ms / 1e3, 1),
                "frames_refs_per_s": round(nref / ms * 1e3, 1)}
         if args.cpu and len(jobs) > 1:
@@ -95,6 +97,25 @@ def main():
                 same = same and bool(np.array_equal(got, st))
             row["all_jobs_equal_oracle"] = same
         print(json.dumps(row), flush=True)
+    # the glue that feeds the search from a resident frame: pad the full-resolution plane, make
+    # the half- and quarter-resolution planes (each call pads its output) -- 3 launches
+    def glue():
+        ctx.plane_pad(do[0], w, h)
+        hres = ctx.plane_downsample(do[0], w, h, 1)
+        return hres, ctx.plane_downsample(hres, w, h, 2)
+    hres, qres = glue()
+    torch.cuda.synchronize()
+    view = lambda t: t.cpu().numpy() if bd == 8 else t.cpu().numpy().view(np.uint16)
+    same = bool(np.array_equal(view(hres.data), po[1].data) and np.array_equal(view(qres.data), po[2].data))
+    t0 = time.perf_counter()
+    for _ in range(20):
+        glue()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    moved = (do[0].data.numel() + 2 * hres.data.numel() + 2 * qres.data.numel()) * do[0].data.element_size()
+    print(json.dumps({"kernel": "r1_plane_pad + 2 x r1_plane_downsample (allocation included)",
+                      "frame": "%dx%d" % (w, h), "bit_depth": bd, "ms": round(ms, 4),
+                      "GB_s": round(moved / ms / 1e6, 1), "equals_host_pyramid": same}), flush=True)
     if args.only >= 0 or args.tile_only:
         ctx.close()
         return
