@@ -71,7 +71,9 @@ def parse():
 
 
 def physical_cores():
-    """(physical cores, logical CPUs) this process may run on"""
+    """(cores the CPU legs may use, logical CPUs visible, note): physical cores in the affinity
+    mask, capped by the container's CPU quota (cgroup cpu.max / cfs_quota) -- more runnable
+    threads than the quota allows only get throttled"""
     try:
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
@@ -82,7 +84,24 @@ def physical_cores():
             sib.add(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip())
         except OSError:
             sib.add(str(c))
-    return max(1, len(sib)), len(cpus)
+    phys, note = max(1, len(sib)), "physical cores in the affinity mask"
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < phys:
+        phys, note = max(1, int(quota)), "cgroup CPU quota of this container (%g CPUs; %d physical cores visible)" % (
+            quota, len(sib))
+    return phys, len(cpus), note
 
 
 def reference_probe():
@@ -124,7 +143,7 @@ def cpu_baseline(args, host_org, host_ref, cands, outs):
     """Time the CPU side on bounded samples of the step that was just timed on the GPU, and check
     the GPU's buffers against it:
       scalar    oracle/batch.c r1o_rdo_cand_batch -- the restatement every parity test uses;
-                a strided sample, all logical CPUs (this is the checker of record);
+                a strided sample, one thread per usable core (this is the checker of record);
       vector    oracle/fast_cand.c -- the same candidate written for the compiler's SIMD
                 (tests/test_oracle_fast.py holds it equal to the scalar one), on every physical
                 core (-> `value`) and on one thread.
@@ -133,7 +152,7 @@ def cpu_baseline(args, host_org, host_ref, cands, outs):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     L = O.lib()
-    phys, logical = physical_cores()
+    phys, logical, cores_note = physical_cores()
     ho = O.HostPlane(args.width, args.height, args.bit_depth)
     hr = O.HostPlane(args.width, args.height, args.bit_depth)
     ho.data, hr.data = host_org, host_ref
@@ -189,21 +208,21 @@ def cpu_baseline(args, host_org, host_ref, cands, outs):
         return {"px": px, "dt": dt, "frac": frac, "reps": reps, "n": n_cmp, "bad": bad, "mpx": px / dt / 1e6}
 
     T = args.cpu_seconds
-    sc = sized("scalar", logical, 0.2 * T)
+    sc = sized("scalar", phys, 0.2 * T)
     vN = sized("vector", phys, 0.4 * T)
     v1 = sized("vector", 1, 0.3 * T)
     res = {"value": round(vN["mpx"], 2), "unit": "Mpixels/s", "cores": phys, "kind": "port",
            "sample": "%.2f%% of the step's candidates (every ladder size, strided) x %d, %.1f s, one "
-                     "OpenMP thread per physical core" % (100 * vN["frac"], vN["reps"], vN["dt"]),
+                     "OpenMP thread per core" % (100 * vN["frac"], vN["reps"], vN["dt"]),
            "impl": "oracle/fast_cand.c: gcc vector extensions (AVX2, 8 x i32) over the same generated "
                    "transform networks as the scalar oracle -- a compiler-vectorised port, NOT rav1e's "
                    "nasm kernels",
            "one_thread": {"value": round(v1["mpx"], 2),
                           "sample": "%.2f%% of the candidates x %d, %.1f s" % (100 * v1["frac"], v1["reps"], v1["dt"])},
-           "scalar_port": {"value": round(sc["mpx"], 2), "threads": logical,
+           "scalar_port": {"value": round(sc["mpx"], 2), "threads": phys,
                            "sample": "%.3f%% of the candidates x %d, %.1f s; oracle/batch.c, the parity checker"
                                      % (100 * sc["frac"], sc["reps"], sc["dt"])},
-           "logical_cpus": logical,
+           "logical_cpus": logical, "cores_note": cores_note,
            "reference_probe": reference_probe()}
     parity = {"parity_checked": sc["n"], "parity_checked_vector_leg": vN["n"] + v1["n"],
               "parity_ok": not (sc["bad"] or vN["bad"] or v1["bad"]),

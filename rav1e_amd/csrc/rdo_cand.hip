@@ -798,7 +798,13 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     constexpr int CH = CBY / P >= 16 ? 16 : CBY / P;   // bytes a lane moves per step
     constexpr int NCH = CBY / P / CH;
     static_assert(CH * NCH * P == CBY && (CH == 16 || CH == 8 || CH == 4), "whole chunks");
-    CT *tile = (CT *)smem + cl2 * EPP;
+    // candidates one row of P elements apart: with the bare stride (a multiple of 32 dwords for
+    // 8x8 / 16x16) the NC candidates of a lane group hit the same banks with their element
+    // writes (4-way at 8x8: SQ_LDS_BANK_CONFLICT 4.1 M -> 20.7 M per launch when this path came in)
+    constexpr int TPAD = NC > 1 ? ((P * ESZ + 15) & ~15) / ESZ : 0;
+    static_assert(NC * (EPP + TPAD) * ESZ <= LDS_BYTES, "the padded tiles fit the LDS of the kernel");
+    static_assert(((EPP + TPAD) * ESZ) % 16 == 0, "16-byte reads stay aligned");
+    CT *tile = (CT *)smem + cl2 * (EPP + TPAD);
     uint8_t *gdst = (uint8_t *)(coeffs + cand2 * (W * H));
 #pragma unroll
     for (int p = 0; p < NP; p++) {
