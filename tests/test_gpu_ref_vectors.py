@@ -157,3 +157,60 @@ def test_comm_c_abi_single_rank(ctx):
     torch.cuda.synchronize()
     assert torch.equal(before, dp.data) and torch.equal(send, recv)
     comm.close()
+
+
+# ---- N2: motion estimation against the executed src/me.rs text (gen_me_ref.py) ----------
+def _me_ref_cases():
+    M = np.load(os.path.join(GOLD, "me_ref.npz"))
+    return sorted(k[:-5] for k in M.files if k.endswith("_meta"))
+
+
+def _me_stats_tensor(a):
+    import torch
+    s = np.zeros(a.shape[:2], O.ME_STATS)
+    s["row"], s["col"], s["normalized_sad"] = a[..., 0], a[..., 1], a[..., 2]
+    return torch.from_numpy(s.view(np.int32).reshape(s.shape[0], s.shape[1], 2).copy()).cuda(), s
+
+
+@pytest.mark.parametrize("name", _me_ref_cases())
+def test_me_ref_tile_motion_and_block_searches(ctx, name):
+    """r1_estimate_tile_motion_batch (all references of a case as the jobs of ONE call) and
+    r1_estimate_motion_batch on what estimate_tile_motion / estimate_motion of the reference's
+    own text produced: every MEStats entry, every (mv, sad, cost)."""
+    from rav1e_amd.api import ME_RESULT
+    M = np.load(os.path.join(GOLD, "me_ref.npz"))
+    w, h, bd, tx, ty, tw, th, hp, full, scale, n_refs, _ = [int(v) for v in M[name + "_meta"]]
+    pads = (88, 44, 22)
+    lam = [int(v) for v in M[name + "_lambda"]]
+    org = [dev_plane(O.plane_from_image(M["%s_org%d" % (name, s)].astype(np.int64), bd, pads[s], pads[s]))
+           for s in range(3)]
+    jobs, wants = [], []
+    for k in range(n_refs):
+        ref = [dev_plane(O.plane_from_image(M["%s_ref%d_%d" % (name, k, s)].astype(np.int64), bd, pads[s], pads[s]))
+               for s in range(3)]
+        want_t, want = _me_stats_tensor(M["%s_stats%d" % (name, k)])
+        prev_t, _ = _me_stats_tensor(M["%s_prev%d" % (name, k)])
+        st, _ = _me_stats_tensor(np.zeros_like(M["%s_stats%d" % (name, k)]))
+        jobs.append(dict(org=org, ref=ref, stats=st, prev=prev_t, tile=(tx, ty, tw, th)))
+        wants.append((want_t, want))
+    cols, rows = (w + 3) // 4, (h + 3) // 4
+    ctx.estimate_tile_motion(jobs, cols, rows, bd, lam, allow_hp=bool(hp), allow_full_search=bool(full),
+                             me_range_scale=scale)
+    for k, (want_t, want) in enumerate(wants):
+        got = jobs[k]["stats"].cpu().numpy().reshape(rows, -1).view(O.ME_STATS).reshape(rows, cols)
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, (name, k, len(bad), bad[:4], got[tuple(bad[0])], want[tuple(bad[0])])
+    if name + "_blk" not in M.files:
+        return
+    blk = M[name + "_blk"]
+    c = np.zeros(len(blk), O.ME_BLOCK_CAND)
+    c["bx"], c["by"], c["w"], c["h"], c["corner"] = blk[:, 0], blk[:, 1], blk[:, 2], blk[:, 3], blk[:, 4]
+    c["pmv"] = blk[:, 5:9].reshape(-1, 2, 2)
+    use_satd, fmode = [int(v) for v in M[name + "_blkcfg"]]
+    job = dict(jobs[0], stats=wants[0][0])
+    got = ctx.estimate_motion_batch(job, c, cols, rows, bd, lam, use_satd=bool(use_satd), filter_mode=fmode,
+                                    allow_hp=bool(hp)).cpu().numpy().view(ME_RESULT)
+    want = M[name + "_blkout"]
+    for i in range(len(blk)):
+        g = (int(got["row"][i]), int(got["col"][i]), int(got["sad"][i]), int(got["cost"][i]))
+        assert g == tuple(int(v) for v in want[i]), (name, i, blk[i], g, want[i])

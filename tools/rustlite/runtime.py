@@ -164,6 +164,11 @@ def store(r, v):
         r.b[r.i] = v
     elif t is MaybeUninitSlot:
         r.write(v)
+    elif isinstance(r, RStruct) and type(v) is t:
+        # `*r = v` through a reference to a struct: references to structs ARE the struct objects
+        # (refmut_local), so the assignment replaces the fields in place
+        for f in r._fields:
+            setattr(r, f, getattr(v, f))
     else:
         raise Panic("store through non-reference %r" % (r,))
 
@@ -1208,6 +1213,17 @@ class PlaneConfig(RStruct):
     _is_copy = False
 
 
+def _plane_config_new(width, height, xdec, ydec, xpad, ypad, type_size):
+    # v_frame PlaneConfig::new: xorigin and stride aligned to 64 BYTES (see Plane.new)
+    al = 64 // type_size
+    xorigin = _align(xpad, al)
+    stride = _align(xorigin + width + xpad, al)
+    return PlaneConfig(stride, ypad + height + ypad, width, height, xdec, ydec, xpad, ypad, xorigin, ypad)
+
+
+PlaneConfig.new = staticmethod(_plane_config_new)
+
+
 class PlaneOffset(RStruct):
     _fields = ("x", "y")
     _rname = "PlaneOffset"
@@ -1246,7 +1262,13 @@ class Plane(RStruct):
     as_region_mut = as_region
 
     def region(self, area):
-        r = area_to_rect(area, self.cfg.xdec, self.cfg.ydec, self.cfg.width, self.cfg.height)
+        # src/frame/plane.rs:24-32: the parent rectangle is the allocation right / below the origin;
+        # PlaneRegion::from_slice's asserts (plane_region.rs:166-169)
+        c = self.cfg
+        r = area_to_rect(area, c.xdec, c.ydec, c.stride - c.xorigin, c.alloc_height - c.yorigin)
+        if not (r[0] >= -c.xorigin and r[1] >= -c.yorigin and c.xorigin + r[0] + r[2] <= c.stride and
+                c.yorigin + r[1] + r[3] <= c.alloc_height):
+            raise Panic("PlaneRegion::from_slice: rectangle %r outside the allocation" % (r,))
         return self._region(r[0], r[1], r[2], r[3])
 
     region_mut = region
@@ -1351,6 +1373,13 @@ class Rect(RStruct):
     _fields = ("x", "y", "width", "height")
     _rname = "Rect"
     _is_copy = True
+    # the name `Rect` is also the variant Area::Rect { x, y, width, height }: patterns written
+    # `Rect { x, y, .. }` are compiled against that variant's positional payload
+    var = "Rect"
+
+    @property
+    def p(self):
+        return (self.x, self.y, self.width, self.height)
 
 
 class PlaneRegion(RStruct):
@@ -1369,6 +1398,16 @@ class PlaneRegion(RStruct):
     @staticmethod
     def new_from_plane(plane):
         return plane.as_region()
+
+    @staticmethod
+    def from_slice(data, cfg, rect):
+        # plane_region.rs: a region over a caller-owned buffer laid out by `cfg`
+        data = deref(data)
+        if isinstance(data, RSlice):
+            assert data.o == 0
+            data = data.b
+        x, y, w, h = rect.p if isinstance(rect, REnum) else (rect.x, rect.y, rect.width, rect.height)
+        return PlaneRegion(data, (cfg.yorigin + y) * cfg.stride + cfg.xorigin + x, cfg, x, y, w, h)
 
     def __getitem__(self, r):
         if not (0 <= r < self.rh):

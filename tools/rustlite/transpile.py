@@ -499,7 +499,9 @@ class FnCompiler:
             return ("ref", inner, bool(t.mut))
         if k == "tptr":
             return ("ptr", self.norm(t.inner))
-        if k in ("tarray", "tslice"):
+        if k == "tarray":
+            return ("arr", self.norm(t.el), t.n)   # the length expression rides along (default_for)
+        if k == "tslice":
             return ("arr", self.norm(t.el))
         if k == "ttuple":
             return ("tup", [self.norm(e) for e in t.els])
@@ -1680,8 +1682,13 @@ class FnCompiler:
         self.frames.append(Frame())
         for i, (pat, ty) in enumerate(e.params):
             nt = self.norm(ty) if ty is not None else None
-            if pat.k == "pident" and pat.name not in self.boxed and not self._is_const_pat(pat.name):
+            is_ref = isinstance(nt, tuple) and nt[0] == "ref"
+            if pat.k == "pident" and (pat.name not in self.boxed or is_ref) and not self._is_const_pat(pat.name):
                 ent = self.declare(pat.name, nt)
+                if is_ref:
+                    # a reference parameter that shares its name with a boxed local of the enclosing
+                    # function (`best: &mut T` beside `let mut best`): the closure's name is the reference
+                    ent["boxed"] = False
                 params.append(ent["py"])
             else:
                 a = "_p%d_%d" % (i, self.tmpn)
@@ -1946,6 +1953,8 @@ class FnCompiler:
             return "R.%s.%s(%s)" % (self.c.shims[a].__name__, name, ", ".join(vals))
         if self.c.autoload(name) or (a is not None and self.c.autoload(a)):
             return self.call_path(p, argn)
+        if name == "default" and a in self.c.structs and not argn:   # #[derive(Default)]
+            return self.default_for(a)
         self.err("unresolved call %s" % "::".join(segs))
 
     def call_info(self, info, p, argn):
@@ -2051,7 +2060,8 @@ class FnCompiler:
             exp = self.strip(self.expected)
             if exp is None:
                 return "None"
-            return self.default_for(exp, uninit=True)
+            d = self.default_for(exp, uninit=True)
+            return "R.Aligned(%s)" % d if (a == "Aligned" and name == "uninitialized") else d
         if name == "default" and (a == "Default" or a is None):
             return self.default_for(self.strip(self.expected))
         if a == "Aligned" and name == "from_fn":
@@ -2100,6 +2110,8 @@ class FnCompiler:
             if t[0] == "opt":
                 return "_NONE"
             if t[0] == "arr":
+                if len(t) > 2 and t[2] is not None:
+                    return "_vrep(%s, %s)" % (self.default_for(t[1]), self.ex(t[2]))
                 self.err("default for array of unknown length")
         self.err("default for %r" % (t,))
 
@@ -2303,4 +2315,39 @@ class FnCompiler:
                     self.err("matches! guard with bindings")
                 cond = "(%s) and (%s)" % (cond, self.ex(e.guard))
             return "(%s)" % cond
+        if n in ("search_pattern", "search_pattern_subpel") and e.args is None:
+            # the two macro_rules! of src/me.rs:928-941, expanded as their bodies say:
+            #   (fa: [a0, a1, ..], fb: [b0, b1, ..]) => [MotionVector { fa: a_k << 3, fb: b_k << 3 }, ..]
+            # (search_pattern_subpel: without the shifts); the expansion is re-parsed as Rust
+            toks = e.raw[1:-1]
+            groups, names, i = [], [], 0
+            while i < len(toks):
+                assert toks[i].k == "id" and toks[i + 1].v == ":" and toks[i + 2].v == "[", toks[i:i + 3]
+                names.append(toks[i].v)
+                i += 3
+                cur, els, depth = [], [], 0
+                while not (toks[i].v == "]" and depth == 0):
+                    if toks[i].v in ("(", "["):
+                        depth += 1
+                    elif toks[i].v in (")", "]"):
+                        depth -= 1
+                    if toks[i].v == "," and depth == 0:
+                        els.append(cur)
+                        cur = []
+                    else:
+                        cur.append(toks[i])
+                    i += 1
+                if cur:
+                    els.append(cur)
+                groups.append(els)
+                i += 1
+                if i < len(toks) and toks[i].v == ",":
+                    i += 1
+            assert len(groups) == 2 and len(groups[0]) == len(groups[1])
+            sh = " << 3" if n == "search_pattern" else ""
+            txt = lambda ts: " ".join(str(t.v[0]) + (t.v[1] or "") if t.k == "int" else str(t.v) for t in ts)
+            src = "[" + ", ".join("MotionVector { %s: (%s)%s, %s: (%s)%s }" % (names[0], txt(a), sh, names[1], txt(b), sh)
+                                  for a, b in zip(*groups)) + "]"
+            from .lexer import lex
+            return self.ex(Parser(lex(src), "<%s!>" % n).parse_expr())
         self.err("macro %s!" % n)
