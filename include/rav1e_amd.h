@@ -319,6 +319,40 @@ int r1_cdef_filter_frame_plane(r1_ctx *ctx, const R1Plane *luma, const R1Plane *
                                const uint8_t *cdef_index_sb, int sb_stride,
                                const R1CdefParams *params, void *stream);
 
+/* CDEF strength search: the CDEF leg of rdo_loop_decision (src/rdo.rs:2104-2560) when no
+ * restoration filter is in play (RestorationFilter::None / no restoration unit,
+ * rdo.rs:2432-2451, 2504-2520).  The reference cuts the deblocked reconstruction into
+ * analysis areas of area_sb_w x area_sb_h superblocks (the largest restoration unit; 1 x 1
+ * with restoration off), takes a scratch copy of each (rdo.rs:2277-2284: the AREA's borders are
+ * picture edges for CDEF) and, for every superblock that is not completely skipped, tries
+ * cdef_index 0 .. n_idx-1: cdef_filter_superblock (src/cdef.rs:405-560), then
+ * rdo_loop_plane_error (rdo.rs:2027-2093: cdef_dist_kernel * bias per 8x8 luma block, sse_wxh
+ * with the bias per chroma block, each plane's sum * fi.dist_scale[pli]) and keeps the first
+ * index of smallest compute_rd_cost(rate 0, err).  One launch evaluates every (superblock,
+ * index) of the frame; no filtered plane is written.
+ *   rec / src: `planes` whole-frame planes (rec deblocked; areas at multiples of the area
+ *   size), skip_mi: Block::skip per 4x4 luma unit, scales: coded_frame_data.distortion_scales
+ *   (Q14, per 8x8 luma block; NULL = DistortionScale::default()).
+ *   err_out: [n_sby][n_sbx][8] ScaledDistortion (0 for skipped superblocks / unused indices),
+ *   best_out: [n_sby][n_sbx], -1 = skipped; n_sb* = ceil(mi / 16).  scratch: DEVICE,
+ *   r1_cdef_strength_search_scratch_bytes() bytes (zeroed here).  All pointers DEVICE. */
+typedef struct R1CdefSearchParams {
+  uint8_t y_strengths[8], uv_strengths[8];   /* fi.cdef_y_strengths / cdef_uv_strengths */
+  int32_t damping, bit_depth;                /* fi.cdef_damping, fi.sequence.bit_depth */
+  int32_t n_idx;                             /* 1 << fi.cdef_bits */
+  int32_t planes;                            /* 1 (Cs400) or 3 */
+  int32_t xdec, ydec;                        /* chroma decimation: (1,1), (1,0) or (0,0) */
+  int32_t crop_w, crop_h;                    /* fi.width, fi.height */
+  int32_t area_sb_w, area_sb_h;
+  uint32_t dist_scale[3];                    /* fi.dist_scale[pli] (DistortionScale, Q14) */
+} R1CdefSearchParams;
+long long r1_cdef_strength_search_scratch_bytes(int mi_cols, int mi_rows);
+int r1_cdef_strength_search(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src,
+                            const uint8_t *skip_mi, int mi_stride, int mi_cols, int mi_rows,
+                            const uint32_t *scales, int scale_stride,
+                            const R1CdefSearchParams *params, uint64_t *err_out,
+                            int8_t *best_out, void *scratch, void *stream);
+
 /* ---- lookahead cost maps (SURVEY.md 8f "N1"; reference:
  * estimate_intra_costs src/api/lookahead.rs:30-123,
  * estimate_importance_block_difference 125-180, the SATD map of

@@ -220,3 +220,142 @@ void r1o_cdef_filter_tile_plane(const r1o_plane *luma, const r1o_plane *in, cons
       }
     }
 }
+
+/* The CDEF leg of rdo_loop_decision (src/rdo.rs:2104-2560) when no restoration filter is
+ * in play (RestorationFilter::None / no LRU, rdo.rs:2432-2451, 2504-2520): the strength
+ * search.  The reference cuts the deblocked reconstruction into analysis areas of
+ * area_sb_w x area_sb_h superblocks (the extent of the largest restoration unit; one
+ * superblock when restoration is off), works on a scratch copy of each (rdo.rs:2277-2284) --
+ * so CDEF sees the AREA's borders as picture edges -- and for every superblock that is not
+ * completely skipped tries cdef_index 0 .. n_idx-1:
+ *   cdef_filter_superblock with that index (cdef.rs:405-560),
+ *   err = sum over planes of [sum over the 8x8 blocks of the superblock inside the block
+ *         grid of: cdef_dist_kernel * bias (luma) / sse_wxh with bias (chroma)] * dist_scale[pli]
+ *         (rdo_loop_plane_error, rdo.rs:2027-2093),
+ *   cost = compute_rd_cost(rate = 0, err) = err as f64 (rdo.rs:718-723); the first index with
+ *   the smallest cost wins (rdo.rs:2523-2527).
+ * rec / src: whole-frame planes (rec deblocked), areas at multiples of the area size; scales:
+ * fi.coded_frame_data.distortion_scales, one per 8x8 luma block of the frame (NULL = default).
+ * err: [n_sby][n_sbx][8] (zero for skipped superblocks), best: [n_sby][n_sbx], -1 = skipped. */
+int r1o_cdef_strength_search(const r1o_plane *rec, const r1o_plane *src, const uint8_t *skip_mi,
+                             int mi_stride, int mi_cols, int mi_rows, const uint32_t *scales,
+                             int scale_stride, const r1o_cdef_search_params *p, uint64_t *err,
+                             int8_t *best) {
+  if (p->n_idx < 1 || p->n_idx > 8 || (p->planes != 1 && p->planes != 3)) return -1;
+  if (p->area_sb_w < 1 || p->area_sb_h < 1) return -1;
+  const int bd = p->bit_depth, coeff_shift = bd - 8, hbd = rec[0].bytes_per_px == 2;
+  const int n_sbx = (mi_cols + 15) / 16, n_sby = (mi_rows + 15) / 16;
+  memset(err, 0, sizeof(uint64_t) * 8 * (size_t)n_sbx * n_sby);
+  for (int fby = 0; fby < n_sby; fby++)
+    for (int fbx = 0; fbx < n_sbx; fbx++) {
+      /* the area this superblock belongs to, and the area's own geometry */
+      const int ax0 = fbx / p->area_sb_w * p->area_sb_w, ay0 = fby / p->area_sb_h * p->area_sb_h;
+      const int sbx = fbx - ax0, sby = fby - ay0;
+      const int sb_w = p->area_sb_w < n_sbx - ax0 ? p->area_sb_w : n_sbx - ax0;
+      const int sb_h = p->area_sb_h < n_sby - ay0 ? p->area_sb_h : n_sby - ay0;
+      const int crop_w = p->crop_w - ax0 * 64, crop_h = p->crop_h - ay0 * 64;
+      const int pixel_w = crop_w < sb_w * 64 ? crop_w : sb_w * 64;
+      const int pixel_h = crop_h < sb_h * 64 ? crop_h : sb_h * 64;
+      const int area_w = (pixel_w + 7) >> 3 << 3, area_h = (pixel_h + 7) >> 3 << 3;
+      /* tileblocks_subset: sb_w * 16 x sb_h * 16 block units, clipped to the block grid */
+      const int blk_cols = sb_w * 16 < mi_cols - ax0 * 16 ? sb_w * 16 : mi_cols - ax0 * 16;
+      const int blk_rows = sb_h * 16 < mi_rows - ay0 * 16 ? sb_h * 16 : mi_rows - ay0 * 16;
+      int8_t *bo = best + fby * n_sbx + fbx;
+      uint64_t *eo = err + 8 * ((size_t)fby * n_sbx + fbx);
+      /* cdef_skip (rdo.rs:2196-2211) */
+      int all_skip = 1;
+      for (int y = 16 * sby; y < 16 * sby + 16 && y < blk_rows; y++)
+        for (int x = 16 * sbx; x < 16 * sbx + 16 && x < blk_cols; x++)
+          all_skip &= skip_mi[(size_t)(ay0 * 16 + y) * mi_stride + ax0 * 16 + x] & 1;
+      if (all_skip) { *bo = -1; continue; }
+      /* cdef_filter_superblock's edge logic on the area frame (cdef.rs:424-459) */
+      const int in_xoff = sbx * 64, in_yoff = sby * 64;
+      const int xavail = area_w - in_xoff, yavail = area_h - in_yoff;
+      const int have_top = sby > 0 ? HAVE_TOP : 0, have_left = sbx > 0 ? HAVE_LEFT : 0;
+      for (int idx = 0; idx < p->n_idx; idx++) {
+        const int ys = p->y_strengths[idx], uvs = p->uv_strengths[idx];
+        const int pri_y = ys / 4, pri_uv = uvs / 4;
+        int sec_y = ys % 4, sec_uv = uvs % 4;
+        if (sec_y == 3) sec_y++;
+        if (sec_uv == 3) sec_uv++;
+        uint64_t plane_sum[3] = {0, 0, 0};
+        int edges = have_top | HAVE_BOTTOM;
+        for (int by = 0; by < 8; by++) {
+          if (by + 1 >= (yavail >> 3)) edges &= ~HAVE_BOTTOM;
+          edges &= ~HAVE_LEFT;
+          edges |= have_left;
+          edges |= HAVE_RIGHT;
+          for (int bx = 0; bx < 8; bx++) {
+            if (bx + 1 >= (xavail >> 3)) edges &= ~HAVE_RIGHT;
+            const int mx = sbx * 16 + 2 * bx, my = sby * 16 + 2 * by;   /* area block units */
+            if (mx < blk_cols && my < blk_rows) {
+              const uint8_t *sk = skip_mi + (size_t)(ay0 * 16 + my) * mi_stride + ax0 * 16 + mx;
+              const int skip = sk[0] & sk[1] & sk[mi_stride] & sk[mi_stride + 1] & 1;
+              /* frame position of the block in luma pixels */
+              const int flx = ax0 * 64 + in_xoff + 8 * bx, fly = ay0 * 64 + in_yoff + 8 * by;
+              uint32_t var = 0;
+              int dir = 0;
+              if (!skip) {
+                const r1o_plane *l = &rec[0];
+                dir = r1o_cdef_find_dir((const uint8_t *)l->data +
+                                            ((size_t)(l->yorigin + fly) * l->stride + l->xorigin + flx) *
+                                                l->bytes_per_px,
+                                        l->stride, &var, coeff_shift, hbd);
+              }
+              const uint32_t bias = scales ? scales[(size_t)(fly >> 3) * scale_stride + (flx >> 3)] : (1u << 14);
+              for (int pl = 0; pl < p->planes; pl++) {
+                const int xdec = pl ? p->xdec : 0, ydec = pl ? p->ydec : 0;
+                const int xs = 8 >> xdec, ysz = 8 >> ydec;
+                const r1o_plane *rp = &rec[pl], *sp = &src[pl];
+                const int px = flx >> xdec, py = fly >> ydec;
+                const uint8_t *rpx = (const uint8_t *)rp->data +
+                                     ((size_t)(rp->yorigin + py) * rp->stride + rp->xorigin + px) * rp->bytes_per_px;
+                const uint8_t *spx = (const uint8_t *)sp->data +
+                                     ((size_t)(sp->yorigin + py) * sp->stride + sp->xorigin + px) * sp->bytes_per_px;
+                uint16_t blk16[64];
+                uint8_t *blk = (uint8_t *)blk16;
+                if (!skip) {
+                  int lpri, lsec, ldamp = p->damping + coeff_shift, ldir;
+                  if (pl == 0) {
+                    lpri = r1o_cdef_adjust_strength(pri_y << coeff_shift, (int)var);
+                    lsec = sec_y << coeff_shift;
+                    ldir = pri_y != 0 ? dir : 0;
+                  } else {
+                    static const uint8_t UVDIR[8] = {7, 0, 2, 4, 5, 6, 6, 6};
+                    lpri = pri_uv << coeff_shift;
+                    lsec = sec_uv << coeff_shift;
+                    ldamp -= 1;
+                    ldir = pri_uv != 0 ? (xdec != ydec ? UVDIR[dir] : dir) : 0;
+                  }
+                  r1o_cdef_filter_block(blk, 8, rpx, rp->stride, lpri, lsec, ldir, ldamp, bd, xdec, ydec,
+                                        edges, hbd);
+                } else {   /* the working copy keeps the deblocked pixels */
+                  for (int i = 0; i < ysz; i++)
+                    memcpy(blk + (size_t)i * 8 * rp->bytes_per_px, rpx + (size_t)i * rp->stride * rp->bytes_per_px,
+                           (size_t)xs * rp->bytes_per_px);
+                }
+                if (pl == 0) {
+                  const uint64_t raw = r1o_cdef_dist_kernel(spx, sp->stride, blk, 8, 8, 8, bd, hbd);
+                  plane_sum[0] += ((uint64_t)bias * raw + 8192) >> 14;     /* RawDistortion * bias */
+                } else {
+                  uint32_t cell[4] = {bias, bias, bias, bias};              /* sse_wxh: |_, _| bias */
+                  plane_sum[pl] += r1o_get_weighted_sse(spx, sp->stride, blk, 8, cell, 2, xs, ysz, hbd);
+                }
+              }
+            }
+            edges |= HAVE_LEFT;
+          }
+          edges |= HAVE_TOP;
+        }
+        uint64_t e = 0;
+        for (int pl = 0; pl < p->planes; pl++)
+          e += ((uint64_t)p->dist_scale[pl] * plane_sum[pl] + 8192) >> 14;   /* Distortion * dist_scale */
+        eo[idx] = e;
+      }
+      int b = 0;   /* f64 costs of u64 errors: exact below 2^53 */
+      for (int idx = 1; idx < p->n_idx; idx++)
+        if ((double)eo[idx] < (double)eo[b]) b = idx;
+      *bo = (int8_t)b;
+    }
+  return 0;
+}

@@ -166,6 +166,19 @@ void r1o_cdef_filter_tile_plane(const r1o_plane *luma, const r1o_plane *in, cons
                                 int mi_rows, const uint8_t *cdef_index_sb, int sb_stride,
                                 const uint8_t *y_strengths, const uint8_t *uv_strengths,
                                 int damping, int bit_depth);
+/* CDEF strength search of rdo_loop_decision (src/rdo.rs:2104-2560, CDEF leg without a
+ * restoration filter; see oracle/cdef.c) */
+typedef struct {
+  uint8_t y_strengths[8], uv_strengths[8];
+  int32_t damping, bit_depth, n_idx, planes, xdec, ydec;
+  int32_t crop_w, crop_h;          /* fi.width / fi.height */
+  int32_t area_sb_w, area_sb_h;    /* analysis area (largest restoration unit) in superblocks */
+  uint32_t dist_scale[3];          /* fi.dist_scale[pli], Q14 */
+} r1o_cdef_search_params;
+int r1o_cdef_strength_search(const r1o_plane *rec, const r1o_plane *src, const uint8_t *skip_mi,
+                             int mi_stride, int mi_cols, int mi_rows, const uint32_t *scales,
+                             int scale_stride, const r1o_cdef_search_params *p, uint64_t *err,
+                             int8_t *best);
 /* lookahead cost maps (src/api/lookahead.rs:30-268) */
 void r1o_estimate_intra_costs(const r1o_plane *plane, int bit_depth, uint32_t *costs);
 uint64_t r1o_importance_block_difference(const r1o_plane *org, const r1o_plane *ref);

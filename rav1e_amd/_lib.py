@@ -22,6 +22,14 @@ class R1CdefParams(C.Structure):
                 ("damping", C.c_uint8), ("bit_depth", C.c_uint8), ("reserved", C.c_uint8 * 2)]
 
 
+class R1CdefSearchParams(C.Structure):
+    _fields_ = [("y_strengths", C.c_uint8 * 8), ("uv_strengths", C.c_uint8 * 8),
+                ("damping", C.c_int32), ("bit_depth", C.c_int32), ("n_idx", C.c_int32),
+                ("planes", C.c_int32), ("xdec", C.c_int32), ("ydec", C.c_int32),
+                ("crop_w", C.c_int32), ("crop_h", C.c_int32), ("area_sb_w", C.c_int32),
+                ("area_sb_h", C.c_int32), ("dist_scale", C.c_uint32 * 3)]
+
+
 class R1MeStats(C.Structure):
     _fields_ = [("row", C.c_int16), ("col", C.c_int16), ("normalized_sad", C.c_uint32)]
 
@@ -65,6 +73,8 @@ SYMBOLS = {
     "r1_cdef_filter_block_batch": (_i, [_vp, _PP, _PP, _i, _i, _vp, _i, _vp]),
     "r1_cdef_filter_frame_plane": (_i, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i, _i,
                                         _vp, _i, C.POINTER(R1CdefParams), _vp]),
+    "r1_cdef_strength_search_scratch_bytes": (C.c_longlong, [_i, _i]),
+    "r1_cdef_strength_search": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "r1_estimate_intra_costs": (_i, [_vp, _PP, _vp, _vp]),
     "r1_estimate_inter_costs": (_i, [_vp, _PP, _PP, _vp, _vp, _vp]),
     "r1_importance_block_difference": (_i, [_vp, _PP, _PP, _vp, _vp]),

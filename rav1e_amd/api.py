@@ -373,6 +373,39 @@ class Context:
             cdef_index_sb.data_ptr(), cdef_index_sb.stride(0), C.byref(prm), _stream_ptr()),
             "r1_cdef_filter_frame_plane")
 
+    def cdef_strength_search(self, rec, src, skip_mi, y_strengths, uv_strengths, damping, bit_depth,
+                             n_idx, xdec, ydec, crop_w, crop_h, area_sb=(1, 1), scales=None,
+                             dist_scale=(1 << 14, 1 << 14, 1 << 14)):
+        """the CDEF leg of rdo_loop_decision (src/rdo.rs:2104-2560, no restoration filter): for
+        every superblock and cdef_index < n_idx the ScaledDistortion of the filtered superblock
+        against the source, and the first index of smallest cost.
+        rec / src: lists of 1 or 3 Planes (whole frame; rec deblocked); skip_mi: (mi_rows, mi_cols)
+        uint8 device tensor; scales: (h/8, w/8) int32 device tensor (Q14) or None.
+        -> (err (n_sby, n_sbx, 8) int64 holding u64, best (n_sby, n_sbx) int8, -1 = skipped)"""
+        prm = _lib.R1CdefSearchParams()
+        for i in range(8):
+            prm.y_strengths[i] = int(y_strengths[i])
+            prm.uv_strengths[i] = int(uv_strengths[i])
+        prm.damping, prm.bit_depth, prm.n_idx, prm.planes = int(damping), int(bit_depth), int(n_idx), len(rec)
+        prm.xdec, prm.ydec, prm.crop_w, prm.crop_h = int(xdec), int(ydec), int(crop_w), int(crop_h)
+        prm.area_sb_w, prm.area_sb_h = int(area_sb[0]), int(area_sb[1])
+        for i in range(3):
+            prm.dist_scale[i] = int(dist_scale[i])
+        mi_rows, mi_cols = skip_mi.shape
+        n_sbx, n_sby = (mi_cols + 15) // 16, (mi_rows + 15) // 16
+        pr = (_lib.R1Plane * 3)(*[(rec[k] if k < len(rec) else rec[0]).cstruct() for k in range(3)])
+        ps = (_lib.R1Plane * 3)(*[(src[k] if k < len(src) else src[0]).cstruct() for k in range(3)])
+        err = torch.empty((n_sby, n_sbx, 8), dtype=torch.int64, device="cuda")
+        best = torch.empty((n_sby, n_sbx), dtype=torch.int8, device="cuda")
+        scratch = torch.empty(self.lib.r1_cdef_strength_search_scratch_bytes(mi_cols, mi_rows),
+                              dtype=torch.uint8, device="cuda")
+        self._check(self.lib.r1_cdef_strength_search(
+            self.h, pr, ps, skip_mi.data_ptr(), skip_mi.stride(0), mi_cols, mi_rows,
+            scales.data_ptr() if scales is not None else None,
+            scales.stride(0) if scales is not None else 0, C.byref(prm), err.data_ptr(), best.data_ptr(),
+            scratch.data_ptr(), _stream_ptr()), "r1_cdef_strength_search")
+        return err, best
+
     # ---- frame glue ----
     def plane_pad(self, plane, w, h, xdec=0, ydec=0):
         """Plane::pad(w, h) in place (FramePad::pad, src/frame/mod.rs:76-86); w, h: frame size"""

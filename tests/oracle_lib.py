@@ -117,6 +117,7 @@ def lib():
         "r1o_sgrproj_solve": (None, [vp, vp, i, i, i, i, i, i, vp]),
         "r1o_estimate_motion_batch": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
         "r1o_rdo_full_cand_batch": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp]),
+        "r1o_cdef_strength_search": (i, [vp, vp, vp, i, i, i, vp, i, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         if hasattr(L, name):
@@ -238,3 +239,41 @@ def me_block_oracle(L, org3, ref3, w_in_b, h_in_b, tile, bit_depth, lambdas, sta
                                      out.ctypes.data)
     assert rc == 0
     return out
+
+
+class CdefSearchParams(C.Structure):
+    """r1o_cdef_search_params == R1CdefSearchParams"""
+    _fields_ = [("y_strengths", C.c_uint8 * 8), ("uv_strengths", C.c_uint8 * 8),
+                ("damping", C.c_int32), ("bit_depth", C.c_int32), ("n_idx", C.c_int32),
+                ("planes", C.c_int32), ("xdec", C.c_int32), ("ydec", C.c_int32),
+                ("crop_w", C.c_int32), ("crop_h", C.c_int32), ("area_sb_w", C.c_int32),
+                ("area_sb_h", C.c_int32), ("dist_scale", C.c_uint32 * 3)]
+
+
+def cdef_search_case(G, name, pad=16):
+    """planes + parameters of one cdef_search_ref.npz case -> (rec HostPlanes, src HostPlanes, skip,
+    scales, CdefSearchParams, want_err, want_best)"""
+    W, H, xdec, ydec, bd, damping, n_idx, asw, ash, planes = [int(v) for v in G[name + "_meta"]]
+    rec = [plane_from_image(G["%s_rec%d" % (name, p)].astype(np.int64), bd, pad, pad) for p in range(3)]
+    src = [plane_from_image(G["%s_src%d" % (name, p)].astype(np.int64), bd, pad, pad) for p in range(3)]
+    prm = CdefSearchParams()
+    prm.y_strengths[:] = [int(v) for v in G[name + "_ystr"]]
+    prm.uv_strengths[:] = [int(v) for v in G[name + "_uvstr"]]
+    prm.damping, prm.bit_depth, prm.n_idx, prm.planes = damping, bd, n_idx, planes
+    prm.xdec, prm.ydec, prm.crop_w, prm.crop_h, prm.area_sb_w, prm.area_sb_h = xdec, ydec, W, H, asw, ash
+    prm.dist_scale[:] = [int(v) for v in G[name + "_dscale"]]
+    return (rec, src, np.ascontiguousarray(G[name + "_skip"]), np.ascontiguousarray(G[name + "_scales"]), prm,
+            G[name + "_err"], G[name + "_best"])
+
+
+def cdef_search_oracle(L, G, name):
+    rec, src, skip, scales, prm, want_err, want_best = cdef_search_case(G, name)
+    pr = (Plane * 3)(*[p.cstruct() for p in rec])
+    ps = (Plane * 3)(*[p.cstruct() for p in src])
+    err = np.zeros_like(want_err)
+    best = np.zeros_like(want_best)
+    rc = L.r1o_cdef_strength_search(pr, ps, skip.ctypes.data, skip.shape[1], skip.shape[1], skip.shape[0],
+                                    scales.ctypes.data, scales.shape[1], C.byref(prm), err.ctypes.data,
+                                    best.ctypes.data)
+    assert rc == 0
+    return err, best, want_err, want_best

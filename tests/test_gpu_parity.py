@@ -1685,3 +1685,58 @@ def test_mc_mfma_variant_equals_dot4_path(ctx, oracle, prep):
         assert np.array_equal(ref, want), (s, "dot4 path")
         bad = np.argwhere(got != want)
         assert len(bad) == 0, (s, prep, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+
+
+# ------------------------ a14: CDEF strength search (rdo_loop_decision's CDEF leg)
+@pytest.mark.parametrize("cfg", [
+    # w, h, bd, (xdec, ydec), planes, n_idx, area
+    (320, 200, 8, (1, 1), 3, 8, (1, 1)),
+    (264, 136, 10, (1, 1), 3, 8, (4, 4)),     # restoration units of 256: areas of 4 x 4 superblocks
+    (192, 128, 8, (0, 0), 3, 4, (2, 1)),      # 4:4:4
+    (192, 136, 12, (1, 0), 3, 8, (1, 2)),     # 4:2:2 (Cdef_Uv_Dir mapping)
+    (136, 200, 10, (1, 1), 1, 2, (1, 1)),     # monochrome
+])
+def test_cdef_strength_search_vs_oracle(ctx, oracle, cfg):
+    import ctypes as C
+    from test_gpu_ref_vectors import run_cdef_search_gpu
+    w, h, bd, (xdec, ydec), planes, n_idx, area = cfg
+    rng = np.random.default_rng(w * 7 + h + bd)
+    yy, xx = np.mgrid[0:h, 0:w]
+    Y = np.clip(((np.sin(xx / 6.0) + np.cos((yy + 2 * xx) / 9.0)) * 45 + 128 + rng.integers(-5, 6, (h, w))), 0, 255)
+    Y = Y.astype(np.int64) << (bd - 8)
+    cw, ch = w >> xdec, h >> ydec
+    U = rng.integers(0, 1 << bd, (ch, cw)) // 4 + (1 << (bd - 2))
+    V = np.clip(Y[::1 << ydec, ::1 << xdec][:ch, :cw] // 2 + (30 << (bd - 8)), 0, (1 << bd) - 1)
+    src_i = [Y, U, V]
+    rec_i = [np.clip(s + rng.integers(-12 << (bd - 8), (12 << (bd - 8)) + 1, s.shape) * (rng.random(s.shape) < 0.3),
+                     0, (1 << bd) - 1) for s in src_i]
+    rec = [O.plane_from_image(a, bd, 16, 16) for a in rec_i]
+    src = [O.plane_from_image(a, bd, 16, 16) for a in src_i]
+    mi_cols, mi_rows = 2 * ((w + 7) // 8), 2 * ((h + 7) // 8)
+    skip = (rng.random((mi_rows, mi_cols)) < 0.4).astype(np.uint8)
+    skip[16:32, :16] = 1
+    scales = rng.integers(1 << 11, 1 << 17, ((h + 7) // 8, (w + 7) // 8)).astype(np.uint32)
+    for use_scales in (True, False):
+        prm = O.CdefSearchParams()
+        prm.y_strengths[:] = [int(v) for v in rng.integers(0, 64, 8)]
+        prm.uv_strengths[:] = [int(v) for v in rng.integers(0, 64, 8)]
+        prm.y_strengths[0], prm.uv_strengths[0] = 0, 0
+        prm.damping, prm.bit_depth, prm.n_idx, prm.planes = int(rng.integers(3, 7)), bd, n_idx, planes
+        prm.xdec, prm.ydec, prm.crop_w, prm.crop_h = xdec, ydec, w, h
+        prm.area_sb_w, prm.area_sb_h = area
+        prm.dist_scale[:] = [int(v) for v in rng.integers(1 << 12, 1 << 16, 3)]
+        n_sbx, n_sby = (mi_cols + 15) // 16, (mi_rows + 15) // 16
+        want_err = np.zeros((n_sby, n_sbx, 8), np.uint64)
+        want_best = np.zeros((n_sby, n_sbx), np.int8)
+        pr = (O.Plane * 3)(*[p.cstruct() for p in rec])
+        ps = (O.Plane * 3)(*[p.cstruct() for p in src])
+        sc = scales if use_scales else None
+        assert oracle.r1o_cdef_strength_search(pr, ps, skip.ctypes.data, mi_cols, mi_cols, mi_rows,
+                                               sc.ctypes.data if sc is not None else None,
+                                               sc.shape[1] if sc is not None else 0, C.byref(prm),
+                                               want_err.ctypes.data, want_best.ctypes.data) == 0
+        got_err, got_best = run_cdef_search_gpu(ctx, rec, src, skip, sc, prm)
+        bad = np.argwhere(got_err != want_err)
+        assert len(bad) == 0, (cfg, use_scales, bad[:4], got_err[tuple(bad[0])], want_err[tuple(bad[0])])
+        assert np.array_equal(got_best, want_best), (cfg, got_best, want_best)
+        assert (want_best == -1).any() and (want_best >= 0).any()

@@ -214,3 +214,34 @@ def test_me_ref_tile_motion_and_block_searches(ctx, name):
     for i in range(len(blk)):
         g = (int(got["row"][i]), int(got["col"][i]), int(got["sad"][i]), int(got["cost"][i]))
         assert g == tuple(int(v) for v in want[i]), (name, i, blk[i], g, want[i])
+
+
+# ---- a14: the CDEF strength search against the executed reference (gen_cdef_search_ref.py) ----
+def _cdef_search_cases():
+    S = np.load(os.path.join(GOLD, "cdef_search_ref.npz"))
+    return sorted(k[:-5] for k in S.files if k.endswith("_meta"))
+
+
+def run_cdef_search_gpu(ctx, rec, src, skip, scales, prm):
+    import torch
+    planes = prm.planes
+    err, best = ctx.cdef_strength_search(
+        [dev_plane(p) for p in rec[:planes]], [dev_plane(p) for p in src[:planes]],
+        torch.from_numpy(skip).cuda(), list(prm.y_strengths), list(prm.uv_strengths), prm.damping,
+        prm.bit_depth, prm.n_idx, prm.xdec, prm.ydec, prm.crop_w, prm.crop_h,
+        area_sb=(prm.area_sb_w, prm.area_sb_h),
+        scales=torch.from_numpy(scales.view(np.int32)).cuda() if scales is not None else None,
+        dist_scale=list(prm.dist_scale))
+    return err.cpu().numpy().view(np.uint64), best.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", _cdef_search_cases())
+def test_cdef_search_ref(ctx, name):
+    """r1_cdef_strength_search on what cdef_filter_superblock + rdo_loop_plane_error of the
+    reference's own text produced: every (superblock, index) error and every pick."""
+    S = np.load(os.path.join(GOLD, "cdef_search_ref.npz"))
+    rec, src, skip, scales, prm, want_err, want_best = O.cdef_search_case(S, name)
+    got_err, got_best = run_cdef_search_gpu(ctx, rec, src, skip, scales, prm)
+    assert np.array_equal(got_best, want_best), (name, got_best, want_best)
+    bad = np.argwhere(got_err != want_err)
+    assert len(bad) == 0, (name, bad[:4], got_err[tuple(bad[0])], want_err[tuple(bad[0])])
