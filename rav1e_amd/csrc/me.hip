@@ -111,62 +111,125 @@ struct Block {
     }
   }
 
-  // compute_mv_rd of this lane's slot candidate (me.rs:1386-1462); every lane
-  // of the slot returns the same (cost, sad).  check: the MV range test of
-  // get_fullpel_mv_rd (full_search calls compute_mv_rd without it).
-  __device__ __forceinline__ void eval(int row, int col, bool valid, bool check,
-                                       unsigned long long &cost, uint32_t &sad) const {
+  // compute_mv_rd of this lane's slot candidate (me.rs:1386-1462) in two halves, so that a
+  // search step can have the reference rows of SEVERAL candidate batches in flight before the
+  // first SAD: a block's search is a chain of dependent steps and a step is one memory round
+  // trip -- batches that do not depend on each other (a predictor list, a search pattern)
+  // share one.  check: the MV range test of get_fullpel_mv_rd (full_search calls
+  // compute_mv_rd without it).
+  __device__ __forceinline__ bool fetch(int row, int col, bool valid, bool check, uint32_t *v) const {
     bool in = valid;
     if (check) in = in && col >= mvx_min && col <= mvx_max && row >= mvy_min && row <= mvy_max;
-    uint32_t part = 0;
+#pragma unroll
+    for (int g = 0; g < GR * WPG; g++) v[g] = 0;
     if (in) {
       const uint8_t *p = ref0 + (long)(div8(row) + r) * sr + (long)div8(col) * BPP;
 #pragma unroll
       for (int g = 0; g < GR; g++) {
         if constexpr (BPP == 1) {
-          if (m[g]) part = __builtin_amdgcn_sad_u8(o[g], ld_u32(p + 4 * g) & m[g], part);
+          if (m[g]) v[g] = ld_u32(p + 4 * g);
         } else {
           if (m[2 * g]) {
-            const U32x2 v = ld_u32x2(p + 8 * g);
-            part = __builtin_amdgcn_sad_u16(o[2 * g], v.a & m[2 * g], part);
-            part = __builtin_amdgcn_sad_u16(o[2 * g + 1], v.b & m[2 * g + 1], part);
+            const U32x2 t = ld_u32x2(p + 8 * g);
+            v[2 * g] = t.a;
+            v[2 * g + 1] = t.b;
           }
         }
       }
     }
+    return in;
+  }
+  // every lane of the slot returns the same (cost, sad)
+  __device__ __forceinline__ void finish(const uint32_t *v, bool in, int row, int col,
+                                         unsigned long long &cost, uint32_t &sad) const {
+    uint32_t part = 0;
 #pragma unroll
-    for (int s = 1; s < RH; s <<= 1) part += __shfl_xor(part, s, 64);
+    for (int g = 0; g < GR * WPG; g++) {
+      if constexpr (BPP == 1) part = __builtin_amdgcn_sad_u8(o[g], v[g] & m[g], part);
+      else part = __builtin_amdgcn_sad_u16(o[g], v[g] & m[g], part);
+    }
+    part = group_sum<RH>(part);   // DPP inside a 16-lane row: no LDS round trips
     cost = in ? mc.cost(row, col, part) : COST_MAX;
     sad = in ? part : 0xFFFFFFFFu;
   }
 
+  // one batch of NCS candidates after its rows have arrived: the slots' costs meet, the
+  // lower candidate index wins ties, `if rd.cost < best.rd.cost { best = cand }`
+  __device__ __forceinline__ void settle(const uint32_t *v, bool in, int idx, int row, int col, Msr &best,
+                                         int *best_idx) const {
+    unsigned long long cost;
+    uint32_t sad;
+    finish(v, in, row, col, cost, sad);
+#pragma unroll
+    for (int s = RH; s < 64; s <<= 1) {
+      auto other = [&](uint32_t x) -> uint32_t { return s == 16 ? lane_xor16(x) : lane_xor32(x); };
+      const unsigned long long oc = ((unsigned long long)other((uint32_t)(cost >> 32)) << 32) | other((uint32_t)cost);
+      const int oi = (int)other((uint32_t)idx), orow = (int)other((uint32_t)row), ocol = (int)other((uint32_t)col);
+      const uint32_t os = other(sad);
+      if (oc < cost || (oc == cost && oi < idx)) {
+        cost = oc; idx = oi; row = orow; col = ocol; sad = os;
+      }
+    }
+    if (cost < best.cost) {
+      best = Msr{row, col, cost, sad};
+      if (best_idx) *best_idx = idx;
+    }
+  }
+
+  // K batches with their loads issued back to back, settled in candidate order
+  template <int K, class Gen>
+  __device__ __forceinline__ void step(int base, int n, Gen gen, bool check, Msr &best, int *best_idx) const {
+    uint32_t v[K][GR * WPG];
+    int idx[K], row[K], col[K];
+    bool in[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      idx[k] = base + k * NCS + slot;
+      const bool valid = idx[k] < n;
+      row[k] = col[k] = 0;
+      if (valid) gen(idx[k], row[k], col[k]);
+      in[k] = fetch(row[k], col[k], valid, check, v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) settle(v[k], in[k], idx[k], row[k], col[k], best, best_idx);
+  }
+
+  // two independent candidate lists (each at most one batch) evaluated in ONE round trip, each
+  // into its own result: the second list is a speculation whose result the caller may drop
+  template <class GenA, class GenB>
+  __device__ __forceinline__ void scan_pair(int na, GenA gen_a, Msr &best_a, int nb, GenB gen_b, Msr &best_b,
+                                            bool check) const {
+    if (na > NCS || nb > NCS) {
+      scan(na, gen_a, check, best_a, nullptr);
+      scan(nb, gen_b, check, best_b, nullptr);
+      return;
+    }
+    uint32_t va[GR * WPG], vb[GR * WPG];
+    int ra = 0, ca = 0, rb = 0, cb = 0;
+    if (slot < na) gen_a(slot, ra, ca);
+    if (slot < nb) gen_b(slot, rb, cb);
+    const bool ia = fetch(ra, ca, slot < na, check, va), ib = fetch(rb, cb, slot < nb, check, vb);
+    settle(va, ia, slot, ra, ca, best_a, nullptr);
+    settle(vb, ib, slot, rb, cb, best_b, nullptr);
+  }
+
   // `for cand in cands { if rd.cost < best.rd.cost { best = cand } }` over
   // n candidates produced by gen(idx, row, col); best_idx: index of the taken one.
+  static constexpr int KMAX = (GR * WPG <= 8) ? 3 : 2;   // registers: GR * WPG per batch in flight
   template <class Gen>
   __device__ __forceinline__ void scan(int n, Gen gen, bool check, Msr &best, int *best_idx) const {
-    for (int base = 0; base < n; base += NCS) {
-      int idx = base + slot;
-      const bool valid = idx < n;
-      int row = 0, col = 0;
-      if (valid) gen(idx, row, col);
-      unsigned long long cost;
-      uint32_t sad;
-      eval(row, col, valid, check, cost, sad);
-#pragma unroll
-      for (int s = RH; s < 64; s <<= 1) {
-        const unsigned long long oc =
-            ((unsigned long long)(uint32_t)__shfl_xor((int)(cost >> 32), s, 64) << 32) |
-            (uint32_t)__shfl_xor((int)(uint32_t)cost, s, 64);
-        const int oi = __shfl_xor(idx, s, 64), orow = __shfl_xor(row, s, 64),
-                  ocol = __shfl_xor(col, s, 64);
-        const uint32_t os = (uint32_t)__shfl_xor((int)sad, s, 64);
-        if (oc < cost || (oc == cost && oi < idx)) {
-          cost = oc; idx = oi; row = orow; col = ocol; sad = os;
-        }
-      }
-      if (cost < best.cost) {
-        best = Msr{row, col, cost, sad};
-        if (best_idx) *best_idx = idx;
+    int base = 0;
+    while (base < n) {
+      const int left = n - base;
+      if (KMAX >= 3 && left > 2 * NCS) {
+        step<KMAX >= 3 ? 3 : 2>(base, n, gen, check, best, best_idx);
+        base += (KMAX >= 3 ? 3 : 2) * NCS;
+      } else if (left > NCS) {
+        step<2>(base, n, gen, check, best, best_idx);
+        base += 2 * NCS;
+      } else {
+        step<1>(base, n, gen, check, best, best_idx);
+        base += NCS;
       }
     }
   }
@@ -181,20 +244,39 @@ __constant__ int8_t kUmh[16][2] = {{4, -2}, {4, -1}, {4, 0}, {4, 1}, {4, 2}, {2,
 
 template <class B>
 __device__ void fullpel_diamond_search(const B &b, Msr &cur) {
+  // me.rs:955-1000: radius 2 until no candidate improves, then radius 1 until none does.  While at
+  // radius 2 the four radius-1 candidates of the same centre are fetched in the same round trip:
+  // they are what the next step evaluates whenever radius 2 brings no improvement (the common
+  // case at the end of every search); otherwise the speculation is dropped.  Same evaluations,
+  // same comparisons, same order -- one memory latency less per search.
   int radius_log2 = 1;
   for (;;) {
     Msr best = msr_empty();
-    const int cr = cur.row, cc = cur.col, sh = 3 + radius_log2;
-    b.scan(4, [&](int i, int &row, int &col) {
-      row = (int16_t)(cr + (kDiamond[i][0] << sh));
-      col = (int16_t)(cc + (kDiamond[i][1] << sh));
-    }, true, best, nullptr);
-    if (cur.cost <= best.cost) {
-      if (radius_log2 == 0) break;
-      radius_log2--;
-    } else {
-      cur = best;
+    const int cr = cur.row, cc = cur.col;
+    if (radius_log2 == 1) {
+      Msr next = msr_empty();
+      b.scan_pair(4, [&](int i, int &row, int &col) {
+        row = (int16_t)(cr + (kDiamond[i][0] << 4));
+        col = (int16_t)(cc + (kDiamond[i][1] << 4));
+      }, best, 4, [&](int i, int &row, int &col) {
+        row = (int16_t)(cr + (kDiamond[i][0] << 3));
+        col = (int16_t)(cc + (kDiamond[i][1] << 3));
+      }, next, true);
+      if (cur.cost <= best.cost) {
+        radius_log2 = 0;
+        if (cur.cost <= next.cost) break;   // the radius-1 step of this centre
+        cur = next;
+      } else {
+        cur = best;
+      }
+      continue;
     }
+    b.scan(4, [&](int i, int &row, int &col) {
+      row = (int16_t)(cr + (kDiamond[i][0] << 3));
+      col = (int16_t)(cc + (kDiamond[i][1] << 3));
+    }, true, best, nullptr);
+    if (cur.cost <= best.cost) break;
+    cur = best;
   }
 }
 
@@ -318,32 +400,72 @@ __device__ __forceinline__ void load_stats(const R1MeStats *s, int &row, int &co
   nsad = (uint32_t)(v >> 32);
 }
 
-// process_cand (me.rs:407-414)
-__device__ __forceinline__ void process_cand(const R1MeStats *s, const int *rng, uint32_t &min_sad,
+// process_cand (me.rs:407-414) on a loaded entry
+__device__ __forceinline__ void process_cand(unsigned long long v, const int *rng, uint32_t &min_sad,
                                              int16_t *out) {
-  int srow, scol;
-  uint32_t ns;
-  load_stats(s, srow, scol, ns);
+  const int srow = (int16_t)(v & 0xFFFF), scol = (int16_t)((v >> 16) & 0xFFFF);
+  const uint32_t ns = (uint32_t)(v >> 32);
   min_sad = ns < min_sad ? ns : min_sad;
   out[0] = (int16_t)iclamp(div8(srow) * 8, rng[2], rng[3]);
   out[1] = (int16_t)iclamp(div8(scol) * 8, rng[0], rng[1]);
 }
 
+// get_subset_predictors (me.rs:386-534).  The up to ten MEStats entries it samples (left, top,
+// right, bottom, centre of this frame; the same five of the previous frame) are fetched by ten
+// LANES in one load instruction and handed round by shuffles: one memory round trip instead of
+// ten dependent ones (a block's search is a latency chain).  Entries of this frame were written
+// by another wave of THIS workgroup a barrier ago (same CU, same L1: workgroup scope is enough
+// -- an agent-scope fence per diagonal would write back / invalidate the XCD's L2 and made the
+// 64-job launches 3.6x slower) or by another workgroup in an earlier launch (kernel boundaries
+// make that visible).
 __device__ void get_subset_predictors(const TileView &t, int bx, int by, int pix_w, int pix_h,
                                       const int *rng, int corner, int ssdec, Subsets &s) {
   uint32_t min_sad = 0xFFFFFFFFu;
   s.nb = s.nc = s.has_median = 0;
+  const int lane = threadIdx.x & 63;
   const int w = ((pix_w << ssdec) + MI - 1) >> 2, h = ((pix_h << ssdec) + MI - 1) >> 2;
   const int half_w = imin(w >> 1, t.tcols - 1 - bx), half_h = imin(h >> 1, t.trows - 1 - by);
-  if (bx > 0) process_cand(t.at(by + half_h, bx - 1), rng, min_sad, s.b + 2 * s.nb++);
-  if (by > 0) process_cand(t.at(by - 1, bx + half_w), rng, min_sad, s.b + 2 * s.nb++);
-  if (corner && (corner & 2) && bx + w < t.tcols)
-    process_cand(t.at(by + half_h, bx + w), rng, min_sad, s.b + 2 * s.nb++);
-  if (corner && (corner & 4) && by + h < t.trows)
-    process_cand(t.at(by + h, bx + half_w), rng, min_sad, s.b + 2 * s.nb++);
+  const int fx = t.tx + bx, fy = t.ty + by;
+  const int hw = imin(w >> 1, t.cols_f - 1 - fx), hh = imin(h >> 1, t.rows_f - 1 - fy);
+  const bool hp = t.prev != nullptr;
+  bool ok[10];
+  ok[0] = bx > 0;
+  ok[1] = by > 0;
+  ok[2] = corner && (corner & 2) && bx + w < t.tcols;
+  ok[3] = corner && (corner & 4) && by + h < t.trows;
+  ok[4] = corner != 0;
+  ok[5] = hp && fx > 0;
+  ok[6] = hp && fy > 0;
+  ok[7] = hp && fx + w < t.cols_f;
+  ok[8] = hp && fy + h < t.rows_f;
+  ok[9] = hp;
+  // (y, x) of entry `lane` in frame coordinates
+  const int ey[10] = {t.ty + by + half_h, t.ty + by - 1, t.ty + by + half_h, t.ty + by + h, t.ty + by + half_h,
+                      fy + hh, fy - 1, fy + hh, fy + h, fy + hh};
+  const int ex[10] = {t.tx + bx - 1, t.tx + bx + half_w, t.tx + bx + w, t.tx + bx + half_w, t.tx + bx + half_w,
+                      fx - 1, fx + hw, fx + w, fx + hw, fx + hw};
+  int my_y = 0, my_x = 0;
+  bool my_ok = false;
+#pragma unroll
+  for (int k = 0; k < 10; k++)
+    if (lane == k) { my_y = ey[k]; my_x = ex[k]; my_ok = ok[k]; }
+  unsigned long long mine = 0;
+  if (my_ok) {
+    const R1MeStats *base = lane < 5 ? (const R1MeStats *)t.stats : t.prev;
+    mine = __hip_atomic_load((const unsigned long long *)(base + (size_t)my_y * t.cols_f + my_x), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  auto entry = [&](int k) -> unsigned long long {
+    return ((unsigned long long)(uint32_t)__shfl((int)(mine >> 32), k, 64) << 32) |
+           (uint32_t)__shfl((int)(uint32_t)mine, k, 64);
+  };
+  if (ok[0]) process_cand(entry(0), rng, min_sad, s.b + 2 * s.nb++);
+  if (ok[1]) process_cand(entry(1), rng, min_sad, s.b + 2 * s.nb++);
+  if (ok[2]) process_cand(entry(2), rng, min_sad, s.b + 2 * s.nb++);
+  if (ok[3]) process_cand(entry(3), rng, min_sad, s.b + 2 * s.nb++);
   if (corner) {
     s.has_median = 1;
-    process_cand(t.at(by + half_h, bx + half_w), rng, min_sad, s.median);
+    process_cand(entry(4), rng, min_sad, s.median);
   } else if (s.nb == 3) {
     // unreachable at INIT (at most left + top), kept for the rule's sake: median of three
     s.has_median = 1;
@@ -355,16 +477,10 @@ __device__ void get_subset_predictors(const TileView &t, int bx, int by, int pix
   s.b[2 * s.nb] = 0;
   s.b[2 * s.nb + 1] = 0;
   s.nb++;
-  if (t.prev) {
-    const int fx = t.tx + bx, fy = t.ty + by;
-    const int hw = imin(w >> 1, t.cols_f - 1 - fx), hh = imin(h >> 1, t.rows_f - 1 - fy);
-#define R1_PREV(y, x) (t.prev + (size_t)(y) * t.cols_f + (x))
-    if (fx > 0) process_cand(R1_PREV(fy + hh, fx - 1), rng, min_sad, s.c + 2 * s.nc++);
-    if (fy > 0) process_cand(R1_PREV(fy - 1, fx + hw), rng, min_sad, s.c + 2 * s.nc++);
-    if (fx + w < t.cols_f) process_cand(R1_PREV(fy + hh, fx + w), rng, min_sad, s.c + 2 * s.nc++);
-    if (fy + h < t.rows_f) process_cand(R1_PREV(fy + h, fx + hw), rng, min_sad, s.c + 2 * s.nc++);
-    process_cand(R1_PREV(fy + hh, fx + hw), rng, min_sad, s.c + 2 * s.nc++);
-#undef R1_PREV
+  if (hp) {
+#pragma unroll
+    for (int k = 5; k < 10; k++)
+      if (ok[k]) process_cand(entry(k), rng, min_sad, s.c + 2 * s.nc++);
   }
   s.min_sad = (uint32_t)(((unsigned long long)min_sad * (unsigned long long)(pix_w * pix_h)) >> 14);
   // dec_mv (me.rs:519-532) and all_mvs (me.rs:371-383)
@@ -475,8 +591,16 @@ __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, i
 // run as soon as pass q has finished diagonal d + 1 -- two launches behind.
 // Pass q on diagonal d + 2 meanwhile touches diagonals d + 1 .. d + 3 only.
 constexpr int kPassSkew = 2;
+#ifdef R1_ME_PROF
+// experiment build only: per pass, [0] workgroups, [1] sum of workgroup lifetimes, [2] longest
+// workgroup, [3] sum of the refinement phase (100 MHz wall-clock ticks)
+__device__ unsigned long long g_me_prof[3][4];
+#endif
+#ifndef R1_ME_DIAG_WAVES
+#define R1_ME_DIAG_WAVES 5
+#endif
 template <int BPP>
-__global__ __launch_bounds__(256, 5) void k_me_diag(const R1MeJob *__restrict__ jobs,
+__global__ __launch_bounds__(256, R1_ME_DIAG_WAVES) void k_me_diag(const R1MeJob *__restrict__ jobs,
                                                  const R1MeParams *__restrict__ pp, int step) {
   const R1MeParams p = *pp;   // uniform: lives in SGPRs; in device memory so that the launch
                               // arguments (and with them the captured graph) do not depend on it
@@ -488,6 +612,10 @@ __global__ __launch_bounds__(256, 5) void k_me_diag(const R1MeJob *__restrict__ 
   if (sby >= sbh || sbx < 0 || sbx >= sbw) return;   // workgroup-uniform
   __shared__ int16_t sh_subsets[4][kSubsetWords];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef R1_ME_PROF
+  const unsigned long long prof_t0 = wall_clock64();
+  unsigned long long prof_t1 = prof_t0;
+#endif
   const bool init = log2b == 4;
   const int ssdec = log2b - 2;
   TileView t{job.stats, job.prev, p.stats_cols, p.stats_rows, job.tile_x / MI, job.tile_y / MI,
@@ -518,6 +646,9 @@ __global__ __launch_bounds__(256, 5) void k_me_diag(const R1MeJob *__restrict__ 
       store_result(t, 1 << (log2b + 1), bx, by, r, w, h, ssdec, lane);
     }
     __syncthreads();   // workgroup-scope release / acquire of the stats just written
+#ifdef R1_ME_PROF
+    prof_t1 = wall_clock64();
+#endif
   }
 
   // estimate_sb_motion: raster order inside the superblock = anti-diagonals
@@ -540,6 +671,15 @@ __global__ __launch_bounds__(256, 5) void k_me_diag(const R1MeJob *__restrict__ 
     }
     __syncthreads();   // workgroup-scope release / acquire of the stats just written
   }
+#ifdef R1_ME_PROF
+  if (threadIdx.x == 0) {
+    const unsigned long long t2 = wall_clock64();
+    atomicAdd(&g_me_prof[blockIdx.z][0], 1ull);
+    atomicAdd(&g_me_prof[blockIdx.z][1], t2 - prof_t0);
+    atomicMax(&g_me_prof[blockIdx.z][2], t2 - prof_t0);
+    atomicAdd(&g_me_prof[blockIdx.z][3], prof_t1 - prof_t0);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -607,6 +747,14 @@ struct WgBlock {
     row = (int)(red[3 * best + 2] >> 32);
     col = (int)(uint32_t)red[3 * best + 2];
     __syncthreads();
+  }
+
+  // the shared search code's two-list step (Block::scan_pair): here simply one list after the other
+  template <class GenA, class GenB>
+  __device__ __forceinline__ void scan_pair(int na, GenA gen_a, Msr &best_a, int nb, GenB gen_b, Msr &best_b,
+                                            bool check) const {
+    scan(na, gen_a, check, best_a, nullptr);
+    scan(nb, gen_b, check, best_b, nullptr);
   }
 
   template <class Gen>
@@ -923,6 +1071,18 @@ __global__ __launch_bounds__(256, 3) void k_me_blocks_small(R1MeJob job, R1MePar
 }
 
 }  // namespace
+
+#ifdef R1_ME_PROF
+extern "C" int r1_debug_me_prof(unsigned long long *out, int reset) {   /* out[3][4] */
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_prof), sizeof(g_me_prof)) != hipSuccess) return -1;
+  if (reset) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_me_prof)) != hipSuccess) return -1;
+    if (hipMemset(p, 0, sizeof(g_me_prof)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, int n_jobs,
                                              const R1MeParams *params, void *stream) {
