@@ -162,7 +162,9 @@ struct Block {
     finish(v, in, row, col, cost, sad);
 #pragma unroll
     for (int s = RH; s < 64; s <<= 1) {
-      auto other = [&](uint32_t x) -> uint32_t { return s == 16 ? lane_xor16(x) : lane_xor32(x); };
+      // (v_permlane16/32_swap instead of these shuffles was tried: no gain, and together with the DPP
+      // row sums above it produced wrong lanes at scale -- left alone)
+      auto other = [&](uint32_t x) -> uint32_t { return (uint32_t)__shfl_xor((int)x, s, 64); };
       const unsigned long long oc = ((unsigned long long)other((uint32_t)(cost >> 32)) << 32) | other((uint32_t)cost);
       const int oi = (int)other((uint32_t)idx), orow = (int)other((uint32_t)row), ocol = (int)other((uint32_t)col);
       const uint32_t os = other(sad);
@@ -199,7 +201,11 @@ struct Block {
   template <class GenA, class GenB>
   __device__ __forceinline__ void scan_pair(int na, GenA gen_a, Msr &best_a, int nb, GenB gen_b, Msr &best_b,
                                             bool check) const {
+#ifdef R1_ME_NO_SPEC
+    if (true) {
+#else
     if (na > NCS || nb > NCS) {
+#endif
       scan(na, gen_a, check, best_a, nullptr);
       scan(nb, gen_b, check, best_b, nullptr);
       return;
@@ -215,7 +221,10 @@ struct Block {
 
   // `for cand in cands { if rd.cost < best.rd.cost { best = cand } }` over
   // n candidates produced by gen(idx, row, col); best_idx: index of the taken one.
-  static constexpr int KMAX = (GR * WPG <= 8) ? 3 : 2;   // registers: GR * WPG per batch in flight
+#ifndef R1_ME_KMAX
+#define R1_ME_KMAX 3
+#endif
+  static constexpr int KMAX = (GR * WPG <= 8) ? R1_ME_KMAX : (R1_ME_KMAX < 2 ? R1_ME_KMAX : 2);   // registers: GR * WPG per batch in flight
   template <class Gen>
   __device__ __forceinline__ void scan(int n, Gen gen, bool check, Msr &best, int *best_idx) const {
     int base = 0;
@@ -224,7 +233,7 @@ struct Block {
       if (KMAX >= 3 && left > 2 * NCS) {
         step<KMAX >= 3 ? 3 : 2>(base, n, gen, check, best, best_idx);
         base += (KMAX >= 3 ? 3 : 2) * NCS;
-      } else if (left > NCS) {
+      } else if (KMAX >= 2 && left > NCS) {
         step<2>(base, n, gen, check, best, best_idx);
         base += 2 * NCS;
       } else {

@@ -136,3 +136,49 @@ def test_pixel_candidate_at_config_size(ctx, oracle, fw, fh, bd):
         assert np.array_equal(o["eob"].cpu().numpy().view(np.uint16), weob), (fw, bd, s)
         assert np.array_equal(o["qcoeffs"].cpu().numpy(), wq), (fw, bd, s)
         assert np.array_equal(o["dist"].cpu().numpy().view(np.uint64), wdist), (fw, bd, s)
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
+def test_motion_estimation_at_config_size_every_16x16_block(ctx, oracle, w, h):
+    """N2 at the BASELINE frame sizes: the three-pass tile ME of the frame (tiles of 512 x 576 as one
+    call) and then the RDO-time search with sub-pel refinement of EVERY 16x16 block of the frame
+    (8040 / 32400 blocks in one launch -- thousands of waves in flight, where a lane-exchange bug
+    that small batches hide shows) against the oracle, every MEStats entry and every result."""
+    import torch
+    from rav1e_amd.api import me_lambdas, ME_BLOCK_CAND, ME_RESULT
+    bd = 8
+    rng = np.random.default_rng(77)
+    f = rng.standard_normal((h + 64, w + 64)).astype(np.float32)
+    for _ in range(3):
+        f = (np.roll(f, 1, 0) + 2 * f + np.roll(f, -1, 0)) / 4
+        f = (np.roll(f, 1, 1) + 2 * f + np.roll(f, -1, 1)) / 4
+    f = ((f - f.min()) / (f.max() - f.min()) * 255).astype(np.int64)
+    org = f[32:32 + h, 32:32 + w]
+    ref = np.clip(f[32 - 9:32 - 9 + h, 32 + 5:32 + 5 + w] + rng.integers(-2, 3, (h, w)), 0, 255)
+    po, pr = O.me_pyramid(org, bd), O.me_pyramid(ref, bd)
+    do, dr = [dev_plane(p) for p in po], [dev_plane(p) for p in pr]
+    lam = me_lambdas(30.0)
+    rows, cols = h // 4, w // 4
+    tiles = [(x, y, min(512, w - x), min(576, h - y)) for y in range(0, h, 576) for x in range(0, w, 512)]
+    want = np.zeros((rows, cols), O.ME_STATS)
+    import os
+    oracle.r1o_set_threads(os.cpu_count() or 1)
+    for t in tiles:
+        O.me_oracle(oracle, po, pr, cols, rows, t, bd, lam, want)
+    st = torch.zeros((rows, cols, 2), dtype=torch.int32, device="cuda")
+    ctx.estimate_tile_motion([dict(org=do, ref=dr, stats=st, tile=t) for t in tiles], cols, rows, bd, lam)
+    got = st.cpu().numpy().reshape(rows, -1).view(O.ME_STATS).reshape(rows, cols)
+    bad = np.argwhere(got != want)
+    assert len(bad) == 0, (len(bad), bad[:4], got[tuple(bad[0])], want[tuple(bad[0])])
+    nx, ny = w // 16, h // 16
+    c = np.zeros(nx * ny, ME_BLOCK_CAND)
+    c["bx"] = np.tile(np.arange(nx) * 4, ny)
+    c["by"] = np.repeat(np.arange(ny) * 4, nx)
+    c["w"] = c["h"] = 16
+    c["corner"] = rng.choice([0, 1, 3, 5, 7], len(c))
+    c["pmv"] = rng.integers(-16, 17, (len(c), 2, 2))
+    job = dict(org=do, ref=dr, stats=st, tile=(0, 0, w, h))
+    res = ctx.estimate_motion_batch(job, c, cols, rows, bd, lam, max_w=16, max_h=16).cpu().numpy().view(ME_RESULT)
+    exp = O.me_block_oracle(oracle, po, pr, cols, rows, (0, 0, w, h), bd, lam, want, None, c)
+    badb = np.nonzero(res != exp)[0]
+    assert len(badb) == 0, (len(badb), c[badb[0]], res[badb[0]], exp[badb[0]])

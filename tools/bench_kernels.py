@@ -191,6 +191,21 @@ def main():
     ms = timeit(lambda: ctx.cdef_filter_frame_plane(ref, ref, dst, 0, 0, 0, fw, fh, skip, ci, ystr,
                                                     ystr, 5, bd))
     report("cdef_filter_tile luma (find_dir + filter)", ms, fw * fh, 2 * fw * fh * bpp)
+    # ---- a14: the CDEF strength search of rdo_loop_decision, 4:2:0 frame, rav1e's 8 presets ----
+    cw2, ch2 = fw // 2, fh // 2
+    ch_rec = [Plane.from_numpy(W.random_plane_array(cw2, ch2, bd, 30 + k, 44, 44), cw2, ch2, bd, 44, 44)
+              for k in range(2)]
+    ch_src = [Plane.from_numpy(W.random_plane_array(cw2, ch2, bd, 40 + k, 44, 44), cw2, ch2, bd, 44, 44)
+              for k in range(2)]
+    presets = [0 * 4 + 0, 1 * 4 + 0, 2 * 4 + 1, 3 * 4 + 1, 5 * 4 + 2, 7 * 4 + 3, 10 * 4 + 3, 13 * 4 + 3]   # encoder.rs:897-916
+    skip_s = torch.zeros((2 * ((fh + 7) // 8), 2 * ((fw + 7) // 8)), dtype=torch.uint8, device="cuda")
+    scl = torch.full(((fh + 7) // 8, (fw + 7) // 8), 1 << 14, dtype=torch.int32, device="cuda")
+    for n_idx in (8, 1):
+        ms = timeit(lambda: ctx.cdef_strength_search([ref, ch_rec[0], ch_rec[1]], [org, ch_src[0], ch_src[1]], skip_s,
+                                                     presets, presets, 5, bd, n_idx, 1, 1, fw, fh, scales=scl))
+        report("cdef strength search 4:2:0, %d cdef_index candidates (filter + distortion per candidate, "
+               "no plane written)" % n_idx, ms, fw * fh * 3 // 2 * n_idx, 2 * (fw * fh * 3 // 2) * bpp,
+               {"pixels_filtered_and_measured": fw * fh * 3 // 2 * n_idx})
     # ---- N3: deblock filter + level search, 4:2:0 frame (luma + two chroma planes) ----
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import deblock_util as D

@@ -63,6 +63,8 @@ def main():
             fn()
         torch.cuda.synchronize()
         stages[name] = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
+        if os.environ.get("R1_VERBOSE"):
+            print(name, stages[name], file=sys.stderr, flush=True)
 
     # 1 lookahead cost maps
     timed("lookahead_intra_costs", lambda: ctx.estimate_intra_costs(org[0]))
@@ -148,6 +150,20 @@ def main():
     ci = torch.zeros(((fh + 63) // 64, (fw + 63) // 64), dtype=torch.uint8, device="cuda")
     timed("cdef_luma", lambda: ctx.cdef_filter_frame_plane(refs[0][0], refs[0][0], dst, 0, 0, 0, fw, fh, skip, ci,
                                                            [36] * 8, [36] * 8, 5, bd))
+    # 8b the CDEF strength search of rdo_loop_decision (8 presets, 4:2:0) -- not part of the sum: rav1e's
+    # default picks the strength from the quantizer (cdef_bits 0); reported beside the stages
+    skip_s = torch.zeros((2 * ((fh + 7) // 8), 2 * ((fw + 7) // 8)), dtype=torch.uint8, device="cuda")
+    presets = [0, 4, 9, 13, 22, 31, 43, 55]    # encoder.rs:897-916
+    cdef_search = lambda: ctx.cdef_strength_search(rec3, src3, skip_s, presets, presets, 5, bd, 8, 1, 1, fw, fh,
+                                                   scales=scales)
+    for _ in range(2):
+        cdef_search()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        cdef_search()
+    torch.cuda.synchronize()
+    cdef_search_ms = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
     # 9 loop restoration (self-guided), luma, every 64x64 unit
     us = 64
     units = np.zeros((max((fh + 32) // us, 1), max((fw + 32) // us, 1), 4), np.uint8)
@@ -186,6 +202,7 @@ def main():
     ov = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
     print(json.dumps({"frame": "%dx%d %d-bit" % (fw, fh, bd), "stage_ms": stages, "sum_ms": total,
                       "frames_per_s_if_serial": round(1e3 / total, 1),
+                      "cdef_strength_search_8_presets_420_ms (optional stage, not in the sum)": cdef_search_ms,
                       "two_stream_ms (ME of the next frame beside the other stages)": ov,
                       "frames_per_s_two_streams": round(1e3 / ov, 1)}))
     ctx.close()
