@@ -264,6 +264,11 @@ __global__ __launch_bounds__(64) void k_cdef_search(SearchArgs a) {
       if (need_own) ta = load_taps(rd, i, j, own, x);
       if (need_zero) tb = own == 0 && need_own ? ta : load_taps(rd, i, j, 0, x);
     }
+    uint32_t m_s = 0, m_s2 = 0;
+    if (luma) {
+      m_s = group_sum<64>((uint32_t)s);
+      m_s2 = group_sum<64>((uint32_t)(s * s));
+    }
     for (int idx = 0; idx < a.p.n_idx; idx++) {
       int32_t v = x;
       if (!skip) {
@@ -280,14 +285,12 @@ __global__ __launch_bounds__(64) void k_cdef_search(SearchArgs a) {
                          : filter_from_taps(tb, x, pri, sec, psh, ssh, coeff_shift);
       }
       if (luma) {
-        // cdef_dist_kernel moments over the 64 pixels (dist.rs:316-345)
-        uint32_t m[5] = {(uint32_t)s, (uint32_t)v, (uint32_t)(s * s), (uint32_t)(v * v), (uint32_t)(s * v)};
-#pragma unroll
-        for (int q = 0; q < 5; q++)
-#pragma unroll
-          for (int sft = 1; sft < 64; sft <<= 1) m[q] += __shfl_xor(m[q], sft, 64);
+        // cdef_dist_kernel moments over the 64 pixels (dist.rs:316-345); the source's two do not
+        // depend on the index (formed once, above the loop)
+        const uint32_t m_d = group_sum<64>((uint32_t)v), m_d2 = group_sum<64>((uint32_t)(v * v)),
+                       m_sd = group_sum<64>((uint32_t)(s * v));
         if (lane == 0) {
-          const unsigned long long d = r1dist::cdef_tile_tail(m[0], m[1], m[2], m[3], m[4], 64, 0, 0, &bias, 0, bd);
+          const unsigned long long d = r1dist::cdef_tile_tail(m_s, m_d, m_s2, m_d2, m_sd, 64, 0, 0, &bias, 0, bd);
           atomicAdd(&ps[idx * 3 + 0], d);
         }
       } else {
@@ -297,10 +300,14 @@ __global__ __launch_bounds__(64) void k_cdef_search(SearchArgs a) {
         uint32_t c = act ? (uint32_t)(df * df) : 0u;
         // cell members: bits 0-1 of j and bits 0-1 of i of the lane index inside the plane
         constexpr int M0 = 1, M1 = 2, M2 = CXS == 8 ? 8 : 4, M3 = CXS == 8 ? 16 : 8;
-        c += __shfl_xor(c, M0, 64);
-        c += __shfl_xor(c, M1, 64);
-        c += __shfl_xor(c, M2, 64);
-        c += __shfl_xor(c, M3, 64);
+        if constexpr (CXS == 4) {
+          c = group_sum<16>(c);   // lanes 16 k .. 16 k + 15 are one cell: DPP inside the row
+        } else {
+          c += __shfl_xor(c, M0, 64);
+          c += __shfl_xor(c, M1, 64);
+          c += __shfl_xor(c, M2, 64);
+          c += __shfl_xor(c, M3, 64);
+        }
         const bool leader = (j & 3) == 0 && (i & 3) == 0;
         unsigned long long w = leader && act ? ((unsigned long long)c * bias + 128) >> 8 : 0ull;
         // the cells of a plane's block: 1 (4x4), 2 (4x8: rows), 4 (8x8)
