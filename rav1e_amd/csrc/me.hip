@@ -221,10 +221,10 @@ struct Block {
 
   // `for cand in cands { if rd.cost < best.rd.cost { best = cand } }` over
   // n candidates produced by gen(idx, row, col); best_idx: index of the taken one.
-#ifndef R1_ME_KMAX
-#define R1_ME_KMAX 3
-#endif
-  static constexpr int KMAX = (GR * WPG <= 8) ? R1_ME_KMAX : (R1_ME_KMAX < 2 ? R1_ME_KMAX : 2);   // registers: GR * WPG per batch in flight
+  // batches in flight: GR * WPG registers each.  Measured (profiles/r02_me_batch_ab.log): three for
+  // 16-row slots of 8-bit pixels (4 registers a batch); two everywhere else -- a third batch of 8 or 16
+  // registers spills and made the 10-bit search 18 % slower than two
+  static constexpr int KMAX = (GR * WPG <= 4) ? 3 : 2;
   template <class Gen>
   __device__ __forceinline__ void scan(int n, Gen gen, bool check, Msr &best, int *best_idx) const {
     int base = 0;

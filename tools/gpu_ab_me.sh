@@ -6,7 +6,7 @@ mkdir -p gpurun_out/abme
 last=""
 for rep in 1 2; do for v in $VARIANTS; do
   cp build/ab/$v.so rav1e_amd/librav1e_hip.so
-  timeout 300 python tools/bench_me.py --tile-only --reps 10 2>&1 | grep "^{" | python3 -c "
+  timeout 300 python tools/bench_me.py --tile-only --reps 10 --bit-depth ${BD:-8} 2>&1 | grep "^{" | python3 -c "
 import sys,json
 print('$v', [(d['jobs'], d['ms']) for d in map(json.loads, sys.stdin) if 'jobs' in d])" | tee -a gpurun_out/abme/ab.log
   last=$v

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== pytest -m gpu"
-timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 | tee $OUT/pytest_gpu.log
+timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -6 | tee $OUT/pytest_gpu.log
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log
 echo "== bench (default flags)"
