@@ -1359,9 +1359,11 @@ def _lrf_run(ctx, cdef, debl, ydec, fh, us, sh, units, bd):
     return do.data.cpu().numpy().view(dt)[hc.yorigin:hc.yorigin + h, hc.xorigin:hc.xorigin + w]
 
 
-def test_lrf_golden_frames(ctx):
-    """the independent-model frames of tests/golden/lrf_golden.npz"""
-    G = dict(np.load(os.path.join(GOLD, "lrf_golden.npz")))
+@pytest.mark.parametrize("fixture", ["lrf_golden.npz", "lrf_ref.npz"])
+def test_lrf_golden_frames(ctx, fixture):
+    """the independent-model frames of tests/golden/lrf_golden.npz and the same frames filtered by
+    the reference's own lrf_filter_frame text (lrf_ref.npz, tests/golden/gen_lrf_ref.py)"""
+    G = dict(np.load(os.path.join(GOLD, fixture)))
     for name in sorted(k[:-5] for k in G if k.endswith("_meta")):
         w, h, ydec, fh, us, sh, bd = [int(v) for v in G[name + "_meta"]]
         got = _lrf_run(ctx, G[name + "_cdef"], G[name + "_debl"], ydec, fh, us, sh, G[name + "_units"], bd)
@@ -1430,6 +1432,21 @@ def test_sgrproj_solve_vs_oracle(ctx, oracle, bd):
                                  int(u["h"][i]), int(u["set"][i]), bd, want.ctypes.data)
         assert np.array_equal(got[i], want), (bd, u[i], got[i], want)
     assert len(np.unique(got, axis=0)) > 12      # the weights actually vary (not all clamped)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_sgrproj_solve_ref(ctx, bd):
+    """r1_sgrproj_solve_batch on what sgrproj_solve of the reference's own text returned (lrf_ref.npz)"""
+    from rav1e_amd.api import SGR_SOLVE_UNIT
+    REF = np.load(os.path.join(GOLD, "lrf_ref.npz"))
+    cdef, src = REF["solve%d_cdef" % bd].astype(np.int64), REF["solve%d_src" % bd].astype(np.int64)
+    hc, hs = O.plane_from_image(cdef, bd, 16, 16), O.plane_from_image(src, bd, 16, 16)
+    cases = REF["solve%d_cases" % bd]
+    u = np.zeros(len(cases), SGR_SOLVE_UNIT)
+    for i, (x0, y0, uw, uh, set_, q0, q1) in enumerate(cases.tolist()):
+        u[i] = (x0, y0, uw, uh, set_, (0, 0, 0))
+    got = ctx.sgrproj_solve_batch(dev_plane(hc), dev_plane(hs), u).cpu().numpy()
+    assert np.array_equal(got.astype(np.int64), cases[:, 5:7].astype(np.int64)), (bd, got[:4], cases[:4])
 
 
 @pytest.mark.parametrize("bd", [8, 10, 12])

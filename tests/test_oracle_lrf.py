@@ -10,6 +10,10 @@ import oracle_lib as O
 
 G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "lrf_golden.npz")))
 CASES = sorted(k[:-5] for k in G if k.endswith("_meta"))
+# the same frames filtered by the reference's own lrf_filter_frame text (tests/golden/gen_lrf_ref.py)
+# + sgrproj_solve results of the reference's text
+REF = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "lrf_ref.npz")))
+REF_CASES = sorted(k[:-5] for k in REF if k.endswith("_meta"))
 
 
 def run_oracle(oracle, cdef, debl, ydec, fh, us, sh, units, bd):
@@ -65,3 +69,25 @@ def test_sgrproj_solve_matches_the_independent_model(oracle, bd):
             oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), x0, y0, uw, uh, set_, bd, got.ctypes.data)
             want = L.solve_unit(cdef, src, x0, y0, uw, uh, set_, bd)
             assert tuple(int(v) for v in got) == want, (bd, x0, y0, set_, got, want)
+
+
+@pytest.mark.parametrize("name", REF_CASES)
+def test_sgrproj_frames_equal_the_executed_reference(oracle, name):
+    """oracle/lrf.c against RestorationState::lrf_filter_frame of the reference's own text"""
+    w, h, ydec, fh, us, sh, bd = [int(v) for v in REF[name + "_meta"]]
+    got = run_oracle(oracle, REF[name + "_cdef"], REF[name + "_debl"], ydec, fh, us, sh, REF[name + "_units"], bd)
+    bad = np.argwhere(got != REF[name + "_out"])
+    assert len(bad) == 0, (name, bad[:5])
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_sgrproj_solve_equals_the_executed_reference(oracle, bd):
+    """xqd of oracle/lrf.c::r1o_sgrproj_solve against sgrproj_solve of the reference's text
+    (setup_integral_image + sgrproj_solve as src/rdo.rs:2651-2684 calls them)"""
+    cdef, src = REF["solve%d_cdef" % bd].astype(np.int64), REF["solve%d_src" % bd].astype(np.int64)
+    pc, ps = O.plane_from_image(cdef, bd, 16, 16), O.plane_from_image(src, bd, 16, 16)
+    cc, cs = pc.cstruct(), ps.cstruct()
+    for (x0, y0, uw, uh, set_, q0, q1) in REF["solve%d_cases" % bd].tolist():
+        got = np.zeros(2, np.int8)
+        oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), x0, y0, uw, uh, set_, bd, got.ctypes.data)
+        assert (int(got[0]), int(got[1])) == (q0, q1), (bd, x0, y0, uw, uh, set_, got, (q0, q1))

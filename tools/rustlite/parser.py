@@ -380,9 +380,12 @@ class Parser:
             self.expect("{")
             variants = []
             nextd = 0
+            default_variant = None
             while not self.at("}"):
-                self.skip_attrs()
+                vattrs = self.skip_attrs()
                 vn = self.ident()
+                if any("default" in a.split() for a in vattrs):
+                    default_variant = vn       # #[default] of #[derive(Default)]
                 kind, fields = "unit", []
                 if self.at("("):
                     kind = "tuple"
@@ -410,7 +413,7 @@ class Parser:
                 if not self.eat(","):
                     break
             self.expect("}")
-            return N("enum", name=name, variants=variants, attrs=attrs)
+            return N("enum", name=name, variants=variants, attrs=attrs, default_variant=default_variant)
         if v == "impl" or (v == "unsafe" and self.at("impl", 1)):
             self.eat("unsafe")
             self.i += 1

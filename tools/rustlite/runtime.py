@@ -1166,6 +1166,11 @@ def int_method(v, t, name, a):
         b = INT_BITS[_need(t, name)] // 8
         return int.from_bytes((v & ((1 << 8 * b) - 1)).to_bytes(b, "little"), "big")
     if name == "mul_add":
+        # f64::mul_add is FUSED (one rounding): exact rational product + sum, rounded once
+        from fractions import Fraction
+        import math
+        if all(isinstance(x, (int, float)) and math.isfinite(x) for x in (v, a[0], a[1])):
+            return float(Fraction(v) * Fraction(a[0]) + Fraction(a[1]))
         return v * a[0] + a[1]
     if name in ("sqrt", "floor", "ceil", "round", "ln", "log2", "exp", "exp2", "powf", "powi", "log10",
                 "is_nan", "is_finite", "trunc", "recip", "cbrt"):
@@ -1277,6 +1282,14 @@ class Plane(RStruct):
         return PlaneRegion(self.data, (self.cfg.yorigin + y) * self.cfg.stride + self.cfg.xorigin + x,
                            self.cfg, x, y, w, h)
 
+    def row_range(self, x, y):
+        # v_frame Plane::row_range: the indices of row y from column x to the end of the row's allocation
+        c = self.cfg
+        if c.yorigin + y < 0 or c.xorigin + x < 0 or c.yorigin + y >= c.alloc_height:
+            raise Panic("Plane::row_range outside the allocation (x %d y %d)" % (x, y))
+        base = (c.yorigin + y) * c.stride + c.xorigin + x
+        return RRange(base, base + c.stride - (c.xorigin + x))
+
     def p(self, x, y):
         return self.data[(self.cfg.yorigin + y) * self.cfg.stride + self.cfg.xorigin + x]
 
@@ -1299,6 +1312,10 @@ class PlaneSlice(RStruct):
     def __getitem__(self, row):
         base, width = self._base(row)
         return RSlice(self.plane.data, base, width)
+
+    def row(self, y):
+        # v_frame PlaneSlice::row: row y of the slice, from its x to the end of the row's allocation
+        return self[y]
 
     def as_ptr(self):
         return RPtr(self.plane.data, self._base(0)[0])

@@ -230,6 +230,19 @@ class Crate:
         if f is None:
             if name in ("clone", "to_owned", "borrow", "as_ref", "as_mut", "into", "deref", "by_ref", "as_const"):
                 return recv
+            ms = self.methods.get(rn) if rn is not None else None
+            if ms and "next" in ms and hasattr(R.RIter, name):
+                # a struct that implements Iterator (its own `next`): the provided adaptors
+                # (map, zip, take, ...) run on a stream of its next() results
+                nxt = ms["next"][0]
+
+                def stream():
+                    while True:
+                        v = self._call_info(nxt, g, (recv,))
+                        if not (isinstance(v, R.REnum) and v.var == "Some"):
+                            return
+                        yield v.p[0]
+                return getattr(R.RIter(stream()), name)(*args)
             raise R.Panic("rustlite: no method %s on %r" % (name, t.__name__))
         return f(*args)
 
@@ -646,6 +659,9 @@ class FnCompiler:
                      "wrapping_shr", "rem_euclid", "div_euclid", "align_power_of_two",
                      "align_power_of_two_and_shift", "to_owned", "copied", "isqrt"):
                 return rt
+            if n in ("get_unchecked", "get_unchecked_mut") and isinstance(rt, tuple) and rt[0] == "arr" and \
+                    e.args and self.strip(self.ty(e.args[0])) in INT:
+                return ("ref", rt[1], n.endswith("mut"))     # slice.get_unchecked(i) -> &T
             if n in ("unsigned_abs", "abs_diff"):
                 if isinstance(rt, str) and rt in INT:
                     return "u" + rt[1:] if rt[0] == "i" else rt
@@ -2104,6 +2120,11 @@ class FnCompiler:
                 st = self.c.structs[t]
                 return "S_%s(%s)" % (t, ", ".join("%s=%s" % (pyfield(f), self.default_for(self.norm(ft)))
                                                   for f, ft in st.node.fields))
+            if t in self.c.enums and getattr(self.c.enums[t], "default_variant", None):
+                dv = self.c.enums[t].default_variant       # #[derive(Default)] + #[default]
+                pn, d, kind, fields = self.c.enum_value(t, dv)
+                if kind == "unit":
+                    return pn
         if isinstance(t, tuple):
             if t[0] == "tup":
                 return "(%s,)" % ", ".join(self.default_for(x) for x in t[1])
