@@ -182,3 +182,45 @@ def test_motion_estimation_at_config_size_every_16x16_block(ctx, oracle, w, h):
     exp = O.me_block_oracle(oracle, po, pr, cols, rows, (0, 0, w, h), bd, lam, want, None, c)
     badb = np.nonzero(res != exp)[0]
     assert len(badb) == 0, (len(badb), c[badb[0]], res[badb[0]], exp[badb[0]])
+
+
+@pytest.mark.parametrize("fw,fh,bd", CONFIGS)
+def test_cdef_strength_search_at_config_size(ctx, oracle, fw, fh, bd):
+    """a14 at the BASELINE frame sizes: r1_cdef_strength_search over rav1e's eight strength presets
+    on a whole 4:2:0 frame (34 x 60 superblocks at 4K, the last row cropped: 2160 = 33.75 x 64)
+    against the oracle -- every (superblock, index) error and every pick."""
+    from test_gpu_ref_vectors import run_cdef_search_gpu
+    rng = np.random.default_rng(fw + bd)
+    planes_src, planes_rec = [], []
+    for pl, (w, h) in enumerate(((fw, fh), (fw // 2, fh // 2), (fw // 2, fh // 2))):
+        yy, xx = np.mgrid[0:h, 0:w]
+        s = np.clip((np.sin(xx / (7.0 + pl)) + np.cos((yy + xx) / 11.0)) * 45 + 128 + rng.integers(-4, 5, (h, w)),
+                    0, 255).astype(np.int64) << (bd - 8)
+        r = np.clip(s + rng.integers(-10 << (bd - 8), (10 << (bd - 8)) + 1, s.shape) * (rng.random(s.shape) < 0.3),
+                    0, (1 << bd) - 1)
+        planes_src.append(O.plane_from_image(s, bd, 16, 16))
+        planes_rec.append(O.plane_from_image(r, bd, 16, 16))
+    mi_cols, mi_rows = 2 * ((fw + 7) // 8), 2 * ((fh + 7) // 8)
+    skip = (rng.random((mi_rows, mi_cols)) < 0.3).astype(np.uint8)
+    skip[32:48, 16:48] = 1                      # two completely skipped superblocks
+    scales = rng.integers(1 << 12, 1 << 16, ((fh + 7) // 8, (fw + 7) // 8)).astype(np.uint32)
+    prm = O.CdefSearchParams()
+    presets = [0, 4, 9, 13, 22, 31, 43, 55]     # fi.cdef_y_strengths / cdef_uv_strengths (src/encoder.rs:897-916)
+    prm.y_strengths[:] = presets
+    prm.uv_strengths[:] = presets
+    prm.damping, prm.bit_depth, prm.n_idx, prm.planes = 5, bd, 8, 3
+    prm.xdec, prm.ydec, prm.crop_w, prm.crop_h, prm.area_sb_w, prm.area_sb_h = 1, 1, fw, fh, 1, 1
+    prm.dist_scale[:] = [1 << 14, 20000, 12000]
+    n_sbx, n_sby = (mi_cols + 15) // 16, (mi_rows + 15) // 16
+    want_err = np.zeros((n_sby, n_sbx, 8), np.uint64)
+    want_best = np.zeros((n_sby, n_sbx), np.int8)
+    pr = (O.Plane * 3)(*[p.cstruct() for p in planes_rec])
+    ps = (O.Plane * 3)(*[p.cstruct() for p in planes_src])
+    assert oracle.r1o_cdef_strength_search(pr, ps, skip.ctypes.data, mi_cols, mi_cols, mi_rows, scales.ctypes.data,
+                                           scales.shape[1], C.byref(prm), want_err.ctypes.data,
+                                           want_best.ctypes.data) == 0
+    got_err, got_best = run_cdef_search_gpu(ctx, planes_rec, planes_src, skip, scales, prm)
+    bad = np.argwhere(got_err != want_err)
+    assert len(bad) == 0, (len(bad), bad[:4], got_err[tuple(bad[0])], want_err[tuple(bad[0])])
+    assert np.array_equal(got_best, want_best)
+    assert (want_best == -1).sum() == 2 and len(np.unique(want_best)) > 2
