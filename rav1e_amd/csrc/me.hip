@@ -610,13 +610,26 @@ __device__ unsigned long long g_me_prof[3][4];
 #endif
 template <int BPP>
 __global__ __launch_bounds__(256, R1_ME_DIAG_WAVES) void k_me_diag(const R1MeJob *__restrict__ jobs,
-                                                 const R1MeParams *__restrict__ pp, int step) {
+                                                 const R1MeParams *__restrict__ pp,
+                                                 R1MeStats *const *__restrict__ rbufs, int step) {
   const R1MeParams p = *pp;   // uniform: lives in SGPRs; in device memory so that the launch
                               // arguments (and with them the captured graph) do not depend on it
-  // blockIdx.z = pass; pass q works kPassSkew * q diagonals behind pass q - 1 (see the host loop)
-  const int log2b = 4 - (int)blockIdx.z, diag = step - kPassSkew * (int)blockIdx.z;
+  // blockIdx.z = role.  0..2: the SEARCH of pass z on diagonal step - kPassSkew * z (pass q works
+  // kPassSkew diagonals behind pass q - 1, see the host loop).  3, 4: the REFINEMENT
+  // (refine_subsampled_sb_motion) for pass z - 2, ONE DIAGONAL AHEAD of that pass' search.  A
+  // superblock's refinement depends on nothing but its own statistics of the previous pass, which
+  // are final one launch before its search; done inside the search workgroup it was 12 of its
+  // 53 us (the chain that bounds every launch), done here it runs beside the searches of the
+  // diagonal before.  Its results must stay invisible to those searches -- their right / bottom
+  // predictors in this superblock are the UNREFINED vectors -- so they go to a second buffer
+  // (rbufs[job], same geometry as the statistics) that the superblock's own search copies in first.
+  const int role = (int)blockIdx.z;
+  const bool refine_role = role >= 3;
+  const int pass = refine_role ? role - 2 : role;
+  const int log2b = 4 - pass, diag = step - kPassSkew * pass + (refine_role ? 1 : 0);
   const R1MeJob &job = jobs[blockIdx.y];
   const int sbw = (job.tile_w + SB - 1) / SB, sbh = (job.tile_h + SB - 1) / SB;
+  if (diag < 0) return;
   const int sby = (int)blockIdx.x + imax(0, diag - (sbw - 1)), sbx = diag - sby;
   if (sby >= sbh || sbx < 0 || sbx >= sbw) return;   // workgroup-uniform
   __shared__ int16_t sh_subsets[4][kSubsetWords];
@@ -629,10 +642,13 @@ __global__ __launch_bounds__(256, R1_ME_DIAG_WAVES) void k_me_diag(const R1MeJob
   const int ssdec = log2b - 2;
   TileView t{job.stats, job.prev, p.stats_cols, p.stats_rows, job.tile_x / MI, job.tile_y / MI,
              job.tile_w / MI, job.tile_h / MI};
+  R1MeStats *const rbuf = rbufs[blockIdx.y];
   const int sb_w = imin(SB, job.tile_w - sbx * SB), sb_h = imin(SB, job.tile_h - sby * SB);
 
-  if (!init) {
-    // refine_subsampled_sb_motion: the previous pass' blocks at this resolution
+  if (refine_role) {
+    // refine_subsampled_sb_motion: the previous pass' blocks at this resolution, into rbuf
+    TileView tr = t;
+    tr.stats = rbuf;
     const int sz = MI << (log2b + 1);
     const int nbx = (sb_w + sz - 1) / sz, nby = (sb_h + sz - 1) / sz;
     if (wave < nbx * nby) {
@@ -652,7 +668,20 @@ __global__ __launch_bounds__(256, R1_ME_DIAG_WAVES) void k_me_diag(const R1MeJob
                                 b.po_x + imin(div8(mvc) + 2, div8(b.mvx_max)),
                                 b.po_y + imax(div8(mvr) - 1, div8(b.mvy_min)),
                                 b.po_y + imin(div8(mvr) + 2, div8(b.mvy_max)), 1);
-      store_result(t, 1 << (log2b + 1), bx, by, r, w, h, ssdec, lane);
+      store_result(tr, 1 << (log2b + 1), bx, by, r, w, h, ssdec, lane);
+    }
+    return;
+  }
+
+  if (!init) {
+    // the refinement of this superblock (previous launch, role 3 / 4) becomes visible now
+    const int bx0 = sbx * 16, by0 = sby * 16;
+    const int nx = imin(16, t.tcols - bx0), ny = imin(16, t.trows - by0);
+    for (int i = threadIdx.x; i < nx * ny; i += 256) {
+      const int y = i / nx, xx = i - y * nx;
+      const size_t o = (size_t)(t.ty + by0 + y) * t.cols_f + t.tx + bx0 + xx;
+      const unsigned long long v = *(const unsigned long long *)(rbuf + o);
+      __hip_atomic_store((unsigned long long *)(t.stats + o), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();   // workgroup-scope release / acquire of the stats just written
 #ifdef R1_ME_PROF
@@ -683,10 +712,10 @@ __global__ __launch_bounds__(256, R1_ME_DIAG_WAVES) void k_me_diag(const R1MeJob
 #ifdef R1_ME_PROF
   if (threadIdx.x == 0) {
     const unsigned long long t2 = wall_clock64();
-    atomicAdd(&g_me_prof[blockIdx.z][0], 1ull);
-    atomicAdd(&g_me_prof[blockIdx.z][1], t2 - prof_t0);
-    atomicMax(&g_me_prof[blockIdx.z][2], t2 - prof_t0);
-    atomicAdd(&g_me_prof[blockIdx.z][3], prof_t1 - prof_t0);
+    atomicAdd(&g_me_prof[pass][0], 1ull);
+    atomicAdd(&g_me_prof[pass][1], t2 - prof_t0);
+    atomicMax(&g_me_prof[pass][2], t2 - prof_t0);
+    atomicAdd(&g_me_prof[pass][3], prof_t1 - prof_t0);
   }
 #endif
 }
@@ -1098,6 +1127,7 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   R1_REQUIRE(ctx && params);
   if (n_jobs <= 0) return R1_OK;
   R1_REQUIRE(jobs);
+  R1_REQUIRE(n_jobs <= 256);   // tiles x reference frames of one frame
   R1_REQUIRE(params->bit_depth == 8 || params->bit_depth == 10 || params->bit_depth == 12);
   R1_REQUIRE(params->stats_cols > 0 && params->stats_rows > 0);
   const int bpp = jobs[0].org[0].bytes_per_px;
@@ -1124,7 +1154,8 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   std::lock_guard<std::mutex> ring_lock(ctx->me_mu);
   R1DeviceGuard dev_guard(ctx);
   const size_t jobs_bytes = ((size_t)n_jobs * sizeof(R1MeJob) + 15) & ~(size_t)15;
-  const size_t bytes = jobs_bytes + sizeof(R1MeParams);
+  const size_t params_bytes = (sizeof(R1MeParams) + 15) & ~(size_t)15;
+  const size_t bytes = jobs_bytes + params_bytes + (size_t)n_jobs * sizeof(R1MeStats *);
   const int slot = ctx->me_next;
   ctx->me_next = (slot + 1) % r1_ctx::kMeSlots;
   if (ctx->me_done[slot]) R1_HIP_CHECK(hipEventSynchronize(ctx->me_done[slot]));
@@ -1140,10 +1171,35 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
     R1_HIP_CHECK(hipHostMalloc(&ctx->me_jobs_host[slot], bytes, hipHostMallocDefault));
     ctx->me_jobs_bytes[slot] = bytes;
   }
+  // the refinement buffers: one MEStats frame per DISTINCT statistics array of the call (the tiles
+  // of a frame share theirs), same geometry, so a job's entries sit at the same offsets
+  const size_t frame_bytes = (size_t)params->stats_cols * params->stats_rows * sizeof(R1MeStats);
+  int uniq_of[256], n_uniq = 0;
+  for (int j = 0; j < n_jobs; j++) {
+    int u = -1;
+    for (int k = 0; k < j && u < 0; k++)
+      if (jobs[k].stats == jobs[j].stats) u = uniq_of[k];
+    uniq_of[j] = u >= 0 ? u : n_uniq++;
+  }
+  if (ctx->me_refine_bytes[slot] < frame_bytes * n_uniq) {
+    if (ctx->me_graph[slot]) (void)hipGraphExecDestroy(ctx->me_graph[slot]);
+    ctx->me_graph[slot] = nullptr;
+    if (ctx->me_refine[slot]) (void)hipFree(ctx->me_refine[slot]);
+    ctx->me_refine[slot] = nullptr;
+    ctx->me_refine_bytes[slot] = 0;
+    R1_HIP_CHECK(hipMalloc(&ctx->me_refine[slot], frame_bytes * n_uniq));
+    ctx->me_refine_bytes[slot] = frame_bytes * n_uniq;
+  }
   memcpy(ctx->me_jobs_host[slot], jobs, (size_t)n_jobs * sizeof(R1MeJob));
   memcpy((uint8_t *)ctx->me_jobs_host[slot] + jobs_bytes, params, sizeof(R1MeParams));
+  {
+    R1MeStats **rp = (R1MeStats **)((uint8_t *)ctx->me_jobs_host[slot] + jobs_bytes + params_bytes);
+    for (int j = 0; j < n_jobs; j++)
+      rp[j] = (R1MeStats *)((uint8_t *)ctx->me_refine[slot] + frame_bytes * uniq_of[j]);
+  }
   const R1MeJob *djobs = (const R1MeJob *)ctx->me_jobs[slot];
   const R1MeParams *dparams = (const R1MeParams *)((const uint8_t *)ctx->me_jobs[slot] + jobs_bytes);
+  R1MeStats *const *drbufs = (R1MeStats *const *)((const uint8_t *)ctx->me_jobs[slot] + jobs_bytes + params_bytes);
   const int ndiag = max_sbw + max_sbh - 1;
   const int dlen = max_sbw < max_sbh ? max_sbw : max_sbh;
   // software pipeline over the passes: launch `step` runs diagonal step - 2 q of pass q
@@ -1154,8 +1210,8 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   if (!use_graph) {
     R1_HIP_CHECK(hipMemcpyAsync(ctx->me_jobs[slot], ctx->me_jobs_host[slot], bytes, hipMemcpyHostToDevice, st));
     for (int step = 0; step < nsteps; step++) {
-      if (bpp == 1) hipLaunchKernelGGL(k_me_diag<1>, dim3(dlen, n_jobs, 3), dim3(256), 0, st, djobs, dparams, step);
-      else hipLaunchKernelGGL(k_me_diag<2>, dim3(dlen, n_jobs, 3), dim3(256), 0, st, djobs, dparams, step);
+      if (bpp == 1) hipLaunchKernelGGL(k_me_diag<1>, dim3(dlen, n_jobs, 5), dim3(256), 0, st, djobs, dparams, drbufs, step);
+      else hipLaunchKernelGGL(k_me_diag<2>, dim3(dlen, n_jobs, 5), dim3(256), 0, st, djobs, dparams, drbufs, step);
     }
     R1_HIP_CHECK(hipGetLastError());
     R1_HIP_CHECK(hipEventRecord(ctx->me_done[slot], st));
@@ -1165,7 +1221,7 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   // is a function of (pixel size, jobs, diagonal length, steps) and of the slot's buffers only --
   // the job contents and the parameters travel through the upload.  It is built once as an
   // explicit hipGraph and replayed with a single hipGraphLaunch per call.
-  const long long sig[4] = {bpp, n_jobs, dlen, nsteps};
+  const long long sig[5] = {bpp, n_jobs, dlen, nsteps, (long long)(size_t)ctx->me_refine[slot]};
   if (!ctx->me_graph[slot] || memcmp(sig, ctx->me_graph_sig[slot], sizeof(sig)) != 0) {
     if (ctx->me_graph[slot]) (void)hipGraphExecDestroy(ctx->me_graph[slot]);
     ctx->me_graph[slot] = nullptr;
@@ -1176,11 +1232,11 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
                                            bytes, hipMemcpyHostToDevice);
     for (int step = 0; step < nsteps && e == hipSuccess; step++) {
       int step_arg = step;
-      void *args[3] = {(void *)&djobs, (void *)&dparams, (void *)&step_arg};
+      void *args[4] = {(void *)&djobs, (void *)&dparams, (void *)&drbufs, (void *)&step_arg};
       hipKernelNodeParams kp;
       memset(&kp, 0, sizeof(kp));
       kp.func = (void *)fn;
-      kp.gridDim = dim3(dlen, n_jobs, 3);
+      kp.gridDim = dim3(dlen, n_jobs, 5);   // roles: three searches, two refinements (k_me_diag)
       kp.blockDim = dim3(256);
       kp.sharedMemBytes = 0;
       kp.kernelParams = args;   // copied at node creation
