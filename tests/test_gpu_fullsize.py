@@ -161,8 +161,6 @@ def test_motion_estimation_at_config_size_every_16x16_block(ctx, oracle, w, h):
     rows, cols = h // 4, w // 4
     tiles = [(x, y, min(512, w - x), min(576, h - y)) for y in range(0, h, 576) for x in range(0, w, 512)]
     want = np.zeros((rows, cols), O.ME_STATS)
-    import os
-    oracle.r1o_set_threads(os.cpu_count() or 1)
     for t in tiles:
         O.me_oracle(oracle, po, pr, cols, rows, t, bd, lam, want)
     st = torch.zeros((rows, cols, 2), dtype=torch.int32, device="cuda")
