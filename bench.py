@@ -55,8 +55,10 @@ def parse():
                          "(r1_rdo_full_cand_batch, SURVEY 8f N4); pixel: carried through quantize / "
                          "inverse transform / cdef_dist (r1_rdo_pixel_cand_batch) -- supplementary lines")
     ap.add_argument("--qindex", type=int, default=100)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="> 1: the launches of a step (one per block size, independent of each other) "
+    ap.add_argument("--streams", type=int, default=0,
+                    help="0 (default): 1 at N = 1, 4 at N > 1 (a rank's tile makes each of the four launches "
+                         "a partial wave of workgroups: +5 %% on a tile-sized workload, same-box A/B). "
+                         "> 1: the launches of a step (one per block size, independent of each other) "
                          "go to one HIP stream per size, so that a launch fills the CUs the previous "
                          "one is draining; the steps that carry timing events stay on one stream")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
@@ -518,6 +520,8 @@ def main():
     EV_EVERY = 4
     nstep = [0]
 
+    if args.streams <= 0:
+        args.streams = 4 if world > 1 else 1
     fan = args.streams > 1
     size_streams = {s: torch.cuda.Stream() for s in W.LADDER} if fan else {}
 
@@ -643,7 +647,7 @@ def main():
                                    % (fw, fh, bd, args.k),
                        "candidates_per_step": int(sum(len(c) for c in cands.values())) if world == 1
                        else None,
-                       "tiles": world, "exchange": exch_note,
+                       "tiles": world, "exchange": exch_note, "launch_streams": args.streams,
                        "parallelism": "tile-per-gpu x%d" % world if world > 1 else "single-gpu"},
             "roofline": roof,
             "prewarm_steps": prewarm_steps,
