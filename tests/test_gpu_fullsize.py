@@ -222,3 +222,59 @@ def test_cdef_strength_search_at_config_size(ctx, oracle, fw, fh, bd):
     assert len(bad) == 0, (len(bad), bad[:4], got_err[tuple(bad[0])], want_err[tuple(bad[0])])
     assert np.array_equal(got_best, want_best)
     assert (want_best == -1).sum() == 2 and len(np.unique(want_best)) > 2
+
+
+@pytest.mark.parametrize("fw,fh,bd", CONFIGS)
+def test_post_filters_at_config_size(ctx, oracle, fw, fh, bd):
+    """N3 / a14 at the BASELINE frame sizes: the deblocking level-search tallies and the deblocking
+    filter of a whole 4:2:0 frame (random AV1 partition trees, 2160 = 33.75 superblock rows), then
+    the CDEF pass of the luma plane over the deblocked frame, against the oracle plane by plane."""
+    import torch
+    import deblock_util as D
+    from test_gpu_parity import _deblock_planes
+    rng = np.random.default_rng(fw * 3 + bd)
+    cw, ch = fw - 2, fh - 6                       # cropped a little inside the last blocks
+    blocks = D.random_blocks(rng, fw // 4, (fh + 3) // 4, 1, 1)
+    dblocks = torch.from_numpy(blocks.view(np.uint8).reshape(blocks.shape + (8,)).copy()).cuda()
+    dt = np.uint8 if bd == 8 else np.uint16
+    imgs = _deblock_planes(rng, fw, fh, bd, 1, 1, blocks)
+    state = D.make_state([22, 17, 12, 15])
+    hp = [O.plane_from_image(rec, bd, 24, 24) for rec, _ in imgs]
+    hs = [O.plane_from_image(src, bd, 24, 24) for _, src in imgs]
+    dp, ds = [dev_plane(p) for p in hp], [dev_plane(p) for p in hs]
+    want_t = np.zeros((3, 2, 65), np.int64)
+    for pli in range(3):
+        xd, yd = (0, 0) if pli == 0 else (1, 1)
+        pc, sc = hp[pli].cstruct(), hs[pli].cstruct()
+        assert oracle.r1o_deblock_sse_plane(C.byref(pc), C.byref(sc), pli, xd, yd, blocks.ctypes.data,
+                                            blocks.shape[1], blocks.shape[1], blocks.shape[0], cw, ch, bd,
+                                            want_t[pli, 0].ctypes.data, want_t[pli, 1].ctypes.data) == 0
+    got_t = ctx.deblock_sse_frame(dp, ds, 1, 1, dblocks, cw, ch)
+    assert np.array_equal(got_t.cpu().numpy(), want_t)
+    for pli in range(3):
+        xd, yd = (0, 0) if pli == 0 else (1, 1)
+        pc = hp[pli].cstruct()
+        assert oracle.r1o_deblock_plane(state.ctypes.data, C.byref(pc), pli, xd, yd, blocks.ctypes.data,
+                                        blocks.shape[1], blocks.shape[1], blocks.shape[0], cw, ch, bd) == 0
+    ctx.deblock_frame(state, dp, 1, 1, dblocks, cw, ch)
+    for pli in range(3):
+        assert np.array_equal(dp[pli].data.cpu().numpy().view(dt), hp[pli].data), pli
+    assert (hp[0].view() != imgs[0][0]).sum() > fw          # the filter did something
+    # CDEF of the deblocked luma plane, per-superblock strength indices, a third of the blocks skipped
+    from rav1e_amd.api import Plane
+    mi_rows, mi_cols = fh // 4, fw // 4
+    skip = (rng.random((mi_rows, mi_cols)) < 0.33).astype(np.uint8)
+    ci = rng.integers(0, 8, ((fh + 63) // 64, (fw + 63) // 64)).astype(np.uint8)
+    ystr = [0, 4, 9, 13, 22, 31, 43, 55]
+    out_h = O.plane_from_image(np.zeros((fh, fw), np.int64), bd, 24, 24)
+    lc, oc = hp[0].cstruct(), out_h.cstruct()
+    ys = (C.c_uint8 * 8)(*ystr)
+    oracle.r1o_cdef_filter_tile_plane(C.byref(lc), C.byref(lc), C.byref(oc), 0, 0, 0, fw, fh, skip.ctypes.data,
+                                      mi_cols, mi_cols, mi_rows, ci.ctypes.data, ci.shape[1], ys, ys, 5, bd)
+    dout = dev_plane(out_h)
+    dout.data.zero_()
+    ctx.cdef_filter_frame_plane(dp[0], dp[0], dout, 0, 0, 0, fw, fh, torch.from_numpy(skip).cuda(),
+                                torch.from_numpy(ci).cuda(), ystr, ystr, 5, bd)
+    got = dout.data.cpu().numpy().view(dt)[out_h.yorigin:out_h.yorigin + (fh // 8) * 8,
+                                           out_h.xorigin:out_h.xorigin + (fw // 8) * 8]
+    assert np.array_equal(got, out_h.view()[:(fh // 8) * 8, :(fw // 8) * 8])
