@@ -468,7 +468,11 @@ int r1_prescreen_select_batch(r1_ctx *ctx, const uint32_t *keys, int n_groups, i
  * 0.125)) as u32, me.rs:175-177 -- f64 arithmetic, evaluated by the host.
  * `jobs` is HOST memory (pointers inside are device pointers) and is consumed
  * before the call returns; the work itself is only ENQUEUED on `stream`
- * (3 x (superblock columns + rows - 1) launches). */
+ * (superblock columns + rows + 3 launches, replayed as one hipGraph; the three
+ * passes run skewed inside them).  At most 256 jobs per call (tiles x reference
+ * frames of one frame).  The context keeps one scratch MEStats frame per distinct
+ * `stats` array of a call (the refinements of a pass are computed one diagonal
+ * ahead of its searches and must stay invisible to them until then). */
 typedef struct R1MeStats {
   int16_t row, col;
   uint32_t normalized_sad;
