@@ -468,8 +468,11 @@ int r1_prescreen_select_batch(r1_ctx *ctx, const uint32_t *keys, int n_groups, i
  * 0.125)) as u32, me.rs:175-177 -- f64 arithmetic, evaluated by the host.
  * `jobs` is HOST memory (pointers inside are device pointers) and is consumed
  * before the call returns; the work itself is only ENQUEUED on `stream`
- * (superblock columns + rows + 3 launches, replayed as one hipGraph; the three
- * passes run skewed inside them).  At most 256 jobs per call (tiles x reference
+ * (launch_mode 1: superblock columns + rows + 3 launches, replayed as one
+ * hipGraph, the three passes skewed inside them; launch_mode 2: ONE persistent launch
+ * whose waves walk block rows and hand results over through progress counters --
+ * every job is pinned to one XCD so that the hand-overs stay in that XCD's L2, which
+ * needs >= 8 jobs to use the chip; launch_mode 0 takes 2 from 12 jobs on, else 1).  At most 256 jobs per call (tiles x reference
  * frames of one frame).  The context keeps one scratch MEStats frame per distinct
  * `stats` array of a call (the refinements of a pass are computed one diagonal
  * ahead of its searches and must stay invisible to them until then). */
@@ -485,7 +488,8 @@ typedef struct R1MeParams {
   int32_t allow_full_search;         /* speed_settings.motion.me_allow_full_search */
   int32_t me_range_scale;            /* fi.me_range_scale */
   uint32_t lambda[3];
-  int32_t reserved;
+  int32_t launch_mode;               /* r1_estimate_tile_motion_batch: 0 = choose (below), 1 = one
+                                      * launch per superblock diagonal, 2 = one persistent launch */
 } R1MeParams;
 typedef struct R1MeJob {
   R1Plane org[3], ref[3];

@@ -38,7 +38,7 @@ class R1MeParams(C.Structure):
     _fields_ = [("w_in_b", C.c_int32), ("h_in_b", C.c_int32), ("stats_cols", C.c_int32),
                 ("stats_rows", C.c_int32), ("bit_depth", C.c_int32), ("allow_hp", C.c_int32),
                 ("allow_full_search", C.c_int32), ("me_range_scale", C.c_int32),
-                ("lambda_", C.c_uint32 * 3), ("reserved", C.c_int32)]
+                ("lambda_", C.c_uint32 * 3), ("launch_mode", C.c_int32)]
 
 
 class R1MeJob(C.Structure):

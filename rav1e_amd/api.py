@@ -584,7 +584,7 @@ class Context:
 
     # ---- me:: ----
     def estimate_tile_motion(self, jobs, w_in_b, h_in_b, bit_depth, lambdas, allow_hp=True,
-                             allow_full_search=False, me_range_scale=1):
+                             allow_full_search=False, me_range_scale=1, launch_mode=0):
         """estimate_tile_motion (src/me.rs:153-218) for a list of independent
         (tile, reference frame) jobs.  Each job: dict(org=[Plane x3], ref=[Plane x3]
         (full, half, quarter resolution), stats=int32 tensor (rows, cols, 2) viewing the
@@ -605,7 +605,7 @@ class Context:
             arr[j].tile_x, arr[j].tile_y, arr[j].tile_w, arr[j].tile_h = job["tile"]
         p = _lib.R1MeParams(w_in_b, h_in_b, cols, rows, bit_depth, int(allow_hp),
                             int(allow_full_search), me_range_scale,
-                            (C.c_uint32 * 3)(*[int(v) for v in lambdas]), 0)
+                            (C.c_uint32 * 3)(*[int(v) for v in lambdas]), int(launch_mode))
         self._check(self.lib.r1_estimate_tile_motion_batch(self.h, arr, n, C.byref(p), _stream_ptr()),
                     "r1_estimate_tile_motion_batch")
 

@@ -44,6 +44,7 @@ extern "C" int r1_ctx_create(int device, r1_ctx **out) {
     c->me_graph[k] = nullptr;
     c->me_refine[k] = nullptr;
     c->me_refine_bytes[k] = 0;
+    c->me_persist[k] = nullptr;
   }
   c->me_next = 0;
   if (r1_scan_tables_create(c) != R1_OK || r1_me_kernel_attrs() != R1_OK) {
@@ -67,6 +68,7 @@ extern "C" void r1_ctx_destroy(r1_ctx *c) {
     }
     if (c->me_graph[k]) (void)hipGraphExecDestroy(c->me_graph[k]);
     if (c->me_refine[k]) (void)hipFree(c->me_refine[k]);
+    r1_me_persist_free(c->me_persist[k]);
     if (c->me_jobs[k]) (void)hipFree(c->me_jobs[k]);
     if (c->me_jobs_host[k]) (void)hipHostFree(c->me_jobs_host[k]);
   }

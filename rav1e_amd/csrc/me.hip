@@ -34,7 +34,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <initializer_list>
 #include <mutex>
+#include <vector>
 
 #include "common.hpp"
 #include "dist_common.hpp"
@@ -378,6 +381,7 @@ struct TileView {
   const R1MeStats *prev;
   int cols_f, rows_f;          // FrameMEStats dims
   int tx, ty, tcols, trows;    // tile origin / size, 4x4 units
+  const R1MeStats *rstats = nullptr;   // k_me_persist: the refined statistics (see there)
   __device__ __forceinline__ R1MeStats *at(int y, int x) const {
     return stats + (size_t)(ty + y) * cols_f + tx + x;
   }
@@ -401,9 +405,16 @@ constexpr int kSubsetWords = 2 * (1 + 5 + 5 + 11);
 // diagonal would write back / invalidate the XCD's L2 and made the 64-job
 // launches 3.6x slower) or by another workgroup in an earlier launch (kernel
 // boundaries make that visible)
+template <bool AGENT = false>
+__device__ __forceinline__ unsigned long long load_entry(const R1MeStats *s) {
+  if constexpr (AGENT)   // k_me_persist: written by a wave anywhere on the device, in this launch
+    return __hip_atomic_load((const unsigned long long *)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    return __hip_atomic_load((const unsigned long long *)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <bool AGENT = false>
 __device__ __forceinline__ void load_stats(const R1MeStats *s, int &row, int &col, uint32_t &nsad) {
-  const unsigned long long v = __hip_atomic_load((const unsigned long long *)s, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned long long v = load_entry<AGENT>(s);
   row = (int16_t)(v & 0xFFFF);
   col = (int16_t)((v >> 16) & 0xFFFF);
   nsad = (uint32_t)(v >> 32);
@@ -427,6 +438,7 @@ __device__ __forceinline__ void process_cand(unsigned long long v, const int *rn
 // -- an agent-scope fence per diagonal would write back / invalidate the XCD's L2 and made the
 // 64-job launches 3.6x slower) or by another workgroup in an earlier launch (kernel boundaries
 // make that visible).
+template <bool AGENT = false>
 __device__ void get_subset_predictors(const TileView &t, int bx, int by, int pix_w, int pix_h,
                                       const int *rng, int corner, int ssdec, Subsets &s) {
   uint32_t min_sad = 0xFFFFFFFFu;
@@ -461,8 +473,13 @@ __device__ void get_subset_predictors(const TileView &t, int bx, int by, int pix
   unsigned long long mine = 0;
   if (my_ok) {
     const R1MeStats *base = lane < 5 ? (const R1MeStats *)t.stats : t.prev;
-    mine = __hip_atomic_load((const unsigned long long *)(base + (size_t)my_y * t.cols_f + my_x), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_WORKGROUP);
+    if constexpr (AGENT) {
+      // k_me_persist: the centre, and the right / bottom samples inside this block's own superblock,
+      // are the REFINED vectors of the previous pass (second buffer); everything else the live array
+      const bool same_sb = ((my_x - t.tx) >> 4) == (bx >> 4) && ((my_y - t.ty) >> 4) == (by >> 4);
+      if (lane == 4 || ((lane == 2 || lane == 3) && same_sb)) base = t.rstats;
+    }
+    mine = load_entry<AGENT && true>(base + (size_t)my_y * t.cols_f + my_x);
   }
   auto entry = [&](int k) -> unsigned long long {
     return ((unsigned long long)(uint32_t)__shfl((int)(mine >> 32), k, 64) << 32) |
@@ -515,7 +532,7 @@ __device__ void try_cands(const B &b, const int16_t *list, int n, Msr &best) {
   if (r.cost < best.cost) best = r;
 }
 
-template <class B>
+template <class B, bool AGENT = false>
 __device__ Msr full_pixel_me(const B &b, const TileView &t, const R1MeParams &p, int bx, int by,
                              const int *rng, int corner, bool extensive, int ssdec,
                              int16_t *lds) {
@@ -524,7 +541,7 @@ __device__ Msr full_pixel_me(const B &b, const TileView &t, const R1MeParams &p,
   s.b = lds + 2;
   s.c = lds + 12;
   s.all = lds + 22;
-  get_subset_predictors(t, bx, by, b.w, b.h, rng, corner, ssdec, s);
+  get_subset_predictors<AGENT>(t, bx, by, b.w, b.h, rng, corner, ssdec, s);
   Msr best = msr_empty();
   if (!extensive) {
     try_cands(b, s.all, s.has_median + s.nb + s.nc, best);
@@ -580,6 +597,7 @@ __device__ __forceinline__ void setup_block(B &b, const R1MeJob &job, const R1Me
 }
 
 // save_me_stats (me.rs:324-337) with the normalisation of me.rs:268-270
+template <bool AGENT = false>
 __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, int bx, int by,
                                              const Msr &r, int w, int h, int ssdec, int lane) {
   const uint32_t nsad = (uint32_t)((((unsigned long long)r.sad) << 14) / (unsigned long long)(w * h));
@@ -588,7 +606,15 @@ __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, i
   v.row = (int16_t)(r.row << ssdec);
   v.col = (int16_t)(r.col << ssdec);
   v.normalized_sad = nsad;
-  for (int i = lane; i < nx * ny; i += 64) *t.at(by + i / nx, bx + i % nx) = v;
+  if constexpr (AGENT) {
+    const unsigned long long bits = ((unsigned long long)v.normalized_sad << 32) |
+                                    ((unsigned long long)(uint16_t)v.col << 16) | (uint16_t)v.row;
+    // plain stores: the line stays in THIS XCD's L2, where the job's other waves (all on this
+    // XCD, see k_me_persist) read it with L1-bypassing loads
+    for (int i = lane; i < nx * ny; i += 64) *(unsigned long long *)t.at(by + i / nx, bx + i % nx) = bits;
+  } else {
+    for (int i = lane; i < nx * ny; i += 64) *t.at(by + i / nx, bx + i % nx) = v;
+  }
 }
 
 // One pass (log2b = 4, 3, 2 <-> ssdec 2, 1, 0) over the superblocks of one
@@ -718,6 +744,177 @@ __global__ __launch_bounds__(256, R1_ME_DIAG_WAVES) void k_me_diag(const R1MeJob
     atomicAdd(&g_me_prof[pass][3], prof_t1 - prof_t0);
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// k_me_persist: the same three passes as ONE launch whose waves hand results over through
+// progress counters in memory instead of kernel boundaries (R1MeParams::launch_mode 2).  A wave WALKS A
+// ROW: the blocks of one block row of one pass (or the refinements of one row of the previous
+// pass' blocks) from left to right.  The left neighbour is then the wave's own previous block;
+// the only same-pass hand-over is the row above, which runs one block ahead -- in the steady
+// state its result is already there when it is asked for, so the chain is rows + columns block
+// steps (127 for a 960 x 1088 tile at 16 x 16) instead of 7 x 31 superblock-diagonal steps.
+// Rows are taken from one atomic counter in an order in which everything a row waits for comes
+// earlier (key = bottom edge of the row in 16-pixel cells + a per-pass offset): a wave only waits
+// for rows that are already running, so there is no deadlock whatever the residency.
+//   a search block (pass q) waits for: the row above having passed it; q > 0: the refinement of
+//   its own parent block and of the parents of its right / bottom sample positions when those lie
+//   in its own superblock (read refined), their pass q - 1 SEARCH when they lie in the next
+//   superblock (read unrefined, from the live array).  A refinement waits for the pass q - 1
+//   search of its block.
+// Statistics are read and written with agent-scope atomics (the waves sit on different XCDs);
+// refined vectors live in the second buffer and are never copied: the samples pick their buffer.
+struct MeRow { uint16_t job; uint8_t kind, pad; uint16_t gy, nb; };   // kind 0..2 search, 3 / 4 refine for pass 1 / 2
+struct MePersistArgs {
+  const R1MeJob *jobs;
+  const R1MeParams *params;
+  R1MeStats *const *rbufs;
+  const MeRow *rows;            // sorted per XCD: rows of the jobs with job % 8 == xcd, in key order
+  int n_rows;
+  int xoff[9];                  // rows of XCD x: [xoff[x], xoff[x + 1])
+  unsigned int *counter;        // [8]: next row of each XCD
+  unsigned int *prog;           // per row: epoch << 16 | blocks done
+  const unsigned int *foff;     // [job][5]: offset of the job's progress array of each kind
+  unsigned int epoch;           // 1 .. 65535
+  unsigned int *err;            // set when a wait ran out of patience
+  int spin;                     // polls before a wait gives up
+};
+
+__device__ __forceinline__ bool me_wait(const unsigned int *f, unsigned int epoch, unsigned int need, int spin) {
+  for (int it = 0; it < spin; it++) {
+    const unsigned int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((v >> 16) == epoch && (v & 0xFFFFu) >= need) return true;
+    if (it > 64) __builtin_amdgcn_s_sleep(8);
+    else if (it > 4) __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
+// up to four progress counters polled by four lanes in ONE load per round (a wait is a memory
+// round trip even when the counter is already there): lane k < n polls f[k] for need[k]
+__device__ __forceinline__ bool me_wait4(const unsigned int *const *f, const unsigned int *need, int n,
+                                         unsigned int epoch, int spin, int lane) {
+  const unsigned int *mf = nullptr;
+  unsigned int mn = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (lane == k && k < n) { mf = f[k]; mn = need[k]; }
+  for (int it = 0; it < spin; it++) {
+    bool done = true;
+    if (mf) {
+      const unsigned int v = __hip_atomic_load(mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      done = (v >> 16) == epoch && (v & 0xFFFFu) >= mn;
+    }
+    if (__all(done)) return true;
+    if (it > 64) __builtin_amdgcn_s_sleep(8);
+    else if (it > 4) __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
+template <int BPP>
+__global__ __launch_bounds__(64, 5) void k_me_persist(MePersistArgs a) {
+  __shared__ int16_t sh_subsets[kSubsetWords];
+  __shared__ unsigned int sh_item;
+  const R1MeParams p = *a.params;
+  const int lane = threadIdx.x;
+  // every wave of a job sits on ONE XCD (the job's rows are handed out only to waves that find
+  // themselves there), so a hand-over never leaves that XCD's L2
+  const int xcd = __builtin_amdgcn_s_getreg(6164) & 7;         // hwreg(HW_REG_XCC_ID, 0, 4)
+  for (;;) {
+    if (lane == 0) sh_item = atomicAdd(a.counter + xcd, 1u);
+    __syncthreads();
+    const unsigned int ii = sh_item + (unsigned int)a.xoff[xcd];
+    __syncthreads();
+    if (ii >= (unsigned int)a.xoff[xcd + 1]) return;
+    const MeRow row = a.rows[ii];
+    const R1MeJob &job = a.jobs[row.job];
+    const unsigned int *fo = a.foff + 5 * row.job;
+    const bool refine = row.kind >= 3;
+    const int pass = refine ? row.kind - 2 : row.kind;         // the pass the row belongs to
+    const int log2b = 4 - pass, ssdec = log2b - 2;
+    const bool init = log2b == 4;
+    TileView t{job.stats, job.prev, p.stats_cols, p.stats_rows, job.tile_x / MI, job.tile_y / MI,
+               job.tile_w / MI, job.tile_h / MI};
+    t.rstats = a.rbufs[row.job];
+    unsigned int *mine = a.prog + fo[row.kind] + row.gy;
+    bool ok = true;
+    for (int gx = 0; gx < row.nb; gx++) {
+      if (refine) {
+        // refine_subsampled_motion_estimate of block (gx, gy) of pass `pass - 1`
+        const int sz = MI << (log2b + 1);
+        const int x = gx * sz, y = row.gy * sz;                // tile px
+        const int sbx = x / SB, sby = y / SB;
+        const int sb_w = imin(SB, job.tile_w - sbx * SB), sb_h = imin(SB, job.tile_h - sby * SB);
+        const int xin = x - sbx * SB, yin = y - sby * SB;
+        const int bx = x / MI, by = y / MI;
+        const int w = imin(sz, sb_w - xin + (1 << ssdec) - 1) >> ssdec;
+        const int h = imin(sz, sb_h - yin + (1 << ssdec) - 1) >> ssdec;
+        Block<BPP, 32> b;
+        int rng[4];
+        setup_block(b, job, p, t, bx, by, w, h, ssdec, lane, rng);
+        if (lane == 0) ok = me_wait(a.prog + fo[pass - 1] + row.gy, a.epoch, gx + 1, a.spin) && ok;
+        ok = __shfl((int)ok, 0, 64) != 0;
+        int mvr, mvc;
+        uint32_t ns;
+        load_stats<true>(t.at(by, bx), mvr, mvc, ns);
+        mvr >>= ssdec;
+        mvc >>= ssdec;
+        const Msr r = full_search(b, b.po_x + imax(div8(mvc) - 1, div8(b.mvx_min)),
+                                  b.po_x + imin(div8(mvc) + 2, div8(b.mvx_max)),
+                                  b.po_y + imax(div8(mvr) - 1, div8(b.mvy_min)),
+                                  b.po_y + imin(div8(mvr) + 2, div8(b.mvy_max)), 1);
+        TileView tr = t;
+        tr.stats = (R1MeStats *)t.rstats;
+        store_result<true>(tr, 1 << (log2b + 1), bx, by, r, w, h, ssdec, lane);
+      } else {
+        const int sz = MI << log2b;
+        const int x = gx * sz, y = row.gy * sz;
+        const int sbx = x / SB, sby = y / SB;
+        const int sb_w = imin(SB, job.tile_w - sbx * SB), sb_h = imin(SB, job.tile_h - sby * SB);
+        const int xin = x - sbx * SB, yin = y - sby * SB;
+        const int bx = x / MI, by = y / MI;
+        const int w = imin(sz, sb_w - xin + (1 << ssdec) - 1) >> ssdec;
+        const int h = imin(sz, sb_h - yin + (1 << ssdec) - 1) >> ssdec;
+        // everything that does not depend on the neighbours first: source rows, masks, MV range
+        Block<BPP, 16> b;
+        int rng[4];
+        setup_block(b, job, p, t, bx, by, w, h, ssdec, lane, rng);
+        {
+          const unsigned int *wf[4];
+          unsigned int wn[4];
+          int nw = 0;
+          if (row.gy > 0) { wf[nw] = a.prog + fo[pass] + row.gy - 1; wn[nw++] = gx + 1; }
+          if (!init) {
+            const int psz = sz * 2;                            // the parents' size, px
+            wf[nw] = a.prog + fo[2 + pass] + y / psz; wn[nw++] = x / psz + 1;   // own parent refined
+            // get_subset_predictors' right / bottom sample positions (me.rs:420-452), tile px
+            const int wu = ((w << ssdec) + MI - 1) >> 2, hu = ((h << ssdec) + MI - 1) >> 2;   // 4x4 units
+            const int half_w = imin(wu >> 1, t.tcols - 1 - bx), half_h = imin(hu >> 1, t.trows - 1 - by);
+            if (bx + wu < t.tcols) {
+              const int px = (bx + wu) * MI, py = (by + half_h) * MI;
+              const bool same = px / SB == sbx && py / SB == sby;
+              wf[nw] = a.prog + fo[same ? 2 + pass : pass - 1] + py / psz; wn[nw++] = px / psz + 1;
+            }
+            if (by + hu < t.trows) {
+              const int px = (bx + half_w) * MI, py = (by + hu) * MI;
+              const bool same = px / SB == sbx && py / SB == sby;
+              wf[nw] = a.prog + fo[same ? 2 + pass : pass - 1] + py / psz; wn[nw++] = px / psz + 1;
+            }
+          }
+          if (nw) ok = me_wait4(wf, wn, nw, a.epoch, a.spin, lane) && ok;
+        }
+        const int corner = init ? 0 : (1 | ((xin & sz) ? 2 : 0) | ((yin & sz) ? 4 : 0));
+        const Msr r = full_pixel_me<Block<BPP, 16>, true>(b, t, p, bx, by, rng, corner, init, ssdec, sh_subsets);
+        store_result<true>(t, 1 << log2b, bx, by, r, w, h, ssdec, lane);
+      }
+      // publish: the statistics first (agent-scope stores, acknowledged), then the progress
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0)
+        __hip_atomic_store(mine, (a.epoch << 16) | (unsigned int)(gx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (lane == 0 && !ok) atomicOr(a.err, 1u);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1122,6 +1319,118 @@ extern "C" int r1_debug_me_prof(unsigned long long *out, int reset) {   /* out[3
 }
 #endif
 
+// ---- k_me_persist, host side: the item list of a call's geometry (cached per ring slot), the
+// flag arrays, one launch ----
+namespace {
+struct MePersistCache {
+  std::vector<int> geo;            // signature: per job tile_w, tile_h
+  void *rows = nullptr;            // device: MeRow[n_rows]
+  void *foff = nullptr;            // device: uint32[n_jobs][5]
+  void *prog = nullptr;            // device: uint32 per row (epoch << 16 | blocks done)
+  void *ctl = nullptr;             // device: counter, err
+  int n_rows = 0;
+  int xoff[9] = {0};
+  unsigned int epoch = 0;
+  bool launched = false;
+};
+
+// ordering key of a row, in half units of 16-pixel cells: its bottom edge plus a per-pass offset
+// chosen so that every row a row waits for has a smaller key
+inline int me_row_key(int kind, int gy) {
+  static const int c2[3] = {0, 18, 32};
+  const int q = kind >= 3 ? kind - 3 : kind, s = 4 >> q;
+  return 2 * (gy * s + s - 1) + c2[q] + (kind >= 3 ? 1 : 0);
+}
+
+int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs, int bpp, const R1MeJob *djobs,
+                         const R1MeParams *dparams, R1MeStats *const *drbufs, size_t upload_bytes,
+                         hipStream_t st) {
+  if (!ctx->me_persist[slot]) ctx->me_persist[slot] = new MePersistCache();
+  MePersistCache &c = *(MePersistCache *)ctx->me_persist[slot];
+  // a dependency wait of the previous call on this slot that ran out of patience (the slot's event
+  // has been waited for): the results of that call are not to be trusted
+  if (c.ctl && c.launched) {
+    unsigned int e = 0;
+    R1_HIP_CHECK(hipMemcpy(&e, (unsigned int *)c.ctl + 8, sizeof(e), hipMemcpyDeviceToHost));
+    c.launched = false;
+    if (e) { r1_set_error("k_me_persist: a dependency wait of the previous call timed out"); return R1_EHIP; }
+  }
+  std::vector<int> geo;
+  for (int j = 0; j < n_jobs; j++) { geo.push_back(jobs[j].tile_w); geo.push_back(jobs[j].tile_h); }
+  if (geo != c.geo || c.epoch >= 65535) {
+    for (void **pp : {&c.rows, &c.foff, &c.prog, &c.ctl})
+      if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+    std::vector<MeRow> rows;
+    std::vector<unsigned int> foff((size_t)n_jobs * 5);
+    unsigned int nprog = 0;
+    for (int j = 0; j < n_jobs; j++) {
+      for (int kind = 0; kind < 5; kind++) {
+        const int q = kind >= 3 ? kind - 3 : kind;
+        const int nbx = (jobs[j].tile_w + (SB >> q) - 1) / (SB >> q), nby = (jobs[j].tile_h + (SB >> q) - 1) / (SB >> q);
+        foff[(size_t)j * 5 + kind] = nprog;
+        nprog += (unsigned int)nby;
+        for (int gy = 0; gy < nby; gy++)
+          rows.push_back(MeRow{(uint16_t)j, (uint8_t)kind, 0, (uint16_t)gy, (uint16_t)nbx});
+      }
+    }
+    std::stable_sort(rows.begin(), rows.end(), [](const MeRow &a, const MeRow &b) {
+      const int xa = a.job & 7, xb = b.job & 7;
+      if (xa != xb) return xa < xb;
+      return me_row_key(a.kind, a.gy) < me_row_key(b.kind, b.gy);
+    });
+    for (int x = 0; x <= 8; x++) c.xoff[x] = 0;
+    for (const MeRow &r : rows) c.xoff[(r.job & 7) + 1]++;
+    for (int x = 0; x < 8; x++) c.xoff[x + 1] += c.xoff[x];
+    R1_HIP_CHECK(hipMalloc(&c.rows, rows.size() * sizeof(MeRow)));
+    R1_HIP_CHECK(hipMalloc(&c.foff, foff.size() * sizeof(unsigned int)));
+    R1_HIP_CHECK(hipMalloc(&c.prog, (size_t)nprog * sizeof(unsigned int)));
+    R1_HIP_CHECK(hipMalloc(&c.ctl, 9 * sizeof(unsigned int)));
+    R1_HIP_CHECK(hipMemcpy(c.rows, rows.data(), rows.size() * sizeof(MeRow), hipMemcpyHostToDevice));
+    R1_HIP_CHECK(hipMemcpy(c.foff, foff.data(), foff.size() * sizeof(unsigned int), hipMemcpyHostToDevice));
+    R1_HIP_CHECK(hipMemset(c.prog, 0, (size_t)nprog * sizeof(unsigned int)));
+    c.n_rows = (int)rows.size();
+    c.epoch = 0;
+    c.geo = geo;
+  }
+  c.epoch++;
+  R1_HIP_CHECK(hipMemcpyAsync(ctx->me_jobs[slot], ctx->me_jobs_host[slot], upload_bytes, hipMemcpyHostToDevice, st));
+  R1_HIP_CHECK(hipMemsetAsync(c.ctl, 0, 9 * sizeof(unsigned int), st));
+  MePersistArgs a;
+  a.jobs = djobs; a.params = dparams; a.rbufs = drbufs;
+  a.rows = (const MeRow *)c.rows; a.n_rows = c.n_rows;
+  a.counter = (unsigned int *)c.ctl; a.err = (unsigned int *)c.ctl + 8;
+  for (int x = 0; x <= 8; x++) a.xoff[x] = c.xoff[x];
+  a.prog = (unsigned int *)c.prog; a.foff = (const unsigned int *)c.foff;
+  a.epoch = c.epoch;
+  a.spin = getenv("R1_ME_PERSISTENT_SPIN") ? atoi(getenv("R1_ME_PERSISTENT_SPIN")) : (1 << 18);
+  const int gmax = getenv("R1_ME_PERSISTENT_GRID") ? atoi(getenv("R1_ME_PERSISTENT_GRID")) : 4096;
+  const int grid = c.n_rows < gmax ? c.n_rows : gmax;
+  if (getenv("R1_ME_PERSISTENT_DEBUG")) fprintf(stderr, "k_me_persist: %d rows, grid %d, epoch %u\n", c.n_rows, grid, a.epoch);
+  if (bpp == 1) hipLaunchKernelGGL(k_me_persist<1>, dim3(grid), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(k_me_persist<2>, dim3(grid), dim3(64), 0, st, a);
+  R1_HIP_CHECK(hipGetLastError());
+  R1_HIP_CHECK(hipEventRecord(ctx->me_done[slot], st));
+  c.launched = true;
+  if (getenv("R1_ME_PERSISTENT_CHECK")) {
+    unsigned int ctl[9] = {0};
+    R1_HIP_CHECK(hipStreamSynchronize(st));
+    R1_HIP_CHECK(hipMemcpy(ctl, c.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+    if (getenv("R1_ME_PERSISTENT_DEBUG")) fprintf(stderr, "k_me_persist: rows %d, counter %u.., err %u\n", c.n_rows, ctl[0], ctl[8]);
+    c.launched = false;
+    if (ctl[8]) { r1_set_error("k_me_persist: a dependency wait timed out"); return R1_EHIP; }
+  }
+  return R1_OK;
+}
+}  // namespace
+
+void r1_me_persist_free(void *cache) {
+  MePersistCache *c = (MePersistCache *)cache;
+  if (!c) return;
+  for (void *p : {c->rows, c->foff, c->prog, c->ctl})
+    if (p) (void)hipFree(p);
+  delete c;
+}
+
 extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, int n_jobs,
                                              const R1MeParams *params, void *stream) {
   R1_REQUIRE(ctx && params);
@@ -1200,6 +1509,13 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   const R1MeJob *djobs = (const R1MeJob *)ctx->me_jobs[slot];
   const R1MeParams *dparams = (const R1MeParams *)((const uint8_t *)ctx->me_jobs[slot] + jobs_bytes);
   R1MeStats *const *drbufs = (R1MeStats *const *)((const uint8_t *)ctx->me_jobs[slot] + jobs_bytes + params_bytes);
+  // one persistent launch (k_me_persist) or one launch per superblock diagonal (k_me_diag): the
+  // persistent path pins every job to one XCD, so it wants at least a job per XCD and a half
+  // (measured: slower below ~8 jobs, -12 ... -19 % at 24, equal at 64)
+  static const char *force = getenv("R1_ME_PERSISTENT");   // "1" / "0": A/B switch for tools/bench_me.py
+  const int mode = params->launch_mode ? params->launch_mode : (force ? (force[0] == '1' ? 2 : 1) : (n_jobs >= 12 ? 2 : 1));
+  R1_REQUIRE(mode == 1 || mode == 2);
+  if (mode == 2) return me_launch_persistent(ctx, slot, jobs, n_jobs, bpp, djobs, dparams, drbufs, bytes, st);
   const int ndiag = max_sbw + max_sbh - 1;
   const int dlen = max_sbw < max_sbh ? max_sbw : max_sbh;
   // software pipeline over the passes: launch `step` runs diagonal step - 2 q of pass q
