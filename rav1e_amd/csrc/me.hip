@@ -579,7 +579,7 @@ __device__ __forceinline__ void mv_range(const R1MeParams &p, int fbx, int fby, 
 }
 
 template <class B>
-__device__ __forceinline__ void setup_block(B &b, const R1MeJob &job, const R1MeParams &p,
+__device__ __forceinline__ void setup_block(B &b, const R1Plane &org, const R1Plane &ref, const R1MeParams &p,
                                             const TileView &t, int bx, int by, int w, int h,
                                             int ssdec, int lane, int *rng) {
   const int fbx = t.tx + bx, fby = t.ty + by;
@@ -593,7 +593,14 @@ __device__ __forceinline__ void setup_block(B &b, const R1MeJob &job, const R1Me
   b.mc.allow_hp = p.allow_hp;
   // estimate_motion with pmv = None / refine_subsampled_motion_estimate: pmv = [0, 0]
   b.mc.pmv_row[0] = b.mc.pmv_row[1] = b.mc.pmv_col[0] = b.mc.pmv_col[1] = 0;
-  b.init(job.org[ssdec], job.ref[ssdec], lane);
+  b.init(org, ref, lane);
+}
+
+template <class B>
+__device__ __forceinline__ void setup_block(B &b, const R1MeJob &job, const R1MeParams &p,
+                                            const TileView &t, int bx, int by, int w, int h,
+                                            int ssdec, int lane, int *rng) {
+  setup_block(b, job.org[ssdec], job.ref[ssdec], p, t, bx, by, w, h, ssdec, lane, rng);
 }
 
 // save_me_stats (me.rs:324-337) with the normalisation of me.rs:268-270
@@ -813,7 +820,7 @@ __device__ __forceinline__ bool me_wait4(const unsigned int *const *f, const uns
 }
 
 template <int BPP>
-__global__ __launch_bounds__(64, 5) void k_me_persist(MePersistArgs a) {
+__global__ __launch_bounds__(64, 4) void k_me_persist(MePersistArgs a) {
   __shared__ int16_t sh_subsets[kSubsetWords];
   __shared__ unsigned int sh_item;
   const R1MeParams p = *a.params;
@@ -824,16 +831,21 @@ __global__ __launch_bounds__(64, 5) void k_me_persist(MePersistArgs a) {
   for (;;) {
     if (lane == 0) sh_item = atomicAdd(a.counter + xcd, 1u);
     __syncthreads();
-    const unsigned int ii = sh_item + (unsigned int)a.xoff[xcd];
+    const unsigned int ii = __builtin_amdgcn_readfirstlane(sh_item) + (unsigned int)a.xoff[xcd];
     __syncthreads();
     if (ii >= (unsigned int)a.xoff[xcd + 1]) return;
     const MeRow row = a.rows[ii];
-    const R1MeJob &job = a.jobs[row.job];
+    // the row's view of its job BY VALUE (scalar registers): nothing of it is re-read per block
+    // behind the stores and atomics of the loop
+    const R1MeJob &gjob = a.jobs[row.job];
+    struct { R1MeStats *stats; const R1MeStats *prev; int tile_x, tile_y, tile_w, tile_h; } job =
+        {gjob.stats, gjob.prev, gjob.tile_x, gjob.tile_y, gjob.tile_w, gjob.tile_h};
     const unsigned int *fo = a.foff + 5 * row.job;
     const bool refine = row.kind >= 3;
     const int pass = refine ? row.kind - 2 : row.kind;         // the pass the row belongs to
     const int log2b = 4 - pass, ssdec = log2b - 2;
     const bool init = log2b == 4;
+    const R1Plane org = gjob.org[ssdec], ref = gjob.ref[ssdec];
     TileView t{job.stats, job.prev, p.stats_cols, p.stats_rows, job.tile_x / MI, job.tile_y / MI,
                job.tile_w / MI, job.tile_h / MI};
     t.rstats = a.rbufs[row.job];
@@ -852,7 +864,7 @@ __global__ __launch_bounds__(64, 5) void k_me_persist(MePersistArgs a) {
         const int h = imin(sz, sb_h - yin + (1 << ssdec) - 1) >> ssdec;
         Block<BPP, 32> b;
         int rng[4];
-        setup_block(b, job, p, t, bx, by, w, h, ssdec, lane, rng);
+        setup_block(b, org, ref, p, t, bx, by, w, h, ssdec, lane, rng);
         if (lane == 0) ok = me_wait(a.prog + fo[pass - 1] + row.gy, a.epoch, gx + 1, a.spin) && ok;
         ok = __shfl((int)ok, 0, 64) != 0;
         int mvr, mvc;
@@ -879,7 +891,7 @@ __global__ __launch_bounds__(64, 5) void k_me_persist(MePersistArgs a) {
         // everything that does not depend on the neighbours first: source rows, masks, MV range
         Block<BPP, 16> b;
         int rng[4];
-        setup_block(b, job, p, t, bx, by, w, h, ssdec, lane, rng);
+        setup_block(b, org, ref, p, t, bx, by, w, h, ssdec, lane, rng);
         {
           const unsigned int *wf[4];
           unsigned int wn[4];
