@@ -1354,6 +1354,28 @@ inline int me_row_key(int kind, int gy) {
   return 2 * (gy * s + s - 1) + c2[q] + (kind >= 3 ? 1 : 0);
 }
 
+// k_me_persist hands a job's rows out to the waves of ONE XCD (job % 8), which is only right on
+// a device whose launches spread over all eight: probed once per context.
+__global__ void k_me_xcd_probe(unsigned int *mask) {
+  if (threadIdx.x == 0) atomicOr(mask, 1u << (__builtin_amdgcn_s_getreg(6164) & 15));
+}
+
+int me_probe_xcds(r1_ctx *ctx, hipStream_t st) {
+  unsigned int *d = nullptr, h = 0;
+  R1_HIP_CHECK(hipMalloc(&d, sizeof(h)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(h), st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_me_xcd_probe, dim3(1024), dim3(64), 0, st, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  R1_HIP_CHECK(e);
+  ctx->me_xcds = h == 0xFFu ? 8 : 0;      // anything but exactly XCD 0..7: no persistent launches
+  return R1_OK;
+}
+
 int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs, int bpp, const R1MeJob *djobs,
                          const R1MeParams *dparams, R1MeStats *const *drbufs, size_t upload_bytes,
                          hipStream_t st) {
@@ -1525,8 +1547,18 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   // persistent path pins every job to one XCD, so it wants at least a job per XCD and a half
   // (measured: slower below ~8 jobs, -12 ... -19 % at 24, equal at 64)
   static const char *force = getenv("R1_ME_PERSISTENT");   // "1" / "0": A/B switch for tools/bench_me.py
-  const int mode = params->launch_mode ? params->launch_mode : (force ? (force[0] == '1' ? 2 : 1) : (n_jobs >= 12 ? 2 : 1));
+  int mode = params->launch_mode ? params->launch_mode : (force ? (force[0] == '1' ? 2 : 1) : (n_jobs >= 12 ? 2 : 1));
   R1_REQUIRE(mode == 1 || mode == 2);
+  if (mode == 2) {
+    if (ctx->me_xcds < 0) { const int rc = me_probe_xcds(ctx, st); if (rc != R1_OK) return rc; }
+    if (ctx->me_xcds != 8) {
+      if (params->launch_mode == 2) {
+        r1_set_error("r1_estimate_tile_motion_batch: launch_mode 2 needs a device whose launches spread over 8 XCDs");
+        return R1_EINVAL;
+      }
+      mode = 1;
+    }
+  }
   if (mode == 2) return me_launch_persistent(ctx, slot, jobs, n_jobs, bpp, djobs, dparams, drbufs, bytes, st);
   const int ndiag = max_sbw + max_sbh - 1;
   const int dlen = max_sbw < max_sbh ? max_sbw : max_sbh;
