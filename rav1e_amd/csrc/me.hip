@@ -1437,7 +1437,12 @@ int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs,
   a.prog = (unsigned int *)c.prog; a.foff = (const unsigned int *)c.foff;
   a.epoch = c.epoch;
   a.spin = getenv("R1_ME_PERSISTENT_SPIN") ? atoi(getenv("R1_ME_PERSISTENT_SPIN")) : (1 << 18);
-  const int gmax = getenv("R1_ME_PERSISTENT_GRID") ? atoi(getenv("R1_ME_PERSISTENT_GRID")) : 4096;
+  // TWO waves per SIMD (256 CUs x 4 SIMDs x 2), not as many as fit: a searching wave wants a VALU
+  // instruction every ~8 cycles at 2.6-4.4 issue cycles each, so a third and fourth wave on a SIMD
+  // stretch every block step of a chain that has no slack (measured, 24 jobs: grid 4096 1.73 ms,
+  // 3072 1.60, 2048 1.50, 1536 1.54, 1024 1.9).  Rows beyond the grid are taken by
+  // the waves that finish theirs, in key order.
+  const int gmax = getenv("R1_ME_PERSISTENT_GRID") ? atoi(getenv("R1_ME_PERSISTENT_GRID")) : 2048;
   const int grid = c.n_rows < gmax ? c.n_rows : gmax;
   if (getenv("R1_ME_PERSISTENT_DEBUG")) fprintf(stderr, "k_me_persist: %d rows, grid %d, epoch %u\n", c.n_rows, grid, a.epoch);
   if (bpp == 1) hipLaunchKernelGGL(k_me_persist<1>, dim3(grid), dim3(64), 0, st, a);
