@@ -472,10 +472,10 @@ int r1_prescreen_select_batch(r1_ctx *ctx, const uint32_t *keys, int n_groups, i
  * hipGraph, the three passes skewed inside them; launch_mode 2: ONE persistent launch
  * whose waves walk block rows and hand results over through progress counters --
  * every job is pinned to one XCD so that the hand-overs stay in that XCD's L2, which
- * needs >= 8 jobs to use the chip and a device whose launches spread over 8 XCDs
+ * needs >= 8 jobs to use the chip (two waves per SIMD, 128 registers and more each) and a device whose launches spread over 8 XCDs
  * (probed once per context; forcing mode 2 elsewhere is R1_EINVAL, a dependency wait
  * that runs out of patience is reported as R1_EHIP by the next call on the ring slot);
- * launch_mode 0 takes 2 from 12 jobs on, else 1).  At most 256 jobs per call (tiles x
+ * launch_mode 0 takes 2 from 8 jobs on, else 1).  At most 256 jobs per call (tiles x
  * reference frames of one frame).  The context keeps one scratch MEStats frame per distinct
  * `stats` array of a call (the refinements of a pass are computed one diagonal
  * ahead of its searches and must stay invisible to them until then). */

@@ -78,7 +78,10 @@ struct MvCost {
 
 // One block of one wave.  RH = rows per candidate slot (16 or 32): the block
 // is at most RH x RH; 64 / RH candidates are evaluated per step.
-template <int BPP, int RH>
+// KM: candidate batches in flight per search step; 0 = by register budget (three while a batch is
+// <= 4 registers, else two: k_me_diag lives on 96 registers); k_me_persist, at two waves per SIMD,
+// affords three always (five: equal, eight: slower -- profiles/r02_me_persistent_experiment.md)
+template <int BPP, int RH, int KM = 0>
 struct Block {
   static constexpr int NCS = 64 / RH, GR = RH / 4, WPG = BPP;   // dwords per 4-px granule
   const uint8_t *ref0;   // (po.x, po.y) of the reference plane
@@ -227,7 +230,7 @@ struct Block {
   // batches in flight: GR * WPG registers each.  Measured (profiles/r02_me_batch_ab.log): three for
   // 16-row slots of 8-bit pixels (4 registers a batch); two everywhere else -- a third batch of 8 or 16
   // registers spills and made the 10-bit search 18 % slower than two
-  static constexpr int KMAX = (GR * WPG <= 4) ? 3 : 2;
+  static constexpr int KMAX = KM ? KM : ((GR * WPG <= 4) ? 3 : 2);
   template <class Gen>
   __device__ __forceinline__ void scan(int n, Gen gen, bool check, Msr &best, int *best_idx) const {
     int base = 0;
@@ -820,7 +823,7 @@ __device__ __forceinline__ bool me_wait4(const unsigned int *const *f, const uns
 }
 
 template <int BPP>
-__global__ __launch_bounds__(64, 4) void k_me_persist(MePersistArgs a) {
+__global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
   __shared__ int16_t sh_subsets[kSubsetWords];
   __shared__ unsigned int sh_item;
   const R1MeParams p = *a.params;
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(64, 4) void k_me_persist(MePersistArgs a) {
         const int bx = x / MI, by = y / MI;
         const int w = imin(sz, sb_w - xin + (1 << ssdec) - 1) >> ssdec;
         const int h = imin(sz, sb_h - yin + (1 << ssdec) - 1) >> ssdec;
-        Block<BPP, 32> b;
+        Block<BPP, 32, 3> b;
         int rng[4];
         setup_block(b, org, ref, p, t, bx, by, w, h, ssdec, lane, rng);
         if (lane == 0) ok = me_wait(a.prog + fo[pass - 1] + row.gy, a.epoch, gx + 1, a.spin) && ok;
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(64, 4) void k_me_persist(MePersistArgs a) {
         const int w = imin(sz, sb_w - xin + (1 << ssdec) - 1) >> ssdec;
         const int h = imin(sz, sb_h - yin + (1 << ssdec) - 1) >> ssdec;
         // everything that does not depend on the neighbours first: source rows, masks, MV range
-        Block<BPP, 16> b;
+        Block<BPP, 16, 3> b;
         int rng[4];
         setup_block(b, org, ref, p, t, bx, by, w, h, ssdec, lane, rng);
         {
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(64, 4) void k_me_persist(MePersistArgs a) {
           if (nw) ok = me_wait4(wf, wn, nw, a.epoch, a.spin, lane) && ok;
         }
         const int corner = init ? 0 : (1 | ((xin & sz) ? 2 : 0) | ((yin & sz) ? 4 : 0));
-        const Msr r = full_pixel_me<Block<BPP, 16>, true>(b, t, p, bx, by, rng, corner, init, ssdec, sh_subsets);
+        const Msr r = full_pixel_me<Block<BPP, 16, 3>, true>(b, t, p, bx, by, rng, corner, init, ssdec, sh_subsets);
         store_result<true>(t, 1 << log2b, bx, by, r, w, h, ssdec, lane);
       }
       // publish: the statistics first (agent-scope stores, acknowledged), then the progress
@@ -1440,7 +1443,7 @@ int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs,
   // TWO waves per SIMD (256 CUs x 4 SIMDs x 2), not as many as fit: a searching wave wants a VALU
   // instruction every ~8 cycles at 2.6-4.4 issue cycles each, so a third and fourth wave on a SIMD
   // stretch every block step of a chain that has no slack (measured, 24 jobs: grid 4096 1.73 ms,
-  // 3072 1.60, 2048 1.50, 1536 1.54, 1024 1.9).  Rows beyond the grid are taken by
+  // 3072 1.60, 2048 1.50, 1536 1.54; 10-bit 2.08 / 1.96 / 1.89 / 2.03, 1024: 2.11).  Rows beyond the grid are taken by
   // the waves that finish theirs, in key order.
   const int gmax = getenv("R1_ME_PERSISTENT_GRID") ? atoi(getenv("R1_ME_PERSISTENT_GRID")) : 2048;
   const int grid = c.n_rows < gmax ? c.n_rows : gmax;
@@ -1549,10 +1552,11 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   const R1MeParams *dparams = (const R1MeParams *)((const uint8_t *)ctx->me_jobs[slot] + jobs_bytes);
   R1MeStats *const *drbufs = (R1MeStats *const *)((const uint8_t *)ctx->me_jobs[slot] + jobs_bytes + params_bytes);
   // one persistent launch (k_me_persist) or one launch per superblock diagonal (k_me_diag): the
-  // persistent path pins every job to one XCD, so it wants at least a job per XCD and a half
-  // (measured: slower below ~8 jobs, -12 ... -19 % at 24, equal at 64)
+  // persistent path pins every job to one XCD, so it wants a job per XCD (measured, 8-bit 4K:
+  // 1 job 9.9 vs 4.1 ms, 4 jobs 4.7 vs 4.8, 8 jobs 1.14 vs 1.75, 24 jobs 1.36 vs 2.07, 64 jobs
+  // 1.69 vs 2.03)
   static const char *force = getenv("R1_ME_PERSISTENT");   // "1" / "0": A/B switch for tools/bench_me.py
-  int mode = params->launch_mode ? params->launch_mode : (force ? (force[0] == '1' ? 2 : 1) : (n_jobs >= 12 ? 2 : 1));
+  int mode = params->launch_mode ? params->launch_mode : (force ? (force[0] == '1' ? 2 : 1) : (n_jobs >= 8 ? 2 : 1));
   R1_REQUIRE(mode == 1 || mode == 2);
   if (mode == 2) {
     if (ctx->me_xcds < 0) { const int rc = me_probe_xcds(ctx, st); if (rc != R1_OK) return rc; }

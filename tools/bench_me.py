@@ -55,12 +55,19 @@ def main():
     ctx = Context(0)
     rows, cols = h // 4, w // 4
 
+    def launch_label(n_jobs):
+        # r1_estimate_tile_motion_batch, launch_mode 0: one persistent launch from 8 jobs on
+        force = os.environ.get("R1_ME_PERSISTENT")
+        if force == "1" or (force is None and n_jobs >= 8):
+            return "one persistent launch (k_me_persist)"
+        return "per-call launches (R1_ME_NO_GRAPH)" if os.environ.get("R1_ME_NO_GRAPH") else "hipGraph replay of the diagonal launches"
+
     def tiles_of(nx, ny):
         tw = -(-(w // nx) // 64) * 64
         th = -(-(h // ny) // 64) * 64
         return [(x, y, min(tw, w - x), min(th, h - y)) for y in range(0, h, th) for x in range(0, w, tw)]
 
-    for ci, (nx, ny, nref) in enumerate(((1, 1, 1), (1, 1, 4), (2, 2, 4), (4, 4, 4))):
+    for ci, (nx, ny, nref) in enumerate(((1, 1, 1), (1, 1, 4), (4, 2, 1), (2, 2, 4), (4, 4, 4))):
         if args.only >= 0 and ci != args.only:
             continue
         tl = tiles_of(nx, ny)
@@ -80,8 +87,7 @@ def main():
         ms = (time.perf_counter() - t0) / args.reps * 1e3
         row = {"kernel": "estimate_tile_motion", "frame": "%dx%d" % (w, h), "bit_depth": bd,
                "tiles": len(tl), "refs": nref, "jobs": len(jobs), "ms": round(ms, 3),
-               "launch": "per-call launches (R1_ME_NO_GRAPH)" if os.environ.get("R1_ME_NO_GRAPH")
-               else "hipGraph replay",
+               "launch": launch_label(len(jobs)),
                "Mpixels_s": round(w * h * nref / ms / 1e3, 1),
                "frames_refs_per_s": round(nref / ms * 1e3, 1)}
         if args.cpu and len(jobs) > 1:

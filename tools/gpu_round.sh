@@ -29,7 +29,7 @@ find /tmp/profp_$TAG -name "*kernel_stats*" -exec cp {} $OUT/frame_pipeline_kern
 echo "== pmc"
 bash tools/gpu_pmc.sh ${TAG}_pmc > $OUT/pmc.log 2>&1
 python tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc $OUT/pmc_summary.json 2>&1 | tail -2
-ls $OUT; for f in $OUT/*_chain_*.json $OUT/bench_10bit.json $OUT/frame_pipeline_*; do python3 -c "
+ls $OUT; for f in $OUT/*_chain_*.json $OUT/bench_10bit.json $OUT/frame_pipeline_*.json; do python3 -c "
 import json,sys
 d=json.loads(open('$f').read()); print('$f'.split('/')[-1], d.get('value'), d.get('kernel_ms'), d.get('stage_ms'), d.get('two_stream_ms (ME of the next frame beside the other stages)'))"; done
 cat $OUT/me_4k.jsonl | cut -c1-160
