@@ -475,7 +475,9 @@ int r1_prescreen_select_batch(r1_ctx *ctx, const uint32_t *keys, int n_groups, i
  * needs >= 8 jobs to use the chip (two waves per SIMD, 128 registers and more each) and a device whose launches spread over 8 XCDs
  * (probed once per context; forcing mode 2 elsewhere is R1_EINVAL, a dependency wait
  * that runs out of patience is reported as R1_EHIP by the next call on the ring slot);
- * launch_mode 0 takes 2 from 8 jobs on, else 1).  At most 256 jobs per call (tiles x
+ * launch_mode 3: the same persistent launch without the pinning -- any wave takes any
+ * row, results are written through at agent scope; launch_mode 0 takes 2 from 8 jobs on,
+ * else 3).  At most 256 jobs per call (tiles x
  * reference frames of one frame).  The context keeps one scratch MEStats frame per distinct
  * `stats` array of a call (the refinements of a pass are computed one diagonal
  * ahead of its searches and must stay invisible to them until then). */
@@ -492,7 +494,8 @@ typedef struct R1MeParams {
   int32_t me_range_scale;            /* fi.me_range_scale */
   uint32_t lambda[3];
   int32_t launch_mode;               /* r1_estimate_tile_motion_batch: 0 = choose (below), 1 = one
-                                      * launch per superblock diagonal, 2 = one persistent launch */
+                                      * launch per superblock diagonal, 2 / 3 = one persistent launch,
+                                      * jobs pinned to an XCD each / not pinned */
 } R1MeParams;
 typedef struct R1MeJob {
   R1Plane org[3], ref[3];

@@ -607,7 +607,7 @@ __device__ __forceinline__ void setup_block(B &b, const R1MeJob &job, const R1Me
 }
 
 // save_me_stats (me.rs:324-337) with the normalisation of me.rs:268-270
-template <bool AGENT = false>
+template <bool AGENT = false, bool WIDE = false>
 __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, int bx, int by,
                                              const Msr &r, int w, int h, int ssdec, int lane) {
   const uint32_t nsad = (uint32_t)((((unsigned long long)r.sad) << 14) / (unsigned long long)(w * h));
@@ -621,7 +621,12 @@ __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, i
                                     ((unsigned long long)(uint16_t)v.col << 16) | (uint16_t)v.row;
     // plain stores: the line stays in THIS XCD's L2, where the job's other waves (all on this
     // XCD, see k_me_persist) read it with L1-bypassing loads
-    for (int i = lane; i < nx * ny; i += 64) *(unsigned long long *)t.at(by + i / nx, bx + i % nx) = bits;
+    // (WIDE: the job's waves sit on any XCD -- agent-scope stores, written through)
+    for (int i = lane; i < nx * ny; i += 64) {
+      unsigned long long *d = (unsigned long long *)t.at(by + i / nx, bx + i % nx);
+      if constexpr (WIDE) __hip_atomic_store(d, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *d = bits;
+    }
   } else {
     for (int i = lane; i < nx * ny; i += 64) *t.at(by + i / nx, bx + i % nx) = v;
   }
@@ -822,7 +827,9 @@ __device__ __forceinline__ bool me_wait4(const unsigned int *const *f, const uns
   return false;
 }
 
-template <int BPP>
+// PIN: every job on one XCD (launch_mode 2); !PIN: one row list for the whole device, results and
+// progress words written through at agent scope (launch_mode 3: fewer jobs than XCDs)
+template <int BPP, bool PIN>
 __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
   __shared__ int16_t sh_subsets[kSubsetWords];
   __shared__ unsigned int sh_item;
@@ -830,7 +837,7 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
   const int lane = threadIdx.x;
   // every wave of a job sits on ONE XCD (the job's rows are handed out only to waves that find
   // themselves there), so a hand-over never leaves that XCD's L2
-  const int xcd = __builtin_amdgcn_s_getreg(6164) & 7;         // hwreg(HW_REG_XCC_ID, 0, 4)
+  const int xcd = PIN ? (__builtin_amdgcn_s_getreg(6164) & 7) : 0;   // hwreg(HW_REG_XCC_ID, 0, 4)
   for (;;) {
     if (lane == 0) sh_item = atomicAdd(a.counter + xcd, 1u);
     __syncthreads();
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
                                   b.po_y + imin(div8(mvr) + 2, div8(b.mvy_max)), 1);
         TileView tr = t;
         tr.stats = (R1MeStats *)t.rstats;
-        store_result<true>(tr, 1 << (log2b + 1), bx, by, r, w, h, ssdec, lane);
+        store_result<true, !PIN>(tr, 1 << (log2b + 1), bx, by, r, w, h, ssdec, lane);
       } else {
         const int sz = MI << log2b;
         const int x = gx * sz, y = row.gy * sz;
@@ -921,12 +928,15 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
         }
         const int corner = init ? 0 : (1 | ((xin & sz) ? 2 : 0) | ((yin & sz) ? 4 : 0));
         const Msr r = full_pixel_me<Block<BPP, 16, 3>, true>(b, t, p, bx, by, rng, corner, init, ssdec, sh_subsets);
-        store_result<true>(t, 1 << log2b, bx, by, r, w, h, ssdec, lane);
+        store_result<true, !PIN>(t, 1 << log2b, bx, by, r, w, h, ssdec, lane);
       }
       // publish: the statistics first (agent-scope stores, acknowledged), then the progress
       __builtin_amdgcn_s_waitcnt(0);
-      if (lane == 0)
-        __hip_atomic_store(mine, (a.epoch << 16) | (unsigned int)(gx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) {
+        const unsigned int word = (a.epoch << 16) | (unsigned int)(gx + 1);
+        if constexpr (PIN) __hip_atomic_store(mine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(mine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (lane == 0 && !ok) atomicOr(a.err, 1u);
   }
@@ -1381,7 +1391,7 @@ int me_probe_xcds(r1_ctx *ctx, hipStream_t st) {
 
 int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs, int bpp, const R1MeJob *djobs,
                          const R1MeParams *dparams, R1MeStats *const *drbufs, size_t upload_bytes,
-                         hipStream_t st) {
+                         hipStream_t st, bool pin) {
   if (!ctx->me_persist[slot]) ctx->me_persist[slot] = new MePersistCache();
   MePersistCache &c = *(MePersistCache *)ctx->me_persist[slot];
   // a dependency wait of the previous call on this slot that ran out of patience (the slot's event
@@ -1393,6 +1403,7 @@ int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs,
     if (e) { r1_set_error("k_me_persist: a dependency wait of the previous call timed out"); return R1_EHIP; }
   }
   std::vector<int> geo;
+  geo.push_back(pin ? 1 : 0);
   for (int j = 0; j < n_jobs; j++) { geo.push_back(jobs[j].tile_w); geo.push_back(jobs[j].tile_h); }
   if (geo != c.geo || c.epoch >= 65535) {
     for (void **pp : {&c.rows, &c.foff, &c.prog, &c.ctl})
@@ -1410,13 +1421,14 @@ int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs,
           rows.push_back(MeRow{(uint16_t)j, (uint8_t)kind, 0, (uint16_t)gy, (uint16_t)nbx});
       }
     }
-    std::stable_sort(rows.begin(), rows.end(), [](const MeRow &a, const MeRow &b) {
-      const int xa = a.job & 7, xb = b.job & 7;
+    const int xmask = pin ? 7 : 0;
+    std::stable_sort(rows.begin(), rows.end(), [xmask](const MeRow &a, const MeRow &b) {
+      const int xa = a.job & xmask, xb = b.job & xmask;
       if (xa != xb) return xa < xb;
       return me_row_key(a.kind, a.gy) < me_row_key(b.kind, b.gy);
     });
     for (int x = 0; x <= 8; x++) c.xoff[x] = 0;
-    for (const MeRow &r : rows) c.xoff[(r.job & 7) + 1]++;
+    for (const MeRow &r : rows) c.xoff[(r.job & xmask) + 1]++;
     for (int x = 0; x < 8; x++) c.xoff[x + 1] += c.xoff[x];
     R1_HIP_CHECK(hipMalloc(&c.rows, rows.size() * sizeof(MeRow)));
     R1_HIP_CHECK(hipMalloc(&c.foff, foff.size() * sizeof(unsigned int)));
@@ -1448,8 +1460,10 @@ int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs,
   const int gmax = getenv("R1_ME_PERSISTENT_GRID") ? atoi(getenv("R1_ME_PERSISTENT_GRID")) : 2048;
   const int grid = c.n_rows < gmax ? c.n_rows : gmax;
   if (getenv("R1_ME_PERSISTENT_DEBUG")) fprintf(stderr, "k_me_persist: %d rows, grid %d, epoch %u\n", c.n_rows, grid, a.epoch);
-  if (bpp == 1) hipLaunchKernelGGL(k_me_persist<1>, dim3(grid), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL(k_me_persist<2>, dim3(grid), dim3(64), 0, st, a);
+  if (bpp == 1 && pin) hipLaunchKernelGGL((k_me_persist<1, true>), dim3(grid), dim3(64), 0, st, a);
+  else if (bpp == 1) hipLaunchKernelGGL((k_me_persist<1, false>), dim3(grid), dim3(64), 0, st, a);
+  else if (pin) hipLaunchKernelGGL((k_me_persist<2, true>), dim3(grid), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((k_me_persist<2, false>), dim3(grid), dim3(64), 0, st, a);
   R1_HIP_CHECK(hipGetLastError());
   R1_HIP_CHECK(hipEventRecord(ctx->me_done[slot], st));
   c.launched = true;
@@ -1552,12 +1566,13 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   const R1MeParams *dparams = (const R1MeParams *)((const uint8_t *)ctx->me_jobs[slot] + jobs_bytes);
   R1MeStats *const *drbufs = (R1MeStats *const *)((const uint8_t *)ctx->me_jobs[slot] + jobs_bytes + params_bytes);
   // one persistent launch (k_me_persist) or one launch per superblock diagonal (k_me_diag): the
-  // persistent path pins every job to one XCD, so it wants a job per XCD (measured, 8-bit 4K:
-  // 1 job 9.9 vs 4.1 ms, 4 jobs 4.7 vs 4.8, 8 jobs 1.14 vs 1.75, 24 jobs 1.36 vs 2.07, 64 jobs
-  // 1.69 vs 2.03)
-  static const char *force = getenv("R1_ME_PERSISTENT");   // "1" / "0": A/B switch for tools/bench_me.py
-  int mode = params->launch_mode ? params->launch_mode : (force ? (force[0] == '1' ? 2 : 1) : (n_jobs >= 8 ? 2 : 1));
-  R1_REQUIRE(mode == 1 || mode == 2);
+  // pinned persistent path (2) puts every job on one XCD, so it wants a job per XCD; below that the
+  // unpinned one (3: any wave takes any row, results written through at agent scope).  Measured,
+  // 8-bit 4K, ms, diagonal launches / pinned / unpinned: 1 job 4.12 / 9.9 / 2.91, 4 jobs 4.80 / 4.7 /
+  // 3.96, 8 jobs 1.74 / 1.14 / 1.31, 16 jobs 2.93 / 2.08 / 2.29, 64 jobs 2.03 / 1.69 / 1.77
+  static const char *force = getenv("R1_ME_PERSISTENT");   // "0" / "1" / "3": A/B switch for tools/bench_me.py (diagonal / pinned / unpinned)
+  int mode = params->launch_mode ? params->launch_mode : (force ? (force[0] == '0' ? 1 : force[0] == '3' ? 3 : 2) : (n_jobs >= 8 ? 2 : 3));
+  R1_REQUIRE(mode >= 1 && mode <= 3);
   if (mode == 2) {
     if (ctx->me_xcds < 0) { const int rc = me_probe_xcds(ctx, st); if (rc != R1_OK) return rc; }
     if (ctx->me_xcds != 8) {
@@ -1565,10 +1580,10 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
         r1_set_error("r1_estimate_tile_motion_batch: launch_mode 2 needs a device whose launches spread over 8 XCDs");
         return R1_EINVAL;
       }
-      mode = 1;
+      mode = 3;
     }
   }
-  if (mode == 2) return me_launch_persistent(ctx, slot, jobs, n_jobs, bpp, djobs, dparams, drbufs, bytes, st);
+  if (mode >= 2) return me_launch_persistent(ctx, slot, jobs, n_jobs, bpp, djobs, dparams, drbufs, bytes, st, mode == 2);
   const int ndiag = max_sbw + max_sbh - 1;
   const int dlen = max_sbw < max_sbh ? max_sbw : max_sbh;
   // software pipeline over the passes: launch `step` runs diagonal step - 2 q of pass q

@@ -138,7 +138,7 @@ def test_pixel_candidate_at_config_size(ctx, oracle, fw, fh, bd):
         assert np.array_equal(o["dist"].cpu().numpy().view(np.uint64), wdist), (fw, bd, s)
 
 
-@pytest.mark.parametrize("launch_mode", [1, 2])
+@pytest.mark.parametrize("launch_mode", [1, 2, 3])
 @pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
 def test_motion_estimation_at_config_size_every_16x16_block(ctx, oracle, w, h, launch_mode):
     """N2 at the BASELINE frame sizes: the three-pass tile ME of the frame (tiles of 512 x 576 as one
@@ -165,7 +165,7 @@ def test_motion_estimation_at_config_size_every_16x16_block(ctx, oracle, w, h, l
     for t in tiles:
         O.me_oracle(oracle, po, pr, cols, rows, t, bd, lam, want)
     st = torch.zeros((rows, cols, 2), dtype=torch.int32, device="cuda")
-    # 8 / 32 tiles: launch_mode 1 = diagonal launches, 2 = the persistent XCD-pinned row walkers
+    # 8 / 32 tiles: launch_mode 1 = diagonal launches, 2 / 3 = the persistent row walkers, XCD-pinned / not
     ctx.estimate_tile_motion([dict(org=do, ref=dr, stats=st, tile=t) for t in tiles], cols, rows, bd, lam,
                              launch_mode=launch_mode)
     got = st.cpu().numpy().reshape(rows, -1).view(O.ME_STATS).reshape(rows, cols)

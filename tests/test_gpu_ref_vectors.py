@@ -172,7 +172,7 @@ def _me_stats_tensor(a):
     return torch.from_numpy(s.view(np.int32).reshape(s.shape[0], s.shape[1], 2).copy()).cuda(), s
 
 
-@pytest.mark.parametrize("launch_mode", [1, 2])
+@pytest.mark.parametrize("launch_mode", [1, 2, 3])
 @pytest.mark.parametrize("name", _me_ref_cases())
 def test_me_ref_tile_motion_and_block_searches(ctx, name, launch_mode):
     """r1_estimate_tile_motion_batch (all references of a case as the jobs of ONE call) and
@@ -195,7 +195,7 @@ def test_me_ref_tile_motion_and_block_searches(ctx, name, launch_mode):
         jobs.append(dict(org=org, ref=ref, stats=st, prev=prev_t, tile=(tx, ty, tw, th)))
         wants.append((want_t, want))
     cols, rows = (w + 3) // 4, (h + 3) // 4
-    # launch_mode 1: one launch per superblock diagonal; 2: the persistent row walkers (XCD-pinned)
+    # launch_mode 1: one launch per superblock diagonal; 2 / 3: the persistent row walkers, XCD-pinned / not
     ctx.estimate_tile_motion(jobs, cols, rows, bd, lam, allow_hp=bool(hp), allow_full_search=bool(full),
                              me_range_scale=scale, launch_mode=launch_mode)
     for k, (want_t, want) in enumerate(wants):

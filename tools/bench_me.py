@@ -56,10 +56,11 @@ def main():
     rows, cols = h // 4, w // 4
 
     def launch_label(n_jobs):
-        # r1_estimate_tile_motion_batch, launch_mode 0: one persistent launch from 8 jobs on
+        # r1_estimate_tile_motion_batch, launch_mode 0: one persistent launch, pinned from 8 jobs on
         force = os.environ.get("R1_ME_PERSISTENT")
-        if force == "1" or (force is None and n_jobs >= 8):
-            return "one persistent launch (k_me_persist)"
+        if force in (None, "1", "3"):
+            pinned = force == "1" or (force is None and n_jobs >= 8)
+            return "one persistent launch (k_me_persist), jobs %s" % ("pinned to an XCD each" if pinned else "not pinned")
         return "per-call launches (R1_ME_NO_GRAPH)" if os.environ.get("R1_ME_NO_GRAPH") else "hipGraph replay of the diagonal launches"
 
     def tiles_of(nx, ny):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Soak of r1_estimate_tile_motion_batch's persistent launch (launch_mode 2: spin-waits on progress
-words, every job pinned to one XCD) against the diagonal launches (launch_mode 1, the path the
+"""Soak of r1_estimate_tile_motion_batch's persistent launches (launch_mode 2: spin-waits on progress
+words, every job pinned to one XCD; launch_mode 3: not pinned) against the diagonal launches (launch_mode 1, the path the
 parity tests pin to the oracle and to the executed reference): random frame sizes (ragged last
 tiles, sizes that are not multiples of 64), tile grids, 1..4 reference frames, previous-frame
 statistics present or not, 8 / 10-bit, repeated calls on the same ring slot (epoch reuse) and
@@ -82,12 +82,13 @@ def main():
         a = run(2)
         b = run(2, side)          # a second persistent launch in flight beside the next one
         c = run(2)
+        d = run(3)                # not pinned: any wave, any row, agent-scope write-through
         torch.cuda.synchronize()
-        calls += 4
+        calls += 5
         cases += 1
         entries += sum(int(x[..., 1].numel()) for x in want)
         moving += sum(int((x[..., 0] != 0).sum()) for x in want)
-        for got in (a, b, c):
+        for got in (a, b, c, d):
             if any(not torch.equal(g, x) for g, x in zip(got, want)):
                 n = sum(int((g != x).any(-1).sum()) for g, x in zip(got, want))
                 bad_cases.append((w, h, bd, nref, tw, th, with_prev, kw, n))
