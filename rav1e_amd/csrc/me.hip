@@ -763,13 +763,13 @@ __global__ __launch_bounds__(256, R1_ME_DIAG_WAVES) void k_me_diag(const R1MeJob
 
 // ---------------------------------------------------------------------------
 // k_me_persist: the same three passes as ONE launch whose waves hand results over through
-// progress counters in memory instead of kernel boundaries (R1MeParams::launch_mode 2).  A wave WALKS A
+// progress counters in memory instead of kernel boundaries (R1MeParams::launch_mode 2 / 3).  A wave WALKS A
 // ROW: the blocks of one block row of one pass (or the refinements of one row of the previous
 // pass' blocks) from left to right.  The left neighbour is then the wave's own previous block;
 // the only same-pass hand-over is the row above, which runs one block ahead -- in the steady
 // state its result is already there when it is asked for, so the chain is rows + columns block
 // steps (127 for a 960 x 1088 tile at 16 x 16) instead of 7 x 31 superblock-diagonal steps.
-// Rows are taken from one atomic counter in an order in which everything a row waits for comes
+// Rows are taken from an atomic counter in an order in which everything a row waits for comes
 // earlier (key = bottom edge of the row in 16-pixel cells + a per-pass offset): a wave only waits
 // for rows that are already running, so there is no deadlock whatever the residency.
 //   a search block (pass q) waits for: the row above having passed it; q > 0: the refinement of
@@ -777,14 +777,24 @@ __global__ __launch_bounds__(256, R1_ME_DIAG_WAVES) void k_me_diag(const R1MeJob
 //   in its own superblock (read refined), their pass q - 1 SEARCH when they lie in the next
 //   superblock (read unrefined, from the live array).  A refinement waits for the pass q - 1
 //   search of its block.
-// Statistics are read and written with agent-scope atomics (the waves sit on different XCDs);
-// refined vectors live in the second buffer and are never copied: the samples pick their buffer.
+// Visibility.  PIN (launch_mode 2): every wave of a job sits on the XCD job % 8 (a wave asks
+// HW_REG_XCC_ID where it is and takes rows from that XCD's list), so results are plain stores --
+// they stay in that XCD's L2 -- read back with L1-bypassing (agent-scope) loads, and the progress
+// word is a workgroup-scope store behind s_waitcnt(0).  !PIN (launch_mode 3, fewer jobs than XCDs):
+// one list, any wave takes any row; results and progress words are agent-scope stores, written
+// through.  (An __ATOMIC_RELEASE agent-scope store for the progress word hung the kernel on this
+// stack; the explicit s_waitcnt + relaxed store does not.)
+// Residency: TWO waves per SIMD (host: grid 2048) -- a searching wave is a dependent instruction
+// chain that wants a VALU slot every ~8 cycles; a third and fourth wave on the SIMD stretch every
+// step of a chain without slack -- so the kernel is not held to k_me_diag's 96
+// registers and keeps three candidate batches in flight at every pixel size.
+// Refined vectors live in the second buffer and are never copied: the samples pick their buffer.
 struct MeRow { uint16_t job; uint8_t kind, pad; uint16_t gy, nb; };   // kind 0..2 search, 3 / 4 refine for pass 1 / 2
 struct MePersistArgs {
   const R1MeJob *jobs;
   const R1MeParams *params;
   R1MeStats *const *rbufs;
-  const MeRow *rows;            // sorted per XCD: rows of the jobs with job % 8 == xcd, in key order
+  const MeRow *rows;            // sorted per XCD: rows of the jobs with job % 8 == xcd (PIN; else one list), in key order
   int n_rows;
   int xoff[9];                  // rows of XCD x: [xoff[x], xoff[x + 1])
   unsigned int *counter;        // [8]: next row of each XCD
