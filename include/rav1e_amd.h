@@ -468,17 +468,18 @@ int r1_prescreen_select_batch(r1_ctx *ctx, const uint32_t *keys, int n_groups, i
  * 0.125)) as u32, me.rs:175-177 -- f64 arithmetic, evaluated by the host.
  * `jobs` is HOST memory (pointers inside are device pointers) and is consumed
  * before the call returns; the work itself is only ENQUEUED on `stream`
- * (launch_mode 1: superblock columns + rows + 3 launches, replayed as one
- * hipGraph, the three passes skewed inside them; launch_mode 2: ONE persistent launch
- * whose waves walk block rows and hand results over through progress counters --
- * every job is pinned to one XCD so that the hand-overs stay in that XCD's L2, which
- * needs >= 8 jobs to use the chip (two waves per SIMD, 128 registers and more each) and a device whose launches spread over 8 XCDs
- * (probed once per context; forcing mode 2 elsewhere is R1_EINVAL, a dependency wait
- * that runs out of patience is reported as R1_EHIP by the next call on the ring slot);
- * launch_mode 3: the same persistent launch without the pinning -- any wave takes any
- * row, results are written through at agent scope; launch_mode 0 takes 2 from 8 jobs on,
- * else 3).  At most 256 jobs per call (tiles x
- * reference frames of one frame).  The context keeps one scratch MEStats frame per distinct
+ * as ONE persistent launch whose waves walk block rows and hand results over
+ * through progress words in memory (two waves per SIMD).  launch_mode 2: every job
+ * is pinned to one XCD so that the hand-overs stay in that XCD's L2 -- wants >= 8
+ * jobs to use the chip and a device whose launches spread over 8 XCDs (probed once
+ * per context; forcing mode 2 elsewhere is R1_EINVAL).  launch_mode 3: not pinned
+ * -- any wave takes any row, results written through at agent scope.  launch_mode 1:
+ * the launch-boundary version (superblock columns + rows + 3 launches replayed as
+ * one hipGraph, the three passes skewed inside them), kept as the cross-check.
+ * launch_mode 0 takes 2 from 8 jobs on, else 3.  A dependency wait of a persistent
+ * launch that runs out of patience is reported as R1_EHIP by the next call on the
+ * ring slot, not as a hang.  At most 256 jobs per call (tiles x reference frames of
+ * one frame).  The context keeps one scratch MEStats frame per distinct
  * `stats` array of a call (the refinements of a pass are computed one diagonal
  * ahead of its searches and must stay invisible to them until then). */
 typedef struct R1MeStats {
