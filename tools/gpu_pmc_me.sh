@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC counters of k_me_diag for one tile-ME configuration (tools/bench_me.py --only N). usage: tools/gpu_pmc_me.sh tag [cfg]
+# PMC counters of k_me_persist / k_me_diag for one tile-ME configuration (tools/bench_me.py --only N). usage: tools/gpu_pmc_me.sh tag [cfg]
 TAG=${1:-pmcme}; CFG=${2:-0}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -20,7 +20,7 @@ out="$OUT"
 for f in sorted(glob.glob(out+"/*.csv")):
     agg=collections.defaultdict(float); n=collections.Counter()
     for r in csv.DictReader(open(f)):
-        if "k_me_diag" not in r.get("Kernel_Name",""): continue
+        if "k_me_diag" not in r.get("Kernel_Name","") and "k_me_persist" not in r.get("Kernel_Name",""): continue
         agg[r["Counter_Name"]]+=float(r["Counter_Value"]); n[r["Counter_Name"]]+=1
     print(f.split("/")[-1], {k:(round(v), n[k]) for k,v in agg.items()})
 PY
