@@ -411,8 +411,27 @@ def extra_lines(ctx, args):
     return lines
 
 
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-exec this very command
+    line under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1, a free port) --
+    the launch the task statement's driver uses.  Under a launcher (WORLD_SIZE set) this is a
+    no-op."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    respawn_under_launcher(args)
     import torch
     import torch.distributed as dist
     from rav1e_amd import tiles
@@ -514,6 +533,11 @@ def main():
     # per-kernel events feed `roofline` (N = 1); at N > 1 they would only add
     # host work to steps that are a fraction of a millisecond long
     use_events = not args.no_events and world == 1
+    # N > 1: three events on every EV_EVERY-th timed step split the step into its launches
+    # (`compute_ms`) and the exchange behind them (`exchange_ms`: stand-in reconstruction write +
+    # halo p2p + tile all-gather); those steps run their launches on the main stream
+    split_events = not args.no_events and world > 1
+    xev = []
 
     # A timing-event pair costs ~0.5 % of a step (the event drains the stream), so every
     # EV_EVERY-th timed step carries them (around each size's launch), the others run bare.
@@ -527,10 +551,11 @@ def main():
 
     def step(timed, exchange=True):
         mark = timed and use_events and nstep[0] % EV_EVERY == 0
+        split = timed and split_events and exchange and nstep[0] % EV_EVERY == 0
         if timed:
             nstep[0] += 1
         main = torch.cuda.current_stream()
-        if fan and not mark:
+        if fan and not mark and not split:
             # independent launches, one stream per block size (each stream is in order with the
             # same size's launch of the previous step, which wrote the same output buffers)
             for s in W.LADDER:
@@ -540,6 +565,9 @@ def main():
         else:
             for st in size_streams.values():
                 main.wait_stream(st)
+            if split:
+                xe = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                xe[0].record()
             for s in W.LADDER:
                 n = len(cands[s])
                 if n == 0:
@@ -551,6 +579,8 @@ def main():
                 if mark:
                     e1.record()
                     ev[s].append((e0, e1))
+            if split:
+                xe[1].record()
             for st in size_streams.values():
                 st.wait_stream(main)
         if world > 1 and exchange:
@@ -564,6 +594,9 @@ def main():
                 comm.allgather_tiles(ref, rects)
             else:
                 tiles.exchange_rows(send, gathered)
+            if split:
+                xe[2].record()
+                xev.append(xe)
             for st in size_streams.values():
                 st.wait_stream(main)
 
@@ -606,6 +639,21 @@ def main():
         total_px = float(p.item())
     else:
         total_px = float(my_px)
+    split_ms = None
+    if world > 1 and split_events:
+        # mean over this rank's marked steps, then the slowest rank's figure and rank 0's own
+        mine = [0.0, 0.0]
+        if xev:
+            mine = [sum(e[0].elapsed_time(e[1]) for e in xev) / len(xev),
+                    sum(e[1].elapsed_time(e[2]) for e in xev) / len(xev)]
+        t = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        split_ms = {"compute_ms": round(float(t[0].item()), 4), "exchange_ms": round(float(t[1].item()), 4),
+                    "rank0_compute_ms": round(mine[0], 4), "rank0_exchange_ms": round(mine[1], 4),
+                    "samples": len(xev),
+                    "note": "HIP events on every %dth timed step (launches on one stream in those steps): "
+                            "compute = the step's launches, exchange = stand-in reconstruction write + "
+                            "r1_comm_exchange_halos + r1_comm_allgather_tiles; max over ranks" % EV_EVERY}
 
     if rank == 0:
         per = {}
@@ -648,12 +696,15 @@ def main():
                        "candidates_per_step": int(sum(len(c) for c in cands.values())) if world == 1
                        else None,
                        "tiles": world, "exchange": exch_note, "launch_streams": args.streams,
+                       "compute_ms": split_ms["compute_ms"] if split_ms else None,
+                       "exchange_ms": split_ms["exchange_ms"] if split_ms else None,
+                       "step_split": split_ms,
                        "parallelism": "tile-per-gpu x%d" % world if world > 1 else "single-gpu"},
             "roofline": roof,
             "prewarm_steps": prewarm_steps,
             "kernel_ms": {str(s): round(v, 4) for s, v in per.items()},
             "kernel_ms_note": "HIP events around each launch of every %dth timed step "
-                              "(%d samples per size)" % (EV_EVERY, max(len(v) for v in ev.values())),
+                              "(%d samples per size)" % (EV_EVERY, max([len(v) for v in ev.values()] + [0])),
         }
         bad = []
         if world == 1 and not full and not args.no_extra:

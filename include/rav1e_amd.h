@@ -41,8 +41,9 @@ extern "C" {
 #define R1_OK 0
 #define R1_EINVAL (-1)   /* bad argument / descriptor (reference: assert! panic) */
 #define R1_EHIP (-2)     /* HIP runtime error; see r1_last_error() */
-#define R1_ECOMM (-3)    /* RCCL error; see r1_last_error() */
-#define R1_ENOMEM (-3)
+#define R1_ECOMM (-3)    /* RCCL error (or no RCCL library to load); see r1_last_error() */
+#define R1_ENOMEM (-4)
+#define R1_ETIMEDOUT (-5) /* r1_me_status: a persistent tile-ME launch flagged a timed-out dependency wait */
 
 /* ---- Plane<T> view (v_frame 0.3.9 PlaneConfig layout; reference use:
  * src/tiling/plane_region.rs:185 -- element (x,y) lives at
@@ -507,6 +508,16 @@ typedef struct R1MeJob {
 } R1MeJob;
 int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, int n_jobs,
                                   const R1MeParams *params, void *stream);
+/* The persistent launches (launch_mode 2 / 3) hand results between waves through memory; a wave
+ * whose dependency wait runs out of patience (a bounded spin: nothing can hang the GPU) carries on
+ * with stale predictors and flags the CALL.  The statistics of a call are valid once r1_me_status
+ * has returned R1_OK after it: wait != 0 first waits for every launch enqueued so far (wait == 0
+ * only looks at launches that have finished).  R1_ETIMEDOUT: *first_failed_call (optional) is the
+ * 1-based index, per context, of the first flagged r1_estimate_tile_motion_batch call -- re-issue
+ * it with launch_mode = 1 (launch boundaries instead of waits); following calls are unaffected.
+ * Flags are consumed by the report.  *calls (optional): calls made on this context so far. */
+int r1_me_status(r1_ctx *ctx, int wait, unsigned long long *first_failed_call,
+                 unsigned long long *calls);
 
 /* estimate_motion with a predicted MV (the RDO-time call, src/rdo.rs:1183-1196:
  * estimate_motion(fi, ts, w, h, tile_bo, ref, Some(pmv), corner, false, 0, None),
@@ -722,6 +733,12 @@ typedef struct R1HaloXfer {
   int32_t dir;             /* 0: send this rectangle of my plane, 1: receive into it */
   int32_t x0, y0, x1, y1;  /* plane pixels, visible-area coordinates, half-open */
 } R1HaloXfer;
+/* RCCL is loaded on first use (dlopen), not linked: a process that never calls r1_comm_* needs no
+ * RCCL at all.  Which library: $R1_RCCL_LIBRARY if set; else a librccl already loaded into the
+ * process (a PyTorch process then has ONE RCCL, torch's own); else librccl.so.1 by the loader's
+ * search path, then /opt/rocm/lib/librccl.so.1.  r1_comm_library() names the one in use (NULL before
+ * the first r1_comm_* call or when none could be loaded; that case is R1_ECOMM). */
+const char *r1_comm_library(void);
 int r1_comm_unique_id(uint8_t *id128);
 int r1_comm_create(r1_ctx *ctx, int rank, int world, const uint8_t *id128, r1_comm **out);
 void r1_comm_destroy(r1_comm *comm);

@@ -82,6 +82,8 @@ SYMBOLS = {
     "r1_mc_prep_batch": (_i, [_vp, _PP, _i, _i, _vp, _i, _vp, _vp]),
     "r1_mc_avg_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "r1_mc_batch_mfma": (_i, [_vp, _i, _PP, _i, _i, _vp, _i, _vp, _vp]),
+    "r1_comm_library": (C.c_char_p, []),
+    "r1_me_status": (_i, [_vp, _i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "r1_comm_unique_id": (_i, [_vp]),
     "r1_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
     "r1_comm_destroy": (None, [_vp]),

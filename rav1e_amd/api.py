@@ -609,6 +609,15 @@ class Context:
         self._check(self.lib.r1_estimate_tile_motion_batch(self.h, arr, n, C.byref(p), _stream_ptr()),
                     "r1_estimate_tile_motion_batch")
 
+    def me_status(self, wait=True):
+        """r1_me_status: (ok, first_failed_call, calls) -- the statistics of the persistent tile-ME
+        launches are valid once this has reported ok after them (include/rav1e_amd.h)."""
+        first, calls = C.c_ulonglong(0), C.c_ulonglong(0)
+        rc = self.lib.r1_me_status(self.h, int(wait), C.byref(first), C.byref(calls))
+        if rc not in (0, -5):
+            self._check(rc, "r1_me_status")
+        return rc == 0, int(first.value), int(calls.value)
+
     def estimate_motion_batch(self, job, cands, w_in_b, h_in_b, bit_depth, lambdas, max_w=64,
                               max_h=64, use_satd=True, filter_mode=0, allow_hp=True, n=None):
         """estimate_motion(.., Some(pmv), ..) of src/rdo.rs:1183-1196 for independent

@@ -17,7 +17,9 @@ void r1_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *r1_last_error(void) { return g_err; }
-extern "C" int r1_abi_version(void) { return 1; }
+// 3: round-3 additions (r1_me_status, r1_comm_library, the predict:: dispatch symbols), R1_ENOMEM /
+// R1_ETIMEDOUT got values of their own, R1MeParams.reserved became launch_mode (round 2)
+extern "C" int r1_abi_version(void) { return 3; }
 
 extern "C" int r1_ctx_create(int device, r1_ctx **out) {
   R1_REQUIRE(out);
@@ -524,6 +526,60 @@ void dequant_shim(int qindex, const int16_t *coeffs, int16_t *rcoeffs, int tx_si
   qp.ac_delta_q = ac_delta_q;
   SHIM_OK(r1_dequantize_batch(c, d, 1, tx_size, &qp, 2, d + cb, st));
   SHIM_HIP(hipMemcpyAsync(rcoeffs, d + cb, (size_t)area * 2, hipMemcpyDeviceToHost, st));
+  SHIM_HIP(hipStreamSynchronize(st));
+}
+
+// The reference's ipred entry points (src/asm/x86/predict.rs:21-236): dst, stride in BYTES,
+// pointer to the top-left element of the IntraEdgeBuffer, and for the directional zones the
+// edge-filter flags folded into `angle` (bit 10 enable, bit 9 smooth neighbour, :301-303).  What
+// the asm does not receive -- how far the edges were initialised, how much of the block lies
+// inside the frame -- is taken as the asm takes it: the edges are valid as far as the mode reads
+// them (left h / above w; the zone's far edge w + h), the block lies inside the frame, z2's
+// filter counts are clipped with the dx / dy it is given (:306-316).  mode / variant are the
+// constants of the symbol (tools/gen_dispatch.py); mode 13 = UV_CFL_PRED with `angle_arg` = alpha.
+void ipred_shim(void *dst, ptrdiff_t stride, const void *topleft, int w, int h, int angle_arg, int mode,
+                int variant, int dx, int dy, const int16_t *ac, int bpp, int bd) {
+  const bool directional = mode == 3 || mode == 4 || mode == 7;
+  int angle = 0, ief = 0, left = h, above = w, aw = w, ah = h;
+  if (directional) {
+    angle = angle_arg & 511;
+    ief = ((angle_arg >> 10) & 1) ? 1 + ((angle_arg >> 9) & 1) : 0;
+    if (mode == 3) above = w + h > 128 ? 128 : w + h;
+    if (mode == 7) left = w + h > 128 ? 128 : w + h;
+    if (mode == 4) {
+      if (dx > 0 && dx < aw) aw = dx;
+      if (dy > 0 && dy < ah) ah = dy;
+    }
+  } else if (mode == 1) {
+    angle = 90;
+  } else if (mode == 2) {
+    angle = 180;
+  } else if (mode == 13) {
+    angle = angle_arg;   // alpha
+  }
+  SHIM_OK(rav1e_ipred_hip(dst, stride, topleft, w, h, angle, mode, variant, ief, left, above, aw, ah, ac, bd));
+  (void)bpp;
+}
+
+// rav1e_ipred_cfl_ac_{420,422,444} (src/asm/x86/predict.rs:142-186, wrapper :873-927): ac = dense
+// width x height int16, src = the luma block under it, w_pad / h_pad in 4-pixel units of the
+// chroma block.  The luma pixels read are those of rust::pred_cfl_ac (src/predict.rs:1020-1063).
+void cfl_ac_shim(int16_t *ac, const void *src, ptrdiff_t stride, int w_pad, int h_pad, int w, int h, int xdec,
+                 int ydec, int bpp, int bd) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  r1_ctx *c = shim_ctx();
+  hipStream_t st = c->own_stream;
+  int lw = (w - 4 * w_pad) << xdec, lh = (h - 4 * h_pad) << ydec;
+  if (lw < 8) lw = 8;
+  if (lh < 8) lh = 8;
+  const size_t row = (size_t)lw * bpp, blk = align256(row * lh), ab = align256((size_t)w * h * 2);
+  uint8_t *d = (uint8_t *)stage(c, blk + ab + 256);
+  SHIM_HIP(hipMemcpy2DAsync(d, row, src, stride, row, lh, hipMemcpyHostToDevice, st));
+  R1CflAcCand cand = {0, 0, (uint8_t)w_pad, (uint8_t)h_pad, {0, 0}};
+  SHIM_HIP(hipMemcpyAsync(d + blk + ab, &cand, sizeof(cand), hipMemcpyHostToDevice, st));
+  R1Plane p = {d, lw, lh, lw, lh, 0, 0, bpp, bd};
+  SHIM_OK(r1_cfl_ac_batch(c, &p, w, h, xdec, ydec, (const R1CflAcCand *)(d + blk + ab), 1, (int16_t *)(d + blk), st));
+  SHIM_HIP(hipMemcpyAsync(ac, d + blk, (size_t)w * h * 2, hipMemcpyDeviceToHost, st));
   SHIM_HIP(hipStreamSynchronize(st));
 }
 }  // namespace

@@ -941,14 +941,18 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
         store_result<true, !PIN>(t, 1 << log2b, bx, by, r, w, h, ssdec, lane);
       }
       // publish: the statistics first (agent-scope stores, acknowledged), then the progress
+      asm volatile("" ::: "memory");   // no result store may sink below the wait, no progress store rise above it
       __builtin_amdgcn_s_waitcnt(0);
+      asm volatile("" ::: "memory");
       if (lane == 0) {
         const unsigned int word = (a.epoch << 16) | (unsigned int)(gx + 1);
         if constexpr (PIN) __hip_atomic_store(mine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_store(mine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (lane == 0 && !ok) atomicOr(a.err, 1u);
+    // the error word is host-mapped pinned memory (one per ring slot): the host reads it where the
+    // slot's event is waited for, without a copy (r1_me_status / the slot's reuse)
+    if (lane == 0 && !ok) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1362,7 +1366,10 @@ struct MePersistCache {
   void *rows = nullptr;            // device: MeRow[n_rows]
   void *foff = nullptr;            // device: uint32[n_jobs][5]
   void *prog = nullptr;            // device: uint32 per row (epoch << 16 | blocks done)
-  void *ctl = nullptr;             // device: counter, err
+  void *ctl = nullptr;             // device: counter
+  unsigned int *err_host = nullptr;   // pinned, host-mapped: set by a wave whose dependency wait ran out
+  unsigned int *err_dev = nullptr;    // the same word as the device sees it
+  unsigned long long call_id = 0;     // r1_estimate_tile_motion_batch call this slot last served
   int n_rows = 0;
   int xoff[9] = {0};
   unsigned int epoch = 0;
@@ -1395,27 +1402,40 @@ int me_probe_xcds(r1_ctx *ctx, hipStream_t st) {
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(d);
   R1_HIP_CHECK(e);
-  ctx->me_xcds = h == 0xFFu ? 8 : 0;      // anything but exactly XCD 0..7: no persistent launches
+  // The pinned hand-over (plain result stores that stay in the job's XCD L2, readers bypassing L1)
+  // leans on gfx942 / gfx950 cache behaviour, not on the HIP memory model: explicit allow-list on
+  // top of the probe.  Anything else takes the unpinned launch (agent-scope write-through).
+  hipDeviceProp_t prop;
+  R1_HIP_CHECK(hipGetDeviceProperties(&prop, ctx->device));
+  const bool arch_ok = !strncmp(prop.gcnArchName, "gfx950", 6) || !strncmp(prop.gcnArchName, "gfx942", 6);
+  ctx->me_xcds = (h == 0xFFu && arch_ok) ? 8 : 0;   // anything but exactly XCD 0..7: no pinned launches
   return R1_OK;
 }
+
+void me_collect_slot(r1_ctx *ctx, MePersistCache &c);
 
 int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs, int bpp, const R1MeJob *djobs,
                          const R1MeParams *dparams, R1MeStats *const *drbufs, size_t upload_bytes,
                          hipStream_t st, bool pin) {
   if (!ctx->me_persist[slot]) ctx->me_persist[slot] = new MePersistCache();
   MePersistCache &c = *(MePersistCache *)ctx->me_persist[slot];
-  // a dependency wait of the previous call on this slot that ran out of patience (the slot's event
-  // has been waited for): the results of that call are not to be trusted
-  if (c.ctl && c.launched) {
-    unsigned int e = 0;
-    R1_HIP_CHECK(hipMemcpy(&e, (unsigned int *)c.ctl + 8, sizeof(e), hipMemcpyDeviceToHost));
-    c.launched = false;
-    if (e) { r1_set_error("k_me_persist: a dependency wait of the previous call timed out"); return R1_EHIP; }
+  // A dependency wait of the previous call on this slot that ran out of patience (the slot's event
+  // has been waited for by the caller of this function): THAT call's statistics are not to be
+  // trusted.  It is recorded against that call (r1_me_status reports its id); this call goes ahead.
+  me_collect_slot(ctx, c);
+  if (!c.err_host) {
+    R1_HIP_CHECK(hipHostMalloc((void **)&c.err_host, 64, hipHostMallocMapped));
+    *c.err_host = 0;
+    hipError_t e = hipHostGetDevicePointer((void **)&c.err_dev, c.err_host, 0);
+    if (e != hipSuccess) { (void)hipHostFree(c.err_host); c.err_host = nullptr; R1_HIP_CHECK(e); }
   }
   std::vector<int> geo;
   geo.push_back(pin ? 1 : 0);
   for (int j = 0; j < n_jobs; j++) { geo.push_back(jobs[j].tile_w); geo.push_back(jobs[j].tile_h); }
   if (geo != c.geo || c.epoch >= 65535) {
+    // nothing of the old geometry survives a failed rebuild: forget it before freeing
+    c.geo.clear();
+    c.n_rows = 0;
     for (void **pp : {&c.rows, &c.foff, &c.prog, &c.ctl})
       if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
     std::vector<MeRow> rows;
@@ -1443,7 +1463,7 @@ int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs,
     R1_HIP_CHECK(hipMalloc(&c.rows, rows.size() * sizeof(MeRow)));
     R1_HIP_CHECK(hipMalloc(&c.foff, foff.size() * sizeof(unsigned int)));
     R1_HIP_CHECK(hipMalloc(&c.prog, (size_t)nprog * sizeof(unsigned int)));
-    R1_HIP_CHECK(hipMalloc(&c.ctl, 9 * sizeof(unsigned int)));
+    R1_HIP_CHECK(hipMalloc(&c.ctl, 8 * sizeof(unsigned int)));
     R1_HIP_CHECK(hipMemcpy(c.rows, rows.data(), rows.size() * sizeof(MeRow), hipMemcpyHostToDevice));
     R1_HIP_CHECK(hipMemcpy(c.foff, foff.data(), foff.size() * sizeof(unsigned int), hipMemcpyHostToDevice));
     R1_HIP_CHECK(hipMemset(c.prog, 0, (size_t)nprog * sizeof(unsigned int)));
@@ -1453,11 +1473,12 @@ int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs,
   }
   c.epoch++;
   R1_HIP_CHECK(hipMemcpyAsync(ctx->me_jobs[slot], ctx->me_jobs_host[slot], upload_bytes, hipMemcpyHostToDevice, st));
-  R1_HIP_CHECK(hipMemsetAsync(c.ctl, 0, 9 * sizeof(unsigned int), st));
+  R1_HIP_CHECK(hipMemsetAsync(c.ctl, 0, 8 * sizeof(unsigned int), st));
+  *c.err_host = 0;   // the slot's previous launch has completed (event) and been collected
   MePersistArgs a;
   a.jobs = djobs; a.params = dparams; a.rbufs = drbufs;
   a.rows = (const MeRow *)c.rows; a.n_rows = c.n_rows;
-  a.counter = (unsigned int *)c.ctl; a.err = (unsigned int *)c.ctl + 8;
+  a.counter = (unsigned int *)c.ctl; a.err = c.err_dev;
   for (int x = 0; x <= 8; x++) a.xoff[x] = c.xoff[x];
   a.prog = (unsigned int *)c.prog; a.foff = (const unsigned int *)c.foff;
   a.epoch = c.epoch;
@@ -1477,23 +1498,66 @@ int me_launch_persistent(r1_ctx *ctx, int slot, const R1MeJob *jobs, int n_jobs,
   R1_HIP_CHECK(hipGetLastError());
   R1_HIP_CHECK(hipEventRecord(ctx->me_done[slot], st));
   c.launched = true;
-  if (getenv("R1_ME_PERSISTENT_CHECK")) {
-    unsigned int ctl[9] = {0};
+  c.call_id = ctx->me_calls;
+  if (getenv("R1_ME_PERSISTENT_CHECK")) {   // debugging aid: synchronous check of this very call
     R1_HIP_CHECK(hipStreamSynchronize(st));
-    R1_HIP_CHECK(hipMemcpy(ctl, c.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
-    if (getenv("R1_ME_PERSISTENT_DEBUG")) fprintf(stderr, "k_me_persist: rows %d, counter %u.., err %u\n", c.n_rows, ctl[0], ctl[8]);
+    const unsigned int e = *(volatile unsigned int *)c.err_host;
+    if (getenv("R1_ME_PERSISTENT_DEBUG")) fprintf(stderr, "k_me_persist: rows %d, err %u\n", c.n_rows, e);
     c.launched = false;
-    if (ctl[8]) { r1_set_error("k_me_persist: a dependency wait timed out"); return R1_EHIP; }
+    if (e) { r1_set_error("k_me_persist: a dependency wait timed out"); return R1_EHIP; }
   }
   return R1_OK;
 }
 }  // namespace
+
+// the error word of a slot whose launch has completed: recorded against the call it served
+namespace {
+void me_collect_slot(r1_ctx *ctx, MePersistCache &c) {
+  if (!c.launched || !c.err_host) return;
+  c.launched = false;
+  if (*(volatile unsigned int *)c.err_host) {
+    ctx->me_failed++;
+    if (!ctx->me_first_failed) ctx->me_first_failed = c.call_id;
+  }
+}
+}  // namespace
+
+// Results of the persistent tile-ME launches (launch_mode 2 / 3) are valid once this has said so:
+// a wave whose dependency wait runs out of patience (a bounded spin, so that a placement the
+// protocol did not foresee cannot hang the GPU) goes on with stale predictors and flags the call.
+// wait != 0: first waits for every launch enqueued so far.  Returns R1_OK when no call since the
+// last r1_me_status has been flagged; R1_ETIMEDOUT otherwise, with *first_failed_call = the 1-based
+// index (per context) of the first flagged r1_estimate_tile_motion_batch call -- the caller
+// re-issues that call with launch_mode = 1 (the launch-boundary version has no waits).  Flags are
+// consumed by the report.  *calls (optional) = calls made on this context so far.
+extern "C" int r1_me_status(r1_ctx *ctx, int wait, unsigned long long *first_failed_call,
+                            unsigned long long *calls) {
+  R1_REQUIRE(ctx);
+  std::lock_guard<std::mutex> ring_lock(ctx->me_mu);
+  R1DeviceGuard dev_guard(ctx);
+  for (int s = 0; s < r1_ctx::kMeSlots; s++) {
+    MePersistCache *c = (MePersistCache *)ctx->me_persist[s];
+    if (!c || !c->launched || !ctx->me_done[s]) continue;
+    if (wait) R1_HIP_CHECK(hipEventSynchronize(ctx->me_done[s]));
+    else if (hipEventQuery(ctx->me_done[s]) != hipSuccess) continue;
+    me_collect_slot(ctx, *c);
+  }
+  if (calls) *calls = ctx->me_calls;
+  if (first_failed_call) *first_failed_call = ctx->me_first_failed;
+  const bool bad = ctx->me_failed != 0;
+  if (bad) r1_set_error("k_me_persist: %d call(s) flagged a timed-out dependency wait, first: call %llu; "
+                        "re-issue with launch_mode 1", ctx->me_failed, ctx->me_first_failed);
+  ctx->me_failed = 0;
+  ctx->me_first_failed = 0;
+  return bad ? R1_ETIMEDOUT : R1_OK;
+}
 
 void r1_me_persist_free(void *cache) {
   MePersistCache *c = (MePersistCache *)cache;
   if (!c) return;
   for (void *p : {c->rows, c->foff, c->prog, c->ctl})
     if (p) (void)hipFree(p);
+  if (c->err_host) (void)hipHostFree(c->err_host);
   delete c;
 }
 
@@ -1528,6 +1592,7 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   // per-tile rayon workers share a context) take turns for the enqueue.
   std::lock_guard<std::mutex> ring_lock(ctx->me_mu);
   R1DeviceGuard dev_guard(ctx);
+  ctx->me_calls++;
   const size_t jobs_bytes = ((size_t)n_jobs * sizeof(R1MeJob) + 15) & ~(size_t)15;
   const size_t params_bytes = (sizeof(R1MeParams) + 15) & ~(size_t)15;
   const size_t bytes = jobs_bytes + params_bytes + (size_t)n_jobs * sizeof(R1MeStats *);

@@ -5,7 +5,8 @@
  * tests/test_dispatch_c.py.
  *
  * fn types: src/asm/x86/dist/mod.rs:21-43, dist/sse.rs:18-34, dist/cdef_dist.rs:18-24,
- * mc.rs:17-78, cdef.rs:16-37,184-191, quantize.rs:22-31, src/asm/shared/transform/inverse.rs:15-19
+ * mc.rs:17-78, cdef.rs:16-37,184-191, quantize.rs:22-31, src/asm/shared/transform/inverse.rs:15-19,
+ * predict.rs:21-236 (angular / z2 / cfl_ac / cfl prediction entry points)
  *
  *   test_dispatch <librav1e_hip.so> [list]     list: only dlsym every symbol (no GPU needed)
  */
@@ -37,6 +38,14 @@ typedef void (*CdefFilterFn)(uint8_t *, ptrdiff_t, const uint16_t *, ptrdiff_t, 
 typedef void (*CdefFilterHBDFn)(uint16_t *, ptrdiff_t, const uint16_t *, ptrdiff_t, int32_t, int32_t, int32_t, int32_t, int32_t);
 typedef int32_t (*CdefDirLBDFn)(const uint8_t *, ptrdiff_t, uint32_t *);
 typedef int32_t (*CdefDirHBDFn)(const uint16_t *, ptrdiff_t, uint32_t *, int32_t);
+typedef void (*IpredFn)(uint8_t *, ptrdiff_t, const uint8_t *, int, int, int);
+typedef void (*IpredHBDFn)(uint16_t *, ptrdiff_t, const uint16_t *, int, int, int, int, int, int);
+typedef void (*IpredZ2Fn)(uint8_t *, ptrdiff_t, const uint8_t *, int, int, int, int, int);
+typedef void (*IpredZ2HBDFn)(uint16_t *, ptrdiff_t, const uint16_t *, int, int, int, int, int, int);
+typedef void (*CflAcFn)(int16_t *, const uint8_t *, ptrdiff_t, int, int, int, int);
+typedef void (*CflAcHBDFn)(int16_t *, const uint16_t *, ptrdiff_t, int, int, int, int);
+typedef void (*CflPredFn)(uint8_t *, ptrdiff_t, const uint8_t *, int, int, const int16_t *, int);
+typedef void (*CflPredHBDFn)(uint16_t *, ptrdiff_t, const uint16_t *, int, int, const int16_t *, int, int);
 typedef void (*DequantizeFn)(uint8_t, const int16_t *, uint16_t, int16_t *, uint8_t, size_t, int8_t, int8_t);
 
 static void *lib;
@@ -300,6 +309,110 @@ static void t_deq(const char *nm) {
   }
 }
 
+/* ---- predict:: entries.  The edge buffer is the reference's IntraEdgeBuffer (257 pixels, top-left
+ * at index 128, left below it, above after it); the oracle gets the same buffer with the edge
+ * lengths the asm contract implies (left h / above w, the zone's far edge w + h) and the whole
+ * block inside the frame; z2 additionally with its dx / dy clip. */
+static void t_ipred(const char *nm, int mode, int variant, int hbd, int z2) {
+  void *f = sym(nm);
+  if (!f || list_only) return;
+  static const int z1a[] = {36, 45, 54, 67, 76, 81, 87}, z2a[] = {93, 104, 113, 135, 157, 166, 177},
+                   z3a[] = {183, 194, 203, 212};
+  const int *angs = mode == 3 ? z1a : (mode == 4 ? z2a : z3a);
+  const int dirn = mode == 3 || mode == 4 || mode == 7;
+  const int nang = !dirn ? 1 : (mode == 7 ? 4 : 7);
+  for (int bd = hbd ? 10 : 8; bd <= (hbd ? 12 : 8); bd += 2)
+    for (int ts = 0; ts < 19; ts++) {
+      const int w = r1o_tx_width(ts), h = r1o_tx_height(ts);
+      for (int ai = 0; ai < nang; ai++)
+        for (int ief = 0; ief < (dirn ? 3 : 1); ief++) {
+          uint8_t e8[257];
+          uint16_t e16[257];
+          for (int i = 0; i < 257; i++) { e8[i] = (uint8_t)rnd(); e16[i] = (uint16_t)(rnd() & ((1 << bd) - 1)); }
+          int angle = 0, left = h, above = w, aw = w, ah = h, dx = 0, dy = 0;
+          if (dirn) angle = angs[ai];
+          else if (mode == 1) angle = 90;
+          else if (mode == 2) angle = 180;
+          if (mode == 3) above = w + h;
+          if (mode == 7) left = w + h;
+          if (z2) {   /* frame edge somewhere inside, or far away */
+            dx = (rnd() & 1) ? w + 8 : (w > 4 ? w / 2 : w);
+            dy = (rnd() & 1) ? h + 8 : (h > 4 ? h / 2 : h);
+            aw = dx < w ? dx : w;
+            ah = dy < h ? dy : h;
+          }
+          const int angle_arg = dirn ? (angle | (ief ? 1 << 10 : 0) | (ief == 2 ? 1 << 9 : 0)) : angle;
+          int ok = 1;
+          if (!hbd) {
+            static uint8_t g[64 * 80], o[64 * 80];
+            memset(g, 0x5a, sizeof(g)); memset(o, 0x5a, sizeof(o));
+            if (z2) ((IpredZ2Fn)f)(g, 80, e8 + 128, w, h, angle_arg, dx, dy);
+            else ((IpredFn)f)(g, 80, e8 + 128, w, h, angle_arg);
+            r1o_dispatch_predict_intra(mode, variant, o, 80, ts, 8, NULL, angle, ief, e8, left, above, aw, ah, 0);
+            ok = !memcmp(g, o, sizeof(g));
+          } else {
+            static uint16_t g[64 * 80], o[64 * 80];
+            memset(g, 0x5a, sizeof(g)); memset(o, 0x5a, sizeof(o));
+            if (z2) ((IpredZ2HBDFn)f)(g, 80 * 2, e16 + 128, w, h, angle_arg, dx, dy, (1 << bd) - 1);
+            else ((IpredHBDFn)f)(g, 80 * 2, e16 + 128, w, h, angle_arg, 0, 0, (1 << bd) - 1);
+            r1o_dispatch_predict_intra(mode, variant, o, 80, ts, bd, NULL, angle, ief, e16, left, above, aw, ah, 1);
+            ok = !memcmp(g, o, sizeof(g));
+          }
+          CHECK(ok, nm);
+        }
+    }
+}
+
+static void t_cfl(const char *nm, int variant, int hbd) {
+  void *f = sym(nm);
+  if (!f || list_only) return;
+  for (int bd = hbd ? 10 : 8; bd <= (hbd ? 12 : 8); bd += 2)
+    for (int ts = 0; ts < 19; ts++) {
+      const int w = r1o_tx_width(ts), h = r1o_tx_height(ts);
+      if (w > 32 || h > 32) continue;   /* CFL blocks are at most 32x32 */
+      uint8_t e8[257];
+      uint16_t e16[257];
+      for (int i = 0; i < 257; i++) { e8[i] = (uint8_t)rnd(); e16[i] = (uint16_t)(rnd() & ((1 << bd) - 1)); }
+      int16_t ac[32 * 32];
+      for (int i = 0; i < w * h; i++) ac[i] = (int16_t)((int)(rnd() % 1024) - 512);
+      const int alpha = (int)(rnd() % 33) - 16;
+      int ok;
+      if (!hbd) {
+        static uint8_t g[32 * 48], o[32 * 48];
+        memset(g, 0x5a, sizeof(g)); memset(o, 0x5a, sizeof(o));
+        ((CflPredFn)f)(g, 48, e8 + 128, w, h, ac, alpha);
+        r1o_dispatch_predict_intra(13, variant, o, 48, ts, 8, ac, alpha, 0, e8, h, w, w, h, 0);
+        ok = !memcmp(g, o, sizeof(g));
+      } else {
+        static uint16_t g[32 * 48], o[32 * 48];
+        memset(g, 0x5a, sizeof(g)); memset(o, 0x5a, sizeof(o));
+        ((CflPredHBDFn)f)(g, 48 * 2, e16 + 128, w, h, ac, alpha, (1 << bd) - 1);
+        r1o_dispatch_predict_intra(13, variant, o, 48, ts, bd, ac, alpha, 0, e16, h, w, w, h, 1);
+        ok = !memcmp(g, o, sizeof(g));
+      }
+      CHECK(ok, nm);
+    }
+}
+
+static void t_cflac(const char *nm, int xdec, int ydec, int hbd) {
+  void *f = sym(nm);
+  if (!f || list_only) return;
+  static const int dims[][2] = {{4, 4}, {4, 8}, {8, 4}, {8, 8}, {8, 16}, {16, 8}, {16, 16}, {16, 32}, {32, 16},
+                                {32, 32}, {4, 16}, {16, 4}, {8, 32}, {32, 8}};
+  fill(hbd ? 10 : 8);
+  for (unsigned i = 0; i < sizeof(dims) / sizeof(dims[0]); i++)
+    for (int pad = 0; pad < 3; pad++) {
+      const int w = dims[i][0], h = dims[i][1];
+      const int w_pad = pad == 1 ? (w / 4) / 2 : 0, h_pad = pad == 2 ? (h / 4) / 2 : 0;
+      if ((w << xdec) + 7 > PW - 8 || (h << ydec) + 5 > PH - 8) continue;
+      int16_t g[32 * 32], o[32 * 32];
+      memset(g, 0x11, sizeof(g)); memset(o, 0x11, sizeof(o));
+      if (!hbd) { ((CflAcFn)f)(g, A8, SA, w_pad, h_pad, w, h); r1o_pred_cfl_ac(o, A8, SA, w, h, w_pad, h_pad, xdec, ydec, 0); }
+      else { ((CflAcHBDFn)f)(g, A16, SA * 2, w_pad, h_pad, w, h); r1o_pred_cfl_ac(o, A16, SA, w, h, w_pad, h_pad, xdec, ydec, 1); }
+      CHECK(!memcmp(g, o, (size_t)w * h * 2), nm);
+    }
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s librav1e_hip.so [list]\n", argv[0]); return 2; }
   lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
@@ -326,6 +439,14 @@ int main(int argc, char **argv) {
 #define X_CDEFD(n, a, b) t_cdef_dir(#n, 0);
 #define X_CDEFD_HBD(n, a, b) t_cdef_dir(#n, 1);
 #define X_DEQ(n, a, b) t_deq(#n);
+#define X_IPRED(n, mode, variant) t_ipred(#n, mode, variant, 0, 0);
+#define X_IPRED_HBD(n, mode, variant) t_ipred(#n, mode, variant, 1, 0);
+#define X_IPRED_Z2(n, mode, variant) t_ipred(#n, mode, variant, 0, 1);
+#define X_IPRED_Z2_HBD(n, mode, variant) t_ipred(#n, mode, variant, 1, 1);
+#define X_CFL(n, mode, variant) t_cfl(#n, variant, 0);
+#define X_CFL_HBD(n, mode, variant) t_cfl(#n, variant, 1);
+#define X_CFLAC(n, xd, yd) t_cflac(#n, xd, yd, 0);
+#define X_CFLAC_HBD(n, xd, yd) t_cflac(#n, xd, yd, 1);
 #include "dispatch_list.h"
   printf("%d symbols, %d checks, %d failures\n", n_syms, n_checks, n_fail);
   return n_fail ? 1 : 0;

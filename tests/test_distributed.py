@@ -252,3 +252,68 @@ def test_tile_halo_plan_is_symmetric():
         for peer, rect in plans[r][1]:
             assert (r, rect) in plans[peer][0]
         assert sum((a[2] - a[0]) * (a[3] - a[1]) for _, a in plans[r][0]) < 400_000   # vs 8.3 M pixels
+
+
+# ---- the RCCL path itself, two ranks on two GPUs (skipped on 1-GPU boxes) ------------------
+def _worker_rccl(rank, world, port, q):
+    try:
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(rank)
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # carries the unique id only
+        from rav1e_amd import tiles
+        from rav1e_amd import workload as W
+        from rav1e_amd.api import Context, Plane
+        fw, fh = 512, 256
+        rects = [(0, 0, 256, 256), (256, 0, 512, 256)]
+        truth = W.random_plane_array(fw, fh, 8, 77)               # what every rank must end up with
+        mine = np.zeros_like(truth)
+        x0, y0, x1, y1 = rects[rank]
+        mine[88 + y0:88 + y1, 88 + x0:88 + x1] = truth[88 + y0:88 + y1, 88 + x0:88 + x1]
+        ctx = Context(rank)
+        dp = Plane.from_numpy(mine, fw, fh, 8, 88, 88)
+        comm = tiles.Comm(ctx, rank, world)
+        lib = comm.lib.r1_comm_library().decode()
+        n = comm.exchange_tile_halos(dp, rects)
+        torch.cuda.synchronize()
+        got = dp.data.cpu().numpy()
+        ex = tiles.expanded_rect(rects[rank], tiles.POSTFILTER_HALO, fw, fh)
+        ok_halo = np.array_equal(got[88 + ex[1]:88 + ex[3], 88 + ex[0]:88 + ex[2]],
+                                 truth[88 + ex[1]:88 + ex[3], 88 + ex[0]:88 + ex[2]])
+        comm.allgather_tiles(dp, rects)
+        torch.cuda.synchronize()
+        got = dp.data.cpu().numpy()
+        ok_all = np.array_equal(got[88:88 + fh, 88:88 + fw], truth[88:88 + fh, 88:88 + fw])
+        comm.close()
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, n, ok_halo, ok_all, lib, None))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put((rank, 0, False, False, "", traceback.format_exc()[-1500:]))
+
+
+@pytest.mark.gpu
+def test_rccl_halo_exchange_and_tile_allgather_two_gpus():
+    """r1_comm_exchange_halos + r1_comm_allgather_tiles with world = 2 over RCCL: every rank ends
+    with its tile plus the 64-px ring after the p2p exchange and with the whole frame after the
+    all-gather.  Needs two GPUs; the 1-GPU boxes of the round run skip it."""
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_worker_rccl, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(60)
+    for rank, n, ok_halo, ok_all, lib, err in res:
+        assert err is None, "rank %d: %s" % (rank, err)
+        assert n == 2 and ok_halo and ok_all, (rank, n, ok_halo, ok_all)
+        assert "librccl" in lib

@@ -198,6 +198,8 @@ def test_me_ref_tile_motion_and_block_searches(ctx, name, launch_mode):
     # launch_mode 1: one launch per superblock diagonal; 2 / 3: the persistent row walkers, XCD-pinned / not
     ctx.estimate_tile_motion(jobs, cols, rows, bd, lam, allow_hp=bool(hp), allow_full_search=bool(full),
                              me_range_scale=scale, launch_mode=launch_mode)
+    ok, first_failed, calls = ctx.me_status(wait=True)   # no dependency wait ran out of patience
+    assert ok and first_failed == 0 and calls >= 1, (ok, first_failed, calls)
     for k, (want_t, want) in enumerate(wants):
         got = jobs[k]["stats"].cpu().numpy().reshape(rows, -1).view(O.ME_STATS).reshape(rows, cols)
         bad = np.argwhere(got != want)

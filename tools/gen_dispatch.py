@@ -17,6 +17,7 @@ Reference tables (file:line under /root/reference/src/asm/x86):
   INV_TXFM_FNS / INV_TXFM_HBD_FNS         transform/inverse.rs:69-330     ([TxSize][TxType])
   CDEF_FILTER_FNS, CDEF_DIR_*_FNS         cdef.rs:16-37,160-191
   DEQUANTIZE_FNS                          quantize.rs:22-37
+  rav1e_ipred_* / ipred_cfl* / cfl_ac_*   predict.rs:21-236               (no table: a match on mode / variant)
 Symbol names follow the reference's pattern with the ISA suffix `hip`.
 """
 import os
@@ -50,7 +51,9 @@ def valid_tx(ts, tt):
     return True
 
 
-def main():
+def main(out_root=None):
+    """writes the three files under `out_root` (default: the repository)"""
+    out_root = out_root or ROOT
     decl, defs, xl = [], [], []
 
     def add(kind, name, cdecl, body, xargs):
@@ -160,6 +163,54 @@ def main():
     add("CDEFD_HBD", "rav1e_cdef_dir_16bpc_hip",
         "int32_t rav1e_cdef_dir_16bpc_hip(const uint16_t *tmp, ptrdiff_t tmp_stride, uint32_t *var, int32_t bitdepth_max)",
         "return cdef_dir_shim(tmp, tmp_stride, var, 2, bd_from_max(bitdepth_max));", "0, 0")
+    # ---- predict:: (src/asm/x86/predict.rs:21-236; consumed by dispatch_predict_intra :239-857 and
+    # pred_cfl_ac :873-927).  `angle` of z1/z2/z3 carries the edge-filter flags in its unused bits
+    # (bit 10 enable_ief, bit 9 smooth neighbour, :301-303); z2 receives dx / dy = distance of the
+    # block to the frame edge in a frame rounded up to 8 px (:306-316); the HBD forms receive
+    # (max_width, max_height, bit_depth_max), z2 dx / dy in the max_* slots (:584-625).
+    ANG = [("dc", 0, 3), ("dc_128", 0, 0), ("dc_left", 0, 1), ("dc_top", 0, 2), ("v", 1, 0), ("h", 2, 0),
+           ("smooth", 9, 0), ("smooth_v", 10, 0), ("smooth_h", 11, 0), ("paeth", 12, 0),
+           ("z1", 3, 0), ("z3", 7, 0)]
+    for (nm, mode, variant) in ANG:
+        n = "rav1e_ipred_%s_8bpc_hip" % nm
+        add("IPRED", n, "void %s(uint8_t *dst, ptrdiff_t stride, const uint8_t *topleft, int width, int height, "
+            "int angle)" % n,
+            "ipred_shim(dst, stride, topleft, width, height, angle, %d, %d, 0, 0, nullptr, 1, 8);" % (mode, variant),
+            "%d, %d" % (mode, variant))
+        n = "rav1e_ipred_%s_16bpc_hip" % nm
+        add("IPRED_HBD", n, "void %s(uint16_t *dst, ptrdiff_t stride, const uint16_t *topleft, int width, "
+            "int height, int angle, int max_width, int max_height, int bit_depth_max)" % n,
+            "(void)max_width; (void)max_height; ipred_shim(dst, stride, topleft, width, height, angle, %d, %d, 0, 0, "
+            "nullptr, 2, bd_from_max(bit_depth_max));" % (mode, variant), "%d, %d" % (mode, variant))
+    add("IPRED_Z2", "rav1e_ipred_z2_8bpc_hip",
+        "void rav1e_ipred_z2_8bpc_hip(uint8_t *dst, ptrdiff_t stride, const uint8_t *topleft, int width, int height, "
+        "int angle, int dx, int dy)",
+        "ipred_shim(dst, stride, topleft, width, height, angle, 4, 0, dx, dy, nullptr, 1, 8);", "4, 0")
+    add("IPRED_Z2_HBD", "rav1e_ipred_z2_16bpc_hip",
+        "void rav1e_ipred_z2_16bpc_hip(uint16_t *dst, ptrdiff_t stride, const uint16_t *topleft, int width, "
+        "int height, int angle, int dx, int dy, int bit_depth_max)",
+        "ipred_shim(dst, stride, topleft, width, height, angle, 4, 0, dx, dy, nullptr, 2, bd_from_max(bit_depth_max));",
+        "4, 0")
+    for (nm, variant) in (("cfl", 3), ("cfl_128", 0), ("cfl_left", 1), ("cfl_top", 2)):
+        n = "rav1e_ipred_%s_8bpc_hip" % nm
+        add("CFL", n, "void %s(uint8_t *dst, ptrdiff_t stride, const uint8_t *topleft, int width, int height, "
+            "const int16_t *ac, int alpha)" % n,
+            "ipred_shim(dst, stride, topleft, width, height, alpha, 13, %d, 0, 0, ac, 1, 8);" % variant,
+            "13, %d" % variant)
+        n = "rav1e_ipred_%s_16bpc_hip" % nm
+        add("CFL_HBD", n, "void %s(uint16_t *dst, ptrdiff_t stride, const uint16_t *topleft, int width, int height, "
+            "const int16_t *ac, int alpha, int bit_depth_max)" % n,
+            "ipred_shim(dst, stride, topleft, width, height, alpha, 13, %d, 0, 0, ac, 2, bd_from_max(bit_depth_max));"
+            % variant, "13, %d" % variant)
+    for (nm, xd, yd) in (("420", 1, 1), ("422", 1, 0), ("444", 0, 0)):
+        n = "rav1e_ipred_cfl_ac_%s_8bpc_hip" % nm
+        add("CFLAC", n, "void %s(int16_t *ac, const uint8_t *src, ptrdiff_t stride, int w_pad, int h_pad, int width, "
+            "int height)" % n,
+            "cfl_ac_shim(ac, src, stride, w_pad, h_pad, width, height, %d, %d, 1, 8);" % (xd, yd), "%d, %d" % (xd, yd))
+        n = "rav1e_ipred_cfl_ac_%s_16bpc_hip" % nm
+        add("CFLAC_HBD", n, "void %s(int16_t *ac, const uint16_t *src, ptrdiff_t stride, int w_pad, int h_pad, "
+            "int width, int height)" % n,
+            "cfl_ac_shim(ac, src, stride, w_pad, h_pad, width, height, %d, %d, 2, 10);" % (xd, yd), "%d, %d" % (xd, yd))
     # ---- dequantize (Rust-internal fn type in the reference; C spelling of the same arguments)
     add("DEQ", "rav1e_dequantize_hip",
         "void rav1e_dequantize_hip(uint8_t qindex, const int16_t *coeffs_ptr, uint16_t eob, int16_t *rcoeffs_ptr, "
@@ -170,17 +221,23 @@ def main():
     hdr = ["/* GENERATED by tools/gen_dispatch.py -- do not edit.",
            " * One symbol per entry of the reference's x86 dispatch tables, with the reference's exact C ABI",
            " * (host pointers, strides in BYTES exactly as the asm receives them, values returned the way the",
-           " * asm returns them).  %d symbols.  See the generator's docstring for the table locations. */" % len(decl),
+           " * asm returns them).  %d symbols.  See the generator's docstring for the table locations." % len(decl),
+           " * Two families have no asm counterpart in the reference and are extensions in the same style:",
+           " * rav1e_cdef_dist_kernel_*_hbd_hip (the reference's HBD entry is a Rust fn returning a tuple,",
+           " * src/asm/x86/dist/cdef_dist.rs:26-48; here the LBD asm's ret_ptr convention) and rav1e_dequantize_hip",
+           " * (a Rust-internal fn type, src/asm/x86/quantize.rs:22-31, in C spelling). */",
            "#ifndef RAV1E_AMD_DISPATCH_H", "#define RAV1E_AMD_DISPATCH_H", "#include <stddef.h>", "#include <stdint.h>",
            "#ifdef __cplusplus", 'extern "C" {', "#endif"] + decl + ["#ifdef __cplusplus", "}", "#endif", "#endif"]
-    open(os.path.join(ROOT, "include", "rav1e_amd_dispatch.h"), "w").write("\n".join(hdr) + "\n")
-    open(os.path.join(ROOT, "rav1e_amd", "csrc", "dispatch_gen.inc"), "w").write(
+    for d in ("include", os.path.join("rav1e_amd", "csrc"), os.path.join("tests", "c")):
+        os.makedirs(os.path.join(out_root, d), exist_ok=True)
+    open(os.path.join(out_root, "include", "rav1e_amd_dispatch.h"), "w").write("\n".join(hdr) + "\n")
+    open(os.path.join(out_root, "rav1e_amd", "csrc", "dispatch_gen.inc"), "w").write(
         "/* GENERATED by tools/gen_dispatch.py -- do not edit. */\n" + "\n".join(defs) + "\n")
-    os.makedirs(os.path.join(ROOT, "tests", "c"), exist_ok=True)
-    open(os.path.join(ROOT, "tests", "c", "dispatch_list.h"), "w").write(
+    open(os.path.join(out_root, "tests", "c", "dispatch_list.h"), "w").write(
         "/* GENERATED by tools/gen_dispatch.py -- do not edit. */\n" + "\n".join(xl) + "\n")
     print(len(decl), "symbols")
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
