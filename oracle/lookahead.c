@@ -3,7 +3,8 @@
  * The lookahead cost maps (SURVEY.md 8f "N1"), composed from the scalar
  * restatements exactly as the reference composes its own kernels:
  *   estimate_intra_costs                  src/api/lookahead.rs:30-123
- *     (get_intra_edges -> DC_PRED predict_intra -> get_satd per 8x8 block)
+ *     (get_intra_edges -> DC_PRED predict_intra -> get_satd per 8x8 block; the variant of the
+ *      prediction is NONE for every block, see the call)
  *   estimate_importance_block_difference  src/api/lookahead.rs:125-180
  *   estimate_inter_costs (the SATD map)   src/api/lookahead.rs:226-268
  *   update_block_importances              src/api/internal.rs:911-1068
@@ -38,7 +39,10 @@ void r1o_estimate_intra_costs(const r1o_plane *plane, int bit_depth, uint32_t *c
       uint16_t pred16[64];
       uint8_t pred8[64];
       void *pred = hbd ? (void *)pred16 : (void *)pred8;
-      r1o_predict_intra(0, x * 8, y * 8, pred, 8, 1, bit_depth, NULL, 0, 0, 0, edge, lens[0], lens[1],
+      /* predict_intra's (x, y) is the block position RELATIVE TO tile_rect, and the reference passes
+       * TileRect { x: x * 8, y: y * 8, .. } (lookahead.rs:84-89): (0, 0) for every block, i.e.
+       * PredictionVariant::NONE -> pred_dc_128 (predict.rs:212-218) */
+      r1o_predict_intra(0, 0, 0, pred, 8, 1, bit_depth, NULL, 0, 0, 0, edge, lens[0], lens[1],
                         8, 8, hbd);
       costs[y * wb + x] = r1o_get_satd(pat(plane, x * 8, y * 8), plane->stride, pred, 8, 8, 8, hbd);
       (void)bpp;

@@ -7,10 +7,8 @@
 // get_intra_edges on the SOURCE plane -> DC_PRED -> get_satd.  Nothing depends
 // on a previous block, so the frame is one launch: one LANE per importance
 // block.  The lane loads its 8x8 source tile with two unaligned dwordx2 /
-// dwordx4 loads per row, forms the DC predictor of the reference's
-// PredictionVariant (frame corner 128 << (bd-8), first row: left only, first
-// column: above only, else both; src/predict.rs:786-838) from the row above
-// and the column to the left, and runs the 8x8 Hadamard in registers.
+// dwordx4 loads per row, subtracts the predictor (pred_dc_128 for every block: see k_intra_costs)
+// and runs the 8x8 Hadamard in registers.
 #include "common.hpp"
 #include "dist_common.hpp"
 
@@ -58,26 +56,13 @@ __global__ __launch_bounds__(64) void k_intra_costs(R1Plane p, int wb, int hb,
   int32_t d[64];
 #pragma unroll
   for (int r = 0; r < 8; r++) load_px_row<BPP, 8>(o + r * st, d + r * 8);
-  // DC predictor
-  uint32_t dc;
-  if (x == 0 && y == 0) {
-    dc = 128u << (p.bit_depth - 8);
-  } else {
-    uint32_t sa = 0, sl = 0;
-    if (y != 0) {
-      int32_t a[8];
-      load_px_row<BPP, 8>(o - st, a);
-#pragma unroll
-      for (int i = 0; i < 8; i++) sa += (uint32_t)a[i];
-    }
-    if (x != 0) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) sl += (uint32_t)ld_px<BPP>(o + i * st - BPP);
-    }
-    if (y == 0) dc = (sl + 4) / 8;            // LEFT variant (pred_dc_left)
-    else if (x == 0) dc = (sa + 4) / 8;       // TOP variant (pred_dc_top)
-    else dc = (sa + sl + 8) / 16;             // BOTH (pred_dc)
-  }
+  // The predictor: estimate_intra_costs hands predict_intra a "tile" rectangle that starts AT the
+  // block (TileRect { x: x * 8, y: y * 8, .. }, lookahead.rs:84-89), and predict_intra takes the
+  // PredictionVariant from the block's position relative to that rectangle (predict.rs:212-218):
+  // always (0, 0) -> PredictionVariant::NONE -> pred_dc_128 for EVERY block, the frame's interior
+  // included.  The edges get_intra_edges gathered are not read.  (Pinned by executing the
+  // reference's text: tests/golden/lookahead_ref.npz.)
+  const uint32_t dc = 128u << (p.bit_depth - 8);
 #pragma unroll
   for (int i = 0; i < 64; i++) d[i] -= (int32_t)dc;
   costs[b] = satd8x8(d);

@@ -257,6 +257,102 @@ __device__ __forceinline__ void stage_window_fast(uint8_t *win, int ws, const R1
   else stage_window_ct<BPP, XORM, P, H, NL>(win, ws, ref, rx, ry, l);
 }
 
+// The same three mappings with the global loads and the LDS writes as separate steps, so that a
+// kernel can issue EVERYTHING it needs from memory (source block, window, tap tables) before it
+// waits for any of it -- written as one call, the source's LDS write sits between the source's
+// loads and the window's, and the wave pays two dependent round trips instead of one.
+template <int BPP, uint32_t XORM, int P, int H, int NL>
+struct WindowStage {
+  static constexpr int ROW_BYTES = (P + 7) * BPP;
+  static constexpr int ND = (ROW_BYTES + 3) >> 2;
+  static constexpr int NDV = (ROW_BYTES + 7) >> 3;
+  static constexpr int NR = H + 7;
+  static constexpr int MODE = (NL <= 16 && NL >= NDV) ? 8 : (NL >= ND ? 4 : 0);   // as stage_window_fast
+  // rows8 / rows
+  static constexpr int CH = MODE == 8 ? NDV : ND;
+  static constexpr int RP = MODE ? NL / CH : 1;
+  static constexpr int PASSES = MODE ? (NR + RP - 1) / RP : 1;
+  // element-mapped
+  static constexpr int TOTAL = NR * ND;
+  static constexpr int PER = (TOTAL + NL - 1) / NL;
+  static constexpr int NV = MODE == 8 ? 2 * PASSES : (MODE == 4 ? PASSES : PER);
+  uint32_t v[NV];
+  int r0, ch, back;
+  bool lane_on;
+  int l;
+
+  __device__ __forceinline__ void load(const R1Plane &ref, int rx, int ry, int lane) {
+    l = lane;
+    const uint32_t gstride = (uint32_t)ref.stride * BPP;
+    const uint8_t *base = (const uint8_t *)ref.data;
+    if constexpr (MODE != 0) {
+      constexpr int CB = MODE;                                   // chunk bytes: 8 or 4
+      constexpr int OVER = CH * CB - ROW_BYTES;                 // overlap of the last chunk of a row
+      r0 = l / CH;
+      ch = l - r0 * CH;
+      lane_on = l < RP * CH;
+      back = ch == CH - 1 ? OVER : 0;
+      uint32_t goff = ((uint32_t)(ref.yorigin + ry - 3 + r0) * (uint32_t)ref.stride +
+                       (uint32_t)(ref.xorigin + rx - 3)) * BPP + (uint32_t)(ch * CB - back);
+#pragma unroll
+      for (int u = 0; u < PASSES; u++) {
+        if constexpr (MODE == 8) {
+          v[2 * u] = 0; v[2 * u + 1] = 0;
+          if (lane_on && r0 + u * RP < NR) { const U32x2 t = ld_u32x2(base + goff); v[2 * u] = t.a; v[2 * u + 1] = t.b; }
+        } else {
+          v[u] = 0;
+          if (lane_on && r0 + u * RP < NR) v[u] = ld_u32(base + goff);
+        }
+        goff += RP * gstride;
+      }
+    } else {
+      const uint8_t *g0 = px_addr<BPP>(ref, rx - 3, ry - 3);
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int i = l + u * NL;
+        v[u] = 0;
+        if (i < TOTAL) {
+          const int r = i / ND, d = i - r * ND;
+          const int over = d * 4 + 4 - ROW_BYTES;
+          const int bk = over > 0 ? over : 0;
+          v[u] = (ld_u32(g0 + (size_t)r * gstride + d * 4 - bk) >> (8 * bk)) ^ XORM;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(uint8_t *win, int ws) const {
+    if constexpr (MODE == 8) {
+      constexpr int WSR = ((ROW_BYTES + 3) >> 2) << 2;          // bytes of an LDS row that may be written
+      uint8_t *w0 = win + r0 * ws + ch * 8;
+      const uint32_t sh = 8u * (uint32_t)back;
+      const bool second = ch * 8 + 4 < WSR;
+#pragma unroll
+      for (int u = 0; u < PASSES; u++)
+        if (lane_on && r0 + u * RP < NR) {
+          const uint64_t q = ((((uint64_t)v[2 * u + 1]) << 32) | v[2 * u]) >> sh;
+          *(uint32_t *)(w0 + u * RP * ws) = (uint32_t)q ^ XORM;
+          if (second) *(uint32_t *)(w0 + u * RP * ws + 4) = (uint32_t)(q >> 32) ^ XORM;
+        }
+    } else if constexpr (MODE == 4) {
+      uint8_t *w0 = win + r0 * ws + ch * 4;
+      const uint32_t sh = 8u * (uint32_t)back;
+#pragma unroll
+      for (int u = 0; u < PASSES; u++)
+        if (lane_on && r0 + u * RP < NR) *(uint32_t *)(w0 + u * RP * ws) = (v[u] >> sh) ^ XORM;
+    } else {
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int i = l + u * NL;
+        if (i < TOTAL) {
+          const int r = i / ND, d = i - r * ND;
+          *(uint32_t *)(win + r * ws + d * 4) = v[u];
+        }
+      }
+    }
+  }
+};
+
 // One column of put_8tap / prep_8tap from a staged window.  `c` is the column
 // inside the slab, `w`/`h` the full block size (they select the 4-tap filter
 // variants).  emit(r, value) receives each output sample: the clamped pixel

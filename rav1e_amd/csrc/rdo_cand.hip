@@ -161,6 +161,18 @@ __device__ __forceinline__ uint32_t habs_lanes_pk(uint32_t x, uint32_t m1, uint3
                                 acc, false);
 }
 
+// (lo >> SH) in the low half, (hi >> SH) in the high half.  (Tried in round 3: the second shift as
+// an SDWA write into the upper word of the first one's register -- two instructions instead of
+// three.  +0.5 % and NOT bit-exact in the 8-bit kernels, with or without the dst_sel wait state;
+// profiles/r03_ab_notes.md.  v_perm it stays.)
+template <int SH>
+__device__ __forceinline__ uint32_t ashr_pair(int32_t lo, int32_t hi) {
+  return __builtin_amdgcn_perm((uint32_t)(hi >> SH), (uint32_t)(lo >> SH), 0x05040100u);
+}
+__device__ __forceinline__ uint32_t ashr_pair_rt(int32_t lo, int32_t hi, int sh) {
+  return __builtin_amdgcn_perm((uint32_t)(hi >> sh), (uint32_t)(lo >> sh), 0x05040100u);
+}
+
 // First link of a dot-product chain with a constant accumulator: the VOP3P
 // forms take the constant as an operand (inline 0 / 64, or an SGPR), whereas
 // the compiler's choice -- the accumulate-in-place v_dot*c forms -- needs a
@@ -257,21 +269,27 @@ __device__ __forceinline__ void mc8_column_t(const uint8_t *win, int c, const Ta
   constexpr int32_t bias = 8192 + 2 + (PREP ? 0 : 32);
   constexpr int WSD = WS / 4;
   const uint32_t *wrow = (const uint32_t *)win + (c >> 2);
-  const uint32_t sh = (uint32_t)(c & 3);
   typedef short v2s __attribute__((ext_vector_type(2)));
+  // The lane's 8 window bytes start at byte c & 3 of three aligned dwords.  Instead of moving the
+  // PIXELS to the taps (two v_alignbyte per row), the TAPS are moved to the pixels once per lane:
+  // the 8 tap bytes shifted up by c & 3 bytes into 12, zero elsewhere -- three v_dot4 per row on
+  // the aligned dwords as they come from LDS.
+  const uint32_t sh8 = 8u * (uint32_t)(c & 3);
+  const uint64_t t64 = (((uint64_t)fx1 << 32) | fx0) << sh8;
+  const uint32_t t0 = (uint32_t)t64, t1 = (uint32_t)(t64 >> 32);
+  const uint32_t t2 = (uint32_t)(((uint64_t)fx1 << sh8) >> 32);
   // the window holds pixels already biased by -128 (staged with xor 0x80)
-  auto hrow = [&](int r) -> int32_t {
+  auto hacc = [&](int r) -> int32_t {   // 4 * intermediate + rounding, before the >> 2
     const uint32_t d0 = wrow[r * WSD], d1 = wrow[r * WSD + 1], d2 = wrow[r * WSD + 2];
-    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    int32_t acc = dot4_seed(lo, fx0, bias);
-    acc = __builtin_amdgcn_sdot4((int)hi, (int)fx1, acc, false);
-    return acc >> 2;
+    int32_t acc = dot4_seed(d0, t0, bias);
+    acc = __builtin_amdgcn_sdot4((int)d1, (int)t1, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)d2, (int)t2, acc, false);
+    return acc;
   };
   auto hpair = [&](int r) -> uint32_t {   // rows r, r+1 packed as i16 x 2
-    const int32_t m0 = hrow(r);
-    const int32_t m1 = r + 1 < H + 7 ? hrow(r + 1) : 0;
-    return __builtin_amdgcn_perm((uint32_t)m1, (uint32_t)m0, 0x05040100u);
+    // the last pair has no second row: its upper half only ever meets a zero tap (tz[4]'s high half)
+    if (r + 1 < H + 7) return ashr_pair<2>(hacc(r), hacc(r + 1));
+    return (uint32_t)(hacc(r) >> 2);
   };
   // rolling window of 5 packed pairs: output rows 2j and 2j+1 need the
   // intermediates 2j .. 2j+8
@@ -353,24 +371,25 @@ __device__ __forceinline__ void mc16_column_t(const uint8_t *win, int c, const T
   const int32_t maxv = (1 << bit_depth) - 1;
   constexpr int WSD = WS / 4;
   const uint32_t *wrow = (const uint32_t *)win + (c >> 1);
-  const uint32_t sh = (uint32_t)(c & 1) * 16;
-  auto hrow = [&](int r) -> int32_t {
+  // as in mc8_column_t the taps go to the pixels: the 8 x-taps shifted up by one i16 for odd
+  // columns into five dwords -- five v_dot2 per row on aligned LDS dwords (was 4 v_alignbit + 4)
+  const bool odd = c & 1;
+  uint32_t u[5];
+  u[0] = odd ? tx[0] << 16 : tx[0];
+#pragma unroll
+  for (int j = 1; j < 4; j++) u[j] = odd ? __builtin_amdgcn_alignbit(tx[j], tx[j - 1], 16) : tx[j];
+  u[4] = odd ? tx[3] >> 16 : 0u;
+  auto hacc = [&](int r) -> int32_t {
     const uint32_t *p = wrow + r * WSD;
-    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
-    const uint32_t q0 = __builtin_amdgcn_alignbit(d1, d0, sh);
-    const uint32_t q1 = __builtin_amdgcn_alignbit(d2, d1, sh);
-    const uint32_t q2 = __builtin_amdgcn_alignbit(d3, d2, sh);
-    const uint32_t q3 = __builtin_amdgcn_alignbit(d4, d3, sh);
-    int32_t acc = dot2_seed(q0, tx[0], hbias);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q1), __builtin_bit_cast(v2s, tx[1]), acc, false);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q2), __builtin_bit_cast(v2s, tx[2]), acc, false);
-    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, q3), __builtin_bit_cast(v2s, tx[3]), acc, false);
-    return acc >> hsh;
+    int32_t acc = dot2_seed(p[0], u[0], hbias);
+#pragma unroll
+    for (int j = 1; j < 5; j++)
+      acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p[j]), __builtin_bit_cast(v2s, u[j]), acc, false);
+    return acc;
   };
   auto hpair = [&](int r) -> uint32_t {   // rows r, r+1 packed as i16 x 2
-    const int32_t m0 = hrow(r);
-    const int32_t m1 = r + 1 < H + 7 ? hrow(r + 1) : 0;
-    return __builtin_amdgcn_perm((uint32_t)m1, (uint32_t)m0, 0x05040100u);
+    if (r + 1 < H + 7) return ashr_pair_rt(hacc(r), hacc(r + 1), hsh);
+    return (uint32_t)(hacc(r) >> hsh);
   };
   uint32_t pk[5];
 #pragma unroll
@@ -554,10 +573,14 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   R1_PROF_INIT;
   const int lane = threadIdx.x;
   const int cl = lane / P, c = lane % P;
-  const long long cand = (long long)blockIdx.x * NC + cl;
-  const bool live = cand < n;
+  // n < 2^31 candidates: the liveness test and the lane-local parts of every address are 32-bit;
+  // what is 64-bit is the workgroup's base (blockIdx.x * per-workgroup bytes), which the scalar
+  // unit computes
+  const int cand_i = (int)blockIdx.x * NC + cl;
+  const long long cand = cand_i;
+  const bool live = cand_i < n;
   R1RdoCand cd = {};
-  if (live) cd = cands[cand];
+  if (live) cd = (cands + (size_t)blockIdx.x * NC)[cl];
 #ifdef R1_PHASE_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   R1_PROF(5);   // A0: descriptor round trip
@@ -575,27 +598,50 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   for (int r = 0; r < H; r++) v[r] = 0;
   const bool col_live = live && c < W;
   const uint8_t *src_l = smem + WIN_PAD + cl * (H * SRC_ROW) + c * BPP;
+  // A.1: every global load the wave needs goes out before it waits for any of them -- source
+  // block, reference window, tap tables depend on the descriptor only (one round trip behind it,
+  // not three)
+  constexpr int CHS = SRC_ROW >= 16 ? 16 : SRC_ROW;      // source bytes per lane per pass
+  constexpr int CPR = SRC_ROW / CHS;                      // chunks per source row
+  constexpr int RPP = P / CPR;                            // rows per pass (P lanes per candidate)
+  constexpr int SPASS = SRC_LDS ? (H + RPP - 1) / RPP : 1;
+  const int srow = c / CPR, sch = c - srow * CPR;
+  U32x4 q[SPASS];
   if constexpr (SRC_LDS) {
-    constexpr int CHS = SRC_ROW >= 16 ? 16 : SRC_ROW;      // bytes per lane per pass
-    constexpr int CPR = SRC_ROW / CHS;                      // chunks per source row
-    constexpr int RPP = P / CPR;                            // rows per pass (P lanes per candidate)
-    constexpr int SPASS = (H + RPP - 1) / RPP;
-    const int srow = c / CPR, sch = c - srow * CPR;
-    if (live) {
-      const uint8_t *po = px_addr<BPP>(org, cd.ox, cd.oy) + sch * CHS;
-      const size_t so = (size_t)org.stride * BPP;
-      uint8_t *sd = smem + WIN_PAD + cl * (H * SRC_ROW) + sch * CHS;
-      U32x4 q[SPASS];
+    // planes are far below 4 GB: a 32-bit byte offset from the allocation's start
+    const uint8_t *po = (const uint8_t *)org.data +
+                        (((uint32_t)(org.yorigin + cd.oy) * (uint32_t)org.stride + (uint32_t)(org.xorigin + cd.ox)) * BPP +
+                         (uint32_t)(sch * CHS));
+    const uint32_t so = (uint32_t)org.stride * BPP;
 #pragma unroll
-      for (int u = 0; u < SPASS; u++) {
-        const int rr = srow + u * RPP;
-        q[u] = U32x4{0, 0, 0, 0};
-        if (rr < H) {
-          if constexpr (CHS == 16) q[u] = ld_u32x4(po + rr * so);
-          else if constexpr (CHS == 8) { const U32x2 t = ld_u32x2(po + rr * so); q[u].a = t.a; q[u].b = t.b; }
-          else q[u].a = ld_u32(po + rr * so);
-        }
+    for (int u = 0; u < SPASS; u++) {
+      const int rr = srow + u * RPP;
+      q[u] = U32x4{0, 0, 0, 0};
+      if (live && rr < H) {
+        if constexpr (CHS == 16) q[u] = ld_u32x4(po + rr * so);
+        else if constexpr (CHS == 8) { const U32x2 t = ld_u32x2(po + rr * so); q[u].a = t.a; q[u].b = t.b; }
+        else q[u].a = ld_u32(po + rr * so);
       }
+    }
+  } else if (col_live) {
+    const uint8_t *po = px_addr<BPP>(org, cd.ox + c, cd.oy);
+    const size_t so = (size_t)org.stride * BPP;
+#pragma unroll
+    for (int r = 0; r < H; r++) v[r] = ld_px<BPP>(po + r * so);
+  }
+  uint8_t *win = smem + cl * (H + 7) * WS;
+  const bool from_ref = live && !qa.pred_in;   // !pred_in is wave-uniform: kernel argument
+  r1mc::WindowStage<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P> wst;
+  if (from_ref) wst.load(ref, cd.rx, cd.ry, c);
+  typename std::conditional<BPP == 1, Taps8, Taps16>::type tp = {};
+  if (from_ref) {
+    if constexpr (BPP == 1) tp = load_taps8<W, H>(cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y);
+    else tp = load_taps16<W, H>(cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y);
+  }
+  // A.2: into LDS
+  if constexpr (SRC_LDS) {
+    if (live) {
+      uint8_t *sd = smem + WIN_PAD + cl * (H * SRC_ROW) + sch * CHS;
 #pragma unroll
       for (int u = 0; u < SPASS; u++) {
         const int rr = srow + u * RPP;
@@ -606,16 +652,8 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         }
       }
     }
-  } else if (col_live) {
-    const uint8_t *po = px_addr<BPP>(org, cd.ox + c, cd.oy);
-    const size_t so = (size_t)org.stride * BPP;
-#pragma unroll
-    for (int r = 0; r < H; r++) v[r] = ld_px<BPP>(po + r * so);
   }
-  uint8_t *win = smem + cl * (H + 7) * WS;
-  if (live && !qa.pred_in)   // wave-uniform: kernel argument
-    r1mc::stage_window_fast<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, P>(win, WS, ref, cd.rx,
-                                                                        cd.ry, c);
+  if (from_ref) wst.store(win, WS);
 #ifdef R1_PHASE_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   R1_PROF(6);   // A1: source column + window round trip (+ LDS writes issued)
@@ -626,7 +664,6 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   // ---- B: prediction column, residual, SAD / SATD ----
   uint32_t sad_acc = 0;
   if constexpr (BPP == 1) {
-    const bool any_cf0 = __any(live && cd.col_frac == 0);
     if (col_live) {
       int32_t pred[H];
       if (qa.pred_in) {
@@ -634,7 +671,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
         for (int r = 0; r < H; r++) pred[r] = pi[(size_t)r * W];
       } else {
-        mc8_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, any_cf0, pred);
+        mc8_column_t<W, H, WS, false>(win, c, tp, pred);
       }
       if (pred_out) {
         uint8_t *pp = (uint8_t *)pred_out + (size_t)cand * W * H + c;
@@ -665,7 +702,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
         for (int r = 0; r < H; r++) pred[r] = pi[(size_t)r * W];
       } else {
-        mc16_column<W, H, WS>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y, BD, pred);
+        mc16_column_t<W, H, WS, false>(win, c, tp, BD, pred);
       }
       if (pred_out) {
         uint16_t *pp = (uint16_t *)pred_out + (size_t)cand * W * H + c;
@@ -697,12 +734,12 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       for (int r = 0; r < H; r++) sad += (uint32_t)iabs32(v[r]);
     }
     const uint32_t s = group_sum<P>(sad);
-    if (live && c == 0) sad_out[cand] = s;
+    if (live && c == 0) (sad_out + (size_t)blockIdx.x * NC)[cl] = s;
   }
   if (satd_out) {
     const uint32_t s = group_sum<P>(satd_column<TS, H, BD>(v, lane));
     constexpr int LN = TS == 4 ? 2 : 3;
-    if (live && c == 0) satd_out[cand] = (s + ((1u << LN) >> 1)) >> LN;
+    if (live && c == 0) (satd_out + (size_t)blockIdx.x * NC)[cl] = (s + ((1u << LN) >> 1)) >> LN;
   }
   R1_PROF(2);   // B2: SAD + SATD
   if (!QUANT && !coeffs) return;   // wave-uniform: kernel argument
@@ -734,11 +771,13 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   if constexpr (!SPLIT_T) __syncthreads();
   R1_PROF(3);   // C: column transform, transpose written
   // ---- D: row transform, transposed store ----
-  const int cl2 = lane / P, r = lane % P;   // P lanes per candidate again
-  const long long cand2 = (long long)blockIdx.x * NC + cl2;
-  const bool live2 = cand2 < n;
+  // P lanes per candidate again: the lane that filtered column c of candidate cl now owns row c
+  // of the same candidate -- its descriptor is still in registers
+  const int cl2 = cl, r = c;
+  const long long cand2 = cand;
+  const bool live2 = live;
   const bool row_live = live2 && r < H;
-  const int tt = live2 ? cands[cand2].tx_type : 0;
+  const int tt = tx_type;
   constexpr int OS = H < 32 ? H : 32, WC = W < 32 ? W : 32;
   T u[W];
   if constexpr (SPLIT_T) {
@@ -767,13 +806,18 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     }
     r1tx::fwd_1d_m24<W>(u, r1tx::htx_1d(tt));
 #pragma unroll
-    for (int k = 0; k < W; k++) u[k] = (T)(CT)r1tx::shift_fwd_ct<SH2>(u[k]);   // `as T::Coeff`
+    for (int k = 0; k < W; k++) {
+      u[k] = r1tx::shift_fwd_ct<SH2>(u[k]);
+      // `as T::Coeff` (forward.rs:157): the stores below truncate by themselves; only the
+      // quantizer variants go on computing with the value
+      if constexpr (QUANT) u[k] = (T)(CT)u[k];
+    }
   }
   if constexpr (!R1_WIDE_STORE_POLICY(P)) {
     // large blocks: direct element stores (measured: the LDS detour costs more than the
     // 16-byte stores save at 32x32 and 64x64, profiles/r02_wide_store_ab.log)
     if (coeffs && row_live) {
-      CT *dst = coeffs + cand2 * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31);
+      CT *dst = coeffs + (size_t)blockIdx.x * (NC * W * H) + (cl2 * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31));
 #pragma unroll
       for (int cg = 0; cg < W; cg += 32)
 #pragma unroll
@@ -805,7 +849,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     static_assert(NC * (EPP + TPAD) * ESZ <= LDS_BYTES, "the padded tiles fit the LDS of the kernel");
     static_assert(((EPP + TPAD) * ESZ) % 16 == 0, "16-byte reads stay aligned");
     CT *tile = (CT *)smem + cl2 * (EPP + TPAD);
-    uint8_t *gdst = (uint8_t *)(coeffs + cand2 * (W * H));
+    uint8_t *gdst = (uint8_t *)(coeffs + (size_t)blockIdx.x * (NC * W * H)) + cl2 * (W * H * ESZ);
 #pragma unroll
     for (int p = 0; p < NP; p++) {
       __syncthreads();   // rows are in registers (pass 0) / the previous half has been copied out
@@ -1089,6 +1133,13 @@ int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n
   constexpr int W = 1 << WL, H = 1 << HL, P = W > H ? W : H, NC = 64 / P;
   typedef typename std::conditional<BD == 8, int16_t, int32_t>::type CT;
   const unsigned grid = (unsigned)((n + NC - 1) / NC);
+#ifdef R1_HEADLINE_ONLY   // experiment builds (tools/build_variant.sh): the headline instantiations only
+  if (qa) return R1_EINVAL;
+  hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, 0>), dim3(grid), dim3(64), 0, st,
+                     org, ref, cands, n, sad, satd, (CT *)coeffs, pred, RdoQuantArgs{});
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+#else
   if (qa && qa->pix_dist)
     hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, 2>), dim3(grid), dim3(64), 0, st,
                        org, ref, cands, n, sad, satd, (CT *)coeffs, pred, *qa);
@@ -1100,6 +1151,7 @@ int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n
                        org, ref, cands, n, sad, satd, (CT *)coeffs, pred, RdoQuantArgs{});
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
+#endif
 }
 
 }  // namespace
@@ -1124,6 +1176,9 @@ int r1_mc_fast_launch(bool prep, const R1Plane *ref, int w, int h, const R1McCan
   for (int t = 0; t < 19; t++)
     if ((1 << r1tx::kTxWLog2[t]) == w && (1 << r1tx::kTxHLog2[t]) == h) ts = t;
   if (ts < 0) return 1;
+#ifdef R1_HEADLINE_ONLY
+  return 1;
+#else
 #define R1_MF_CASE(ID, WL, HL)                                                         \
   case ID:                                                                             \
     return ref->bytes_per_px == 1 ? launch_mc_fast<1, WL, HL>(prep, *ref, cands, n, dst, st) \
@@ -1139,6 +1194,7 @@ int r1_mc_fast_launch(bool prep, const R1Plane *ref, int w, int h, const R1McCan
   }
 #undef R1_MF_CASE
   return 1;
+#endif
 }
 
 namespace {
@@ -1173,6 +1229,9 @@ int rdo_dispatch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w, int
                       : launch<12, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,  \
                                            coeffs, pred_out, qa, st);
   switch (tx_size) {
+#ifdef R1_HEADLINE_ONLY
+    R1_RC_CASE(1, 3, 3) R1_RC_CASE(2, 4, 4) R1_RC_CASE(3, 5, 5) R1_RC_CASE(4, 6, 6)
+#else
     R1_RC_CASE(0, 2, 2) R1_RC_CASE(1, 3, 3) R1_RC_CASE(2, 4, 4)
     R1_RC_CASE(3, 5, 5) R1_RC_CASE(4, 6, 6) R1_RC_CASE(5, 2, 3)
     R1_RC_CASE(6, 3, 2) R1_RC_CASE(7, 3, 4) R1_RC_CASE(8, 4, 3)
@@ -1180,6 +1239,7 @@ int rdo_dispatch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w, int
     R1_RC_CASE(12, 6, 5) R1_RC_CASE(13, 2, 4) R1_RC_CASE(14, 4, 2)
     R1_RC_CASE(15, 3, 5) R1_RC_CASE(16, 5, 3) R1_RC_CASE(17, 4, 6)
     R1_RC_CASE(18, 6, 4)
+#endif
   }
 #undef R1_RC_CASE
   return R1_EINVAL;

@@ -59,20 +59,30 @@ __device__ __forceinline__ T mul_rs(T a) {
 }  // namespace m24
 #undef TX1D_FN
 
-// 1-D transform classes: 0 DCT, 1 ADST, 2 FLIPADST, 3 IDTX, 4 WHT
+// 1-D transform classes: 0 DCT, 1 ADST, 2 FLIPADST, 3 IDTX, 4 WHT (VTX_TAB / HTX_TAB,
+// src/transform/mod.rs:364-402).  Two bits per tx_type 0..15 in one immediate (WHT = 16 apart):
+// a table in memory would be a dependent global load in the middle of a kernel.
+constexpr uint32_t pack_tx_tab(const uint8_t (&t)[16]) {
+  uint32_t v = 0;
+  for (int i = 0; i < 16; i++) v |= (uint32_t)t[i] << (2 * i);
+  return v;
+}
 __host__ __device__ inline int vtx_1d(int tx_type) {
-  constexpr uint8_t t[17] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3, 4};
-  return t[tx_type];
+  constexpr uint8_t t[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3};
+  constexpr uint32_t k = pack_tx_tab(t);
+  return tx_type == 16 ? 4 : (int)((k >> (2 * tx_type)) & 3u);
 }
 __host__ __device__ inline int htx_1d(int tx_type) {
-  constexpr uint8_t t[17] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2, 4};
-  return t[tx_type];
+  constexpr uint8_t t[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2};
+  constexpr uint32_t k = pack_tx_tab(t);
+  return tx_type == 16 ? 4 : (int)((k >> (2 * tx_type)) & 3u);
 }
+// get_flip_cfg (src/transform/forward_shared.rs:155-164) as bit masks over tx_type
 __host__ __device__ inline bool ud_flip(int tx_type) {
-  return tx_type == 4 || tx_type == 8 || tx_type == 14 || tx_type == 6;
+  return ((1u << 4 | 1u << 8 | 1u << 14 | 1u << 6) >> tx_type) & 1u;
 }
 __host__ __device__ inline bool lr_flip(int tx_type) {
-  return tx_type == 5 || tx_type == 7 || tx_type == 15 || tx_type == 6;
+  return ((1u << 5 | 1u << 7 | 1u << 15 | 1u << 6) >> tx_type) & 1u;
 }
 
 static const uint8_t kTxWLog2[19] = {2, 3, 4, 5, 6, 2, 3, 3, 4, 4,

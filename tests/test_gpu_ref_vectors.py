@@ -159,6 +159,34 @@ def test_comm_c_abi_single_rank(ctx):
     comm.close()
 
 
+def test_lookahead_ref_maps_and_importances(ctx):
+    """N1 against the executed reference text (lookahead_ref.npz: estimate_intra_costs,
+    estimate_importance_block_difference, the cost loop of estimate_inter_costs,
+    update_block_importances -- src/api/lookahead.rs:30-267, src/api/internal.rs:912-1068)."""
+    import torch
+    G = np.load(os.path.join(GOLD, "lookahead_ref.npz"))
+    for k in G["keys"]:
+        k = str(k)
+        bd, w, h = [int(v) for v in k.split("_")[:3]]
+        hb, wb = h // 8, w // 8
+        org, ref = O.plane_from_image(G["org_" + k], bd, 16, 16), O.plane_from_image(G["ref_" + k], bd, 16, 16)
+        do, dr = dev_plane(org), dev_plane(ref)
+        intra = ctx.estimate_intra_costs(do)
+        assert np.array_equal(intra.cpu().numpy().view(np.uint32), G["intra_" + k]), k
+        assert ctx.importance_block_difference(do, dr) == float(G["blockdiff_" + k][0]), k
+        mvs = torch.from_numpy(np.ascontiguousarray(G["mv_" + k])).cuda()
+        inter = ctx.estimate_inter_costs(do, dr, mvs)
+        tot = int(inter.cpu().numpy().view(np.uint32).astype(np.uint64).sum())
+        assert tot / (wb * hb) == float(G["inter_mean_" + k][0]), k
+        fut = torch.from_numpy(np.ascontiguousarray(G["future_" + k])).cuda()
+        for ln in (1, 4):
+            acc = torch.from_numpy(np.ascontiguousarray(G["refimp_in_%d_%s" % (ln, k)]).copy()).cuda()
+            ctx.update_block_importances(intra.reshape(-1), fut.reshape(-1), inter.reshape(-1),
+                                         mvs.reshape(-1, 2), wb, hb, ln, acc.reshape(-1))
+            want = G["refimp_out_%d_%s" % (ln, k)]
+            assert np.array_equal(acc.cpu().numpy().view(np.uint32), want.view(np.uint32)), (k, ln)
+
+
 # ---- N2: motion estimation against the executed src/me.rs text (gen_me_ref.py) ----------
 def _me_ref_cases():
     M = np.load(os.path.join(GOLD, "me_ref.npz"))

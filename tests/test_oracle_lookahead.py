@@ -1,6 +1,6 @@
-"""Lookahead cost maps of the oracle (src/api/lookahead.rs:30-268): definition
-checks on small frames (the reference holds no vectors for these; they are
-compositions of get_intra_edges / DC_PRED / get_satd, each pinned elsewhere)."""
+"""Lookahead cost maps of the oracle (src/api/lookahead.rs:30-268): definition checks on small
+frames.  The pin is tests/test_oracle_lookahead_ref.py (vectors from executing the reference's
+text); these stay as a second, independent statement."""
 import ctypes as C
 
 import numpy as np
@@ -25,15 +25,9 @@ def test_intra_costs_definition(oracle):
     for by in range(3):
         for bx in range(5):
             blk = img[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8]
-            if bx == 0 and by == 0:
-                dc = 128
-            elif by == 0:
-                dc = (img[0:8, bx * 8 - 1].sum() + 4) // 8
-            elif bx == 0:
-                dc = (img[by * 8 - 1, 0:8].sum() + 4) // 8
-            else:
-                dc = (img[by * 8:by * 8 + 8, bx * 8 - 1].sum() + img[by * 8 - 1, bx * 8:bx * 8 + 8].sum() + 8) // 16
-            assert got[by * 5 + bx] == satd8(blk - dc), (bx, by)
+            # the block is the origin of the TileRect the reference hands to predict_intra
+            # (lookahead.rs:84-89): PredictionVariant::NONE, pred_dc_128, everywhere
+            assert got[by * 5 + bx] == satd8(blk - 128), (bx, by)
 
 
 def test_inter_costs_and_block_difference(oracle):

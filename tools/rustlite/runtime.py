@@ -44,6 +44,31 @@ def f32(x):
     return _struct.unpack("f", _struct.pack("f", x))[0]
 
 
+class F32(float):
+    """A Rust f32 value: every arithmetic operation it takes part in is rounded to f32 (IEEE
+    single precision, one operation at a time -- Rust never contracts or re-associates).  The
+    operation is carried out in f64 and rounded once more, which for + - * / of two f32 operands
+    is the correctly rounded f32 result (53 >= 2 * 24 + 2 bits).  Untyped float literals are plain
+    Python floats and adapt to the F32 operand, as Rust's literal inference does; an f64 never
+    meets an f32 without an `as` cast in Rust source."""
+    __slots__ = ()
+
+    def __new__(cls, v=0.0):
+        return float.__new__(cls, f32(float(v)))
+
+    def __add__(self, o): return F32(float(self) + float(o))
+    def __radd__(self, o): return F32(float(o) + float(self))
+    def __sub__(self, o): return F32(float(self) - float(o))
+    def __rsub__(self, o): return F32(float(o) - float(self))
+    def __mul__(self, o): return F32(float(self) * float(o))
+    def __rmul__(self, o): return F32(float(o) * float(self))
+    def __truediv__(self, o): return F32(float(self) / float(o))
+    def __rtruediv__(self, o): return F32(float(o) / float(self))
+    def __neg__(self): return F32(-float(self))
+    def __abs__(self): return F32(abs(float(self)))
+    def __repr__(self): return "F32(%r)" % float(self)
+
+
 def cast(v, t):
     """Rust `v as t`."""
     if t in INT_BITS:
@@ -60,7 +85,7 @@ def cast(v, t):
     if t == "f64":
         return float(v)
     if t == "f32":
-        return f32(float(v))
+        return F32(float(v))
     if t == "bool":
         return bool(v)
     if t == "char":

@@ -129,6 +129,19 @@ class Crate:
         self.files[rel] = (p, items)
         self._register(items, p, (), rel)
 
+    def load_text(self, name, text):
+        """Rust source text that is not a file of the tree: a function wrapped around a SLICE of a
+        reference function's lines (the generator states which lines, and what the wrapper
+        replaces), parsed and registered like a file."""
+        from .lexer import lex
+        from .parser import Parser
+        if name in self.files:
+            return
+        p = Parser(lex(text), name)
+        items = p.parse_items()
+        self.files[name] = (p, items)
+        self._register(items, p, (), name)
+
     def _register(self, items, p, modpath, fname, owner=None, owner_gens=(), trait=None):
         for it in items:
             if any("cfg ( test )" in a or "cfg(test)" in a.replace(" ", "") for a in it.attrs):
@@ -2075,6 +2088,12 @@ class FnCompiler:
                     return "0"
             exp = self.strip(self.expected)
             if exp is None:
+                if a == "Aligned" and name == "uninit_array":
+                    # `let mut edge_buf = Aligned::uninit_array();` -- the type comes from the later
+                    # call (inference this transpiler does not do).  Every such site of the reference
+                    # is an IntraEdgeBuffer = Aligned<[MaybeUninit<T>; 4 * MAX_TX_SIZE + 1]>
+                    # (src/partition.rs:600; api/lookahead.rs:57, encoder.rs:1476, rdo.rs:1437,1624)
+                    return "R.Aligned(_S([0] * 257))"
                 return "None"
             d = self.default_for(exp, uninit=True)
             return "R.Aligned(%s)" % d if (a == "Aligned" and name == "uninitialized") else d
