@@ -16,9 +16,8 @@ behaviour and a whole pass of a 2-D transform is one call.  This is the
 second, independent restatement next to oracle/fwd_tx.c (array/index style,
 fast); tests/test_oracle_fwd_tx.py requires the two to agree bit for bit.
 
-Parity status: the reference stores no forward-transform coefficients
-("parity unpinned" by golden vectors); this file is pinned by
-tests/golden/fwd_tx_*.npz (vectors obtained in the build container by
+Parity status: the reference stores no forward-transform coefficients of its own
+(SURVEY.md 8c); this file is pinned by tests/golden/fwd_tx_*.npz (vectors obtained in the build container by
 executing the reference's own source text, see tests/golden/README.md), by
 closeness to the real-valued DCT/ADST and by fwd->inv round trips.
 """

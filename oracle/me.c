@@ -16,12 +16,12 @@
  *   get_subpel_mv_rd 1411-1443 (+ PredictionMode::get_mv_params src/predict.rs:284-297)
  * MotionVector arithmetic: src/mc.rs:28-100 (i16 components, 1/8 pel).
  *
- * PARITY UNPINNED: the reference holds no test vectors for me.rs (no #[test]
- * in the file, no golden MVs anywhere in the tree) and cannot be built here
- * (Rust).  This file is a line-by-line restatement; the GPU path is checked
- * against it, and both against the structural properties in
- * tests/test_oracle_me.py (zero-motion and pure-translation recovery,
- * monotone cost, range clamping).
+ * Pinning: the reference holds no test vectors for me.rs (no #[test] in the file) and cannot be
+ * built here (Rust); the vectors come from EXECUTING its source text (tools/rustlite):
+ * tests/golden/me_ref.npz (gen_me_ref.py -- 14 tile searches, 37 block searches with the sub-pel
+ * diamond), reproduced entry by entry in tests/test_oracle_me_ref.py.  The structural properties
+ * in tests/test_oracle_me.py (zero-motion and pure-translation recovery, monotone cost, range
+ * clamping) and the second restatement tests/me_model.py stay as independent checks.
  *
  * Planes: index 0 = full resolution, 1 = half, 2 = quarter (FrameState
  * input_hres / input_qres, src/encoder.rs:412-413, produced by v_frame's

@@ -7,15 +7,12 @@
  * or call it, and only as the checker / the timed CPU baseline.  The product
  * (rav1e_amd/csrc, librav1e_hip.so) never includes or links anything here.
  *
- * Pinning status (see DESIGN.md "Oracle"):
- *   - get_sad / get_satd: pinned by the reference's own known-answer tables
- *     (src/dist.rs:418-441, 477-500), reproduced in tests/test_oracle_dist.py.
- *   - forward transform, put/prep_8tap, mc_avg, weighted SSE, cdef_dist:
- *     the reference holds no golden vectors for these ("parity unpinned" by
- *     constants); pinned here by spec properties (float DCT/ADST closeness,
- *     fwd->inv round trip tolerances of src/transform/mod.rs:555-603,
- *     filter-tap normalisation) and by tests/golden/ vectors produced in the
- *     build container from the reference source text (see tests/golden/README).
+ * Pinning status (DESIGN.md section 4 has the table): every function a GPU test compares against
+ * reproduces either known answers the reference itself holds (get_sad / get_satd: src/dist.rs:418-500;
+ * 4x4 intra prediction: src/predict.rs:1523-1693; estimate_rate: src/rdo.rs:2749) or vectors made by
+ * EXECUTING the reference's source text in the build container (tools/rustlite,
+ * tests/golden/gen_*_ref.py -> tests/golden/*_ref.npz; tests/test_oracle_*_ref.py).  Exception:
+ * Plane::pad / Plane::downsampled restate the un-vendored v_frame 0.3.9 crate (oracle/plane.c).
  *
  * Conventions: strides are in ELEMENTS (not bytes); `hbd` != 0 means the
  * pixel type is u16 (rav1e Pixel = u16), else u8.  Pointers address the
@@ -190,7 +187,7 @@ void r1o_update_block_importances(const uint32_t *intra_costs, const float *futu
 /* hierarchical motion estimation of one tile against one reference
  * (src/me.rs:153-335, see oracle/me.c).  org3 / ref3: [full, half, quarter]
  * resolution planes; stats: FrameMEStats of this reference (in/out), prev: the
- * previous frame's (EPZS subset C) or NULL.  PARITY UNPINNED (no reference vectors). */
+ * previous frame's (EPZS subset C) or NULL.  Pinned by me_ref.npz (executed src/me.rs text). */
 typedef struct { int16_t row, col; uint32_t normalized_sad; } r1o_me_stats;
 typedef struct {
   int32_t w_in_b, h_in_b;                 /* fi.w_in_b / fi.h_in_b: frame size in 4x4 units */

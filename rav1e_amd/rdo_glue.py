@@ -1,0 +1,93 @@
+"""Host-side glue of the RDO path: the small pieces of encoder logic that sit between the
+reference's callers and the batch entry points -- descriptor arithmetic, no pixels.  Each function
+restates a reference function (file:line); tests/golden/rdo_glue_ref.npz pins them together with
+the kernels by executing the reference's own text (tests/golden/gen_rdo_glue_ref.py).
+
+  get_mv_params              src/predict.rs:284-297   (MV -> integer offset + 1/16-pel fractions)
+  clip_visible_bsize         src/rdo.rs:228-251
+  luma_ac_pads               src/predict.rs:644-688   (luma_ac's w_pad / h_pad and its luma offset)
+  largest_chroma_tx_size     src/partition.rs:385-393
+  chroma_dist_dims           src/rdo.rs:404-413       (chroma_w / chroma_h of compute_tx_distortion)
+  scale_distortion           src/rdo.rs:613-615,674-695   (RawDistortion * DistortionScale -> mul_u64)
+  compute_tx_distortion      src/rdo.rs:349-434       (composition; the SSE comes from a callable:
+                                                       Context.dist_scaled_batch on the GPU)
+"""
+from .types import BlockSize, TxSize
+
+MI_SIZE_LOG2 = 2
+DIST_SCALE_SHIFT = 14
+
+
+def get_mv_params(mv_row, mv_col, po_x, po_y, xdec=0, ydec=0):
+    """-> (row_frac, col_frac, x, y): put_8tap / prep_8tap read the block whose top-left pixel is
+    (x, y) (the reference slices at (x - 3, y - 3) and steps 3 in: the filter's own margin)"""
+    row_offset = mv_row >> (3 + ydec)
+    col_offset = mv_col >> (3 + xdec)
+    row_frac = (mv_row << (1 - ydec)) & 0xf
+    col_frac = (mv_col << (1 - xdec)) & 0xf
+    return row_frac, col_frac, po_x + col_offset, po_y + row_offset
+
+
+def clip_visible_bsize(frame_w, frame_h, blk_w, blk_h, x, y):
+    vw = blk_w if x + blk_w <= frame_w else (0 if x >= frame_w else frame_w - x)
+    vh = blk_h if y + blk_h <= frame_h else (0 if y >= frame_h else frame_h - y)
+    return vw, vh
+
+
+def largest_chroma_tx_size(bsize, xdec, ydec):
+    """TxSize of the chroma transform block of a luma partition: the subsampled block size, its
+    largest rectangular transform, 64-point sides coded as 32 (av1_get_coded_tx_size)"""
+    w, h = BlockSize(bsize).dims
+    cw, ch = max(4, w >> xdec), max(4, h >> ydec)     # subsampled_size: sub-8x8 blocks share a 4x4
+    return TxSize.by_dims(min(cw, 32), min(ch, 32))
+
+
+def luma_ac_pads(bsize, luma_tx_size, bo_x, bo_y, w_in_b, h_in_b, xdec, ydec):
+    """luma_ac: (w_pad, h_pad, luma_x, luma_y) -- pads in 4-pixel units of the chroma block, and the
+    luma position pred_cfl_ac reads (sub-8x8 partitions read from the 8x8 that contains them)"""
+    bw, bh = BlockSize(bsize).dims
+    if (xdec and bw == 4) or (ydec and bh == 4):          # is_sub8x8 -> sub8x8_offset
+        bo_x += -1 if (xdec and bw == 4) else 0
+        bo_y += -1 if (ydec and bh == 4) else 0
+    clipped_bw = min((w_in_b - bo_x) << MI_SIZE_LOG2, bw)
+    clipped_bh = min((h_in_b - bo_y) << MI_SIZE_LOG2, bh)
+    tw, th = TxSize(luma_tx_size).dims
+    max_luma_w = ((clipped_bw + tw - 1) // tw) * tw if bw > 8 else bw
+    max_luma_h = ((clipped_bh + th - 1) // th) * th if bh > 8 else bh
+    return (bw - max_luma_w) >> (2 + xdec), (bh - max_luma_h) >> (2 + ydec), bo_x << MI_SIZE_LOG2, bo_y << MI_SIZE_LOG2
+
+
+def chroma_dist_dims(bsize, visible_w, visible_h, xdec, ydec):
+    bw, bh = BlockSize(bsize).dims
+    cw = (visible_w + xdec) >> xdec if (bw >= 8 or xdec == 0) else (4 + visible_w + xdec) >> xdec
+    ch = (visible_h + ydec) >> ydec if (bh >= 8 or ydec == 0) else (4 + visible_h + ydec) >> ydec
+    return cw, ch
+
+
+def scale_distortion(dist, scale_q14):
+    """Distortion * DistortionScale (mul_u64): (scale * dist + 2^13) >> 14"""
+    return (int(scale_q14) * int(dist) + (1 << DIST_SCALE_SHIFT >> 1)) >> DIST_SCALE_SHIFT
+
+
+def compute_tx_distortion(sse_wxh, frame_w, frame_h, bsize, is_chroma_block, bo_x, bo_y, tx_dist, skip,
+                          luma_only, dist_scale, xdec=1, ydec=1, monochrome=False):
+    """compute_tx_distortion for one block.  sse_wxh(plane_index, x, y, w, h) -> the RawDistortion
+    of sse_wxh on that plane at plane position (x, y) (r1_dist_scaled_batch, kind WSSE; the per-
+    block bias of temporal RDO is inside it).  tx_dist: the ScaledDistortion the transform blocks
+    accumulated.  dist_scale: fi.dist_scale (three Q14 values)."""
+    bw, bh = BlockSize(bsize).dims
+    if not skip:
+        vw, vh = bw, bh
+    else:
+        vw, vh = clip_visible_bsize(frame_w, frame_h, bw, bh, bo_x << MI_SIZE_LOG2, bo_y << MI_SIZE_LOG2)
+    if vw == 0 or vh == 0:
+        return 0
+    x, y = bo_x << MI_SIZE_LOG2, bo_y << MI_SIZE_LOG2
+    dist = scale_distortion(sse_wxh(0, x, y, vw, vh), dist_scale[0]) if skip else int(tx_dist)
+    if is_chroma_block and not luma_only and skip and not monochrome:
+        cw, ch = chroma_dist_dims(bsize, vw, vh, xdec, ydec)
+        # Area::BlockStartingAt on a decimated plane: (bo >> dec) << 2 (tiling/plane_region.rs:100-108)
+        cx, cy = (bo_x >> xdec) << MI_SIZE_LOG2, (bo_y >> ydec) << MI_SIZE_LOG2
+        for p in (1, 2):
+            dist += scale_distortion(sse_wxh(p, cx, cy, cw, ch), dist_scale[p])
+    return dist

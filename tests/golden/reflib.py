@@ -30,6 +30,17 @@ def crate(*files):
     return c
 
 
+# Types of the un-vendored v_frame 0.3.9 crate that reference code names (Cargo.lock:2075-2077);
+# restated, not executed: variant order as in v_frame::pixel::ChromaSampling.
+V_FRAME_TEXT = """
+pub enum ChromaSampling { Cs420, Cs422, Cs444, Cs400 }
+"""
+
+
+def load_v_frame_types(c):
+    c.load_text("<v_frame 0.3.9: ChromaSampling>", V_FRAME_TEXT)
+
+
 def pixel_type(bd):
     return {"T": "u8" if bd == 8 else "u16"}
 

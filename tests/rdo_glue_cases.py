@@ -1,0 +1,114 @@
+"""Shared driver of tests/test_oracle_rdo_glue_ref.py and the GPU test of the same vectors
+(tests/golden/rdo_glue_ref.npz, produced by executing the reference's text:
+tests/golden/gen_rdo_glue_ref.py).  A backend supplies the kernels: the CPU oracle or the C ABI."""
+import os
+
+import numpy as np
+
+import oracle_lib as O
+from rav1e_amd import rdo_glue as RG
+from rav1e_amd.types import BlockSize, TxSize
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "rdo_glue_ref.npz")
+TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+
+
+def check_tx_blocks(G, full_cand):
+    """encode_tx_block (TxDistEstRate): full_cand(bd, ts, tt, qidx, src_plane, pred_plane) ->
+    (tx_dist, est_rate) of the zero-motion candidate at (8, 8)"""
+    n = 0
+    for k in G["tb_keys"]:
+        k = str(k)
+        bd, ts, tt, qidx = [int(v) for v in k.split("_")]
+        w, h = TX_W[ts], TX_H[ts]
+        src = O.HostPlane(w + 16, h + 16, bd, 16, 16)
+        pred = O.HostPlane(w + 16, h + 16, bd, 16, 16)
+        src.view()[8:8 + h, 8:8 + w] = G["tb_src_" + k]
+        pred.view()[8:8 + h, 8:8 + w] = G["tb_pred_" + k]
+        got = full_cand(bd, ts, tt, qidx, src, pred)
+        want = G["tb_out_" + k]
+        assert (int(got[0]), int(got[1])) == (int(want[0]), int(want[1])), (k, got, want)
+        n += 1
+    return n
+
+
+def check_compute_tx_distortion(G, make_sse):
+    """make_sse(bd, planes_src, planes_rec) -> sse_wxh(plane, x, y, w, h)"""
+    n = 0
+    for bd in G["td_keys"]:
+        bd = int(bd)
+        srcs = [O.plane_from_image(G["td_src_%d_%d" % (bd, p)], bd, 16 >> (1 if p else 0), 16 >> (1 if p else 0))
+                for p in range(3)]
+        recs = [O.plane_from_image(G["td_rec_%d_%d" % (bd, p)], bd, 16 >> (1 if p else 0), 16 >> (1 if p else 0))
+                for p in range(3)]
+        sse = make_sse(bd, srcs, recs)
+        scales = [int(v) for v in G["td_scales_%d" % bd]]
+        fw, fh = srcs[0].width, srcs[0].height
+        for row in G["td_rows_%d" % bd]:
+            bw, bh, bx, by, skip, luma_only, is_chroma, txd, want = [int(v) for v in row]
+            bs = BlockSize["BLOCK_%dX%d" % (bw, bh)]
+            got = RG.compute_tx_distortion(sse, fw, fh, bs, bool(is_chroma), bx, by, txd, bool(skip),
+                                           bool(luma_only), scales, 1, 1)
+            assert got == want, (bd, tuple(int(v) for v in row), got)
+            n += 1
+    return n
+
+
+def check_cfl_alpha(G, alpha_search):
+    """alpha_search(bd, xdec, ydec, planes_src, planes_rec, uv_tx_size, pli, cx, cy, luma_x, luma_y,
+    w_pad, h_pad, vis_w, vis_h, variant) -> alpha"""
+    n = 0
+    for k0 in G["cfl_keys"]:
+        k0 = str(k0)
+        bd = int(k0.split("_")[0])
+        xdec, ydec = [int(v) for v in G["cfl_dec_" + k0]]
+        srcs, recs = [], []
+        for p in range(3):
+            xd, yd = (xdec, ydec) if p else (0, 0)
+            srcs.append(O.plane_from_image(G["cfl_src_%s_%d" % (k0, p)], bd, 16 >> xd, 16 >> yd))
+            recs.append(O.plane_from_image(G["cfl_rec_%s_%d" % (k0, p)], bd, 16 >> xd, 16 >> yd))
+        fw, fh = srcs[0].width, srcs[0].height
+        for row in G["cfl_rows_" + k0]:
+            bw, bh, lts, bx, by, au, av = [int(v) for v in row]
+            bs = BlockSize["BLOCK_%dX%d" % (bw, bh)]
+            uv_ts = RG.largest_chroma_tx_size(bs, xdec, ydec)
+            tw, th = TxSize(uv_ts).dims
+            cx, cy = (bx << 2) >> xdec, (by << 2) >> ydec
+            vw, vh = RG.clip_visible_bsize((fw + xdec) >> xdec, (fh + ydec) >> ydec, tw, th, cx, cy)
+            w_pad, h_pad, lx, ly = RG.luma_ac_pads(bs, lts, bx, by, (fw + 3) // 4, (fh + 3) // 4, xdec, ydec)
+            variant = 0 if (cx == 0 and cy == 0) else (1 if cy == 0 else (2 if cx == 0 else 3))
+            for pli, want in ((1, au), (2, av)):
+                got = alpha_search(bd, xdec, ydec, srcs, recs, int(uv_ts), pli, cx, cy, lx, ly, w_pad, h_pad,
+                                   vw, vh, variant)
+                assert int(got) == want, (k0, tuple(int(v) for v in row), pli, got)
+                n += 1
+    return n
+
+
+def check_compound(G, compound):
+    """compound(bd, filter_mode, ref_planes, w, h, (x0, y0, col_frac0, row_frac0), (x1, ...)) -> (h, w)"""
+    n = 0
+    for k in G["pic_keys"]:
+        k = str(k)
+        bd, filt = int(k.split("_")[0]), {"REGULAR": 0, "SHARP": 2}[k.split("_")[1]]
+        refs = []
+        for i in range(2):
+            pad = G["pic_ref%d_%d" % (i, bd)]
+            hp = O.HostPlane(pad.shape[1] - 48, pad.shape[0] - 48, bd, 24, 24)
+            hp.data[hp.yorigin - 24:hp.yorigin + hp.height + 24, hp.xorigin - 24:hp.xorigin + hp.width + 24] = pad
+            refs.append(hp)
+        preds = G["pic_pred_" + k]
+        off = 0
+        for row in G["pic_rows_" + k]:
+            w, h, x, y, r0, c0, r1, c1, _ = [int(v) for v in row]
+            ps = []
+            for (mr, mc) in ((r0, c0), (r1, c1)):
+                rf, cf, px, py = RG.get_mv_params(mr, mc, x, y)
+                ps.append((px, py, cf, rf))
+            got = np.asarray(compound(bd, filt, refs, w, h, ps[0], ps[1])).reshape(h, w)
+            want = preds[off:off + w * h].reshape(h, w)
+            off += w * h
+            assert np.array_equal(got.astype(np.int64), want.astype(np.int64)), (k, tuple(int(v) for v in row))
+            n += 1
+    return n

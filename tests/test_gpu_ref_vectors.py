@@ -187,6 +187,96 @@ def test_lookahead_ref_maps_and_importances(ctx):
             assert np.array_equal(acc.cpu().numpy().view(np.uint32), want.view(np.uint32)), (k, ln)
 
 
+# ---- N4 glue against the executed reference text (gen_rdo_glue_ref.py) ----------------------
+def test_rdo_glue_ref_tx_block_rate_and_distortion(ctx):
+    """encode_tx_block's TxDistEstRate evaluation (src/encoder.rs:1404-1661) as executed from the
+    reference's text: r1_rdo_full_cand_batch on the zero-motion candidate reproduces the
+    transform-domain distortion and estimate_rate's value of every case."""
+    import rdo_glue_cases as RC
+    from rav1e_amd.api import RDO_CAND
+    G = np.load(RC.GOLD)
+
+    def full_cand(bd, ts, tt, qidx, src, pred):
+        w, h = RC.TX_W[ts], RC.TX_H[ts]
+        c = np.zeros(1, RDO_CAND)
+        c["ox"], c["oy"], c["rx"], c["ry"], c["tx_type"] = 8, 8, 8, 8, tt
+        o = ctx.rdo_full_cand_batch(dev_plane(src), dev_plane(pred), w, h, c, qidx, is_intra=0)
+        return int(o["tx_dist"].cpu().numpy().view(np.uint64)[0]), int(o["est_rate"].cpu().numpy().view(np.uint64)[0])
+    assert RC.check_tx_blocks(G, full_cand) == 156
+
+
+def test_rdo_glue_ref_compute_tx_distortion(ctx):
+    """compute_tx_distortion (src/rdo.rs:349-434): rav1e_amd.rdo_glue's composition over
+    r1_dist_scaled_batch (sse_wxh)"""
+    import rdo_glue_cases as RC
+    from rav1e_amd.api import DIST_CAND
+    G = np.load(RC.GOLD)
+
+    def make_sse(bd, srcs, recs):
+        ds, dr = [dev_plane(p) for p in srcs], [dev_plane(p) for p in recs]
+
+        def sse(p, x, y, w, h):
+            c = np.zeros(1, DIST_CAND)
+            c["ox"], c["oy"], c["rx"], c["ry"] = x, y, x, y
+            dec = 1 if p else 0
+            return int(ctx.dist_scaled_batch(2, ds[p], dr[p], w, h, c, None, dec, dec).cpu().numpy().view(np.uint64)[0])
+        return sse
+    assert RC.check_compute_tx_distortion(G, make_sse) == 2 * 11 * 8
+
+
+def test_rdo_glue_ref_cfl_alpha(ctx):
+    """rdo_cfl_alpha (src/rdo.rs:1593-1688) as executed from the reference's text: luma_ac ->
+    get_intra_edges -> the 33-alpha search, through r1_cfl_ac_batch / r1_intra_edges_batch /
+    r1_cfl_alpha_search_batch with rav1e_amd.rdo_glue's descriptor arithmetic."""
+    import rdo_glue_cases as RC
+    from rav1e_amd.api import CFL_AC_CAND, CFL_ALPHA_CAND, INTRA_EDGE_CAND
+    G = np.load(RC.GOLD)
+    cache = {}
+
+    def alpha_search(bd, xdec, ydec, srcs, recs, uv_ts, pli, cx, cy, lx, ly, w_pad, h_pad, vw, vh, variant):
+        key = id(srcs)
+        if key not in cache:
+            cache.clear()
+            cache[key] = ([dev_plane(p) for p in srcs], [dev_plane(p) for p in recs])
+        ds, dr = cache[key]
+        tw, th = RC.TX_W[uv_ts], RC.TX_H[uv_ts]
+        ec = np.zeros(1, INTRA_EDGE_CAND)
+        ec["x"], ec["y"], ec["mode"], ec["flags"] = cx, cy, 13, 1
+        rec = recs[pli]
+        edges, lens = ctx.intra_edges_batch(dr[pli], (0, 0, rec.width, rec.height), uv_ts, ec)
+        ac_c = np.zeros(1, CFL_AC_CAND)
+        ac_c["x"], ac_c["y"], ac_c["w_pad"], ac_c["h_pad"] = lx, ly, w_pad, h_pad
+        ac = ctx.cfl_ac_batch(dr[0], tw, th, xdec, ydec, ac_c)
+        cc = np.zeros(1, CFL_ALPHA_CAND)
+        cc["x"], cc["y"], cc["variant"], cc["vis_w"], cc["vis_h"] = cx, cy, variant, vw, vh
+        alpha, _ = ctx.cfl_alpha_search_batch(ds[pli], uv_ts, cc, edges, lens, ac)
+        return int(alpha.cpu().numpy()[0])
+    assert RC.check_cfl_alpha(G, alpha_search) == 4 * 8 * 2
+
+
+def test_rdo_glue_ref_predict_inter_compound(ctx):
+    """predict_inter_compound (src/predict.rs:339-382): get_mv_params on the host, prep_8tap x 2
+    and mc_avg on the device"""
+    import rdo_glue_cases as RC
+    from rav1e_amd.api import MC_CAND
+    G = np.load(RC.GOLD)
+    cache = {}
+
+    def compound(bd, filt, refs, w, h, p0, p1):
+        key = id(refs[0])
+        if key not in cache:
+            cache.clear()
+            cache[key] = [dev_plane(p) for p in refs]
+        tmps = []
+        for dp, (x, y, cf, rf) in zip(cache[key], (p0, p1)):
+            c = np.zeros(1, MC_CAND)
+            c["rx"], c["ry"], c["col_frac"], c["row_frac"], c["mode_x"], c["mode_y"] = x, y, cf, rf, filt, filt
+            tmps.append(ctx.prep_8tap_batch(dp, w, h, c))
+        out = ctx.mc_avg_batch(tmps[0], tmps[1], w, h, bd)
+        return out.cpu().numpy().view(np.uint8 if bd == 8 else np.uint16)
+    assert RC.check_compound(G, compound) == 3 * 2 * 21
+
+
 # ---- N2: motion estimation against the executed src/me.rs text (gen_me_ref.py) ----------
 def _me_ref_cases():
     M = np.load(os.path.join(GOLD, "me_ref.npz"))

@@ -161,6 +161,8 @@ class Parser:
         return self.parse_path(in_type=True)
 
     def parse_bounds(self):
+        """-> the trait names of the bound list (last path segment each)"""
+        names = []
         while True:
             self.eat("?")
             if self.peek().k == "life":
@@ -168,13 +170,16 @@ class Parser:
             elif self.at("("):
                 self.skip_balanced("(", ")")
             else:
-                self.parse_path(in_type=True)
+                pth = self.parse_path(in_type=True)
+                if getattr(pth, "segs", None):
+                    names.append(pth.segs[-1])
                 if self.at("("):  # Fn(A) -> B
                     self.skip_balanced("(", ")")
                     if self.eat("->"):
                         self.parse_type()
             if not self.eat("+"):
                 break
+        return names
 
     def parse_generic_args(self):
         """after `<`; returns list of N (types / const exprs / lifetimes dropped)."""
@@ -258,11 +263,10 @@ class Parser:
                 out.append(("const", name, ty))
             else:
                 name = self.ident()
-                if self.eat(":"):
-                    self.parse_bounds()
+                bounds = self.parse_bounds() if self.eat(":") else []
                 if self.eat("="):
                     self.parse_type()
-                out.append(("type", name, None))
+                out.append(("type", name, tuple(bounds)))
             if not self.eat(","):
                 break
         self.split_shift()

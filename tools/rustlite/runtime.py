@@ -1264,6 +1264,18 @@ def _align(v, a):
     return (v + a - 1) // a * a
 
 
+class PlaneData(list):
+    """Plane::data (a PlaneData<T> that derefs to [T]) where reference code slices it directly
+    (`&plane.data[..]`): a list that also takes Rust ranges"""
+
+    def __getitem__(self, i):
+        if type(i) is RRange:
+            lo = i.lo or 0
+            hi = len(self) if i.hi is None else i.hi
+            return RSlice(self, lo, hi - lo)
+        return list.__getitem__(self, i)
+
+
 class Plane(RStruct):
     _fields = ("data", "cfg")
     _rname = "Plane"
@@ -1279,6 +1291,16 @@ class Plane(RStruct):
         cfg = PlaneConfig(stride, alloc_height, width, height, xdec, ydec, xpad, ypad, xorigin, yorigin)
         fill = 128 if bpp == 1 else 0  # contents are always overwritten by the generators
         return Plane([fill] * (stride * alloc_height), cfg)
+
+    @staticmethod
+    def from_slice(data, stride):
+        # v_frame 0.3.9 Plane::from_slice: a plane of width = stride, height = len / stride, no
+        # padding, holding a copy of the data (used by the reference's unit tests)
+        vals = list(data)
+        if stride <= 0 or len(vals) % stride:
+            raise Panic("Plane::from_slice: %d elements, stride %d" % (len(vals), stride))
+        h = len(vals) // stride
+        return Plane(PlaneData(vals), PlaneConfig(stride, h, stride, h, 0, 0, 0, 0, 0, 0))
 
     def slice(self, po):
         return PlaneSlice(self, po.x, po.y)

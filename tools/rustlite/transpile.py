@@ -122,12 +122,30 @@ class Crate:
                 return True
         return False
 
-    def load(self, rel):
+    def load(self, rel, tests=False):
+        """tests=True also registers the file's `#[cfg(test)]` items: the reference's own unit
+        tests, which tests/test_reference_unit_tests.py runs as this transpiler's self-test"""
         if rel in self.files:
             return
         p, items = parse_file(os.path.join(self.root, rel))
         self.files[rel] = (p, items)
-        self._register(items, p, (), rel)
+        self.include_tests = tests
+        try:
+            self._register(items, p, (), rel)
+        finally:
+            self.include_tests = False
+
+    def define_py(self, name, pyfunc):
+        """A crate-level function supplied by the generator as a Python callable f(_g, *args): for
+        the few reference functions that live inside a macro body (macro expansion is not part of
+        this transpiler), e.g. get_func of impl_1d_tx! (src/transform/forward_shared.rs:201-218).
+        The generator says what stands behind it."""
+        node = N("fn", name=name, gens=[], params=[], ret=None, body=None, has_self=False, attrs=[], parsed=None)
+        info = FnInfo(node, None, (), "<python: %s>" % name)
+        info.pyname = "py_%s_%d" % (name, len(self.G))
+        info.compiled = True
+        self.G[info.pyname] = pyfunc
+        self.fns.setdefault(name, []).insert(0, info)
 
     def load_text(self, name, text):
         """Rust source text that is not a file of the tree: a function wrapped around a SLICE of a
@@ -144,7 +162,8 @@ class Crate:
 
     def _register(self, items, p, modpath, fname, owner=None, owner_gens=(), trait=None):
         for it in items:
-            if any("cfg ( test )" in a or "cfg(test)" in a.replace(" ", "") for a in it.attrs):
+            if any("cfg ( test )" in a or "cfg(test)" in a.replace(" ", "") for a in it.attrs) and \
+                    not getattr(self, "include_tests", False):
                 continue
             k = it.k
             if k == "mod":
@@ -219,6 +238,8 @@ class Crate:
             return R.int_method(recv, hint if hint in INT else None, name, args)
         if t is tuple:
             return R.tuple_method(recv, name, args)
+        if issubclass(t, list):   # a raw backing store (Plane::data): the slice methods on a view of it
+            return self._mc(g, R.RSlice(recv), hint, name, args)
         if t is R.Cell or t is R.RRef:
             if name == "write" and len(args) == 1:
                 recv.set(args[0])
@@ -270,6 +291,13 @@ class Crate:
         return self._mc({}, recv, None, name, tuple(args))
 
     def _call_info(self, info, g, args):
+        # run-time dispatched (method) calls hand the caller's bindings on by name as well: a
+        # pixel type arriving at a `T: Coefficient` parameter is the caller's `T: Pixel` (see
+        # gen_dict) -- a Coefficient is never u8 / u16
+        for gg in info.gens:
+            if gg[0] == "type" and gg[2] and "Coefficient" in gg[2] and g.get(gg[1]) in ("u8", "u16"):
+                g = dict(g)
+                g[gg[1]] = "i16" if g[gg[1]] == "u8" else "i32"
         return self.pyfn(info)(g, *args)
 
     def _tf(self, v, i):
@@ -1709,8 +1737,12 @@ class FnCompiler:
         binds = []
         self.push()
         self.frames.append(Frame())
+        hints = getattr(self, "closure_param_hint", None)
+        self.closure_param_hint = None
         for i, (pat, ty) in enumerate(e.params):
             nt = self.norm(ty) if ty is not None else None
+            if nt is None and hints and i < len(hints):
+                nt = hints[i]      # the callee's signature fixes it (Aligned::from_fn: FnMut(usize) -> T)
             is_ref = isinstance(nt, tuple) and nt[0] == "ref"
             if pat.k == "pident" and (pat.name not in self.boxed or is_ref) and not self._is_const_pat(pat.name):
                 ent = self.declare(pat.name, nt)
@@ -1802,6 +1834,15 @@ class FnCompiler:
         ga = p.gen.get(len(p.segs) - 1) if p is not None else None
         own = [g for g in info.node.gens]
         if not ga:
+            # No turbofish: the callee's parameters are inferred from the arguments, which this
+            # transpiler does not do -- the caller's bindings are handed on by NAME.  One case where
+            # the same name means two things is all over the reference: a function generic over
+            # `T: Pixel` calling one generic over `T: Coefficient` with T::Coeff buffers
+            # (encode_tx_block -> forward_transform / quantize / dequantize / inverse_transform_add).
+            mine = {g[1]: g[2] for g in self.info.gens if g[0] == "type" and g[2]}
+            for g in own:
+                if g[0] == "type" and g[2] and "Coefficient" in g[2] and "Pixel" in mine.get(g[1], ()):
+                    return "{**_g, %r: ('i16' if _g[%r] == 'u8' else 'i32')}" % (g[1], g[1])
             return "_g"
         items = []
         for g, a in zip(own, ga):
@@ -2000,6 +2041,12 @@ class FnCompiler:
         full = "::".join(segs)
         if a == "Self":
             a = self.info.owner
+        if a == "CpuFeatureLevel" and name == "default" and not argn:
+            return "None"   # the CPU dispatch level: carried around, never inspected by rust:: code
+        if len(segs) == 3 and segs[0] in self.type_params and segs[1] == "Coeff" and name in ("cast_from", "from"):
+            # <T as Pixel>::Coeff: i16 for u8 pixels, i32 for u16 (v_frame 0.3.9 pixel.rs)
+            v = self.args(argn)[0]
+            return "_cast(%s, 'i16' if _g[%r] == 'u8' else 'i32')" % (v, segs[0])
         if a is not None and a in self.c.aliases and a not in self.c.structs:
             na = self.norm(self.c.aliases[a])
             if isinstance(na, str):
@@ -2087,6 +2134,9 @@ class FnCompiler:
                 if self.is_scalar_ty(t) or t in self.type_params:
                     return "0"
             exp = self.strip(self.expected)
+            if exp is None and gen0 and a == "Aligned" and name == "uninit_array":
+                # Aligned::<[MaybeUninit<X>; N]>::uninit_array() bound to an untyped `let`
+                return "R.Aligned(%s)" % self.default_for(self.strip(self.norm(gen0[0])), uninit=True)
             if exp is None:
                 if a == "Aligned" and name == "uninit_array":
                     # `let mut edge_buf = Aligned::uninit_array();` -- the type comes from the later
@@ -2100,8 +2150,14 @@ class FnCompiler:
         if name == "default" and (a == "Default" or a is None):
             return self.default_for(self.strip(self.expected))
         if a == "Aligned" and name == "from_fn":
+            self.closure_param_hint = ["usize"]
             f = self.args(argn)[0]
+            self.closure_param_hint = None
             exp = self.strip(self.expected)
+            if exp is None:
+                # `let edge_buf = Aligned::from_fn(|i| ..)` handed to IntraEdge::mock: an IntraEdgeMock
+                # = Aligned<[T; 4 * MAX_TX_SIZE + 1]> (partition.rs:603; the untyped sites of the tree)
+                return "R.Aligned(_S([(%s)(_i) for _i in range(257)]))" % f
             self.err("Aligned::from_fn")
         if full == "ILog::ilog" and len(argn) == 1:
             return "_im(%s, None, 'ilog', ())" % self.args(argn)[0]
@@ -2129,7 +2185,7 @@ class FnCompiler:
                 return "0.0"
             if t == "bool":
                 return "False"
-            if t in self.type_params:
+            if t in self.type_params or t == "Coeff":    # <T as Pixel>::Coeff: i16 / i32
                 return "0"
             m = self.c.find_method(t, "default")
             if m is not None:
