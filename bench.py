@@ -411,6 +411,280 @@ def extra_lines(ctx, args):
     return lines
 
 
+def config_lines(ctx, args):
+    """BASELINE.json configs 2-4 in the driver-run record, a few timed launches each,
+    HIP events per launch, algorithmic bytes of SURVEY 8(d), a strided sample of every launch
+    checked against the scalar oracle:
+      config2_dist_1080p      1920x1080 8-bit: get_sad (K = 32) + get_satd (K = 8) over the ladder
+                              (benches/dist.rs), r1_dist_batch
+      config2_fwd_dct_1080p   forward DCT_DCT of every transform block of a 1080p frame at 64/32/16/8
+                              (benches/transform.rs), r1_fwd_txfm_batch
+      config3_mc_1080p        put_8tap + prep_8tap over the ladder, random 1/16-pel fractions
+                              (benches/mc.rs), r1_mc_put_batch / r1_mc_prep_batch
+      fused_4k_10bit          the headline step on 3840x2160 10-bit planes
+      config4_proxy_4k_10bit  4K 10-bit: the pixel-domain candidate chain (-> quantize -> inverse ->
+                              cdef_dist) + the CDEF luma pass + the CDEF strength search (8 presets)"""
+    import torch
+    from rav1e_amd import workload as W
+    from rav1e_amd.api import DIST_CAND, MC_CAND, Plane
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    L = O.lib()
+    L.r1o_set_threads(os.cpu_count() or 1)
+    NCHK, REPS = 48, 5
+    lines = []
+
+    def timed(fns):
+        """fns: [(tag, callable)] -> ({tag: ms per launch}, ms per pass)"""
+        for _, f in fns:
+            f()
+        torch.cuda.synchronize()
+        ev = []
+        t0 = time.perf_counter()
+        for _ in range(REPS):
+            for tag, f in fns:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                f()
+                e1.record()
+                ev.append((tag, e0, e1))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / REPS * 1e3
+        per = {}
+        for tag, a, b in ev:
+            per.setdefault(tag, []).append(a.elapsed_time(b))
+        return {t: sum(v) / len(v) for t, v in per.items()}, dt
+
+    def line(name, desc, px, per, step_ms, abytes_by_tag, n_chk, bad, extra=None):
+        dom = max(per, key=lambda t: per[t])
+        roof = build_roofline("%s: %s" % (name, dom), abytes_by_tag[dom], per[dom], None, None, None)
+        d = {"name": name, "metric": "Mpixels/s", "value": round(px / (step_ms * 1e-3) / 1e6, 2), "unit": "Mpixels/s",
+             "steps": REPS, "ms_per_step": round(step_ms, 4), "config": {"workload": desc},
+             "kernel_ms": {str(t): round(v, 4) for t, v in per.items()}, "roofline": roof,
+             "parity_checked": n_chk, "parity_ok": not bad, "parity_bad": bad}
+        if extra:
+            d.update(extra)
+        lines.append(d)
+
+    def sample(n):
+        return np.arange(0, n, max(1, n // NCHK))[:NCHK]
+
+    # ---------------- 1080p 8-bit planes (configs 2 and 3)
+    w, h, bd = 1920, 1080, 8
+    ho, hr = W.random_plane_array(w, h, bd, 1), W.random_plane_array(w, h, bd, 2)
+    po, pr = Plane.from_numpy(ho, w, h, bd, 88, 88), Plane.from_numpy(hr, w, h, bd, 88, 88)
+    a, b = O.HostPlane(w, h, bd), O.HostPlane(w, h, bd)
+    a.data, b.data = ho, hr
+    pa, pb = a.cstruct(), b.cstruct()
+    # config 2: SAD K = 32, SATD K = 8
+    fns, abytes, px, chk = [], {}, 0, []
+    for kind, k, nm in ((0, 32, "sad"), (1, 8, "satd")):
+        cands = W.speed6_ladder(w, h, k, seed=3, mv_range=32)
+        for sz, c in cands.items():
+            dcand = np.zeros(len(c), DIST_CAND)
+            for f in ("ox", "oy", "rx", "ry"):
+                dcand[f] = c[f]
+            dev = torch.from_numpy(dcand.view(np.uint8).reshape(-1).copy()).cuda()
+            out = torch.empty(len(c), dtype=torch.int32, device="cuda")
+            tag = "%s %dx%d" % (nm, sz, sz)
+            fns.append((tag, lambda kind=kind, sz=sz, dev=dev, n=len(c), out=out: ctx.dist_batch(kind, po, pr, sz, sz, dev, n=n, out=out)))
+            abytes[tag] = (2 * sz * sz + 4) * len(c)
+            px += len(c) * sz * sz
+            chk.append((kind, sz, dcand, out))
+    per, step = timed(fns)
+    n_chk, bad = 0, []
+    for kind, sz, dcand, out in chk:
+        idx = sample(len(dcand))
+        sub = np.ascontiguousarray(dcand[idx])
+        want = np.zeros(len(sub), np.uint32)
+        assert L.r1o_dist_batch(kind, C.byref(pa), C.byref(pb), sz, sz, O.ptr(sub), len(sub), O.ptr(want)) == 0
+        got = out.index_select(0, torch.from_numpy(idx.astype(np.int64)).cuda()).cpu().numpy().view(np.uint32)
+        n_chk += len(idx)
+        if not np.array_equal(got, want):
+            bad.append("%s %d" % ("satd" if kind else "sad", sz))
+    line("config2_dist_1080p", "1920x1080 8-bit luma, speed-6 ladder 64/32/16/8: get_sad K=32 + get_satd K=8 per block, "
+         "MV +-32 px (benches/dist.rs)", px, per, step, abytes, n_chk, bad)
+    # config 2: forward DCT of every transform block of the frame
+    fns, abytes, px, chk = [], {}, 0, []
+    from rav1e_amd.types import TxSize
+    rng = np.random.default_rng(5)
+    for sz in W.LADDER:
+        nb = (w // sz) * (h // sz)
+        res = rng.integers(-255, 256, (nb, sz, sz)).astype(np.int16)
+        dres = torch.from_numpy(res).cuda()
+        out = torch.empty((nb, sz * sz), dtype=torch.int16, device="cuda")
+        ts = int(TxSize.by_dims(sz, sz))
+        tag = "fdct %dx%d" % (sz, sz)
+        fns.append((tag, lambda dres=dres, ts=ts, out=out: ctx.forward_transform_batch(dres, ts, 0, 8, out=out)))
+        abytes[tag] = nb * (2 * sz * sz + 2 * sz * sz)
+        px += nb * sz * sz
+        chk.append((sz, ts, res, out))
+    per, step = timed(fns)
+    n_chk, bad = 0, []
+    for sz, ts, res, out in chk:
+        idx = sample(len(res))
+        sub = np.ascontiguousarray(res[idx])
+        want = np.zeros((len(sub), sz * sz), np.int16)
+        assert L.r1o_fwd_txfm_batch(O.ptr(sub), O.ptr(want), len(sub), ts, 0, 8, 2) == 0
+        got = out.index_select(0, torch.from_numpy(idx.astype(np.int64)).cuda()).cpu().numpy()
+        n_chk += len(idx)
+        if not np.array_equal(got, want):
+            bad.append("fdct %d" % sz)
+    line("config2_fwd_dct_1080p", "every transform block of a 1920x1080 frame at 64/32/16/8, DCT_DCT, residual uniform "
+         "[-255, 255] (benches/transform.rs)", px, per, step, abytes, n_chk, bad)
+    # config 3: put_8tap / prep_8tap
+    fns, abytes, px, chk = [], {}, 0, []
+    cands = W.speed6_ladder(w, h, 8, seed=4, mv_range=32)
+    for sz, c in cands.items():
+        mc = np.zeros(len(c), MC_CAND)
+        for f in ("rx", "ry", "col_frac", "row_frac", "mode_x", "mode_y"):
+            mc[f] = c[f]
+        dev = torch.from_numpy(mc.view(np.uint8).reshape(-1).copy()).cuda()
+        o_put = torch.empty((len(c), sz, sz), dtype=torch.uint8, device="cuda")
+        o_prep = torch.empty((len(c), sz, sz), dtype=torch.int16, device="cuda")
+        fns.append(("put %dx%d" % (sz, sz), lambda sz=sz, dev=dev, n=len(c), o=o_put: ctx.put_8tap_batch(pr, sz, sz, dev, n=n, out=o)))
+        fns.append(("prep %dx%d" % (sz, sz), lambda sz=sz, dev=dev, n=len(c), o=o_prep: ctx.prep_8tap_batch(pr, sz, sz, dev, n=n, out=o)))
+        abytes["put %dx%d" % (sz, sz)] = len(c) * ((sz + 7) * (sz + 7) + sz * sz)
+        abytes["prep %dx%d" % (sz, sz)] = len(c) * ((sz + 7) * (sz + 7) + 2 * sz * sz)
+        px += 2 * len(c) * sz * sz
+        chk.append((sz, mc, o_put, o_prep))
+    per, step = timed(fns)
+    n_chk, bad = 0, []
+    for sz, mc, o_put, o_prep in chk:
+        idx = sample(len(mc))
+        sub = np.ascontiguousarray(mc[idx])
+        w_put, w_prep = np.zeros((len(sub), sz, sz), np.uint8), np.zeros((len(sub), sz, sz), np.int16)
+        assert L.r1o_mc_put_batch(C.byref(pb), sz, sz, O.ptr(sub), len(sub), O.ptr(w_put)) == 0
+        assert L.r1o_mc_prep_batch(C.byref(pb), sz, sz, O.ptr(sub), len(sub), O.ptr(w_prep)) == 0
+        ix = torch.from_numpy(idx.astype(np.int64)).cuda()
+        n_chk += 2 * len(idx)
+        if not (np.array_equal(o_put.index_select(0, ix).cpu().numpy(), w_put) and
+                np.array_equal(o_prep.index_select(0, ix).cpu().numpy(), w_prep)):
+            bad.append("mc %d" % sz)
+    line("config3_mc_1080p", "1920x1080 8-bit luma, ladder 64/32/16/8, K=8: put_8tap + prep_8tap REGULAR with random "
+         "1/16-pel fractions, MV +-32 px (benches/mc.rs)", px, per, step, abytes, n_chk, bad)
+    del po, pr, fns, chk
+    torch.cuda.empty_cache()
+
+    # ---------------- 4K 10-bit: the fused candidate and the config-4 proxy
+    w, h, bd, k = args.width, args.height, 10, args.k
+    ho, hr = W.random_plane_array(w, h, bd, 1), W.random_plane_array(w, h, bd, 2)
+    po, pr = Plane.from_numpy(ho, w, h, bd, 88, 88), Plane.from_numpy(hr, w, h, bd, 88, 88)
+    a, b = O.HostPlane(w, h, bd), O.HostPlane(w, h, bd)
+    a.data, b.data = ho, hr
+    pa, pb = a.cstruct(), b.cstruct()
+    cands = W.speed6_ladder(w, h, k)
+    dc = {s: torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda() for s, c in cands.items()}
+    TS = {64: 4, 32: 3, 16: 2, 8: 1}
+    fns, abytes, px, outs = [], {}, 0, {}
+    for s, c in cands.items():
+        n = len(c)
+        outs[s] = {"sad": torch.empty(n, dtype=torch.int32, device="cuda"), "satd": torch.empty(n, dtype=torch.int32, device="cuda"),
+                   "coeffs": torch.empty((n, s * s), dtype=torch.int32, device="cuda")}
+        fns.append(("%dx%d" % (s, s), ctx.prepare_rdo_cand(po, pr, s, s, dc[s], n, outs[s])))
+        abytes["%dx%d" % (s, s)] = W.algorithmic_bytes_per_cand(s, s, 2) * n
+        px += n * s * s
+    per, step = timed(fns)
+    n_chk, bad = 0, []
+    for s, c in cands.items():
+        idx = sample(len(c))
+        sub = np.ascontiguousarray(c[idx])
+        sad, satd = np.zeros(len(sub), np.uint32), np.zeros(len(sub), np.uint32)
+        co = np.zeros((len(sub), s * s), np.int32)
+        assert L.r1o_rdo_cand_batch(C.byref(pa), C.byref(pb), s, s, TS[s], O.ptr(sub), len(sub), O.ptr(sad), O.ptr(satd),
+                                    O.ptr(co), None) == 0
+        ix = torch.from_numpy(idx.astype(np.int64)).cuda()
+        n_chk += len(idx)
+        if not (np.array_equal(outs[s]["sad"].index_select(0, ix).cpu().numpy().view(np.uint32), sad) and
+                np.array_equal(outs[s]["satd"].index_select(0, ix).cpu().numpy().view(np.uint32), satd) and
+                np.array_equal(outs[s]["coeffs"].index_select(0, ix).cpu().numpy(), co)):
+            bad.append("fused %d" % s)
+    line("fused_4k_10bit", "%dx%d 10-bit luma, speed-6 ladder, K=%d fused candidates (the headline step at the config-4 "
+         "pixel format)" % (w, h, k), px, per, step, abytes, n_chk, bad, {"dtype": "u16"})
+    del outs, fns
+    torch.cuda.empty_cache()
+    # config-4 proxy: pixel-domain chain + CDEF luma pass + CDEF strength search
+    scales = torch.from_numpy(np.random.default_rng(9).integers(1 << 12, 1 << 16, ((h + 7) // 8, (w + 7) // 8)).astype(np.int32)).cuda()
+    fns, abytes, px, pouts = [], {}, 0, {}
+    for s, c in cands.items():
+        n = len(c)
+        pouts[s] = {"eob": torch.empty(n, dtype=torch.int16, device="cuda"), "dist": torch.empty(n, dtype=torch.int64, device="cuda"),
+                    "sad": torch.empty(n, dtype=torch.int32, device="cuda"), "satd": torch.empty(n, dtype=torch.int32, device="cuda")}
+        fns.append(("pixel %dx%d" % (s, s), lambda s=s, n=n: ctx.rdo_pixel_cand_batch(po, pr, s, s, dc[s], args.qindex, 3, scales=scales,
+                                                                                         n=n, outs=pouts[s])))
+        abytes["pixel %dx%d" % (s, s)] = (2 * ((s + 7) * (s + 7) + 2 * s * s) + 18) * n
+        px += n * s * s
+    # CDEF over the luma plane (every 8x8 block coded, strengths of rav1e's preset 2) and the strength search
+    cw, chh = w // 2, h // 2
+    chroma = [Plane.from_numpy(W.random_plane_array(cw, chh, bd, 30 + i, 44, 44), cw, chh, bd, 44, 44) for i in range(4)]
+    rec3, src3 = [pr, chroma[0], chroma[2]], [po, chroma[1], chroma[3]]
+    dst = Plane(w, h, bd)
+    skip = torch.zeros((h // 4, w // 4), dtype=torch.uint8, device="cuda")
+    ci = torch.zeros(((h + 63) // 64, (w + 63) // 64), dtype=torch.uint8, device="cuda")
+    skip_s = torch.zeros((2 * ((h + 7) // 8), 2 * ((w + 7) // 8)), dtype=torch.uint8, device="cuda")
+    presets = [0, 4, 9, 13, 22, 31, 43, 55]    # fi.cdef_y_strengths, src/encoder.rs:897-916
+    fns.append(("cdef luma pass", lambda: ctx.cdef_filter_frame_plane(pr, pr, dst, 0, 0, 0, w, h, skip, ci, [36] * 8, [36] * 8, 5, bd)))
+    fns.append(("cdef strength search", lambda: ctx.cdef_strength_search(rec3, src3, skip_s, presets, presets, 5, bd, 8, 1, 1, w, h,
+                                                                          scales=scales)))
+    abytes["cdef luma pass"] = 2 * w * h * 2
+    abytes["cdef strength search"] = 2 * (w * h + 2 * cw * chh) * 2
+
+    def cdef_chk(L):
+        """the two CDEF entry points against the oracle on a 512 x 256 frame of the same kind (the
+        whole-frame comparison at 4K is tests/test_gpu_fullsize.py)"""
+        sw, sh = 512, 256
+        rng = np.random.default_rng(77)
+        imgs = [rng.integers(0, 1 << bd, ((sh >> (1 if i else 0)), (sw >> (1 if i else 0)))) for i in range(3)]
+        recs = [np.clip(im + rng.integers(-20, 21, im.shape), 0, (1 << bd) - 1) for im in imgs]
+        hp_s = [O.plane_from_image(im, bd, 16, 16) for im in imgs]
+        hp_r = [O.plane_from_image(im, bd, 16, 16) for im in recs]
+        dev = lambda hp: Plane.from_numpy(hp.data, hp.width, hp.height, bd, hp.xpad, hp.ypad)
+        d_s, d_r = [dev(x) for x in hp_s], [dev(x) for x in hp_r]
+        mi_cols, mi_rows = 2 * ((sw + 7) // 8), 2 * ((sh + 7) // 8)
+        sk = np.zeros((mi_rows, mi_cols), np.uint8)
+        sc = rng.integers(1 << 12, 1 << 16, ((sh + 7) // 8, (sw + 7) // 8)).astype(np.uint32)
+        prm = O.CdefSearchParams()
+        prm.y_strengths[:] = presets
+        prm.uv_strengths[:] = presets
+        prm.damping, prm.bit_depth, prm.n_idx, prm.planes = 5, bd, 8, 3
+        prm.xdec, prm.ydec, prm.crop_w, prm.crop_h, prm.area_sb_w, prm.area_sb_h = 1, 1, sw, sh, 1, 1
+        prm.dist_scale[:] = [1 << 14, 1 << 14, 1 << 14]
+        n_sbx, n_sby = (mi_cols + 15) // 16, (mi_rows + 15) // 16
+        want_err, want_best = np.zeros((n_sby, n_sbx, 8), np.uint64), np.zeros((n_sby, n_sbx), np.int8)
+        pr3 = (O.Plane * 3)(*[x.cstruct() for x in hp_r])
+        ps3 = (O.Plane * 3)(*[x.cstruct() for x in hp_s])
+        assert L.r1o_cdef_strength_search(pr3, ps3, sk.ctypes.data, mi_cols, mi_cols, mi_rows, sc.ctypes.data, sc.shape[1],
+                                          C.byref(prm), want_err.ctypes.data, want_best.ctypes.data) == 0
+        err, best = ctx.cdef_strength_search(d_r, d_s, torch.from_numpy(sk).cuda(), presets, presets, 5, bd, 8, 1, 1, sw, sh,
+                                             scales=torch.from_numpy(sc.view(np.int32)).cuda())
+        ok = (np.array_equal(err.cpu().numpy().view(np.uint64), want_err) and np.array_equal(best.cpu().numpy(), want_best))
+        return n_sbx * n_sby * 8, ([] if ok else ["cdef strength search"])
+    per, step = timed(fns)
+    n_chk, bad = 0, []
+    for s, c in cands.items():
+        idx = sample(len(c))[:16]
+        sub = np.ascontiguousarray(c[idx])
+        sad, satd = np.zeros(len(sub), np.uint32), np.zeros(len(sub), np.uint32)
+        eob, dist = np.zeros(len(sub), np.uint16), np.zeros(len(sub), np.uint64)
+        hs = scales.cpu().numpy().view(np.uint32)
+        assert L.r1o_rdo_pixel_cand_batch(C.byref(pa), C.byref(pb), s, s, TS[s], O.ptr(sub), len(sub), args.qindex, 0, 0, 0, 3,
+                                          O.ptr(hs), hs.shape[1], 0, 0, O.ptr(sad), O.ptr(satd), O.ptr(eob), O.ptr(dist),
+                                          None, None, None) == 0
+        ix = torch.from_numpy(idx.astype(np.int64)).cuda()
+        n_chk += len(idx)
+        if not (np.array_equal(pouts[s]["dist"].index_select(0, ix).cpu().numpy().view(np.uint64), dist) and
+                np.array_equal(pouts[s]["eob"].index_select(0, ix).cpu().numpy().view(np.uint16), eob)):
+            bad.append("pixel %d" % s)
+    c_n, c_bad = cdef_chk(L)
+    n_chk += c_n
+    bad += c_bad
+    line("config4_proxy_4k_10bit", "%dx%d 10-bit: pixel-domain candidate chain over the ladder (K=%d: mc -> dist -> fwd -> quantize "
+         "-> inverse -> cdef_dist) + CDEF luma pass + CDEF strength search over rav1e's 8 presets (4:2:0)" % (w, h, k),
+         px, per, step, abytes, n_chk, bad, {"dtype": "u16", "px_note": "Mpixels/s counts the candidate pixels of the chain; the "
+                                             "two CDEF launches are inside the step time"})
+    return lines
+
+
 def respawn_under_launcher(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: re-exec this very command
     line under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1, a free port) --
@@ -709,6 +983,8 @@ def main():
         bad = []
         if world == 1 and not full and not args.no_extra:
             res["extra_lines"] = extra_lines(ctx, args)
+            if (fw, fh, bd) == (3840, 2160, 8):   # the default run: BASELINE configs 2-4 beside the headline
+                res["extra_lines"] += config_lines(ctx, args)
             bad += ["extra:" + e["name"] for e in res["extra_lines"] if not e.get("parity_ok", True)]
         if world == 1 and args.cpu_seconds > 0 and not full:
             # the CPU legs evaluate strided samples of this very step at 4K: what they return is

@@ -122,7 +122,9 @@ int r1_dist_batch(r1_ctx *ctx, int kind, const R1Plane *org,
  * 8x8 kernel (CDEF) -- exactly what the compute_bias closure at
  * src/rdo.rs:283-303 looks up.  NULL = DistortionScale::default() (1 << 14).
  * out[i] = the reference's Distortion (u64), before `* fi.dist_scale[p]`.
- * w, h: multiples of 4, <= 128 (visible block size after frame clipping). */
+ * w, h <= 128: the visible block size after frame clipping.  R1_DIST_CDEF: multiples of 4.
+ * R1_DIST_WSSE: any size >= 1 -- like get_weighted_sse, only whole 4x4 cells are measured (a
+ * clipped chroma block may be 2 wide: its distortion is 0, as in the reference). */
 int r1_dist_scaled_batch(r1_ctx *ctx, int kind, const R1Plane *org,
                          const R1Plane *ref, int w, int h,
                          const R1DistCand *cands, int n, const uint32_t *scales,
@@ -319,6 +321,24 @@ int r1_cdef_filter_frame_plane(r1_ctx *ctx, const R1Plane *luma, const R1Plane *
                                int mi_stride, int mi_cols, int mi_rows,
                                const uint8_t *cdef_index_sb, int sb_stride,
                                const R1CdefParams *params, void *stream);
+
+/* The same in two steps, as the reference does it per superblock (cdef_analyze_superblock once,
+ * src/cdef.rs:340-373, then cdef_filter_superblock for each plane, 405-560): the analysis
+ * writes (dir, var) of every 8x8 luma block, raster order over the grid of
+ * nbx = 8*ceil(tile_w/64) by nby = 8*ceil(tile_h/64) blocks (r1_cdef_analyze_blocks() entries;
+ * blocks outside mi_cols x mi_rows are not written; skipped blocks are analysed too, their
+ * entries are never read), and three filter calls share it.  r1_cdef_filter_frame_plane is
+ * analysis + one plane with stream-ordered scratch.  tile_w / tile_h here = the frame's luma size. */
+long long r1_cdef_analyze_blocks(int tile_w, int tile_h);
+int r1_cdef_analyze_frame(r1_ctx *ctx, const R1Plane *luma, int tile_w, int tile_h,
+                          int mi_cols, int mi_rows, uint8_t *dir_out, int32_t *var_out,
+                          void *stream);
+int r1_cdef_filter_frame_plane_dirs(r1_ctx *ctx, const uint8_t *dirs, const int32_t *vars,
+                                    const R1Plane *in, const R1Plane *out, int p, int xdec,
+                                    int ydec, int tile_w, int tile_h, const uint8_t *skip_mi,
+                                    int mi_stride, int mi_cols, int mi_rows,
+                                    const uint8_t *cdef_index_sb, int sb_stride,
+                                    const R1CdefParams *params, void *stream);
 
 /* CDEF strength search: the CDEF leg of rdo_loop_decision (src/rdo.rs:2104-2560) when no
  * restoration filter is in play (RestorationFilter::None / no restoration unit,

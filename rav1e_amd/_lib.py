@@ -73,6 +73,10 @@ SYMBOLS = {
     "r1_cdef_filter_block_batch": (_i, [_vp, _PP, _PP, _i, _i, _vp, _i, _vp]),
     "r1_cdef_filter_frame_plane": (_i, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i, _i,
                                         _vp, _i, C.POINTER(R1CdefParams), _vp]),
+    "r1_cdef_analyze_blocks": (C.c_longlong, [_i, _i]),
+    "r1_cdef_analyze_frame": (_i, [_vp, _PP, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "r1_cdef_filter_frame_plane_dirs": (_i, [_vp, _vp, _vp, _PP, _PP, _i, _i, _i, _i, _i, _vp, _i, _i, _i,
+                                             _vp, _i, C.POINTER(R1CdefParams), _vp]),
     "r1_cdef_strength_search_scratch_bytes": (C.c_longlong, [_i, _i]),
     "r1_cdef_strength_search": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "r1_estimate_intra_costs": (_i, [_vp, _PP, _vp, _vp]),

@@ -357,21 +357,50 @@ class Context:
                                                         dc.data_ptr(), n, _stream_ptr()),
                     "r1_cdef_filter_block_batch")
 
-    def cdef_filter_frame_plane(self, luma, src, dst, p, xdec, ydec, tile_w, tile_h, skip_mi,
-                                cdef_index_sb, y_strengths, uv_strengths, damping, bit_depth):
-        """cdef_filter_tile (src/cdef.rs:600-625) for plane p of the whole frame.
-        skip_mi: (mi_rows, mi_cols) uint8 device tensor; cdef_index_sb: (sb_rows, sb_cols)."""
+    @staticmethod
+    def _cdef_params(y_strengths, uv_strengths, damping, bit_depth):
         prm = _lib.R1CdefParams()
         for i in range(8):
             prm.y_strengths[i] = int(y_strengths[i])
             prm.uv_strengths[i] = int(uv_strengths[i])
         prm.damping, prm.bit_depth = int(damping), int(bit_depth)
+        return prm
+
+    def cdef_filter_frame_plane(self, luma, src, dst, p, xdec, ydec, tile_w, tile_h, skip_mi,
+                                cdef_index_sb, y_strengths, uv_strengths, damping, bit_depth):
+        """cdef_filter_tile (src/cdef.rs:600-625) for plane p of the whole frame.
+        skip_mi: (mi_rows, mi_cols) uint8 device tensor; cdef_index_sb: (sb_rows, sb_cols)."""
+        prm = self._cdef_params(y_strengths, uv_strengths, damping, bit_depth)
         l, a, b = luma.cstruct(), src.cstruct(), dst.cstruct()
         self._check(self.lib.r1_cdef_filter_frame_plane(
             self.h, C.byref(l), C.byref(a), C.byref(b), p, xdec, ydec, tile_w, tile_h,
             skip_mi.data_ptr(), skip_mi.stride(0), skip_mi.shape[1], skip_mi.shape[0],
             cdef_index_sb.data_ptr(), cdef_index_sb.stride(0), C.byref(prm), _stream_ptr()),
             "r1_cdef_filter_frame_plane")
+
+    def cdef_analyze_frame(self, luma, tile_w, tile_h, mi_cols, mi_rows):
+        """cdef_analyze_superblock (src/cdef.rs:340-373) for every 8x8 luma block of the frame ->
+        (dir uint8 [nby, nbx], var int32 [nby, nbx]); blocks outside mi_cols x mi_rows stay 0"""
+        nbx, nby = ((tile_w + 63) // 64) * 8, ((tile_h + 63) // 64) * 8
+        assert self.lib.r1_cdef_analyze_blocks(tile_w, tile_h) == nbx * nby
+        d = torch.zeros((nby, nbx), dtype=torch.uint8, device="cuda")
+        v = torch.zeros((nby, nbx), dtype=torch.int32, device="cuda")
+        l = luma.cstruct()
+        self._check(self.lib.r1_cdef_analyze_frame(self.h, C.byref(l), tile_w, tile_h, mi_cols, mi_rows,
+                                                   d.data_ptr(), v.data_ptr(), _stream_ptr()),
+                    "r1_cdef_analyze_frame")
+        return d, v
+
+    def cdef_filter_frame_plane_dirs(self, dirs, variances, src, dst, p, xdec, ydec, tile_w, tile_h,
+                                     skip_mi, cdef_index_sb, y_strengths, uv_strengths, damping, bit_depth):
+        """cdef_filter_superblock over the frame for plane p with the analysis of cdef_analyze_frame"""
+        prm = self._cdef_params(y_strengths, uv_strengths, damping, bit_depth)
+        a, b = src.cstruct(), dst.cstruct()
+        self._check(self.lib.r1_cdef_filter_frame_plane_dirs(
+            self.h, dirs.data_ptr(), variances.data_ptr(), C.byref(a), C.byref(b), p, xdec, ydec,
+            tile_w, tile_h, skip_mi.data_ptr(), skip_mi.stride(0), skip_mi.shape[1], skip_mi.shape[0],
+            cdef_index_sb.data_ptr(), cdef_index_sb.stride(0), C.byref(prm), _stream_ptr()),
+            "r1_cdef_filter_frame_plane_dirs")
 
     def cdef_strength_search(self, rec, src, skip_mi, y_strengths, uv_strengths, damping, bit_depth,
                              n_idx, xdec, ydec, crop_w, crop_h, area_sb=(1, 1), scales=None,

@@ -105,107 +105,315 @@ struct CdefFrameArgs {
   int sb_stride;
   R1CdefParams prm;
   int nbx, nby;
+  const uint8_t *dirs;    // [nby][nbx], k_cdef_analyze
+  const int32_t *vars;
 };
 
-// The 2 x 2 blocks of a workgroup share one LDS tile of the input plane (their
-// region plus the 2-pixel halo), staged once with CDEF_VERY_LARGE where the
-// frame ends.  A halo pixel is missing exactly when it lies outside
-// [0, 8*floor(W/8)) x [0, 8*floor(H/8)) in luma units: that is what the
-// reference's edge flags (`bx + 1 >= xavail >> 3`, first row / column of the
-// frame; cdef.rs:441-459) say for every block at once.
-template <int BPP, int XD, int YD>
-__global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
-  __shared__ int32_t part[4][128];
-  __shared__ uint16_t tile[20 * 20];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // the plane's decimation is a template parameter: tile geometry, the index
-  // arithmetic of the staging and the lane -> pixel map become constants
-  constexpr int xs = 8 >> XD, ys = 8 >> YD;
-  constexpr int TW = 2 * xs + 4, TH = 2 * ys + 4;
-  const int gbx = blockIdx.x * 2 + (wave & 1), gby = blockIdx.y * 2 + (wave >> 1);
-  const int fbx = gbx >> 3, fby = gby >> 3, bx = gbx & 7, by = gby & 7;
-  const int mx = gbx * 2, my = gby * 2;
-  const bool in_grid = gbx < a.nbx && gby < a.nby && mx < a.mi_cols && my < a.mi_rows;
-  const int bd = a.prm.bit_depth, coeff_shift = bd - 8;
-  const int in_xoff = fbx * 64, in_yoff = fby * 64;
-  // ---- every global read of this block is issued here, before the barrier,
-  // so that a wave pays one memory round trip, not five dependent ones ----
-  int skip = 1, ci = 0;
-  int32_t lum = 0;
-  if (in_grid) {
-    const uint8_t *sk = a.skip_mi + (size_t)my * a.mi_stride + mx;
-    skip = sk[0] & sk[1] & sk[a.mi_stride] & sk[a.mi_stride + 1];
-    ci = a.cdef_index_sb[fby * a.sb_stride + fbx];
-    lum = ldpx<BPP>(px_addr<BPP>(a.luma, in_xoff + 8 * bx + (lane & 7), in_yoff + 8 * by + (lane >> 3)));
-  }
-  // plane position of the workgroup's region (no tile offset: whole frame)
-  const int rx0 = (blockIdx.x * 2) * xs, ry0 = (blockIdx.y * 2) * ys;
-  const int lim_x = ((a.luma.width >> 3) << 3) >> XD, lim_y = ((a.luma.height >> 3) << 3) >> YD;
-  {
-    // all loads of the tile first (a luma thread has two), then the LDS stores: one
-    // memory round trip instead of one per loop iteration
-    const uint8_t *p0 = (const uint8_t *)a.in.data;
-    constexpr int NLD = (TW * TH + 255) / 256;
-    int32_t tv[NLD];
+// ---- cdef_analyze_superblock for the whole frame (cdef.rs:340-373): one THREAD per 8x8 luma
+// block, the 64 pixels in registers.  A wave per block spends most of its instructions moving
+// partial sums between lanes (ds_add by 64 lanes: ~150 instructions per pixel); here every add is
+// an add (about 300 adds + 170 multiplies per block, < 10 instructions per pixel) and the lanes of
+// a wave read neighbouring blocks, i.e. whole rows.  The direction of a skipped block is never
+// read, so it is computed for every block of the grid.
+template <int BPP>
+__global__ __launch_bounds__(64) void k_cdef_analyze(R1Plane luma, int nbx, int nby, int mi_cols,
+                                                     int mi_rows, uint8_t *__restrict__ dir_out,
+                                                     int32_t *__restrict__ var_out) {
+  const int gbx = blockIdx.x * 64 + threadIdx.x, gby = blockIdx.y;
+  if (gbx >= nbx || gby >= nby || gbx * 2 >= mi_cols || gby * 2 >= mi_rows) return;
+  const int cs = luma.bit_depth - 8;
+  int32_t x[8][8];
+  const uint8_t *p0 = px_addr<BPP>(luma, gbx * 8, gby * 8);
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const int t = threadIdx.x + 256 * k;
-      const int ty = t / TW, tx = t - ty * TW;
-      const int py = ry0 + ty - 2, px = rx0 + tx - 2;
-      tv[k] = VERY_LARGE;
-      if (t < TW * TH && py >= 0 && py < lim_y && px >= 0 && px < lim_x)
-        tv[k] = ldpx<BPP>(p0 + ((size_t)(a.in.yorigin + py) * a.in.stride + a.in.xorigin + px) * BPP);
+  for (int i = 0; i < 8; i++) {
+    load_px_row<BPP, 8>(p0 + (size_t)i * luma.stride * BPP, x[i]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[i][j] = (x[i][j] >> cs) - 128;
+  }
+  // pair sums shared by the half-slope directions: h = two neighbours of a row, v = of a column
+  int32_t h[8][4], v[4][8];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int m = 0; m < 4; m++) h[i][m] = x[i][2 * m] + x[i][2 * m + 1];
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[q][j] = x[2 * q][j] + x[2 * q + 1][j];
+  int32_t part[8][15];
+#pragma unroll
+  for (int d = 0; d < 8; d++)
+#pragma unroll
+    for (int m = 0; m < 15; m++) part[d][m] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      part[0][i + j] += x[i][j];
+      part[4][7 + i - j] += x[i][j];
     }
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const int t = threadIdx.x + 256 * k;
-      if (t < TW * TH) tile[t] = (uint16_t)tv[k];
+    for (int m = 0; m < 4; m++) {
+      part[1][i + m] += h[i][m];
+      part[3][3 + i - m] += h[i][m];
+      part[2][i] += h[i][m];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      part[5][3 - q + j] += v[q][j];
+      part[7][q + j] += v[q][j];
+      part[6][j] += v[q][j];
+    }
+  // cost = sum of squared line sums * 840 / line length (cdef.rs:110-133); |line sum| <= 1024 and
+  // its square * 840 < 2^30: the 24-bit multiplier is exact
+  constexpr int32_t DIV[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
+  int32_t cost[8];
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    int32_t c = 0;
+    if (d == 2 || d == 6) {
+      int32_t sq = 0;
+#pragma unroll
+      for (int m = 0; m < 8; m++) sq += __mul24(part[d][m], part[d][m]);
+      c = sq * 105;
+    } else if (d == 0 || d == 4) {
+#pragma unroll
+      for (int m = 0; m < 7; m++)
+        c += __mul24(__mul24(part[d][m], part[d][m]) + __mul24(part[d][14 - m], part[d][14 - m]), DIV[m + 1]);
+      c += __mul24(__mul24(part[d][7], part[d][7]), 105);
+    } else {
+      int32_t sq = 0;
+#pragma unroll
+      for (int m = 3; m < 8; m++) sq += __mul24(part[d][m], part[d][m]);
+      c = sq * 105;
+#pragma unroll
+      for (int m = 0; m < 3; m++)
+        c += __mul24(__mul24(part[d][m], part[d][m]) + __mul24(part[d][10 - m], part[d][10 - m]), DIV[2 * m + 2]);
+    }
+    cost[d] = c;
+  }
+  int best = 0;
+  int32_t best_cost = cost[0];
+#pragma unroll
+  for (int d = 1; d < 8; d++)
+    if (cost[d] > best_cost) { best_cost = cost[d]; best = d; }   // first maximum (cdef.rs:64-73)
+  int32_t orth = cost[4];
+#pragma unroll
+  for (int d = 1; d < 8; d++)
+    if (best == d) orth = cost[(d + 4) & 7];
+  dir_out[(size_t)gby * nbx + gbx] = (uint8_t)best;
+  var_out[(size_t)gby * nbx + gbx] = (best_cost - orth) >> 10;
+}
+
+// ---- cdef_filter_superblock for one plane of the whole frame.
+// Workgroup = 4 waves = a 32 x 16 pixel region of the plane, wave = 16 x 8 of it, LANE = TWO
+// horizontally adjacent pixels held as one packed i16 pair: all of constrain(), the tap sum and
+// the min / max tracking run on v_pk_* instructions, 12 per tap for two pixels.
+//  * the region plus its halo (2 rows above / below, 4 columns left / right so that every global
+//    load is one aligned 4-pixel group) is staged once in LDS as u16 with CDEF_VERY_LARGE where
+//    the picture ends -- a halo pixel is missing exactly when it lies outside
+//    [0, 8*floor(W/8)) x [0, 8*floor(H/8)) in luma units, which is what the reference's edge flags
+//    say block by block (`bx + 1 >= xavail >> 3`, first row / column; cdef.rs:441-459);
+//  * what depends on the 8x8 block only (skip, strengths after adjust_strength, damping shifts,
+//    the six tap offsets of its direction) is worked out once per block by the first lanes of
+//    wave 0 and left in LDS as a 16-dword record: the pixel lanes read it back with four
+//    ds_read_b128 and unpack nothing;
+//  * the LDS row stride is 24 dwords: the four rows a half-wave reads fall into disjoint bank
+//    octets for any tap offset;
+//  * 0x8000 is the smallest i16: the signed maximum ignores it, the unsigned minimum sees it as
+//    large, and constrain() of it is 0 because (0x8000 >> shift) >= threshold for every legal
+//    strength / damping -- the three things the reference does with CDEF_VERY_LARGE.
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+union Pk {
+  uint32_t u;
+  i16x2 s;
+  u16x2 v;
+};
+constexpr int CT_STRIDE = 48;           // u16 per tile row (40 used)
+constexpr int CT_ROWS = 20, CT_X0 = 4, CT_Y0 = 2;
+constexpr int CT_REC = 16;              // dwords per block record
+
+// the pair at LDS byte address a / a + 2 (a is only 2-byte aligned: two 16-bit reads, the second
+// into the high half -- a 32-bit read of an odd pixel position is an order of magnitude slower)
+__device__ __forceinline__ uint32_t lds_pair(uint32_t a) {
+  uint32_t v;
+  asm volatile("ds_read_u16 %0, %1\n\tds_read_u16_d16_hi %0, %1 offset:2" : "=&v"(v) : "v"(a) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ i16x2 constrain2(i16x2 d, i16x2 thr, u16x2 sh) {
+  const i16x2 ad = __builtin_elementwise_max(d, -d);
+  i16x2 m = thr - (i16x2)((u16x2)ad >> sh);
+  m = __builtin_elementwise_max(m, (i16x2)0);
+  return __builtin_elementwise_max(__builtin_elementwise_min(d, m), -m);
+}
+
+template <int BPP, int XD, int YD>
+__global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[CT_ROWS * CT_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t rec[32 * CT_REC];
+  constexpr int xs = 8 >> XD, ys = 8 >> YD;
+  constexpr int NBX = 32 / xs, NBY = 16 / ys, NB = NBX * NBY;     // blocks of the workgroup
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int cs = a.prm.bit_depth - 8;
+  const int rx0 = blockIdx.x * 32, ry0 = blockIdx.y * 16;         // plane position of the region
+  // ---- per-block records (wave 0; the loads overlap the tile's)
+  if (tid < NB) {
+    const int gbx = blockIdx.x * NBX + tid % NBX, gby = blockIdx.y * NBY + tid / NBX;
+    const int mx = gbx * 2, my = gby * 2;
+    const bool in_grid = gbx < a.nbx && gby < a.nby && mx < a.mi_cols && my < a.mi_rows;
+    // every load of the record is issued here, together (one round trip for wave 0)
+    int skip = 1, ci = 0, dir = 0, var = 0;
+    if (in_grid) {
+      const uint8_t *sk = a.skip_mi + (size_t)my * a.mi_stride + mx;
+      const uint32_t s0 = *(const uint16_t *)sk, s1 = *(const uint16_t *)(sk + a.mi_stride);   // mx is even
+      ci = a.cdef_index_sb[(gby >> 3) * a.sb_stride + (gbx >> 3)];
+      dir = a.dirs[(size_t)gby * a.nbx + gbx];
+      var = a.vars[(size_t)gby * a.nbx + gbx];
+      const uint32_t s01 = s0 & s1;
+      skip = (int)(s01 & (s01 >> 8) & 0xff);
+    }
+    // strengths of the superblock's cdef_index out of the argument registers (no dependent load)
+    uint32_t st8[2];
+    __builtin_memcpy(st8, a.p == 0 ? a.prm.y_strengths : a.prm.uv_strengths, 8);
+    const int strength = (int)(((ci & 4 ? st8[1] : st8[0]) >> (8 * (ci & 3))) & 0xff);
+    const int pri_s = strength >> 2;
+    int sec_s = strength & 3;
+    sec_s += sec_s == 3;
+    int lpri = 0, lsec = 0, ldir = 0, ldamp = a.prm.damping + cs;
+    if (a.p != 0) ldamp -= 1;
+    if (!skip) {
+      lsec = sec_s << cs;
+      if (a.p == 0) {
+        lpri = adjust_strength(pri_s << cs, var);
+        ldir = pri_s != 0 ? dir : 0;
+      } else {
+        // Cdef_Uv_Dir for 4:2:2: {7, 0, 2, 4, 5, 6, 6, 6} packed as nibbles
+        const int uvdir = (int)((0x66654207u >> (4 * dir)) & 0xf);
+        lpri = pri_s << cs;
+        ldir = pri_s != 0 ? (XD != YD ? uvdir : dir) : 0;
+      }
+    }
+    auto shift_of = [&](int thr) {
+      const int sft = thr ? ldamp - (31 - __clz(thr)) : 0;
+      return sft < 0 ? 0 : sft;
+    };
+    const uint32_t psh = shift_of(lpri), ssh = shift_of(lsec);
+    const int odd = (lpri >> cs) & 1;
+    // cdef_directions (cdef.rs:225-234) packed as nibbles (value + 2)
+    constexpr uint32_t DY0 = 0x33332221u, DX0 = 0x22233333u, DY1 = 0x44443210u, DX1 = 0x12344444u;
+    auto off = [&](int d, int k) -> uint32_t {
+      const int sh4 = 4 * (d & 7);
+      const int dy = (int)(((k == 0 ? DY0 : DY1) >> sh4) & 0xf) - 2;
+      const int dx = (int)(((k == 0 ? DX0 : DX1) >> sh4) & 0xf) - 2;
+      return (uint32_t)((dy * CT_STRIDE + dx) * 2);
+    };
+    uint32_t *r = rec + tid * CT_REC;
+    r[0] = (uint32_t)lpri * 0x10001u;
+    r[1] = (uint32_t)lsec * 0x10001u;
+    r[2] = psh * 0x10001u;
+    r[3] = ssh * 0x10001u;
+    r[4] = (odd ? 3u : 4u) * 0x10001u;
+    r[5] = (odd ? 3u : 2u) * 0x10001u;
+    r[6] = (in_grid ? 1u : 0u) | (skip ? 0u : 2u);
+    r[7] = 0;
+    r[8] = off(ldir, 0);
+    r[9] = off(ldir, 1);
+    r[10] = off(ldir + 2, 0);
+    r[11] = off(ldir + 2, 1);
+    r[12] = off(ldir + 6, 0);
+    r[13] = off(ldir + 6, 1);
+    r[14] = 0;
+    r[15] = 0;
+  }
+  // ---- the tile: 20 rows x 10 groups of 4 pixels, one per thread
+  {
+    const int lim_x = ((a.luma.width >> 3) << 3) >> XD, lim_y = ((a.luma.height >> 3) << 3) >> YD;
+    if (tid < CT_ROWS * 10) {
+      const int ty = tid / 10, tq = tid - ty * 10;
+      const int py = ry0 - CT_Y0 + ty, px = rx0 - CT_X0 + 4 * tq;
+      uint32_t lo = 0x80008000u, hi = 0x80008000u;
+      if (py >= 0 && py < lim_y && px >= 0 && px < lim_x) {
+        const uint8_t *g = (const uint8_t *)a.in.data +
+                           ((size_t)(a.in.yorigin + py) * a.in.stride + a.in.xorigin + px) * BPP;
+        if constexpr (BPP == 1) {
+          const uint32_t q = ld_u32(g);
+          lo = __builtin_amdgcn_perm(0, q, 0x0c010c00u);
+          hi = __builtin_amdgcn_perm(0, q, 0x0c030c02u);
+        } else {
+          const U32x2 q = ld_u32x2(g);
+          lo = q.a;
+          hi = q.b;
+        }
+      }
+      *(uint2 *)(tile + ty * CT_STRIDE + 4 * tq) = make_uint2(lo, hi);
     }
   }
   __syncthreads();
-  if (!in_grid) return;
-  const int px = (in_xoff >> XD) + bx * xs, py = (in_yoff >> YD) + by * ys;
-  uint8_t *dst = (uint8_t *)px_addr<BPP>(a.out, px, py);
-  const size_t dstb = (size_t)a.out.stride * BPP;
-  const int i = lane / xs, j = lane % xs;
-  const bool act = lane < xs * ys;
-  // this block's top-left inside the tile
-  const uint16_t *t0 = tile + ((wave >> 1) * ys + 2) * TW + (wave & 1) * xs + 2;
-  if (skip) {   // wave-uniform
-    if (act) stpx<BPP>(dst + i * dstb + j * BPP, t0[i * TW + j]);
+  // ---- lane -> pixel pair
+  const int r = lane >> 3, pc = lane & 7;
+  const int lx = (wave & 1) * 16 + 2 * pc, ly = (wave >> 1) * 8 + r;     // inside the region
+  const int blk = (ly / ys) * NBX + lx / xs;
+  const uint4 q0 = *(const uint4 *)(rec + blk * CT_REC);
+  const uint32_t flags = rec[blk * CT_REC + 6];
+  const uint32_t base = (uint32_t)(((ly + CT_Y0) * CT_STRIDE + lx + CT_X0) * 2);
+  Pk x;
+  x.u = *(const uint32_t *)((const uint8_t *)tile + base);
+  if (!(flags & 1)) return;
+  uint8_t *dst = (uint8_t *)px_addr<BPP>(a.out, rx0 + lx, ry0 + ly);
+  auto store = [&](Pk v) {
+    if constexpr (BPP == 1) *(uint16_t *)dst = (uint16_t)__builtin_amdgcn_perm(0, v.u, 0x0c0c0200u);
+    else *(uint32_t *)dst = v.u;
+  };
+  if (!__any((int)(flags & 2))) {   // every block of the wave is skipped: copy
+    store(x);
     return;
   }
-  // everything below the direction search is the same in all 64 lanes of the block: keep it in
-  // scalar registers (strengths, direction, damping, the tap offsets they select)
-  uint32_t var_v = 0;
-  const int dir = __builtin_amdgcn_readfirstlane(find_dir_wave(lum, coeff_shift, part[wave], var_v));
-  const uint32_t var = (uint32_t)__builtin_amdgcn_readfirstlane((int)var_v);
-  ci = __builtin_amdgcn_readfirstlane(ci);
-  const int ysr = a.prm.y_strengths[ci], uvs = a.prm.uv_strengths[ci];
-  int lpri, lsec, ldir, ldamp = a.prm.damping + coeff_shift;
-  if (a.p == 0) {
-    const int pri_y = ysr / 4;
-    int sec_y = ysr % 4;
-    sec_y += sec_y == 3;
-    lpri = adjust_strength(pri_y << coeff_shift, (int)var);
-    lsec = sec_y << coeff_shift;
-    ldir = pri_y != 0 ? dir : 0;
-  } else {
-    // Cdef_Uv_Dir for 4:2:2: {7, 0, 2, 4, 5, 6, 6, 6} packed as nibbles
-    const int uvdir = (int)((0x66654207u >> (4 * dir)) & 0xf);
-    const int pri_uv = uvs / 4;
-    int sec_uv = uvs % 4;
-    sec_uv += sec_uv == 3;
-    lpri = pri_uv << coeff_shift;
-    lsec = sec_uv << coeff_shift;
-    ldamp -= 1;
-    ldir = pri_uv != 0 ? (XD != YD ? uvdir : dir) : 0;
+  const uint4 q1 = *(const uint4 *)(rec + blk * CT_REC + 4);
+  const uint4 q2 = *(const uint4 *)(rec + blk * CT_REC + 8);
+  const uint2 q3 = *(const uint2 *)(rec + blk * CT_REC + 12);
+  Pk pri, sec, psh, ssh, pt0, pt1;
+  pri.u = q0.x; sec.u = q0.y; psh.u = q0.z; ssh.u = q0.w;
+  pt0.u = q1.x; pt1.u = q1.y;
+  const uint32_t offs[6] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
+  // all 24 pair reads are issued before the first is used
+  uint32_t tp[12];
+#pragma unroll
+  for (int t = 0; t < 6; t++) {
+    tp[2 * t] = lds_pair(base + offs[t]);
+    tp[2 * t + 1] = lds_pair(base - offs[t]);
   }
-  if (act) {
-    auto rd = [&](int yy, int xx) -> int32_t { return t0[yy * TW + xx]; };
-    stpx<BPP>(dst + i * dstb + j * BPP,
-              filter_pixel_rd(rd, i, j, lpri, lsec, ldir, ldamp, coeff_shift));
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(tp[0]), "+v"(tp[1]), "+v"(tp[2]), "+v"(tp[3]), "+v"(tp[4]), "+v"(tp[5]),
+                 "+v"(tp[6]), "+v"(tp[7]), "+v"(tp[8]), "+v"(tp[9]), "+v"(tp[10]), "+v"(tp[11])
+               :: "memory");
+  i16x2 sum = (i16x2)0, mx = x.s;
+  u16x2 mn = x.v;
+#pragma unroll
+  for (int t = 0; t < 12; t++) {
+    Pk p;
+    p.u = tp[t];
+    const int dirsel = t >> 1;             // 0,1: primary k = 0,1; 2,3: dir + 2; 4,5: dir + 6
+    const int k = dirsel & 1;
+    mx = __builtin_elementwise_max(mx, p.s);
+    mn = __builtin_elementwise_min(mn, p.v);
+    if (dirsel < 2) {
+      const i16x2 c = constrain2(p.s - x.s, pri.s, psh.v);
+      sum += c * (k == 0 ? pt0.s : pt1.s);
+    } else {
+      const i16x2 c = constrain2(p.s - x.s, sec.s, ssh.v);
+      sum += k == 0 ? c * (i16x2)2 : c;
+    }
   }
+  // x + ((8 + sum - (sum < 0)) >> 4), clamped to the taps' range
+  Pk v;
+  v.s = x.s + ((sum + (sum >> (i16x2)15) + (i16x2)8) >> (i16x2)4);
+  v.s = __builtin_elementwise_min(__builtin_elementwise_max(v.s, (i16x2)mn), mx);
+  store(v);
 }
 
 template <int BPP>
@@ -276,43 +484,134 @@ extern "C" int r1_cdef_filter_block_batch(r1_ctx *ctx, const R1Plane *in, const 
   return R1_OK;
 }
 
-extern "C" int r1_cdef_filter_frame_plane(r1_ctx *ctx, const R1Plane *luma, const R1Plane *in,
-                                          const R1Plane *out, int p, int xdec, int ydec,
-                                          int tile_w, int tile_h, const uint8_t *skip_mi,
-                                          int mi_stride, int mi_cols, int mi_rows,
-                                          const uint8_t *cdef_index_sb, int sb_stride,
-                                          const R1CdefParams *params, void *stream) {
-  R1_REQUIRE(ctx && luma && in && out && params && skip_mi && cdef_index_sb);
-  R1_REQUIRE(in->bytes_per_px == out->bytes_per_px && in->bytes_per_px == luma->bytes_per_px);
+namespace {
+int cdef_grid(int tile_w, int tile_h, int *nbx, int *nby) {
+  // fb loops run over ceil(tile / 64) superblocks x 8x8 block positions
+  *nbx = ((tile_w + 63) / 64) * 8;
+  *nby = ((tile_h + 63) / 64) * 8;
+  return *nbx * *nby;
+}
+
+int cdef_analyze_launch(const R1Plane *luma, int nbx, int nby, int mi_cols, int mi_rows,
+                        uint8_t *dirs, int32_t *vars, hipStream_t st) {
+  const dim3 grid((nbx + 63) / 64, nby);
+  if (luma->bytes_per_px == 1)
+    hipLaunchKernelGGL((k_cdef_analyze<1>), grid, dim3(64), 0, st, *luma, nbx, nby, mi_cols, mi_rows, dirs, vars);
+  else
+    hipLaunchKernelGGL((k_cdef_analyze<2>), grid, dim3(64), 0, st, *luma, nbx, nby, mi_cols, mi_rows, dirs, vars);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+int cdef_filter_launch(const CdefFrameArgs &a, int bpp, hipStream_t st) {
+  // plane pixels the grid covers, in 32 x 16 regions
+  const int pw = (a.nbx * 8) >> a.xdec, ph = (a.nby * 8) >> a.ydec;
+  const dim3 grid((pw + 31) / 32, (ph + 15) / 16);
+#define R1_CDEF_LAUNCH(B, X, Y) hipLaunchKernelGGL((k_cdef_frame<B, X, Y>), grid, dim3(256), 0, st, a)
+#define R1_CDEF_DEC(B)                                   \
+  do {                                                   \
+    if (a.xdec == 0 && a.ydec == 0) R1_CDEF_LAUNCH(B, 0, 0); \
+    else if (a.xdec == 1 && a.ydec == 1) R1_CDEF_LAUNCH(B, 1, 1); \
+    else if (a.xdec == 1) R1_CDEF_LAUNCH(B, 1, 0);       \
+    else R1_CDEF_LAUNCH(B, 0, 1);                        \
+  } while (0)
+  if (bpp == 1) R1_CDEF_DEC(1);
+  else R1_CDEF_DEC(2);
+#undef R1_CDEF_DEC
+#undef R1_CDEF_LAUNCH
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+}  // namespace
+
+extern "C" long long r1_cdef_analyze_blocks(int tile_w, int tile_h) {
+  int nbx, nby;
+  return tile_w > 0 && tile_h > 0 ? cdef_grid(tile_w, tile_h, &nbx, &nby) : 0;
+}
+
+extern "C" int r1_cdef_analyze_frame(r1_ctx *ctx, const R1Plane *luma, int tile_w, int tile_h,
+                                     int mi_cols, int mi_rows, uint8_t *dir_out, int32_t *var_out,
+                                     void *stream) {
+  R1_REQUIRE(ctx && luma && dir_out && var_out);
+  R1_REQUIRE(luma->bytes_per_px == 1 || luma->bytes_per_px == 2);
+  R1_REQUIRE(luma->bit_depth == 8 || luma->bit_depth == 10 || luma->bit_depth == 12);
+  R1_REQUIRE(tile_w > 0 && tile_h > 0);
+  R1DeviceGuard guard(ctx);
+  int nbx, nby;
+  cdef_grid(tile_w, tile_h, &nbx, &nby);
+  return cdef_analyze_launch(luma, nbx, nby, mi_cols, mi_rows, dir_out, var_out, (hipStream_t)stream);
+}
+
+namespace {
+int cdef_frame_plane(r1_ctx *ctx, const R1Plane *luma, const uint8_t *dirs, const int32_t *vars,
+                     const R1Plane *in, const R1Plane *out, int p, int xdec, int ydec, int tile_w,
+                     int tile_h, const uint8_t *skip_mi, int mi_stride, int mi_cols, int mi_rows,
+                     const uint8_t *cdef_index_sb, int sb_stride, const R1CdefParams *params,
+                     void *stream) {
+  R1_REQUIRE(ctx && in && out && params && skip_mi && cdef_index_sb && (luma || (dirs && vars)));
+  R1_REQUIRE(in->bytes_per_px == out->bytes_per_px);
+  R1_REQUIRE(!luma || in->bytes_per_px == luma->bytes_per_px);
   R1_REQUIRE(in->bytes_per_px == 1 || in->bytes_per_px == 2);
   R1_REQUIRE(in->data != out->data);
   R1_REQUIRE(p >= 0 && p <= 2 && xdec >= 0 && xdec <= 1 && ydec >= 0 && ydec <= 1);
   R1_REQUIRE(p != 0 || (xdec == 0 && ydec == 0));
   R1_REQUIRE(tile_w > 0 && tile_h > 0 && mi_stride >= mi_cols);
   R1_REQUIRE(params->bit_depth == 8 || params->bit_depth == 10 || params->bit_depth == 12);
+  R1DeviceGuard guard(ctx);
+  hipStream_t st = (hipStream_t)stream;
   CdefFrameArgs a;
-  a.luma = *luma; a.in = *in; a.out = *out;
+  a.in = *in; a.out = *out;
+  // the picture's limits are the luma plane's; without one, the tile's (the whole frame)
+  a.luma = luma ? *luma : *in;
+  if (!luma) {
+    a.luma.width = tile_w;
+    a.luma.height = tile_h;
+  }
   a.p = p; a.xdec = xdec; a.ydec = ydec; a.tile_w = tile_w; a.tile_h = tile_h;
   a.skip_mi = skip_mi; a.mi_stride = mi_stride; a.mi_cols = mi_cols; a.mi_rows = mi_rows;
   a.cdef_index_sb = cdef_index_sb; a.sb_stride = sb_stride;
   a.prm = *params;
-  // fb loops run over ceil(tile / 64) superblocks x 8x8 block positions
-  a.nbx = ((tile_w + 63) / 64) * 8;
-  a.nby = ((tile_h + 63) / 64) * 8;
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((a.nbx + 1) / 2, (a.nby + 1) / 2);
-#define R1_CDEF_LAUNCH(B, X, Y) hipLaunchKernelGGL((k_cdef_frame<B, X, Y>), grid, dim3(256), 0, st, a)
-#define R1_CDEF_DEC(B)                                   \
-  do {                                                   \
-    if (xdec == 0 && ydec == 0) R1_CDEF_LAUNCH(B, 0, 0); \
-    else if (xdec == 1 && ydec == 1) R1_CDEF_LAUNCH(B, 1, 1); \
-    else if (xdec == 1) R1_CDEF_LAUNCH(B, 1, 0);         \
-    else R1_CDEF_LAUNCH(B, 0, 1);                        \
-  } while (0)
-  if (in->bytes_per_px == 1) R1_CDEF_DEC(1);
-  else R1_CDEF_DEC(2);
-#undef R1_CDEF_DEC
-#undef R1_CDEF_LAUNCH
-  R1_HIP_CHECK(hipGetLastError());
-  return R1_OK;
+  const int nb = cdef_grid(tile_w, tile_h, &a.nbx, &a.nby);
+  void *tmp = nullptr;
+  if (!dirs) {
+    // directions of this call only: stream-ordered scratch, freed behind the filter
+    R1_HIP_CHECK(hipMallocAsync(&tmp, (size_t)nb * 5, st));
+    int32_t *v = (int32_t *)tmp;
+    uint8_t *d = (uint8_t *)tmp + (size_t)nb * 4;
+    const int rc = cdef_analyze_launch(luma, a.nbx, a.nby, mi_cols, mi_rows, d, v, st);
+    if (rc != R1_OK) {
+      (void)hipFreeAsync(tmp, st);
+      return rc;
+    }
+    dirs = d;
+    vars = v;
+  }
+  a.dirs = dirs;
+  a.vars = vars;
+  const int rc = cdef_filter_launch(a, in->bytes_per_px, st);
+  if (tmp) R1_HIP_CHECK(hipFreeAsync(tmp, st));
+  return rc;
+}
+}  // namespace
+
+extern "C" int r1_cdef_filter_frame_plane(r1_ctx *ctx, const R1Plane *luma, const R1Plane *in,
+                                          const R1Plane *out, int p, int xdec, int ydec,
+                                          int tile_w, int tile_h, const uint8_t *skip_mi,
+                                          int mi_stride, int mi_cols, int mi_rows,
+                                          const uint8_t *cdef_index_sb, int sb_stride,
+                                          const R1CdefParams *params, void *stream) {
+  R1_REQUIRE(luma);
+  return cdef_frame_plane(ctx, luma, nullptr, nullptr, in, out, p, xdec, ydec, tile_w, tile_h, skip_mi,
+                          mi_stride, mi_cols, mi_rows, cdef_index_sb, sb_stride, params, stream);
+}
+
+extern "C" int r1_cdef_filter_frame_plane_dirs(r1_ctx *ctx, const uint8_t *dirs, const int32_t *vars,
+                                               const R1Plane *in, const R1Plane *out, int p, int xdec,
+                                               int ydec, int tile_w, int tile_h, const uint8_t *skip_mi,
+                                               int mi_stride, int mi_cols, int mi_rows,
+                                               const uint8_t *cdef_index_sb, int sb_stride,
+                                               const R1CdefParams *params, void *stream) {
+  R1_REQUIRE(dirs && vars);
+  return cdef_frame_plane(ctx, nullptr, dirs, vars, in, out, p, xdec, ydec, tile_w, tile_h, skip_mi,
+                          mi_stride, mi_cols, mi_rows, cdef_index_sb, sb_stride, params, stream);
 }

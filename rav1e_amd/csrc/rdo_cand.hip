@@ -61,6 +61,25 @@ __device__ unsigned long long g_phase[4096][8];
 #ifndef R1_SRC_LDS_POLICY
 #define R1_SRC_LDS_POLICY(BPP, P) ((BPP) == 1 || (P) <= 32)
 #endif
+// (Round 3 tried a software pipeline over two candidate groups per wave -- next group's loads in
+// flight under this group's arithmetic.  Measured, profiles/r03_ab_notes.md ab3: -2.3 % on the 8-bit
+// 8x8 launch, a LOSS everywhere else (the launches are VALU-issue bound; the registers of the loads
+// in flight cost more occupancy than the hidden round trip is worth), and the machine scheduler did
+// not terminate on the QM = 2 instantiations of that loop.  Not kept.)
+// Translation units.  k_rdo_cand has 19 sizes x 3 bit depths x 3 QM variants = 171 instantiations;
+// compiled in one piece they take minutes of one core.  The Makefile compiles this
+// file ten times: nine slices (-DR1_RDO_TU_BD=8|10|12 -DR1_RDO_TU_QM=0|1|2: the kernel and one
+// r1_rdo_slice_b*_q* launcher each) in parallel, and once without either macro (k_mc_fast, the
+// dispatch and the entry points).  Experiment builds (-DR1_HEADLINE_ONLY) are one unit.
+#if defined(R1_HEADLINE_ONLY)
+#define R1_RDO_SLICE_TU
+#define R1_RDO_DISPATCH_TU
+#elif defined(R1_RDO_TU_BD)
+#define R1_RDO_SLICE_TU
+#else
+#define R1_RDO_DISPATCH_TU
+#endif
+
 // which instantiations send the coefficients through LDS for 16-byte stores
 #ifndef R1_WIDE_STORE_POLICY
 #define R1_WIDE_STORE_POLICY(P) ((P) <= 16)
@@ -500,6 +519,7 @@ __device__ __forceinline__ uint32_t satd_column(const T *v, int lane) {
 // quantize + dequantize + transform-domain distortion + estimate_rate, i.e.
 // encode_tx_block's RDOType::TxDistEstRate evaluation (src/encoder.rs:1533-1650)
 // -- and only (eob, distortion, rate) leave the CU.
+}  // namespace
 struct RdoQuantArgs {
   r1q::QParams qp;
   const uint16_t *scan[3];   // av1_scan_orders[tx_size]: default / mrow / mcol
@@ -519,6 +539,8 @@ struct RdoQuantArgs {
   // averages) instead of put_8tap of the reference plane
   const void *pred_in;
 };
+namespace {
+using r1tx::T;
 
 // QM: 0 = coefficients to HBM (headline), 1 = + quantizer, tx-domain distortion,
 // rate (N4), 2 = + quantizer, inverse transform, pixel-domain distortion.
@@ -526,6 +548,12 @@ struct RdoQuantArgs {
 // where the kernel sits a few registers above an allocation step (512 / n, in eights) and
 // the step costs no spill worth mentioning -- measured, see DESIGN.md 5.1 "occupancy".
 constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm) {
+#ifdef R1_HINT_8X8
+  if (wl == 3 && hl == 3 && qm == 0) return R1_HINT_8X8;   // A/B: the pipelined 8x8 kernel sits at 69 (8-bit)
+#endif
+#ifdef R1_HINT_16X16
+  if (wl == 4 && hl == 4 && qm == 0) return R1_HINT_16X16;
+#endif
   if (wl == 5 && hl == 5 && qm == 2 && bd == 8) return 4;   // 132 VGPRs -> 128 (10-bit: 149, spills)
   if (wl == 5 && hl == 5 && qm == 1 && bd == 8) return 5;   // 97 -> 96
   if (wl == 6 && hl == 6 && qm == 2) return 3;              // 176 / 181 -> 168
@@ -1075,6 +1103,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   }
 }
 
+#ifdef R1_RDO_DISPATCH_TU
 // put_8tap / prep_8tap alone on the same machinery (blocks whose size is a
 // transform size): window staged with one round trip, dot4 / dot2 columns.
 template <int BPP, int WL, int HL, bool PREP>
@@ -1126,33 +1155,56 @@ int launch_mc_fast(bool prep, const R1Plane &ref, const R1McCand *cands, int n, 
   return R1_OK;
 }
 
-template <int BD, int WL, int HL>
+#endif   // R1_RDO_DISPATCH_TU
+
+#ifdef R1_RDO_SLICE_TU
+template <int BD, int WL, int HL, int QM>
 int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n,
            uint32_t *sad, uint32_t *satd, void *coeffs, void *pred, const RdoQuantArgs *qa,
            hipStream_t st) {
   constexpr int W = 1 << WL, H = 1 << HL, P = W > H ? W : H, NC = 64 / P;
   typedef typename std::conditional<BD == 8, int16_t, int32_t>::type CT;
-  const unsigned grid = (unsigned)((n + NC - 1) / NC);
-#ifdef R1_HEADLINE_ONLY   // experiment builds (tools/build_variant.sh): the headline instantiations only
-  if (qa) return R1_EINVAL;
-  hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, 0>), dim3(grid), dim3(64), 0, st,
-                     org, ref, cands, n, sad, satd, (CT *)coeffs, pred, RdoQuantArgs{});
+  const unsigned groups = (unsigned)((n + NC - 1) / NC);
+  const unsigned grid = groups;
+  hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, QM>), dim3(grid), dim3(64), 0, st,
+                     org, ref, cands, n, sad, satd, (CT *)coeffs, pred, qa ? *qa : RdoQuantArgs{});
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
-#else
-  if (qa && qa->pix_dist)
-    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, 2>), dim3(grid), dim3(64), 0, st,
-                       org, ref, cands, n, sad, satd, (CT *)coeffs, pred, *qa);
-  else if (qa)
-    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, 1>), dim3(grid), dim3(64), 0, st,
-                       org, ref, cands, n, sad, satd, (CT *)coeffs, pred, *qa);
-  else
-    hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, 0>), dim3(grid), dim3(64), 0, st,
-                       org, ref, cands, n, sad, satd, (CT *)coeffs, pred, RdoQuantArgs{});
-  R1_HIP_CHECK(hipGetLastError());
-  return R1_OK;
-#endif
 }
+
+// one (bit depth, QM) slice: tx_size -> instantiation
+template <int BD, int QM>
+int slice(int tx_size, const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n,
+          uint32_t *sad, uint32_t *satd, void *coeffs, void *pred, const RdoQuantArgs *qa,
+          hipStream_t st) {
+  // R1_RDO_TU_TSMASK: the transform sizes this unit instantiates (the Makefile cuts the slow QM = 2
+  // slices into parts by size)
+#ifndef R1_RDO_TU_TSMASK
+#define R1_RDO_TU_TSMASK 0x7ffff
+#endif
+#define R1_RC_CASE(ID, WL, HL)                                                                   \
+  case ID:                                                                                       \
+    if constexpr (((R1_RDO_TU_TSMASK) >> ID) & 1)                                                \
+      return launch<BD, WL, HL, QM>(org, ref, cands, n, sad, satd, coeffs, pred, qa, st);        \
+    else                                                                                         \
+      break;
+  switch (tx_size) {
+#ifdef R1_HEADLINE_ONLY   // experiment builds (tools/build_variant.sh): the headline instantiations only
+    R1_RC_CASE(1, 3, 3) R1_RC_CASE(2, 4, 4) R1_RC_CASE(3, 5, 5) R1_RC_CASE(4, 6, 6)
+#else
+    R1_RC_CASE(0, 2, 2) R1_RC_CASE(1, 3, 3) R1_RC_CASE(2, 4, 4)
+    R1_RC_CASE(3, 5, 5) R1_RC_CASE(4, 6, 6) R1_RC_CASE(5, 2, 3)
+    R1_RC_CASE(6, 3, 2) R1_RC_CASE(7, 3, 4) R1_RC_CASE(8, 4, 3)
+    R1_RC_CASE(9, 4, 5) R1_RC_CASE(10, 5, 4) R1_RC_CASE(11, 5, 6)
+    R1_RC_CASE(12, 6, 5) R1_RC_CASE(13, 2, 4) R1_RC_CASE(14, 4, 2)
+    R1_RC_CASE(15, 3, 5) R1_RC_CASE(16, 5, 3) R1_RC_CASE(17, 4, 6)
+    R1_RC_CASE(18, 6, 4)
+#endif
+  }
+#undef R1_RC_CASE
+  return R1_EINVAL;
+}
+#endif
 
 }  // namespace
 
@@ -1168,6 +1220,23 @@ extern "C" int r1_debug_phase_prof(unsigned long long *out, int reset) {   /* ou
 }
 #endif
 
+#define R1_SLICE_ARGS                                                                         \
+  int tx_size, const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n,         \
+      uint32_t *sad, uint32_t *satd, void *coeffs, void *pred, const RdoQuantArgs *qa, hipStream_t st
+#define R1_SLICE_NAME2(B, Q) r1_rdo_slice_b##B##_q##Q
+#define R1_SLICE_NAME(B, Q) R1_SLICE_NAME2(B, Q)
+#if defined(R1_RDO_TU_BD) && !defined(R1_HEADLINE_ONLY)
+int R1_SLICE_NAME(R1_RDO_TU_BD, R1_RDO_TU_QM)(R1_SLICE_ARGS) {
+  return slice<R1_RDO_TU_BD, R1_RDO_TU_QM>(tx_size, org, ref, cands, n, sad, satd, coeffs, pred, qa, st);
+}
+#endif
+
+#ifdef R1_RDO_DISPATCH_TU
+#ifndef R1_HEADLINE_ONLY
+int r1_rdo_slice_b8_q0(R1_SLICE_ARGS);  int r1_rdo_slice_b8_q1(R1_SLICE_ARGS);  int r1_rdo_slice_b8_q2(R1_SLICE_ARGS);
+int r1_rdo_slice_b10_q0(R1_SLICE_ARGS); int r1_rdo_slice_b10_q1(R1_SLICE_ARGS); int r1_rdo_slice_b10_q2(R1_SLICE_ARGS);
+int r1_rdo_slice_b12_q0(R1_SLICE_ARGS); int r1_rdo_slice_b12_q1(R1_SLICE_ARGS); int r1_rdo_slice_b12_q2(R1_SLICE_ARGS);
+#endif
 // Used by r1_mc_put_batch / r1_mc_prep_batch (mc.hip) for block sizes that are
 // transform sizes; returns 1 when (w, h) is not one of them.
 int r1_mc_fast_launch(bool prep, const R1Plane *ref, int w, int h, const R1McCand *cands, int n,
@@ -1220,29 +1289,19 @@ int rdo_dispatch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w, int
   // compile-time constants of the instantiation
   const int bd = org->bit_depth;
   R1_REQUIRE(bd == 8 || bd == 10 || bd == 12);
-#define R1_RC_CASE(ID, WL, HL)                                                        \
-  case ID:                                                                            \
-    return bd == 8    ? launch<8, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,   \
-                                          coeffs, pred_out, qa, st)                   \
-           : bd == 10 ? launch<10, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,  \
-                                           coeffs, pred_out, qa, st)                  \
-                      : launch<12, WL, HL>(*org, *ref, cands, n, sad_out, satd_out,  \
-                                           coeffs, pred_out, qa, st);
-  switch (tx_size) {
+  const int qm = !qa ? 0 : (qa->pix_dist ? 2 : 1);
 #ifdef R1_HEADLINE_ONLY
-    R1_RC_CASE(1, 3, 3) R1_RC_CASE(2, 4, 4) R1_RC_CASE(3, 5, 5) R1_RC_CASE(4, 6, 6)
+  if (qm != 0 || bd == 12) return R1_EINVAL;
+  return bd == 8 ? slice<8, 0>(tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out, nullptr, st)
+                 : slice<10, 0>(tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out, nullptr, st);
 #else
-    R1_RC_CASE(0, 2, 2) R1_RC_CASE(1, 3, 3) R1_RC_CASE(2, 4, 4)
-    R1_RC_CASE(3, 5, 5) R1_RC_CASE(4, 6, 6) R1_RC_CASE(5, 2, 3)
-    R1_RC_CASE(6, 3, 2) R1_RC_CASE(7, 3, 4) R1_RC_CASE(8, 4, 3)
-    R1_RC_CASE(9, 4, 5) R1_RC_CASE(10, 5, 4) R1_RC_CASE(11, 5, 6)
-    R1_RC_CASE(12, 6, 5) R1_RC_CASE(13, 2, 4) R1_RC_CASE(14, 4, 2)
-    R1_RC_CASE(15, 3, 5) R1_RC_CASE(16, 5, 3) R1_RC_CASE(17, 4, 6)
-    R1_RC_CASE(18, 6, 4)
+  typedef int (*SliceFn)(R1_SLICE_ARGS);
+  static const SliceFn kSlices[3][3] = {
+      {r1_rdo_slice_b8_q0, r1_rdo_slice_b8_q1, r1_rdo_slice_b8_q2},
+      {r1_rdo_slice_b10_q0, r1_rdo_slice_b10_q1, r1_rdo_slice_b10_q2},
+      {r1_rdo_slice_b12_q0, r1_rdo_slice_b12_q1, r1_rdo_slice_b12_q2}};
+  return kSlices[(bd - 8) / 2][qm](tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out, qa, st);
 #endif
-  }
-#undef R1_RC_CASE
-  return R1_EINVAL;
 }
 }  // namespace
 
@@ -1348,3 +1407,4 @@ extern "C" int r1_rdo_pred_cand_batch(r1_ctx *ctx, const R1Plane *org, const voi
   return rdo_dispatch(ctx, org, nullptr, w, h, tx_size, cands, n, sad_out, satd_out, nullptr, nullptr,
                       &qa, stream);
 }
+#endif   // R1_RDO_DISPATCH_TU

@@ -12,7 +12,7 @@ import oracle_lib as O
 from rav1e_amd import workload as W
 
 pytestmark = pytest.mark.gpu
-CONFIGS = [(1920, 1080, 8), (3840, 2160, 10)]
+CONFIGS = [(1920, 1080, 8), (3840, 2160, 8), (3840, 2160, 10)]   # config 2/3, the headline, config 4
 TS_OF = {64: 4, 32: 3, 16: 2, 8: 1}
 
 

@@ -700,6 +700,18 @@ def test_cdef_frames_spec_model(ctx, fixture, ncases):
         ns = ~np.array([[G[k + "_skip"][2 * by:2 * by + 2, 2 * bx:2 * bx + 2].all()
                          for bx in range(nbx)] for by in range(nby)])
         assert np.array_equal(d[ns], G[k + "_dir"][ns]) and np.array_equal(v[ns], G[k + "_var"][ns])
+        # the two-step form: one analysis of the frame (a thread per 8x8 block), three filters
+        da, va = ctx.cdef_analyze_frame(planes_[0][1], W, H, skip.shape[1], skip.shape[0])
+        da_h, va_h = da.cpu().numpy()[:nby, :nbx], va.cpu().numpy()[:nby, :nbx]
+        assert np.array_equal(da_h[ns], G[k + "_dir"][ns]) and np.array_equal(va_h[ns], G[k + "_var"][ns])
+        assert np.array_equal(da_h, d) and np.array_equal(va_h, v)      # skipped blocks too
+        for p in range(3):
+            xd, yd = (0, 0) if p == 0 else (xdec, ydec)
+            _, dst = _plane_from(np.zeros_like(G[k + "_in%d" % p]).astype(dt), bd)
+            ctx.cdef_filter_frame_plane_dirs(da, va, planes_[p][1], dst, p, xd, yd, W, H, skip, ci,
+                                             G[k + "_ystr"], G[k + "_uvstr"], damping, bd)
+            got = dst.data.cpu().numpy().view(dt)[16:16 + (H >> yd), dst.xorigin:dst.xorigin + (W >> xd)]
+            assert np.array_equal(got.astype(np.uint16), G[k + "_out%d" % p]), (c, p, "dirs")
 
 
 @pytest.mark.parametrize("bd", [8, 10])
