@@ -211,7 +211,8 @@ __global__ __launch_bounds__(64) void k_cdef_analyze(R1Plane luma, int nbx, int 
 // ---- cdef_filter_superblock for one plane of the whole frame.
 // Workgroup = 4 waves = a 32 x 16 pixel region of the plane, wave = 16 x 8 of it, LANE = TWO
 // horizontally adjacent pixels held as one packed i16 pair: all of constrain(), the tap sum and
-// the min / max tracking run on v_pk_* instructions, 12 per tap for two pixels.
+// the min / max tracking run on v_pk_* instructions, 12 (+ 1 to pair the two reads) per tap for
+// two pixels.
 //  * the region plus its halo (2 rows above / below, 4 columns left / right so that every global
 //    load is one aligned 4-pixel group) is staged once in LDS as u16 with CDEF_VERY_LARGE where
 //    the picture ends -- a halo pixel is missing exactly when it lies outside
@@ -237,12 +238,20 @@ constexpr int CT_STRIDE = 48;           // u16 per tile row (40 used)
 constexpr int CT_ROWS = 20, CT_X0 = 4, CT_Y0 = 2;
 constexpr int CT_REC = 16;              // dwords per block record
 
-// the pair at LDS byte address a / a + 2 (a is only 2-byte aligned: two 16-bit reads, the second
-// into the high half -- a 32-bit read of an odd pixel position is an order of magnitude slower)
-__device__ __forceinline__ uint32_t lds_pair(uint32_t a) {
-  uint32_t v;
-  asm volatile("ds_read_u16 %0, %1\n\tds_read_u16_d16_hi %0, %1 offset:2" : "=&v"(v) : "v"(a) : "memory");
-  return v;
+// the two pixels at LDS byte address a / a + 2 (a is only 2-byte aligned: a 32-bit read of an odd
+// pixel position is an order of magnitude slower, and the compiler would merge two 16-bit reads into
+// one -- hence asm; d16_hi loads do not keep the other half on this chip (SRAM ECC), hence two
+// registers and one v_lshl_or to pair them).  The caller waits (lds_wait) before it looks at them.
+__device__ __forceinline__ void lds_two(uint32_t a, uint32_t &lo, uint32_t &hi) {
+  asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:2" : "=&v"(lo), "=&v"(hi) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_wait(uint32_t (&lo)[12], uint32_t (&hi)[12]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]),
+                 "+v"(lo[7]), "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11]), "+v"(hi[0]), "+v"(hi[1]),
+                 "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]), "+v"(hi[8]),
+                 "+v"(hi[9]), "+v"(hi[10]), "+v"(hi[11])
+               :: "memory");
 }
 
 __device__ __forceinline__ i16x2 constrain2(i16x2 d, i16x2 thr, u16x2 sh) {
@@ -363,6 +372,9 @@ __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
   const uint32_t base = (uint32_t)(((ly + CT_Y0) * CT_STRIDE + lx + CT_X0) * 2);
   Pk x;
   x.u = *(const uint32_t *)((const uint8_t *)tile + base);
+  // lds_pair takes LDS byte addresses, not offsets into the tile
+  typedef __attribute__((address_space(3))) uint16_t LdsU16;
+  const uint32_t tbase = (uint32_t)(uintptr_t)(LdsU16 *)tile + base;
   if (!(flags & 1)) return;
   uint8_t *dst = (uint8_t *)px_addr<BPP>(a.out, rx0 + lx, ry0 + ly);
   auto store = [&](Pk v) {
@@ -380,17 +392,16 @@ __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
   pri.u = q0.x; sec.u = q0.y; psh.u = q0.z; ssh.u = q0.w;
   pt0.u = q1.x; pt1.u = q1.y;
   const uint32_t offs[6] = {q2.x, q2.y, q2.z, q2.w, q3.x, q3.y};
-  // all 24 pair reads are issued before the first is used
-  uint32_t tp[12];
+  // all 24 reads are issued before the first is used
+  uint32_t tlo[12], thi[12], tp[12];
 #pragma unroll
   for (int t = 0; t < 6; t++) {
-    tp[2 * t] = lds_pair(base + offs[t]);
-    tp[2 * t + 1] = lds_pair(base - offs[t]);
+    lds_two(tbase + offs[t], tlo[2 * t], thi[2 * t]);
+    lds_two(tbase - offs[t], tlo[2 * t + 1], thi[2 * t + 1]);
   }
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(tp[0]), "+v"(tp[1]), "+v"(tp[2]), "+v"(tp[3]), "+v"(tp[4]), "+v"(tp[5]),
-                 "+v"(tp[6]), "+v"(tp[7]), "+v"(tp[8]), "+v"(tp[9]), "+v"(tp[10]), "+v"(tp[11])
-               :: "memory");
+  lds_wait(tlo, thi);
+#pragma unroll
+  for (int t = 0; t < 12; t++) tp[t] = tlo[t] | (thi[t] << 16);
   i16x2 sum = (i16x2)0, mx = x.s;
   u16x2 mn = x.v;
 #pragma unroll
@@ -524,6 +535,16 @@ int cdef_filter_launch(const CdefFrameArgs &a, int bpp, hipStream_t st) {
 }
 }  // namespace
 
+void r1_cdef_scratch_free(r1_ctx *c) {
+  for (int k = 0; k < r1_ctx::kCdefSlots; k++) {
+    if (c->cdef_done[k]) {
+      (void)hipEventSynchronize(c->cdef_done[k]);
+      (void)hipEventDestroy(c->cdef_done[k]);
+    }
+    if (c->cdef_scratch[k]) (void)hipFree(c->cdef_scratch[k]);
+  }
+}
+
 extern "C" long long r1_cdef_analyze_blocks(int tile_w, int tile_h) {
   int nbx, nby;
   return tile_w > 0 && tile_h > 0 ? cdef_grid(tile_w, tile_h, &nbx, &nby) : 0;
@@ -572,24 +593,35 @@ int cdef_frame_plane(r1_ctx *ctx, const R1Plane *luma, const uint8_t *dirs, cons
   a.cdef_index_sb = cdef_index_sb; a.sb_stride = sb_stride;
   a.prm = *params;
   const int nb = cdef_grid(tile_w, tile_h, &a.nbx, &a.nby);
-  void *tmp = nullptr;
-  if (!dirs) {
-    // directions of this call only: stream-ordered scratch, freed behind the filter
-    R1_HIP_CHECK(hipMallocAsync(&tmp, (size_t)nb * 5, st));
-    int32_t *v = (int32_t *)tmp;
-    uint8_t *d = (uint8_t *)tmp + (size_t)nb * 4;
-    const int rc = cdef_analyze_launch(luma, a.nbx, a.nby, mi_cols, mi_rows, d, v, st);
-    if (rc != R1_OK) {
-      (void)hipFreeAsync(tmp, st);
-      return rc;
-    }
-    dirs = d;
-    vars = v;
+  if (dirs) {
+    a.dirs = dirs;
+    a.vars = vars;
+    return cdef_filter_launch(a, in->bytes_per_px, st);
   }
-  a.dirs = dirs;
-  a.vars = vars;
-  const int rc = cdef_filter_launch(a, in->bytes_per_px, st);
-  if (tmp) R1_HIP_CHECK(hipFreeAsync(tmp, st));
+  // directions of this call only, in a slot of the context's ring (not hipMallocAsync: the default
+  // pool hands its memory back at every synchronisation and the next call pays a driver allocation)
+  std::lock_guard<std::mutex> lock(ctx->cdef_mu);
+  const int slot = ctx->cdef_next;
+  ctx->cdef_next = (slot + 1) % r1_ctx::kCdefSlots;
+  if (!ctx->cdef_done[slot]) R1_HIP_CHECK(hipEventCreateWithFlags(&ctx->cdef_done[slot], hipEventDisableTiming));
+  else R1_HIP_CHECK(hipEventSynchronize(ctx->cdef_done[slot]));
+  const size_t need = (size_t)nb * 5;
+  if (ctx->cdef_scratch_bytes[slot] < need) {
+    if (ctx->cdef_scratch[slot]) R1_HIP_CHECK(hipFree(ctx->cdef_scratch[slot]));
+    ctx->cdef_scratch[slot] = nullptr;
+    ctx->cdef_scratch_bytes[slot] = 0;
+    R1_HIP_CHECK(hipMalloc(&ctx->cdef_scratch[slot], need));
+    ctx->cdef_scratch_bytes[slot] = need;
+  }
+  int32_t *v = (int32_t *)ctx->cdef_scratch[slot];
+  uint8_t *d = (uint8_t *)ctx->cdef_scratch[slot] + (size_t)nb * 4;
+  int rc = cdef_analyze_launch(luma, a.nbx, a.nby, mi_cols, mi_rows, d, v, st);
+  if (rc == R1_OK) {
+    a.dirs = d;
+    a.vars = v;
+    rc = cdef_filter_launch(a, in->bytes_per_px, st);
+  }
+  R1_HIP_CHECK(hipEventRecord(ctx->cdef_done[slot], st));
   return rc;
 }
 }  // namespace

@@ -74,6 +74,7 @@ extern "C" void r1_ctx_destroy(r1_ctx *c) {
     if (c->me_jobs[k]) (void)hipFree(c->me_jobs[k]);
     if (c->me_jobs_host[k]) (void)hipHostFree(c->me_jobs_host[k]);
   }
+  r1_cdef_scratch_free(c);
   r1_scan_tables_destroy(c);
   (void)hipStreamDestroy(c->own_stream);
   delete c;

@@ -237,8 +237,8 @@ def test_rdo_glue_ref_cfl_alpha(ctx):
         key = id(srcs)
         if key not in cache:
             cache.clear()
-            cache[key] = ([dev_plane(p) for p in srcs], [dev_plane(p) for p in recs])
-        ds, dr = cache[key]
+            cache[key] = ([dev_plane(p) for p in srcs], [dev_plane(p) for p in recs], srcs)   # srcs held: id stays unique
+        ds, dr, _ = cache[key]
         tw, th = RC.TX_W[uv_ts], RC.TX_H[uv_ts]
         ec = np.zeros(1, INTRA_EDGE_CAND)
         ec["x"], ec["y"], ec["mode"], ec["flags"] = cx, cy, 13, 1
@@ -266,9 +266,9 @@ def test_rdo_glue_ref_predict_inter_compound(ctx):
         key = id(refs[0])
         if key not in cache:
             cache.clear()
-            cache[key] = [dev_plane(p) for p in refs]
+            cache[key] = (refs, [dev_plane(p) for p in refs])   # holds refs: the id cannot be reused
         tmps = []
-        for dp, (x, y, cf, rf) in zip(cache[key], (p0, p1)):
+        for dp, (x, y, cf, rf) in zip(cache[key][1], (p0, p1)):
             c = np.zeros(1, MC_CAND)
             c["rx"], c["ry"], c["col_frac"], c["row_frac"], c["mode_x"], c["mode_y"] = x, y, cf, rf, filt, filt
             tmps.append(ctx.prep_8tap_batch(dp, w, h, c))

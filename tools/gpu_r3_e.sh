@@ -21,3 +21,4 @@ except Exception as ex:
     print("summary failed", ex)
 PY
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -25 | tee $OUT/pytest_gpu.log
+for i in 1 2 3; do timeout 300 python -m pytest tests/test_gpu_ref_vectors.py -q -m gpu -k compound 2>&1 | grep -E "^E  |passed|failed" | head -5; done | tee $OUT/compound_repeat.log
