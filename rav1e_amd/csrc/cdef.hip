@@ -109,105 +109,6 @@ struct CdefFrameArgs {
   const int32_t *vars;
 };
 
-// ---- cdef_analyze_superblock for the whole frame (cdef.rs:340-373): one THREAD per 8x8 luma
-// block, the 64 pixels in registers.  A wave per block spends most of its instructions moving
-// partial sums between lanes (ds_add by 64 lanes: ~150 instructions per pixel); here every add is
-// an add (about 300 adds + 170 multiplies per block, < 10 instructions per pixel) and the lanes of
-// a wave read neighbouring blocks, i.e. whole rows.  The direction of a skipped block is never
-// read, so it is computed for every block of the grid.
-template <int BPP>
-__global__ __launch_bounds__(64) void k_cdef_analyze(R1Plane luma, int nbx, int nby, int mi_cols,
-                                                     int mi_rows, uint8_t *__restrict__ dir_out,
-                                                     int32_t *__restrict__ var_out) {
-  const int gbx = blockIdx.x * 64 + threadIdx.x, gby = blockIdx.y;
-  if (gbx >= nbx || gby >= nby || gbx * 2 >= mi_cols || gby * 2 >= mi_rows) return;
-  const int cs = luma.bit_depth - 8;
-  int32_t x[8][8];
-  const uint8_t *p0 = px_addr<BPP>(luma, gbx * 8, gby * 8);
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    load_px_row<BPP, 8>(p0 + (size_t)i * luma.stride * BPP, x[i]);
-#pragma unroll
-    for (int j = 0; j < 8; j++) x[i][j] = (x[i][j] >> cs) - 128;
-  }
-  // pair sums shared by the half-slope directions: h = two neighbours of a row, v = of a column
-  int32_t h[8][4], v[4][8];
-#pragma unroll
-  for (int i = 0; i < 8; i++)
-#pragma unroll
-    for (int m = 0; m < 4; m++) h[i][m] = x[i][2 * m] + x[i][2 * m + 1];
-#pragma unroll
-  for (int q = 0; q < 4; q++)
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[q][j] = x[2 * q][j] + x[2 * q + 1][j];
-  int32_t part[8][15];
-#pragma unroll
-  for (int d = 0; d < 8; d++)
-#pragma unroll
-    for (int m = 0; m < 15; m++) part[d][m] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      part[0][i + j] += x[i][j];
-      part[4][7 + i - j] += x[i][j];
-    }
-#pragma unroll
-    for (int m = 0; m < 4; m++) {
-      part[1][i + m] += h[i][m];
-      part[3][3 + i - m] += h[i][m];
-      part[2][i] += h[i][m];
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 4; q++)
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      part[5][3 - q + j] += v[q][j];
-      part[7][q + j] += v[q][j];
-      part[6][j] += v[q][j];
-    }
-  // cost = sum of squared line sums * 840 / line length (cdef.rs:110-133); |line sum| <= 1024 and
-  // its square * 840 < 2^30: the 24-bit multiplier is exact
-  constexpr int32_t DIV[9] = {0, 840, 420, 280, 210, 168, 140, 120, 105};
-  int32_t cost[8];
-#pragma unroll
-  for (int d = 0; d < 8; d++) {
-    int32_t c = 0;
-    if (d == 2 || d == 6) {
-      int32_t sq = 0;
-#pragma unroll
-      for (int m = 0; m < 8; m++) sq += __mul24(part[d][m], part[d][m]);
-      c = sq * 105;
-    } else if (d == 0 || d == 4) {
-#pragma unroll
-      for (int m = 0; m < 7; m++)
-        c += __mul24(__mul24(part[d][m], part[d][m]) + __mul24(part[d][14 - m], part[d][14 - m]), DIV[m + 1]);
-      c += __mul24(__mul24(part[d][7], part[d][7]), 105);
-    } else {
-      int32_t sq = 0;
-#pragma unroll
-      for (int m = 3; m < 8; m++) sq += __mul24(part[d][m], part[d][m]);
-      c = sq * 105;
-#pragma unroll
-      for (int m = 0; m < 3; m++)
-        c += __mul24(__mul24(part[d][m], part[d][m]) + __mul24(part[d][10 - m], part[d][10 - m]), DIV[2 * m + 2]);
-    }
-    cost[d] = c;
-  }
-  int best = 0;
-  int32_t best_cost = cost[0];
-#pragma unroll
-  for (int d = 1; d < 8; d++)
-    if (cost[d] > best_cost) { best_cost = cost[d]; best = d; }   // first maximum (cdef.rs:64-73)
-  int32_t orth = cost[4];
-#pragma unroll
-  for (int d = 1; d < 8; d++)
-    if (best == d) orth = cost[(d + 4) & 7];
-  dir_out[(size_t)gby * nbx + gbx] = (uint8_t)best;
-  var_out[(size_t)gby * nbx + gbx] = (best_cost - orth) >> 10;
-}
-
 // ---- cdef_filter_superblock for one plane of the whole frame.
 // Workgroup = 4 waves = a 32 x 16 pixel region of the plane, wave = 16 x 8 of it, LANE = TWO
 // horizontally adjacent pixels held as one packed i16 pair: all of constrain(), the tap sum and
@@ -227,39 +128,9 @@ __global__ __launch_bounds__(64) void k_cdef_analyze(R1Plane luma, int nbx, int 
 //  * 0x8000 is the smallest i16: the signed maximum ignores it, the unsigned minimum sees it as
 //    large, and constrain() of it is 0 because (0x8000 >> shift) >= threshold for every legal
 //    strength / damping -- the three things the reference does with CDEF_VERY_LARGE.
-typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
-typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-union Pk {
-  uint32_t u;
-  i16x2 s;
-  u16x2 v;
-};
 constexpr int CT_STRIDE = 48;           // u16 per tile row (40 used)
 constexpr int CT_ROWS = 20, CT_X0 = 4, CT_Y0 = 2;
 constexpr int CT_REC = 16;              // dwords per block record
-
-// the two pixels at LDS byte address a / a + 2 (a is only 2-byte aligned: a 32-bit read of an odd
-// pixel position is an order of magnitude slower, and the compiler would merge two 16-bit reads into
-// one -- hence asm; d16_hi loads do not keep the other half on this chip (SRAM ECC), hence two
-// registers and one v_lshl_or to pair them).  The caller waits (lds_wait) before it looks at them.
-__device__ __forceinline__ void lds_two(uint32_t a, uint32_t &lo, uint32_t &hi) {
-  asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:2" : "=&v"(lo), "=&v"(hi) : "v"(a) : "memory");
-}
-__device__ __forceinline__ void lds_wait(uint32_t (&lo)[12], uint32_t (&hi)[12]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]),
-                 "+v"(lo[7]), "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11]), "+v"(hi[0]), "+v"(hi[1]),
-                 "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]), "+v"(hi[8]),
-                 "+v"(hi[9]), "+v"(hi[10]), "+v"(hi[11])
-               :: "memory");
-}
-
-__device__ __forceinline__ i16x2 constrain2(i16x2 d, i16x2 thr, u16x2 sh) {
-  const i16x2 ad = __builtin_elementwise_max(d, -d);
-  i16x2 m = thr - (i16x2)((u16x2)ad >> sh);
-  m = __builtin_elementwise_max(m, (i16x2)0);
-  return __builtin_elementwise_max(__builtin_elementwise_min(d, m), -m);
-}
 
 template <int BPP, int XD, int YD>
 __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
@@ -501,17 +372,6 @@ int cdef_grid(int tile_w, int tile_h, int *nbx, int *nby) {
   *nbx = ((tile_w + 63) / 64) * 8;
   *nby = ((tile_h + 63) / 64) * 8;
   return *nbx * *nby;
-}
-
-int cdef_analyze_launch(const R1Plane *luma, int nbx, int nby, int mi_cols, int mi_rows,
-                        uint8_t *dirs, int32_t *vars, hipStream_t st) {
-  const dim3 grid((nbx + 63) / 64, nby);
-  if (luma->bytes_per_px == 1)
-    hipLaunchKernelGGL((k_cdef_analyze<1>), grid, dim3(64), 0, st, *luma, nbx, nby, mi_cols, mi_rows, dirs, vars);
-  else
-    hipLaunchKernelGGL((k_cdef_analyze<2>), grid, dim3(64), 0, st, *luma, nbx, nby, mi_cols, mi_rows, dirs, vars);
-  R1_HIP_CHECK(hipGetLastError());
-  return R1_OK;
 }
 
 int cdef_filter_launch(const CdefFrameArgs &a, int bpp, hipStream_t st) {

@@ -6,18 +6,13 @@
 //
 // The reference filters every superblock of an analysis area once per cdef_index into a
 // working copy and then measures the copy against the source, one 8x8 block at a time.
-// Here ONE launch does all of that without ever materialising a filtered plane:
-//   wave = one 8x8 luma block position (its luma block and both chroma blocks),
-//   lane = pixel.  The direction search runs once; the twelve taps of a pixel are read
-//   once for each of the (at most two) directions the index set can ask for (its own
-//   direction, or 0 when a primary strength is 0) and stay in registers; their min / max
-//   (the clamp of cdef.rs:284-292) is formed once per direction; then for every
-//   cdef_index only the twelve `constrain` terms are evaluated, and the filtered pixel goes
-//   straight into the block's distortion sums: the five moments of cdef_dist_kernel
-//   (wave reduction, fixed-point tail + ssim boost + DistortionScale on one lane) for luma,
-//   4x4-cell squared errors weighted by the block's DistortionScale for chroma.
-//   The per-plane sums of a superblock meet by 64-bit integer atomics (order-free), and a
-//   second, tiny kernel applies fi.dist_scale, adds the planes and picks the first minimum.
+// Here no filtered plane is ever materialised: one analysis launch (k_cdef_analyze, a thread per
+// 8x8 luma block) + one launch per plane kind (k_cdef_search_pk: luma; both chroma planes) work
+// out, for every block and every cdef_index, the filtered pixels in registers (packed pairs, see
+// the kernel) and feed them straight into the block's distortion sums: the five moments of
+// cdef_dist_kernel for luma, 4x4-cell squared errors weighted by the block's DistortionScale for
+// chroma.  The per-plane sums of a superblock meet by 64-bit integer atomics (order-free), and a
+// last, tiny kernel applies fi.dist_scale, adds the planes and picks the first minimum.
 // The analysis area's borders count as picture edges exactly as on the reference's
 // scratch copy (rdo.rs:2277-2284).  Integer arithmetic throughout.
 #include "cdef_common.hpp"
@@ -26,72 +21,10 @@
 namespace {
 using namespace r1cdef;
 
-// constrain (cdef.rs:146-159) with the shift of this (threshold, damping) already formed
-__device__ __forceinline__ int32_t constrain_s(int32_t diff, int32_t threshold, int shift) {
-  const int32_t ad = diff < 0 ? -diff : diff;
-  int32_t mag = threshold - (ad >> shift);
-  mag = mag < 0 ? 0 : (mag > ad ? ad : mag);
-  return diff < 0 ? -mag : mag;
-}
 __device__ __forceinline__ int constrain_shift(int threshold, int damping) {
   if (!threshold) return 0;
   const int s = damping - (31 - __clz(threshold));
   return s < 0 ? 0 : s;
-}
-
-// the twelve taps of one pixel for direction `dir`: t[0..1] primary k = 0, t[2..5] secondary
-// k = 0, t[6..7] primary k = 1, t[8..11] secondary k = 1 (cdef.rs:255-283); mn / mx: the clamp
-// range over the centre and the taps that exist
-struct Taps { int32_t t[12], mn, mx; };
-template <typename RD>
-__device__ __forceinline__ Taps load_taps(RD rd, int i, int j, int dir, int32_t x) {
-  constexpr uint32_t DY0 = 0x33332221u, DX0 = 0x22233333u, DY1 = 0x44443210u, DX1 = 0x12344444u;
-  auto dyx = [&](int d, int k, int &dy, int &dx) {
-    const int sh = 4 * d;
-    dy = (int)(((k == 0 ? DY0 : DY1) >> sh) & 0xf) - 2;
-    dx = (int)(((k == 0 ? DX0 : DX1) >> sh) & 0xf) - 2;
-  };
-  Taps tp;
-  tp.mn = x;
-  tp.mx = x;
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    int d0y, d0x, d1y, d1x, d2y, d2x;
-    dyx(dir, k, d0y, d0x);
-    dyx((dir + 2) & 7, k, d1y, d1x);
-    dyx((dir + 6) & 7, k, d2y, d2x);
-    int32_t *t = tp.t + 6 * k;
-    t[0] = rd(i + d0y, j + d0x);
-    t[1] = rd(i - d0y, j - d0x);
-    t[2] = rd(i + d1y, j + d1x);
-    t[3] = rd(i - d1y, j - d1x);
-    t[4] = rd(i + d2y, j + d2x);
-    t[5] = rd(i - d2y, j - d2x);
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-      if (t[q] != VERY_LARGE && t[q] > tp.mx) tp.mx = t[q];
-      if (t[q] < tp.mn) tp.mn = t[q];
-    }
-  }
-  return tp;
-}
-
-__device__ __forceinline__ int32_t filter_from_taps(const Taps &tp, int32_t x, int pri, int sec, int pri_shift,
-                                                    int sec_shift, int coeff_shift) {
-  const int odd = (pri >> coeff_shift) & 1;
-  int32_t sum = 0;
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int pri_tap = odd ? 3 : (k == 0 ? 4 : 2);
-    const int sec_tap = k == 0 ? 2 : 1;
-    const int32_t *t = tp.t + 6 * k;
-    if (pri) sum += pri_tap * (constrain_s(t[0] - x, pri, pri_shift) + constrain_s(t[1] - x, pri, pri_shift));
-    if (sec)
-      sum += sec_tap * (constrain_s(t[2] - x, sec, sec_shift) + constrain_s(t[3] - x, sec, sec_shift) +
-                        constrain_s(t[4] - x, sec, sec_shift) + constrain_s(t[5] - x, sec, sec_shift));
-  }
-  const int32_t v = x + ((8 + sum - (sum < 0)) >> 4);
-  return v < tp.mn ? tp.mn : (v > tp.mx ? tp.mx : v);
 }
 
 struct SearchArgs {
@@ -103,6 +36,9 @@ struct SearchArgs {
   R1CdefSearchParams p;
   int n_sbx, n_sby;
   unsigned long long *psum;   // [n_sb][8][3]
+  const uint8_t *dirs;        // [n_sby * 8][nbx] of k_cdef_analyze (rec luma)
+  const int32_t *vars;
+  int nbx;
 };
 
 // geometry of the analysis area a superblock belongs to (rdo.rs:2149-2166, 2184-2190)
@@ -136,121 +72,298 @@ __device__ __forceinline__ bool sb_all_skip(const SearchArgs &a, const AreaGeo &
   return __all(all);
 }
 
-template <int BPP, int XD, int YD>
-__global__ __launch_bounds__(64) void k_cdef_search(SearchArgs a) {
-  __shared__ int32_t part[128];
-  const int lane = threadIdx.x;
-  const int gbx = blockIdx.x, gby = blockIdx.y;          // 8x8 luma block of the frame grid
-  const int fbx = gbx >> 3, fby = gby >> 3, bx = gbx & 7, by = gby & 7;
-  const AreaGeo g = area_of(a, fbx, fby);
-  const int mx = g.sbx * 16 + 2 * bx, my = g.sby * 16 + 2 * by;   // area block units
-  if (!(mx < g.blk_cols && my < g.blk_rows)) return;
-  if (sb_all_skip(a, g, lane)) return;
-  const int bd = a.p.bit_depth, coeff_shift = bd - 8;
-  const uint8_t *sk = a.skip_mi + (size_t)(g.ay0 * 16 + my) * a.mi_stride + g.ax0 * 16 + mx;
-  const int skip = sk[0] & sk[1] & sk[a.mi_stride] & sk[a.mi_stride + 1] & 1;
-  const int flx = fbx * 64 + 8 * bx, fly = fby * 64 + 8 * by;   // frame position, luma px
-  // edge flags on the area frame (cdef.rs:441-459)
-  const int xavail = g.area_w - g.sbx * 64, yavail = g.area_h - g.sby * 64;
-  const int edges = ((g.sby > 0 || by > 0) ? HAVE_TOP : 0) | ((g.sbx > 0 || bx > 0) ? HAVE_LEFT : 0) |
-                    ((by + 1 < (yavail >> 3)) ? HAVE_BOTTOM : 0) | ((bx + 1 < (xavail >> 3)) ? HAVE_RIGHT : 0);
-  int dir = 0;
-  uint32_t var = 0;
-  if (!skip) {
-    const int32_t lum = ldpx<BPP>(px_addr<BPP>(a.rec[0], flx + (lane & 7), fly + (lane >> 3)));
-    uint32_t var_v;
-    dir = __builtin_amdgcn_readfirstlane(find_dir_wave(lum, coeff_shift, part, var_v));
-    var = (uint32_t)__builtin_amdgcn_readfirstlane((int)var_v);
-  }
-  const uint32_t bias = a.scales ? a.scales[(size_t)(fly >> 3) * a.scale_stride + (flx >> 3)] : (1u << 14);
-  unsigned long long *ps = a.psum + (size_t)(fby * a.n_sbx + fbx) * 24;
+// ---- the search for one plane (LUMA) or both chroma planes (blockIdx.z), packed pairs.
+// Geometry as k_cdef_frame's (cdef.hip): workgroup = 32 x 16 pixels of the plane (always inside one
+// superblock), wave = 16 x 8, lane = two horizontally adjacent pixels; here lane = hb*32 + row*4 +
+// pair, so that the 32 lanes of an 8-pixel-wide half are one luma block and DPP sums stay inside
+// it.  The tile in LDS holds CDEF_VERY_LARGE outside the ANALYSIS AREA's rectangle: that is what
+// the reference's edge flags on its scratch copy of the area say block by block.
+//  * per block (first lanes of wave 0, once): skip, bias, the six tap offsets of its direction,
+//    and for every cdef_index the primary strength after adjust_strength, its shift and taps;
+//    the secondary strength / shift of an index do not depend on the block (scalar registers);
+//  * the twelve taps are read once per direction set (the block's own direction, and direction 0
+//    for an index whose primary strength is 0) and kept in registers;
+//  * the secondary sum of an index is reused while the next index has the same secondary strength
+//    and direction set (rav1e's presets: 3 evaluations for 8 indices);
+//  * nothing per-index runs on a single lane: the block / cell sums of every index go to LDS and
+//    ONE pass of the workgroup does all tails (cdef_dist_kernel's fixed point, the weighted-SSE
+//    scaling) and the 64-bit atomics, a (block, index) pair per thread.
+constexpr int SR_REC = 48;   // dwords per block record
+constexpr int ST_STRIDE = 40, ST_ROWS = 20, ST_X0 = 4, ST_Y0 = 2;   // tile: 20 dwords per row, conflict-free for 8 rows x 4 pairs
 
-  // ---- passes: 0 = luma; then the chroma planes (two per pass when subsampled) ----
-  constexpr int CXS = 8 >> XD, CYS = 8 >> YD, CPX = CXS * CYS;
-  constexpr int NPASS_C = CPX == 64 ? 2 : 1;
-  const int npass = a.p.planes == 1 ? 1 : 1 + NPASS_C;
-  for (int pass = 0; pass < npass; pass++) {
-    const bool luma = pass == 0;
-    const int xs = luma ? 8 : CXS, ys = luma ? 8 : CYS, npx = xs * ys;
-    const int pl = luma ? 0 : (CPX == 64 ? pass : 1 + lane / CPX);
-    const bool act = luma || CPX == 64 || lane < 2 * CPX;
-    const int pli = act ? pl : 1;
-    const int l = lane % npx, i = l / xs, j = l % xs;
-    const R1Plane &rp = a.rec[pli], &sp = a.src[pli];
-    const int px = luma ? flx : flx >> XD, py = luma ? fly : fly >> YD;
-    const uint8_t *r0 = px_addr<BPP>(rp, px, py);
-    const ptrdiff_t rstr = (ptrdiff_t)rp.stride * BPP;
-    auto rd = [&](int yy, int xx) -> int32_t {
-      const bool ok = (yy >= 0 || (edges & HAVE_TOP)) && (yy < ys || (edges & HAVE_BOTTOM)) &&
-                      (xx >= 0 || (edges & HAVE_LEFT)) && (xx < xs || (edges & HAVE_RIGHT));
-      return ok ? ldpx<BPP>(r0 + yy * rstr + (ptrdiff_t)xx * BPP) : VERY_LARGE;
-    };
-    const int32_t x = ldpx<BPP>(r0 + i * rstr + j * BPP);
-    const int32_t s = ldpx<BPP>(px_addr<BPP>(sp, px + j, py + i));
-    // the directions the index set can select: the block's own (mapped for 4:2:2 chroma), or 0
-    const int own = luma ? dir : (XD != YD ? (int)((0x66654207u >> (4 * dir)) & 0xf) : dir);
-    Taps ta = {}, tb = {};
-    bool need_own = false, need_zero = false;
-    for (int idx = 0; idx < a.p.n_idx; idx++) {
-      const int st = luma ? a.p.y_strengths[idx] : a.p.uv_strengths[idx];
-      if (st / 4 != 0) need_own = true; else need_zero = true;
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t add_dpp_m(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// sum over the 32 lanes of a half-wave; the total is in its last lane (31 / 63)
+__device__ __forceinline__ uint32_t half_sum_last(uint32_t v) {
+  v = add_dpp<0xB1>(v);            // quad_perm [1,0,3,2]
+  v = add_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+  v = add_dpp<0x141>(v);           // row_half_mirror
+  v = add_dpp<0x140>(v);           // row_mirror
+  return add_dpp_m<0x142, 0xa>(v); // row_bcast15 into rows 1 and 3
+}
+__device__ __forceinline__ uint32_t swz_xor4(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1f);
+}
+
+template <int BPP, int XD, int YD, bool LUMA>
+__global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[ST_ROWS * ST_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint32_t rec[32 * SR_REC];
+  __shared__ uint32_t acc[32 * 8 * 3 + 16];   // luma: [8 blocks][8 idx][d, d2, sd] + [8][s, s2]; chroma: [32 cells][8 idx]
+  constexpr int xs = 8 >> XD, ys = 8 >> YD;
+  constexpr int NBX = 32 / xs, NBY = 16 / ys, NB = NBX * NBY;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int pli = LUMA ? 0 : 1 + (int)blockIdx.z;
+  const int cs = a.p.bit_depth - 8, bd = a.p.bit_depth;
+  const int rx0 = blockIdx.x * 32, ry0 = blockIdx.y * 16;          // plane position of the region
+  const int fbx = (rx0 << XD) >> 6, fby = (ry0 << YD) >> 6;        // its superblock
+  if (fbx >= a.n_sbx || fby >= a.n_sby) return;
+  const AreaGeo g = area_of(a, fbx, fby);
+  if (sb_all_skip(a, g, lane)) return;                             // workgroup-uniform
+  const R1Plane &rp = a.rec[pli], &sp = a.src[pli];
+  const int n_idx = a.p.n_idx;
+  const uint8_t *strengths = LUMA ? a.p.y_strengths : a.p.uv_strengths;
+  const int damping = a.p.damping + cs - (LUMA ? 0 : 1);
+  // cdef_directions (cdef.rs:225-234) packed as nibbles (value + 2)
+  constexpr uint32_t DY0 = 0x33332221u, DX0 = 0x22233333u, DY1 = 0x44443210u, DX1 = 0x12344444u;
+  auto off = [&](int d, int k) -> uint32_t {
+    const int sh4 = 4 * (d & 7);
+    const int dy = (int)(((k == 0 ? DY0 : DY1) >> sh4) & 0xf) - 2;
+    const int dx = (int)(((k == 0 ? DX0 : DX1) >> sh4) & 0xf) - 2;
+    return (uint32_t)((dy * ST_STRIDE + dx) * 2);
+  };
+  // ---- per-block records
+  if (tid < NB) {
+    const int gbx = blockIdx.x * NBX + tid % NBX, gby = blockIdx.y * NBY + tid / NBX;   // frame 8x8 grid
+    const int bx = gbx & 7, by = gby & 7;
+    const int mx = g.sbx * 16 + 2 * bx, my = g.sby * 16 + 2 * by;                        // area block units
+    const bool in_grid = mx < g.blk_cols && my < g.blk_rows;
+    int skip = 1, dir = 0, var = 0;
+    uint32_t bias = 1u << 14;
+    if (in_grid) {
+      const uint8_t *sk = a.skip_mi + (size_t)(g.ay0 * 16 + my) * a.mi_stride + g.ax0 * 16 + mx;
+      const uint32_t s0 = *(const uint16_t *)sk, s1 = *(const uint16_t *)(sk + a.mi_stride);
+      dir = a.dirs[(size_t)gby * a.nbx + gbx];
+      var = a.vars[(size_t)gby * a.nbx + gbx];
+      if (a.scales) bias = a.scales[(size_t)gby * a.scale_stride + gbx];
+      const uint32_t s01 = s0 & s1;
+      skip = (int)(s01 & (s01 >> 8) & 1);
     }
-    if (!skip) {
-      if (need_own) ta = load_taps(rd, i, j, own, x);
-      if (need_zero) tb = own == 0 && need_own ? ta : load_taps(rd, i, j, 0, x);
+    const int own = LUMA ? dir : (XD != YD ? (int)((0x66654207u >> (4 * dir)) & 0xf) : dir);
+    uint32_t *r = rec + tid * SR_REC;
+    r[0] = (in_grid ? 1u : 0u) | (skip ? 0u : 2u);
+    r[1] = bias;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      r[2 + k] = off(own, k);
+      r[4 + k] = off(own + 2, k);
+      r[6 + k] = off(own + 6, k);
     }
-    uint32_t m_s = 0, m_s2 = 0;
-    if (luma) {
-      m_s = group_sum<64>((uint32_t)s);
-      m_s2 = group_sum<64>((uint32_t)(s * s));
+    for (int idx = 0; idx < 8; idx++) {
+      const int st = idx < n_idx ? strengths[idx] : 0;
+      const int pri_raw = st >> 2;
+      const int pri = LUMA ? adjust_strength(pri_raw << cs, var) : pri_raw << cs;
+      const uint32_t psh = (uint32_t)constrain_shift(pri, damping);
+      const int odd = (pri >> cs) & 1;
+      r[16 + 4 * idx + 0] = (uint32_t)pri * 0x10001u;
+      r[16 + 4 * idx + 1] = psh * 0x10001u;
+      r[16 + 4 * idx + 2] = (odd ? 3u : 4u) * 0x10001u;
+      r[16 + 4 * idx + 3] = (odd ? 3u : 2u) * 0x10001u;
     }
-    for (int idx = 0; idx < a.p.n_idx; idx++) {
-      int32_t v = x;
-      if (!skip) {
-        const int st = luma ? a.p.y_strengths[idx] : a.p.uv_strengths[idx];
-        const int pri_raw = st / 4;
-        int sec_raw = st % 4;
-        sec_raw += sec_raw == 3;
-        const int damping = a.p.damping + coeff_shift - (luma ? 0 : 1);
-        const int pri = luma ? adjust_strength(pri_raw << coeff_shift, (int)var) : pri_raw << coeff_shift;
-        const int sec = sec_raw << coeff_shift;
-        const int psh = constrain_shift(pri, damping), ssh = constrain_shift(sec, damping);
-        // wave-uniform choice of the tap set
-        v = pri_raw != 0 ? filter_from_taps(ta, x, pri, sec, psh, ssh, coeff_shift)
-                         : filter_from_taps(tb, x, pri, sec, psh, ssh, coeff_shift);
-      }
-      if (luma) {
-        // cdef_dist_kernel moments over the 64 pixels (dist.rs:316-345); the source's two do not
-        // depend on the index (formed once, above the loop)
-        const uint32_t m_d = group_sum<64>((uint32_t)v), m_d2 = group_sum<64>((uint32_t)(v * v)),
-                       m_sd = group_sum<64>((uint32_t)(s * v));
-        if (lane == 0) {
-          const unsigned long long d = r1dist::cdef_tile_tail(m_s, m_d, m_s2, m_d2, m_sd, 64, 0, 0, &bias, 0, bd);
-          atomicAdd(&ps[idx * 3 + 0], d);
-        }
-      } else {
-        // sse_wxh with a constant bias: 4x4 cells, each (sse * bias + 128) >> 8, the block's
-        // sum through get_weighted_sse's (sum + 32) / 64 (rdo.rs:177-224, dist.rs:234-283)
-        const int32_t df = s - v;
-        uint32_t c = act ? (uint32_t)(df * df) : 0u;
-        // cell members: bits 0-1 of j and bits 0-1 of i of the lane index inside the plane
-        constexpr int M0 = 1, M1 = 2, M2 = CXS == 8 ? 8 : 4, M3 = CXS == 8 ? 16 : 8;
-        if constexpr (CXS == 4) {
-          c = group_sum<16>(c);   // lanes 16 k .. 16 k + 15 are one cell: DPP inside the row
+  }
+  // ---- the tile: the area's rectangle in plane pixels, CDEF_VERY_LARGE outside
+  {
+    const int ax = (g.ax0 * 64) >> XD, ay = (g.ay0 * 64) >> YD;
+    const int ax1 = (g.ax0 * 64 + g.area_w) >> XD, ay1 = (g.ay0 * 64 + g.area_h) >> YD;
+    if (tid < ST_ROWS * 10) {
+      const int ty = tid / 10, tq = tid - ty * 10;
+      const int py = ry0 - ST_Y0 + ty, px = rx0 - ST_X0 + 4 * tq;
+      uint32_t lo = 0x80008000u, hi = 0x80008000u;
+      if (py >= ay && py < ay1 && px >= ax && px < ax1) {
+        const uint8_t *gp = px_addr<BPP>(rp, px, py);
+        if constexpr (BPP == 1) {
+          const uint32_t q = ld_u32(gp);
+          lo = __builtin_amdgcn_perm(0, q, 0x0c010c00u);
+          hi = __builtin_amdgcn_perm(0, q, 0x0c030c02u);
         } else {
-          c += __shfl_xor(c, M0, 64);
-          c += __shfl_xor(c, M1, 64);
-          c += __shfl_xor(c, M2, 64);
-          c += __shfl_xor(c, M3, 64);
+          const U32x2 q = ld_u32x2(gp);
+          lo = q.a;
+          hi = q.b;
         }
-        const bool leader = (j & 3) == 0 && (i & 3) == 0;
-        unsigned long long w = leader && act ? ((unsigned long long)c * bias + 128) >> 8 : 0ull;
-        // the cells of a plane's block: 1 (4x4), 2 (4x8: rows), 4 (8x8)
-        if constexpr (CXS == 8) w += (unsigned long long)__shfl_xor((long long)w, 4, 64);
-        if constexpr (CYS == 8) w += (unsigned long long)__shfl_xor((long long)w, CXS == 8 ? 32 : 16, 64);
-        if (act && l == 0) atomicAdd(&ps[idx * 3 + pl], (w + 32) >> 6);
       }
+      *(uint2 *)(tile + ty * ST_STRIDE + 4 * tq) = make_uint2(lo, hi);
     }
+  }
+  __syncthreads();
+  // ---- lane -> pixel pair: half-wave hb = 8 columns, row, pair
+  const int hb = lane >> 5, row = (lane >> 2) & 7, pq = lane & 3;
+  const int lx = (wave & 1) * 16 + hb * 8 + 2 * pq, ly = (wave >> 1) * 8 + row;
+  const int blk = (ly / ys) * NBX + lx / xs;
+  const uint32_t *rb = rec + blk * SR_REC;
+  const uint32_t flags = rb[0];
+  const bool in_grid = flags & 1, filt = (flags & 2) != 0;
+  const uint32_t base = (uint32_t)(((ly + ST_Y0) * ST_STRIDE + lx + ST_X0) * 2);
+  Pk x, s;
+  x.u = *(const uint32_t *)((const uint8_t *)tile + base);
+  s.u = 0;
+  if (in_grid) {
+    const uint8_t *gp = px_addr<BPP>(sp, rx0 + lx, ry0 + ly);
+    if constexpr (BPP == 1) s.u = __builtin_amdgcn_perm(0, (uint32_t) * (const uint16_t *)gp, 0x0c010c00u);
+    else s.u = ld_u32(gp);
+  }
+  typedef __attribute__((address_space(3))) uint16_t LdsU16;
+  const uint32_t tbase = (uint32_t)(uintptr_t)(LdsU16 *)tile + base;
+  // which direction sets the index set asks for (scalar)
+  bool need_own = false, need_zero = false;
+  for (int idx = 0; idx < n_idx; idx++) {
+    const int st = strengths[idx];
+    if ((st >> 2) != 0) need_own = true;
+    else if ((st & 3) != 0) need_zero = true;
+  }
+  struct TapSet { uint32_t tp[12]; i16x2 mx; u16x2 mn; };
+  auto load_set = [&](const uint32_t (&offs)[6]) {
+    TapSet ts;
+    uint32_t tlo[12], thi[12];
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      lds_two(tbase + offs[t], tlo[2 * t], thi[2 * t]);
+      lds_two(tbase - offs[t], tlo[2 * t + 1], thi[2 * t + 1]);
+    }
+    lds_wait(tlo, thi);
+    ts.mx = x.s;
+    ts.mn = x.v;
+#pragma unroll
+    for (int t = 0; t < 12; t++) {
+      // a skipped block is not filtered: all its taps read as the centre (every term 0, clamp = x)
+      Pk p;
+      p.u = filt ? (tlo[t] | (thi[t] << 16)) : x.u;
+      ts.tp[t] = p.u;
+      ts.mx = __builtin_elementwise_max(ts.mx, p.s);
+      ts.mn = __builtin_elementwise_min(ts.mn, p.v);
+    }
+    return ts;
+  };
+  TapSet own = {}, zero = {};
+  if (need_own) {
+    const uint32_t offs[6] = {rb[2], rb[3], rb[4], rb[5], rb[6], rb[7]};
+    own = load_set(offs);
+  }
+  if (need_zero) {
+    const uint32_t offs[6] = {off(0, 0), off(0, 1), off(2, 0), off(2, 1), off(6, 0), off(6, 1)};
+    zero = load_set(offs);
+  }
+  // the source's two moments of a luma block do not depend on the index
+  if constexpr (LUMA) {
+    Pk one;
+    one.u = 0x00010001u;
+    const uint32_t m_s = half_sum_last(__builtin_amdgcn_udot2(s.v, one.v, 0u, false));
+    const uint32_t m_s2 = half_sum_last(__builtin_amdgcn_udot2(s.v, s.v, 0u, false));
+    if ((lane & 31) == 31) {
+      acc[32 * 8 * 3 + (wave * 2 + hb) * 2 + 0] = m_s;
+      acc[32 * 8 * 3 + (wave * 2 + hb) * 2 + 1] = m_s2;
+    }
+  }
+  int sec_key = -1;
+  i16x2 sec_sum = (i16x2)0;
+  for (int idx = 0; idx < n_idx; idx++) {
+    const int st = strengths[idx];
+    const int pri_raw = st >> 2;
+    int sec_raw = st & 3;
+    sec_raw += sec_raw == 3;
+    Pk v = x;
+    if (pri_raw != 0 || sec_raw != 0) {          // scalar
+      const bool use_own = pri_raw != 0;
+      const TapSet &ts = use_own ? own : zero;
+      // secondary taps: tp[4..11] ((dir + 2, k), (dir + 6, k)), weights 2 (k = 0) / 1 (k = 1)
+      const int key = sec_raw * 2 + (use_own ? 1 : 0);
+      if (key != sec_key) {
+        sec_key = key;
+        sec_sum = (i16x2)0;
+        if (sec_raw != 0) {
+          const uint32_t sec = (uint32_t)(sec_raw << cs), ssh = (uint32_t)constrain_shift((int)sec, damping);
+          Pk sec2, ssh2;
+          sec2.u = sec * 0x10001u;
+          ssh2.u = ssh * 0x10001u;
+          i16x2 s2 = (i16x2)0, s1 = (i16x2)0;
+#pragma unroll
+          for (int t = 4; t < 12; t++) {
+            Pk p;
+            p.u = ts.tp[t];
+            const i16x2 c = constrain2(p.s - x.s, sec2.s, ssh2.v);
+            if (((t >> 1) & 1) == 0) s2 += c; else s1 += c;
+          }
+          sec_sum = s2 + s2 + s1;
+        }
+      }
+      i16x2 sum = sec_sum;
+      if (pri_raw != 0) {
+        const uint4 pr = *(const uint4 *)(rb + 16 + 4 * idx);
+        Pk pri2, psh2, pt0, pt1, p0, p1, p2, p3;
+        pri2.u = pr.x; psh2.u = pr.y; pt0.u = pr.z; pt1.u = pr.w;
+        p0.u = ts.tp[0]; p1.u = ts.tp[1]; p2.u = ts.tp[2]; p3.u = ts.tp[3];
+        sum += (constrain2(p0.s - x.s, pri2.s, psh2.v) + constrain2(p1.s - x.s, pri2.s, psh2.v)) * pt0.s;
+        sum += (constrain2(p2.s - x.s, pri2.s, psh2.v) + constrain2(p3.s - x.s, pri2.s, psh2.v)) * pt1.s;
+      }
+      v.s = x.s + ((sum + (sum >> (i16x2)15) + (i16x2)8) >> (i16x2)4);
+      v.s = __builtin_elementwise_min(__builtin_elementwise_max(v.s, (i16x2)ts.mn), ts.mx);
+    }
+    if constexpr (LUMA) {
+      // cdef_dist_kernel's moments of the filtered block (dist.rs:316-345)
+      Pk one;
+      one.u = 0x00010001u;
+      const uint32_t m_d = half_sum_last(__builtin_amdgcn_udot2(v.v, one.v, 0u, false));
+      const uint32_t m_d2 = half_sum_last(__builtin_amdgcn_udot2(v.v, v.v, 0u, false));
+      const uint32_t m_sd = half_sum_last(__builtin_amdgcn_udot2(s.v, v.v, 0u, false));
+      if ((lane & 31) == 31) {
+        uint32_t *ap = acc + ((wave * 2 + hb) * 8 + idx) * 3;
+        ap[0] = m_d;
+        ap[1] = m_d2;
+        ap[2] = m_sd;
+      }
+    } else {
+      // squared error of the 4x4 cell: lanes pq & 1 (bit 0), row & 3 (bits 2, 3)
+      const i16x2 df = s.s - v.s;
+      uint32_t c = (uint32_t)__builtin_amdgcn_sdot2(df, df, 0, false);
+      c = add_dpp<0xB1>(c);                 // quad_perm [1,0,3,2]
+      c += swz_xor4(c);                     // lane ^ 4
+      c = add_dpp<0x128>(c);                // row_ror:8 = lane ^ 8 inside the row
+      if ((pq & 1) == 0 && (row & 3) == 0) acc[((ly >> 2) * 8 + (lx >> 2)) * 8 + idx] = c;
+    }
+  }
+  __syncthreads();
+  // ---- one (block, index) pair per thread: tails and atomics
+  unsigned long long *ps = a.psum + (size_t)(fby * a.n_sbx + fbx) * 24;
+  const int tb = tid >> 3, tidx = tid & 7;
+  if (tidx >= n_idx) return;
+  if constexpr (LUMA) {
+    if (tb >= 8) return;
+    // luma block tb of the workgroup = (wave, hb): its record
+    const int w = tb >> 1, h2 = tb & 1;
+    const int blx = (w & 1) * 2 + h2, bly = w >> 1;
+    const uint32_t *r = rec + (bly * NBX + blx) * SR_REC;
+    if (!(r[0] & 1)) return;
+    const uint32_t *ap = acc + (tb * 8 + tidx) * 3;
+    const uint32_t bias = r[1];
+    const unsigned long long d = r1dist::cdef_tile_tail(acc[32 * 8 * 3 + tb * 2], ap[0], acc[32 * 8 * 3 + tb * 2 + 1], ap[1],
+                                                        ap[2], 64, 0, 0, &bias, 0, bd);
+    atomicAdd(&ps[tidx * 3 + 0], d);
+  } else {
+    if (tb >= NB) return;
+    const uint32_t *r = rec + tb * SR_REC;
+    if (!(r[0] & 1)) return;
+    const uint32_t bias = r[1];
+    // sse_wxh with a constant bias: 4x4 cells, each (sse * bias + 128) >> 8, the block's sum through
+    // get_weighted_sse's (sum + 32) / 64 (rdo.rs:177-224, dist.rs:234-283)
+    const int cx0 = (tb % NBX) * (xs / 4), cy0 = (tb / NBX) * (ys / 4);
+    unsigned long long w = 0;
+#pragma unroll
+    for (int cy = 0; cy < ys / 4; cy++)
+#pragma unroll
+      for (int cx = 0; cx < xs / 4; cx++)
+        w += ((unsigned long long)acc[((cy0 + cy) * 8 + cx0 + cx) * 8 + tidx] * bias + 128) >> 8;
+    atomicAdd(&ps[tidx * 3 + pli], (w + 32) >> 6);
   }
 }
 
@@ -277,8 +390,10 @@ __global__ __launch_bounds__(64) void k_cdef_search_final(SearchArgs a, unsigned
 
 }  // namespace
 
+// scratch: the per-superblock sums [n_sb][8][3] u64, then (var i32, dir u8) per 8x8 block of the grid
 extern "C" long long r1_cdef_strength_search_scratch_bytes(int mi_cols, int mi_rows) {
-  return (long long)((mi_cols + 15) / 16) * ((mi_rows + 15) / 16) * 24 * 8;
+  const long long n_sb = (long long)((mi_cols + 15) / 16) * ((mi_rows + 15) / 16);
+  return n_sb * 24 * 8 + n_sb * 64 * 5;
 }
 
 extern "C" int r1_cdef_strength_search(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src,
@@ -317,19 +432,29 @@ extern "C" int r1_cdef_strength_search(r1_ctx *ctx, const R1Plane *rec, const R1
   a.n_sby = (mi_rows + 15) / 16;
   a.psum = (unsigned long long *)scratch;
   hipStream_t st = (hipStream_t)stream;
-  R1_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)r1_cdef_strength_search_scratch_bytes(mi_cols, mi_rows), st));
-  const dim3 grid(a.n_sbx * 8, a.n_sby * 8);
-  const int xd = np == 1 ? 1 : p.xdec, yd = np == 1 ? 1 : p.ydec;
-#define R1_CS_LAUNCH(B, X, Y) hipLaunchKernelGGL((k_cdef_search<B, X, Y>), grid, dim3(64), 0, st, a)
-#define R1_CS_DEC(B)                                      \
-  do {                                                    \
-    if (xd == 1 && yd == 1) R1_CS_LAUNCH(B, 1, 1);        \
-    else if (xd == 1) R1_CS_LAUNCH(B, 1, 0);              \
-    else R1_CS_LAUNCH(B, 0, 0);                           \
+  const size_t n_sb = (size_t)a.n_sbx * a.n_sby;
+  R1_HIP_CHECK(hipMemsetAsync(scratch, 0, n_sb * 24 * 8, st));
+  // cdef_analyze_superblock once for the frame (a thread per 8x8 block), shared by the planes
+  int32_t *vars = (int32_t *)((uint8_t *)scratch + n_sb * 24 * 8);
+  uint8_t *dirs = (uint8_t *)(vars + n_sb * 64);
+  a.nbx = a.n_sbx * 8;
+  a.dirs = dirs;
+  a.vars = vars;
+  const int rc = cdef_analyze_launch(&rec[0], a.nbx, a.n_sby * 8, mi_cols, mi_rows, dirs, vars, st);
+  if (rc != R1_OK) return rc;
+  const int xd = np == 1 ? 0 : p.xdec, yd = np == 1 ? 0 : p.ydec;
+  const dim3 grid_y(a.n_sbx * 2, a.n_sby * 4), grid_c((a.n_sbx * 64 >> xd) / 32, (a.n_sby * 64 >> yd) / 16, 2);
+#define R1_CS_LAUNCH(B)                                                                                   \
+  do {                                                                                                    \
+    hipLaunchKernelGGL((k_cdef_search_pk<B, 0, 0, true>), grid_y, dim3(256), 0, st, a);                   \
+    if (np == 3) {                                                                                        \
+      if (xd == 1 && yd == 1) hipLaunchKernelGGL((k_cdef_search_pk<B, 1, 1, false>), grid_c, dim3(256), 0, st, a); \
+      else if (xd == 1) hipLaunchKernelGGL((k_cdef_search_pk<B, 1, 0, false>), grid_c, dim3(256), 0, st, a);       \
+      else hipLaunchKernelGGL((k_cdef_search_pk<B, 0, 0, false>), grid_c, dim3(256), 0, st, a);           \
+    }                                                                                                     \
   } while (0)
-  if (rec[0].bytes_per_px == 1) R1_CS_DEC(1);
-  else R1_CS_DEC(2);
-#undef R1_CS_DEC
+  if (rec[0].bytes_per_px == 1) R1_CS_LAUNCH(1);
+  else R1_CS_LAUNCH(2);
 #undef R1_CS_LAUNCH
   R1_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(k_cdef_search_final, dim3(a.n_sbx, a.n_sby), dim3(64), 0, st, a,

@@ -44,6 +44,13 @@ def main():
         res["luma_filter_ms"] = ev_time(lambda: ctx.cdef_filter_frame_plane_dirs(d, v, luma, out, 0, 0, 0, w, h, skip, ci, ys, uvs, 5, bd), args.reps)
         res["chroma420_filter_ms"] = ev_time(lambda: ctx.cdef_filter_frame_plane_dirs(d, v, cin, cout, 1, 1, 1, w, h, skip, ci, ys, uvs, 5, bd), args.reps)
         res["luma_composite_ms"] = ev_time(lambda: ctx.cdef_filter_frame_plane(luma, luma, out, 0, 0, 0, w, h, skip, ci, ys, uvs, 5, bd), args.reps)
+        cin2 = Plane.from_numpy(W.random_plane_array(cw, ch, bd, 5, 44, 44), cw, ch, bd, 44, 44)
+        cout2 = Plane.from_numpy(W.random_plane_array(cw, ch, bd, 6, 44, 44), cw, ch, bd, 44, 44)
+        skip_s = torch.zeros((2 * ((h + 7) // 8), 2 * ((w + 7) // 8)), dtype=torch.uint8, device="cuda")
+        presets = [0, 4, 9, 13, 22, 31, 43, 55]
+        scales = torch.from_numpy(rng.integers(1 << 12, 1 << 16, ((h + 7) // 8, (w + 7) // 8)).astype(np.int32)).cuda()
+        res["strength_search_8_presets_420_ms"] = ev_time(lambda: ctx.cdef_strength_search(
+            [luma, cin, cin2], [out, cout, cout2], skip_s, presets, presets, 5, bd, 8, 1, 1, w, h, scales=scales), args.reps)
         bpp = 2 if bd > 8 else 1
         res["luma_filter_GBps"] = round(2 * w * h * bpp / (res["luma_filter_ms"] * 1e-3) / 1e9, 1)
         print(json.dumps(res), flush=True)
