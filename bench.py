@@ -431,13 +431,14 @@ def config_lines(ctx, args):
     import oracle_lib as O
     L = O.lib()
     L.r1o_set_threads(os.cpu_count() or 1)
-    NCHK, REPS = 48, 5
+    NCHK, REPS, WARM = 48, 20, 5
     lines = []
 
     def timed(fns):
         """fns: [(tag, callable)] -> ({tag: ms per launch}, ms per pass)"""
-        for _, f in fns:
-            f()
+        for _ in range(WARM):          # clocks ramp over the first passes: time the sustained state
+            for _, f in fns:
+                f()
         torch.cuda.synchronize()
         ev = []
         t0 = time.perf_counter()

@@ -80,6 +80,10 @@ __device__ unsigned long long g_phase[4096][8];
 #define R1_RDO_DISPATCH_TU
 #endif
 
+// which instantiations run their dead candidate slots unmasked (see k_rdo_cand)
+#ifndef R1_UNMASK_POLICY
+#define R1_UNMASK_POLICY(BD, WL, HL) (!((BD) == 8 && (WL) == 6 && (HL) == 6))
+#endif
 // which instantiations send the coefficients through LDS for 16-byte stores
 #ifndef R1_WIDE_STORE_POLICY
 #define R1_WIDE_STORE_POLICY(P) ((P) <= 16)
@@ -606,9 +610,20 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   // unit computes
   const int cand_i = (int)blockIdx.x * NC + cl;
   const long long cand = cand_i;
-  const bool live = cand_i < n;
+  // Only STORES look at whether this lane's candidate exists (live_st).  The dead slots of the
+  // launch's last wave load and compute the launch's last candidate once more: no masked regions,
+  // no zero-initialised registers for the lanes that would have sat out (35 v_mov of the 8x8
+  // kernel's 766 VALU instructions), every wave runs the same straight line.
+  // Measured (profiles/r03_ab_notes.md, ab4): -3 % at 8x8, -1 % at 16x16 / 32x32, +2 % on the 10-bit
+  // step; the 8-bit 64x64 instantiation alone loses (121 -> 143 VGPRs, 4 -> 3 waves per SIMD) and
+  // keeps its masked regions.
+  constexpr bool UNMASK = R1_UNMASK_POLICY(BD, WL, HL);
+  const bool live_st = cand_i < n;
+  const bool live = UNMASK || live_st;
+  const int cl_ld = live_st ? cl : n - 1 - (int)blockIdx.x * NC;     // >= 0: the wave's first candidate exists
+  const long long cand_ld = live_st ? cand : (long long)n - 1;
   R1RdoCand cd = {};
-  if (live) cd = (cands + (size_t)blockIdx.x * NC)[cl];
+  if (live) cd = (cands + (size_t)blockIdx.x * NC)[cl_ld];
 #ifdef R1_PHASE_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   R1_PROF(5);   // A0: descriptor round trip
@@ -695,13 +710,13 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     if (col_live) {
       int32_t pred[H];
       if (qa.pred_in) {
-        const uint8_t *pi = (const uint8_t *)qa.pred_in + (size_t)cand * W * H + c;
+        const uint8_t *pi = (const uint8_t *)qa.pred_in + (size_t)cand_ld * W * H + c;
 #pragma unroll
         for (int r = 0; r < H; r++) pred[r] = pi[(size_t)r * W];
       } else {
         mc8_column_t<W, H, WS, false>(win, c, tp, pred);
       }
-      if (pred_out) {
+      if (pred_out && live_st) {
         uint8_t *pp = (uint8_t *)pred_out + (size_t)cand * W * H + c;
 #pragma unroll
         for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint8_t)pred[r];
@@ -726,13 +741,13 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     if (col_live) {
       int32_t pred[H];
       if (qa.pred_in) {
-        const uint16_t *pi = (const uint16_t *)qa.pred_in + (size_t)cand * W * H + c;
+        const uint16_t *pi = (const uint16_t *)qa.pred_in + (size_t)cand_ld * W * H + c;
 #pragma unroll
         for (int r = 0; r < H; r++) pred[r] = pi[(size_t)r * W];
       } else {
         mc16_column_t<W, H, WS, false>(win, c, tp, BD, pred);
       }
-      if (pred_out) {
+      if (pred_out && live_st) {
         uint16_t *pp = (uint16_t *)pred_out + (size_t)cand * W * H + c;
 #pragma unroll
         for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint16_t)pred[r];
@@ -762,12 +777,12 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       for (int r = 0; r < H; r++) sad += (uint32_t)iabs32(v[r]);
     }
     const uint32_t s = group_sum<P>(sad);
-    if (live && c == 0) (sad_out + (size_t)blockIdx.x * NC)[cl] = s;
+    if (live_st && c == 0) (sad_out + (size_t)blockIdx.x * NC)[cl] = s;
   }
   if (satd_out) {
     const uint32_t s = group_sum<P>(satd_column<TS, H, BD>(v, lane));
     constexpr int LN = TS == 4 ? 2 : 3;
-    if (live && c == 0) (satd_out + (size_t)blockIdx.x * NC)[cl] = (s + ((1u << LN) >> 1)) >> LN;
+    if (live_st && c == 0) (satd_out + (size_t)blockIdx.x * NC)[cl] = (s + ((1u << LN) >> 1)) >> LN;
   }
   R1_PROF(2);   // B2: SAD + SATD
   if (!QUANT && !coeffs) return;   // wave-uniform: kernel argument
@@ -844,7 +859,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   if constexpr (!R1_WIDE_STORE_POLICY(P)) {
     // large blocks: direct element stores (measured: the LDS detour costs more than the
     // 16-byte stores save at 32x32 and 64x64, profiles/r02_wide_store_ab.log)
-    if (coeffs && row_live) {
+    if (coeffs && row_live && live_st) {
       CT *dst = coeffs + (size_t)blockIdx.x * (NC * W * H) + (cl2 * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31));
 #pragma unroll
       for (int cg = 0; cg < W; cg += 32)
@@ -890,7 +905,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         }
       }
       __syncthreads();
-      if (live2) {
+      if (live_st) {
         const uint8_t *src = (const uint8_t *)tile + r * CH;
         uint8_t *dst = gdst + p * CBY + r * CH;
 #pragma unroll
@@ -929,7 +944,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     unsigned long long dist = 0;
     r1q::quantize_group<CT, PL, NPLQ, QM == 1>(tile, cl2 * P, r, live2, qa.scan[kind], qa.qp, tail,
                                                eob, dist);
-    if (live2 && r == 0) {
+    if (live_st && r == 0) {
       qa.eob[cand2] = (uint16_t)eob;
       if constexpr (QM == 1) {
         qa.tx_dist[cand2] = dist;
@@ -938,7 +953,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     }
     if (qa.qcoeffs) {
       __syncthreads();
-      if (live2) {
+      if (live_st) {
         CT *qd = (CT *)qa.qcoeffs + cand2 * CODED;
 #pragma unroll
         for (int k = 0; k < NPLQ; k++) qd[k * P + r] = (CT)tile[k * P + r];
@@ -998,7 +1013,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
           rc[rr] = px < 0 ? 0 : (px > pmax ? pmax : px);
         }
       }
-      if (col_live && qa.rec) {
+      if (col_live && live_st && qa.rec) {
         if constexpr (BPP == 1) {
           uint8_t *d = (uint8_t *)qa.rec + (size_t)cand * W * H + c;
 #pragma unroll
@@ -1098,7 +1113,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         const uint32_t hi = __shfl_xor((uint32_t)(acc >> 32), m, 64);
         acc += ((unsigned long long)hi << 32) | lo;
       }
-      if (live && c == 0) qa.pix_dist[cand] = qa.dist_kind == R1_DIST_WSSE ? (acc + 32) / 64 : acc;
+      if (live_st && c == 0) qa.pix_dist[cand] = qa.dist_kind == R1_DIST_WSSE ? (acc + 32) / 64 : acc;
     }
   }
 }

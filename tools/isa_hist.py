@@ -2,25 +2,27 @@
 """Instruction histogram of the gfx950 code of one .hip file, per kernel.
 
   python tools/isa_hist.py rav1e_amd/csrc/rdo_cand.hip [kernel-name-substring ...]
-  python tools/isa_hist.py --json profiles/r02_isa_mix.json rav1e_amd/csrc/rdo_cand.hip k_rdo_cand
+  python tools/isa_hist.py --json profiles/r03_isa_mix.json -DR1_HEADLINE_ONLY rav1e_amd/csrc/rdo_cand.hip k_rdo_cand
       (the per-kernel VALU mix bench.py's `roofline` prices the VALU-issue roof with)
 
 Compiles the file to device assembly (hipcc -S --cuda-device-only) and counts, per kernel,
 VALU / SALU / LDS / VMEM instructions.  VALU is weighted with the issue costs measured by
-tools/ubench/valu_rate.hip on MI355X (gpurun_out/r02c/valu_rate.txt): add / sub / shifts /
-and / or / xor / mov issue in ~2.6 cycles per wave64, everything else (mul24, mad24, min /
+tools/ubench/valu_rate{,2}.hip on MI355X: add / sub / right shifts /
+and / or / xor / mov issue in ~2.5 cycles per wave64, everything else (mul24, mad24, min /
 max, med3, dot2 / dot4, v_pk_*, v_perm, v_alignb*, DPP, SDWA, v_sad, v_bfe, cvt_pk ...) in
-~4.4.  Straight-line code only: loops count once (the fused kernels are fully unrolled)."""
+~4.5 (v_lshlrev_b32 too).  Straight-line code only: loops count once (the fused kernels are fully unrolled)."""
 import collections
 import os
 import re
 import subprocess
 import sys
 
+# round 3 (tools/ubench/valu_rate2.hip, profiles/r03_ab_notes.md): v_lshlrev_b32 is NOT in the fast
+# class (4.3 cycles; the right shifts are), fast = 2.5, slow = 4.3 .. 4.8
 FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co_u32", "v_sub_co_u32", "v_addc_co_u32",
-        "v_ashrrev_i32", "v_lshrrev_b32", "v_lshlrev_b32", "v_and_b32", "v_or_b32", "v_xor_b32",
-        "v_mov_b32", "v_not_b32", "v_add_f32", "v_sub_f32", "v_accvgpr", "v_subb_co_u32", "v_nop")
-COST_FAST, COST_SLOW = 2.6, 4.4
+        "v_ashrrev_i32", "v_lshrrev_b32", "v_and_b32", "v_or_b32", "v_xor_b32",
+        "v_mov_b32", "v_not_b32", "v_add_f32", "v_sub_f32", "v_accvgpr", "v_subb_co_u32", "v_nop", "v_min_i16")
+COST_FAST, COST_SLOW = 2.5, 4.5
 
 
 def main():
@@ -28,6 +30,8 @@ def main():
     jpath = None
     if argv and argv[0] == "--json":
         jpath, argv = argv[1], argv[2:]
+    defs = [a for a in argv if a.startswith("-D")]      # e.g. -DR1_HEADLINE_ONLY for rdo_cand.hip
+    argv = [a for a in argv if not a.startswith("-D")]
     src = argv[0]
     pats = argv[1:]
     jout = {"_model": {"fast_cycles": COST_FAST, "slow_cycles": COST_SLOW,
@@ -36,8 +40,8 @@ def main():
     here = os.path.dirname(os.path.abspath(src))
     out = "/tmp/isa_hist_%d.s" % os.getpid()
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S",
-                           "--cuda-device-only", "-Wno-unused-function", "-Wno-pass-failed", "-I", here,
-                           src, "-o", out], stderr=subprocess.DEVNULL)
+                           "--cuda-device-only", "-Wno-unused-function", "-Wno-pass-failed", "-I", here] + defs +
+                          [src, "-o", out], stderr=subprocess.DEVNULL)
     kern, rows = None, collections.OrderedDict()
     meta = {}
     for line in open(out):
