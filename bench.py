@@ -296,10 +296,15 @@ def build_roofline(kname, abytes, launch_ms, pmc, pmc_src, mix):
         cost = mix["issue_cycles_per_valu"]
         ach = pmc["SQ_INSTS_VALU"] / sec / 1e9
         peak = N_SIMD * NOMINAL_GHZ / cost
+        # two yardsticks: `peak` prices this kernel's instruction mix with the issue cycles measured on the
+        # chip (tools/ubench/valu_rate{,2}.hip: 2.5 / 4.5 cycles per wave64 instruction); `peak_guide` is
+        # MI355X_MICROARCH.md's constant (a wave64 VALU instruction issues in 2 cycles on a SIMD-32)
+        peak_guide = N_SIMD * NOMINAL_GHZ / 2.0
         valu = {"achieved": round(ach, 2), "peak": round(peak, 2), "unit": "G wave64-instr/s",
-                "frac": round(ach / peak, 4), "insts_per_launch": int(pmc["SQ_INSTS_VALU"]),
+                "frac": round(ach / peak, 4), "peak_guide": round(peak_guide, 2),
+                "frac_guide": round(ach / peak_guide, 4), "insts_per_launch": int(pmc["SQ_INSTS_VALU"]),
                 "issue_cycles_per_inst": cost, "fast_slow_static": [mix["fast"], mix["slow"]],
-                "sources": [pmc_src, mix["source"], "tools/ubench/valu_rate.hip"]}
+                "sources": [pmc_src, mix["source"], "tools/ubench/valu_rate.hip", "tools/ubench/valu_rate2.hip"]}
         if valu["frac"] >= hbm["frac"]:
             return dict(common, bound="valu", achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"],
                         frac=valu["frac"], valu=valu)
