@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_imp_pairs(const uint32_t *__restrict__ 
   }
 }
 
-// exclusive prefix sum of count[n] -> offset[n]: tile sums, scan of the tile sums, tile scans
+// exclusive prefix sum of count[n] -> offset[n]: tile sums, then tile scans (each adds the sums before it)
 __global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *__restrict__ count, int n,
                                                     uint32_t *__restrict__ tile_sum) {
   __shared__ uint32_t red[256];
@@ -77,19 +77,24 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *__restrict__
   }
   if (threadIdx.x == 0) tile_sum[blockIdx.x] = red[0];
 }
-__global__ void k_scan_sums(uint32_t *tile_sum, int n_tiles) {   // one thread: a few hundred tiles
-  uint32_t run = 0;
-  for (int t = 0; t < n_tiles; t++) {
-    const uint32_t v = tile_sum[t];
-    tile_sum[t] = run;
-    run += v;
-  }
-}
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__ count, int n,
                                                     const uint32_t *__restrict__ tile_sum,
                                                     uint32_t *__restrict__ offset) {
-  // thread t owns 4 consecutive entries of the tile: local serial scan + scan across threads
+  // thread t owns 4 consecutive entries of the tile: local serial scan + scan across threads.
+  // The tile's own offset = the sum of the tile sums before it, formed here by the block itself
+  // (a few hundred values): a separate one-thread scan kernel between the two launches cost 14 us.
   __shared__ uint32_t part[256];
+  __shared__ uint32_t pre[256];
+  {
+    uint32_t ps = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) ps += tile_sum[t];
+    pre[threadIdx.x] = ps;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+      if ((int)threadIdx.x < m) pre[threadIdx.x] += pre[threadIdx.x + m];
+      __syncthreads();
+    }
+  }
   const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
   uint32_t v[4], s = 0;
 #pragma unroll
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
     part[threadIdx.x] += add;
     __syncthreads();
   }
-  uint32_t run = tile_sum[blockIdx.x] + part[threadIdx.x] - s;
+  uint32_t run = pre[0] + part[threadIdx.x] - s;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     if (base + k < n) offset[base + k] = run;
@@ -226,7 +231,6 @@ extern "C" int r1_update_block_importances(r1_ctx *ctx, const uint32_t *intra_co
   hipLaunchKernelGGL(k_imp_pairs, dim3(gb), dim3(256), 0, st, intra_costs, future_importances,
                      inter_costs, mvs, w_in_imp_b, h_in_imp_b, (float)len, dest, vals, count);
   hipLaunchKernelGGL(k_scan_tiles, dim3(s.n_tiles), dim3(256), 0, st, count, nb, tiles);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1), 0, st, tiles, s.n_tiles);
   hipLaunchKernelGGL(k_scan_apply, dim3(s.n_tiles), dim3(256), 0, st, count, nb, tiles, offset);
   hipLaunchKernelGGL(k_imp_scatter, dim3(gp), dim3(256), 0, st, dest, vals, 4 * nb, offset, fill, seg);
   hipLaunchKernelGGL(k_imp_accumulate, dim3(gb), dim3(256), 0, st, seg, offset, count, nb,
