@@ -42,8 +42,48 @@
 #include "common.hpp"
 #include "dist_common.hpp"
 #include "mc_common.hpp"
+#include "tx_common.hpp"
 
 namespace {
+using r1tx::T;
+#include "mc_taps_packed.inc"
+#include "cand_helpers.inc"
+
+// One sub-pel candidate of a W x H block (W, H in {8, 16}) inside a 16-lane group, on the fused
+// candidate kernel's machinery (rdo_cand.hip): window staged by the group with one round trip,
+// lane = column, v_dot4 / v_dot2 column filter, residual against the source block (in LDS for the
+// whole search), SATD by the DPP Hadamard (or SAD).  Returns this lane's share; the caller sums the
+// group.  The generic path it replaces for these sizes (scalar taps from byte reads, one lane per
+// 8x8 Hadamard tile = 4 of 16 lanes busy) cost about three times the instructions.
+template <int BPP, int W, int H, int BD>
+__device__ __forceinline__ uint32_t subpel_group_dist(uint8_t *win, const R1Plane &ref, int x, int y, int cf,
+                                                      int rf, int fm, int gl, int lane, const uint8_t *src /* LDS: the W x H source block, dense */,
+                                                      bool satd, int bit_depth) {
+  constexpr int WS = (((W + 7) * BPP + 3) >> 2) << 2;
+  r1mc::stage_window_fast<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, 16>(win, WS, ref, x, y, gl);
+  __builtin_amdgcn_wave_barrier();
+  T v[H];
+#pragma unroll
+  for (int r = 0; r < H; r++) v[r] = 0;
+  if (gl < W) {
+    int32_t pred[H];
+    if constexpr (BPP == 1) {
+      const Taps8 tp = load_taps8<W, H>(cf, rf, fm, fm);
+      mc8_column_t<W, H, WS, false>(win, gl, tp, pred);
+    } else {
+      const Taps16 tp = load_taps16<W, H>(cf, rf, fm, fm);
+      mc16_column_t<W, H, WS, false>(win, gl, tp, bit_depth, pred);
+    }
+#pragma unroll
+    for (int r = 0; r < H; r++) v[r] = ld_px<BPP>(src + (r * W + gl) * BPP) - pred[r];
+  }
+  __builtin_amdgcn_wave_barrier();   // the window is rewritten by the next candidate of this group
+  if (satd) return satd_column<8, H, BD>(v, lane);
+  uint32_t s = 0;
+#pragma unroll
+  for (int r = 0; r < H; r++) s += (uint32_t)iabs32(v[r]);
+  return s;
+}
 
 constexpr int MI = 4, SB = 64;
 constexpr unsigned long long COST_MAX = ~0ull;
@@ -1225,6 +1265,7 @@ __global__ __launch_bounds__(256, 3) void k_me_blocks_small(R1MeJob job, R1MePar
   constexpr int GROUP_BYTES = ((23 * WS_MAX + 15) & ~15) + 16 * 16 * BPP;   // window + prediction
   __shared__ __attribute__((aligned(16))) uint8_t sh_grp[4][4][GROUP_BYTES];
   __shared__ int16_t sh_subsets[4][kSubsetWords];
+  __shared__ __attribute__((aligned(16))) uint8_t sh_src[4][16 * 16 * BPP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long bi = (long long)blockIdx.x * 4 + wave;
   if (bi >= n) return;                         // wave-uniform; no barriers below
@@ -1290,11 +1331,43 @@ __global__ __launch_bounds__(256, 3) void k_me_blocks_small(R1MeJob job, R1MePar
   const int ws = (((w + 7) * BPP + 3) >> 2) << 2;
   int radius_log2 = 2;
   const int end_log2 = p.allow_hp ? 0 : 1;
+  // blocks whose sides are 8 or 16: the source block waits in LDS for the whole search
+  const bool fast = (w == 8 || w == 16) && (h == 8 || h == 16);
+  uint8_t *srcc = sh_src[wave];
+  if (fast) {
+    const int wl = w == 16 ? 4 : 3;
+    for (int i = lane; i < w * h; i += 64) {
+      const int r = i >> wl, c = i & (w - 1);
+      if constexpr (BPP == 1) srcc[i] = (uint8_t)ld_px<1>(o0 + (size_t)r * so + c);
+      else ((uint16_t *)srcc)[i] = (uint16_t)ld_px<2>(o0 + (size_t)r * so + c * 2);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
   for (;;) {
     int row = (int16_t)(best.row + (kDiamond[g][0] << radius_log2));
     int col = (int16_t)(best.col + (kDiamond[g][1] << radius_log2));
     const bool ok = in_range(row, col);
     uint32_t s = 0;
+    if (fast) {   // wave-uniform: 8 / 16 sizes on the fused-candidate machinery
+      if (ok) {
+        const int x = b.po_x + (col >> 3), y = b.po_y + (row >> 3), cf = (col << 1) & 15, rf = (row << 1) & 15;
+        const bool sd = use_satd != 0;
+        const int bd = ref.bit_depth;
+#define R1_SP(W_, H_, BD_) s = subpel_group_dist<BPP, W_, H_, BD_>(win, ref, x, y, cf, rf, filter_mode, gl, lane, srcc, sd, bd)
+#define R1_SP_BD(W_, H_)                                                  \
+  do {                                                                    \
+    if constexpr (BPP == 1) R1_SP(W_, H_, 8);                             \
+    else if (bd <= 10) R1_SP(W_, H_, 10);                                 \
+    else R1_SP(W_, H_, 12);                                               \
+  } while (0)
+        if (w == 16 && h == 16) R1_SP_BD(16, 16);
+        else if (w == 8 && h == 8) R1_SP_BD(8, 8);
+        else if (w == 16) R1_SP_BD(16, 8);
+        else R1_SP_BD(8, 16);
+#undef R1_SP_BD
+#undef R1_SP
+      }
+    } else {
     if (ok) {
       // get_mv_params (src/predict.rs:284-297): floor offset, 1/16 fraction
       r1mc::stage_window<BPP>(win, ws, ref, b.po_x + (col >> 3), b.po_y + (row >> 3), w, h, gl, 16);
@@ -1313,8 +1386,8 @@ __global__ __launch_bounds__(256, 3) void k_me_blocks_small(R1MeJob job, R1MePar
     }
     __builtin_amdgcn_wave_barrier();
     if (ok) s = block_dist(pred, (size_t)w * BPP, gl, use_satd != 0);
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+    }
+    s = group_sum<16>(s);
     uint32_t sad = use_satd ? (s + ((1u << ln) >> 1)) >> ln : s;
     unsigned long long cost = ok ? b.mc.cost(row, col, sad) : COST_MAX;
     if (!ok) sad = 0xFFFFFFFFu;

@@ -94,429 +94,7 @@ using r1tx::T;
 
 #include "mc_taps_packed.inc"
 
-// ---- cross-lane Hadamard with DPP --------------------------------------
-// DPP controls: quad_perm [1,0,3,2] = 0xB1 (lane ^ 1), [2,3,0,1] = 0x4E
-// (lane ^ 2), row_half_mirror = 0x141 (lane -> 7 - lane inside each 8).
-template <int CTRL>
-__device__ __forceinline__ int32_t dpp(int32_t x) {
-  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
-}
-// One butterfly stage across lanes: partner value p, the "lower" lane of a
-// pair keeps x + p, the "upper" lane p - x.  sm = upper ? -1 : 0.
-template <int CTRL>
-__device__ __forceinline__ int32_t bfly_lanes(int32_t x, int32_t sm) {
-  // +-x + partner as one v_mad_i32_i24 (|x| < 2^19 for 12-bit pixels)
-  return __mul24(x, sm | 1) + dpp<CTRL>(x);
-}
-// |Hadamard across the TS lanes of a tile| of x, as this lane's share of the
-// tile's sum: the last butterfly stage is folded into the abs because
-// |a + b| + |a - b| = 2 max(|a|, |b|) -- each lane of the final pair
-// contributes max(|a|, |b|).
-// The 8-lane version pairs lanes with masks {1, 2, 7}: those span (Z/2)^3, so
-// the three stages are a Walsh-Hadamard transform in a relabelled lane order
-// -- the same multiset of coefficients as masks {1, 2, 4}, hence the same sum
-// of absolute values (dist.rs:214).  "Upper" lanes are those whose coordinate
-// w.r.t. the basis {1, 2, 7} is 1: y1 = b0 ^ b2, y2 = b1 ^ b2 (y3 = b2).
-struct LaneSigns { int32_t s1, s2; };
-template <int TS>
-__device__ __forceinline__ LaneSigns lane_signs(int lane) {
-  LaneSigns s;
-  if constexpr (TS == 8) {
-    s.s1 = -(int32_t)((lane ^ (lane >> 2)) & 1);
-    s.s2 = -(int32_t)(((lane >> 1) ^ (lane >> 2)) & 1);
-  } else {
-    s.s1 = -(int32_t)(lane & 1);
-    s.s2 = 0;
-  }
-  return s;
-}
-template <int TS>
-__device__ __forceinline__ uint32_t habs_lanes(int32_t x, LaneSigns sg) {
-  x = bfly_lanes<0xB1>(x, sg.s1);
-  if constexpr (TS == 8) x = bfly_lanes<0x4E>(x, sg.s2);
-  const int32_t ax = iabs32(x);
-  const int32_t ap = TS == 8 ? dpp<0x141>(ax) : dpp<0x4E>(ax);
-  return (uint32_t)(ax > ap ? ax : ap);
-}
-
-__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc) {
-  uint32_t r;
-  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
-  return r;
-}
-
-// ---- the same on two i16 per register (VOP3P) ------------------------------
-// For pixels of up to 10 bits the 8x8 Hadamard fits i16 until its last stage:
-// |residual| <= 1023, five butterfly stages reach 32 * 1023 = 32736, and the
-// sixth stage is the max(|a|, |b|) fold above.  Two 8-row groups of a column
-// (or the two halves of one group after its first stage) share a register, so
-// every butterfly, abs and max works on two coefficients per lane per issue.
-typedef short v2s_t __attribute__((ext_vector_type(2)));
-typedef unsigned short v2us_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, (v2s_t)(__builtin_bit_cast(v2s_t, a) + __builtin_bit_cast(v2s_t, b)));
-}
-__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, (v2s_t)(__builtin_bit_cast(v2s_t, a) - __builtin_bit_cast(v2s_t, b)));
-}
-__device__ __forceinline__ uint32_t pk_mad(uint32_t x, uint32_t s, uint32_t p) {
-  uint32_t r;
-  asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(s), "v"(p));
-  return r;
-}
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// both halves of (lo, hi) from the low halves of two i32
-__device__ __forceinline__ uint32_t pk_pair(int32_t lo, int32_t hi) {
-  return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
-}
-// this lane's share of sum |Hadamard across the 8 lanes| for both halves of x,
-// added to acc; m1 / m2: packed +-1 of the two lane stages
-__device__ __forceinline__ uint32_t habs_lanes_pk(uint32_t x, uint32_t m1, uint32_t m2, uint32_t acc) {
-  x = pk_mad(x, m1, (uint32_t)dpp<0xB1>((int32_t)x));
-  x = pk_mad(x, m2, (uint32_t)dpp<0x4E>((int32_t)x));
-  const uint32_t ax = pk_max(x, pk_sub(0u, x));
-  const uint32_t mx = pk_max(ax, (uint32_t)dpp<0x141>((int32_t)ax));
-  return __builtin_amdgcn_udot2(__builtin_bit_cast(v2us_t, mx), __builtin_bit_cast(v2us_t, 0x00010001u),
-                                acc, false);
-}
-
-// (lo >> SH) in the low half, (hi >> SH) in the high half.  (Tried in round 3: the second shift as
-// an SDWA write into the upper word of the first one's register -- two instructions instead of
-// three.  +0.5 % and NOT bit-exact in the 8-bit kernels, with or without the dst_sel wait state;
-// profiles/r03_ab_notes.md.  v_perm it stays.)
-template <int SH>
-__device__ __forceinline__ uint32_t ashr_pair(int32_t lo, int32_t hi) {
-  return __builtin_amdgcn_perm((uint32_t)(hi >> SH), (uint32_t)(lo >> SH), 0x05040100u);
-}
-__device__ __forceinline__ uint32_t ashr_pair_rt(int32_t lo, int32_t hi, int sh) {
-  return __builtin_amdgcn_perm((uint32_t)(hi >> sh), (uint32_t)(lo >> sh), 0x05040100u);
-}
-
-// First link of a dot-product chain with a constant accumulator: the VOP3P
-// forms take the constant as an operand (inline 0 / 64, or an SGPR), whereas
-// the compiler's choice -- the accumulate-in-place v_dot*c forms -- needs a
-// v_mov to seed the accumulator first.  One instruction instead of two.
-__device__ __forceinline__ int32_t dot2_seed0(uint32_t a, uint32_t b) {
-  int32_t r;
-  asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ int32_t dot2_seed64(uint32_t a, uint32_t b) {
-  int32_t r;
-  asm("v_dot2_i32_i16 %0, %1, %2, 64" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ int32_t dot2_seed(uint32_t a, uint32_t b, int32_t c_uniform) {
-  int32_t r;
-  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
-  return r;
-}
-__device__ __forceinline__ int32_t dot4_seed(uint32_t a, uint32_t b, int32_t c_uniform) {
-  int32_t r;
-  asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
-  return r;
-}
-
-// ---- 8-bit fast path of put_8tap for one column ---------------------------
-// Unified 2-D evaluation.  With x-taps t (sum 128) and y-taps u (sum 128),
-// ib = 4 (8-bit): mid = (sum t*p + 4) >> 3, out = clamp((sum u*mid + 1024) >> 11).
-//  * col_frac == 0 (t = 128 at tap 3): mid = 16 p exactly, out =
-//    (16 S + 1024) >> 11 = (S + 64) >> 7 = round_shift(S, 7)     (mc.rs:272-291)
-//  * row_frac == 0 (u = 128 at tap 3): out = (128 mid + 1024) >> 11 =
-//    (mid + 8) >> 4 = round_shift(round_shift(S, 3), 4)            (mc.rs:292-312)
-//  * both 0: out = p                                              (mc.rs:265-271)
-// so one path is bit-exact for all four cases.  The 128 tap does not fit int8,
-// but every AV1 tap is even: the i8 table stores t / 2 and the shift is one less.
-// PREP: prep_8tap (mc.rs:360-451) -- the i16 intermediate of the same filter,
-// (sum u*mid + 64) >> 7 without clamp; the same algebra makes the one path
-// exact for its four cases too (mid = 16 p when col_frac == 0, u = 128 picks
-// mid when row_frac == 0).
-// the taps of one candidate, loaded ahead of their use (the pipelined kernel fetches the
-// next group's taps while the current group computes)
-struct Taps8 { uint32_t fx0, fx1, ty[4]; };
-template <int W, int H>
-__device__ __forceinline__ Taps8 load_taps8(int cf, int rf, int mx, int my) {
-  const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
-  const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
-  Taps8 t;
-  t.fx0 = kTapI8[fxi][cf][0];
-  t.fx1 = kTapI8[fxi][cf][1];
-#pragma unroll
-  for (int j = 0; j < 4; j++) t.ty[j] = kTapI16[fyi][rf][j];
-  return t;
-}
-struct Taps16 { uint32_t tx[4], ty[4]; };
-template <int W, int H>
-__device__ __forceinline__ Taps16 load_taps16(int cf, int rf, int mx, int my) {
-  const int fxi = (mx == R1_FILTER_BILINEAR || W > 4) ? mx : (mx < 1 ? mx : 1) + 4;
-  const int fyi = (my == R1_FILTER_BILINEAR || H > 4) ? my : (my < 1 ? my : 1) + 4;
-  Taps16 t;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    t.tx[j] = kTapI16[fxi][cf][j];
-    t.ty[j] = kTapI16[fyi][rf][j];
-  }
-  return t;
-}
-
-template <int W, int H, int WS, bool PREP = false>
-__device__ __forceinline__ void mc8_column_t(const uint8_t *win, int c, const Taps8 &tp, int32_t *pred);
-
-template <int W, int H, int WS, bool PREP = false>
-__device__ __forceinline__ void mc8_column(const uint8_t *win, int c, int cf, int rf, int mx,
-                                           int my, bool any_cf0, int32_t *pred) {
-  (void)any_cf0;
-  const Taps8 tp = load_taps8<W, H>(cf, rf, mx, my);
-  mc8_column_t<W, H, WS, PREP>(win, c, tp, pred);
-}
-
-template <int W, int H, int WS, bool PREP>
-__device__ __forceinline__ void mc8_column_t(const uint8_t *win, int c, const Taps8 &tp, int32_t *pred) {
-  const uint32_t fx0 = tp.fx0, fx1 = tp.fx1;
-  uint32_t ty[4], tz[5];
-#pragma unroll
-  for (int j = 0; j < 4; j++) ty[j] = tp.ty[j];
-  tz[0] = ty[0] << 16;
-#pragma unroll
-  for (int j = 1; j < 4; j++) tz[j] = __builtin_amdgcn_alignbit(ty[j], ty[j - 1], 16);
-  tz[4] = ty[3] >> 16;
-  // The i8 table holds h = t / 2 (all AV1 taps are even; sum h = 64).  With the
-  // staged q = p - 128:  sum t*p = 2 (sum h*q + 128 * 64), so
-  //   mid = (sum t*p + 4) >> 3 = (sum h*q + 8192 + 2) >> 2.
-  // put only: the vertical rounding 1024 = 128 * 8 is pre-added to the
-  // intermediates (every tap row sums to 128): + 8 after the shift = + 32 before.
-  constexpr int32_t bias = 8192 + 2 + (PREP ? 0 : 32);
-  constexpr int WSD = WS / 4;
-  const uint32_t *wrow = (const uint32_t *)win + (c >> 2);
-  typedef short v2s __attribute__((ext_vector_type(2)));
-  // The lane's 8 window bytes start at byte c & 3 of three aligned dwords.  Instead of moving the
-  // PIXELS to the taps (two v_alignbyte per row), the TAPS are moved to the pixels once per lane:
-  // the 8 tap bytes shifted up by c & 3 bytes into 12, zero elsewhere -- three v_dot4 per row on
-  // the aligned dwords as they come from LDS.
-  const uint32_t sh8 = 8u * (uint32_t)(c & 3);
-  const uint64_t t64 = (((uint64_t)fx1 << 32) | fx0) << sh8;
-  const uint32_t t0 = (uint32_t)t64, t1 = (uint32_t)(t64 >> 32);
-  const uint32_t t2 = (uint32_t)(((uint64_t)fx1 << sh8) >> 32);
-  // the window holds pixels already biased by -128 (staged with xor 0x80)
-  auto hacc = [&](int r) -> int32_t {   // 4 * intermediate + rounding, before the >> 2
-    const uint32_t d0 = wrow[r * WSD], d1 = wrow[r * WSD + 1], d2 = wrow[r * WSD + 2];
-    int32_t acc = dot4_seed(d0, t0, bias);
-    acc = __builtin_amdgcn_sdot4((int)d1, (int)t1, acc, false);
-    acc = __builtin_amdgcn_sdot4((int)d2, (int)t2, acc, false);
-    return acc;
-  };
-  auto hpair = [&](int r) -> uint32_t {   // rows r, r+1 packed as i16 x 2
-    // the last pair has no second row: its upper half only ever meets a zero tap (tz[4]'s high half)
-    if (r + 1 < H + 7) return ashr_pair<2>(hacc(r), hacc(r + 1));
-    return (uint32_t)(hacc(r) >> 2);
-  };
-  // rolling window of 5 packed pairs: output rows 2j and 2j+1 need the
-  // intermediates 2j .. 2j+8
-  uint32_t pk[5];
-#pragma unroll
-  for (int j = 0; j < 4; j++) pk[j] = hpair(2 * j);
-#pragma unroll
-  for (int j = 0; j < H / 2; j++) {
-    pk[4] = hpair(2 * j + 8);
-    // put: the rounding is already inside the intermediates; prep: + 64
-    int32_t a0 = PREP ? dot2_seed64(pk[0], ty[0]) : dot2_seed0(pk[0], ty[0]);
-    int32_t a1 = PREP ? dot2_seed64(pk[0], tz[0]) : dot2_seed0(pk[0], tz[0]);
-#pragma unroll
-    for (int k = 1; k < 4; k++)
-      a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]),
-                                  __builtin_bit_cast(v2s, ty[k]), a0, false);
-#pragma unroll
-    for (int k = 1; k < 5; k++)
-      a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]),
-                                  __builtin_bit_cast(v2s, tz[k]), a1, false);
-    if constexpr (PREP) {
-      pred[2 * j] = a0 >> 7;
-      pred[2 * j + 1] = a1 >> 7;
-    } else {
-      a0 >>= 11;
-      a1 >>= 11;
-      pred[2 * j] = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0);
-      pred[2 * j + 1] = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) pk[k] = pk[k + 1];
-  }
-}
-
-// ---- 10/12-bit fast path of put_8tap for one column -------------------------
-// Same unified evaluation as mc8_column, on u16 pixels: intermediate_bits
-// ib = 4 (10-bit) or 2 (12-bit);  mid = (sum t*p + 2^(6-ib)) >> (7-ib) fits
-// i16 (mc.rs:314,326), out = clamp((sum u*mid + 2^(6+ib)) >> (7+ib)).
-//  * col_frac == 0 (t = 128 at tap 3): mid = p << ib exactly, out =
-//    (2^ib * S + 2^(6+ib)) >> (7+ib) = round_shift(S, 7)           (mc.rs:272-291)
-//  * row_frac == 0 (u = 128 at tap 3): out = (128 mid + 2^(6+ib)) >> (7+ib)
-//    = round_shift(mid, ib)                                         (mc.rs:292-312)
-//  * both 0: out = p                                               (mc.rs:265-271)
-// The taps (128 included) and the pixels (<= 4095) fit i16, so the 8 horizontal
-// taps are 4 v_dot2_i32_i16 on pixel pairs funnel-shifted to the lane's
-// column, and the vertical taps 4-5 v_dot2_i32_i16 on packed intermediates.
-// The rounding of the vertical pass is pre-added to the intermediates:
-// 2^(6+ib) = 128 * 2^(ib-1) and every tap row sums to 128.
-// PREP: (sum u*mid + 64) >> 7 - PREP_BIAS (8192), no clamp (mc.rs:355-451).
-template <int W, int H, int WS, bool PREP = false>
-__device__ __forceinline__ void mc16_column_t(const uint8_t *win, int c, const Taps16 &tp, int bit_depth,
-                                              int32_t *pred);
-
-template <int W, int H, int WS, bool PREP = false>
-__device__ __forceinline__ void mc16_column(const uint8_t *win, int c, int cf, int rf, int mx,
-                                            int my, int bit_depth, int32_t *pred) {
-  const Taps16 tp = load_taps16<W, H>(cf, rf, mx, my);
-  mc16_column_t<W, H, WS, PREP>(win, c, tp, bit_depth, pred);
-}
-
-template <int W, int H, int WS, bool PREP>
-__device__ __forceinline__ void mc16_column_t(const uint8_t *win, int c, const Taps16 &tp, int bit_depth,
-                                              int32_t *pred) {
-  typedef short v2s __attribute__((ext_vector_type(2)));
-  uint32_t tx[4], ty[4], tz[5];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    tx[j] = tp.tx[j];
-    ty[j] = tp.ty[j];
-  }
-  tz[0] = ty[0] << 16;
-#pragma unroll
-  for (int j = 1; j < 4; j++) tz[j] = __builtin_amdgcn_alignbit(ty[j], ty[j - 1], 16);
-  tz[4] = ty[3] >> 16;
-  const int ib = bit_depth == 12 ? 2 : 4;
-  const int hsh = 7 - ib, vsh = 7 + ib;
-  // H rounding, plus (put only) the V rounding 2^(ib-1) << hsh = 64 folded into mid
-  const int32_t hbias = (1 << (6 - ib)) + (PREP ? 0 : 64);
-  const int32_t maxv = (1 << bit_depth) - 1;
-  constexpr int WSD = WS / 4;
-  const uint32_t *wrow = (const uint32_t *)win + (c >> 1);
-  // as in mc8_column_t the taps go to the pixels: the 8 x-taps shifted up by one i16 for odd
-  // columns into five dwords -- five v_dot2 per row on aligned LDS dwords (was 4 v_alignbit + 4)
-  const bool odd = c & 1;
-  uint32_t u[5];
-  u[0] = odd ? tx[0] << 16 : tx[0];
-#pragma unroll
-  for (int j = 1; j < 4; j++) u[j] = odd ? __builtin_amdgcn_alignbit(tx[j], tx[j - 1], 16) : tx[j];
-  u[4] = odd ? tx[3] >> 16 : 0u;
-  auto hacc = [&](int r) -> int32_t {
-    const uint32_t *p = wrow + r * WSD;
-    int32_t acc = dot2_seed(p[0], u[0], hbias);
-#pragma unroll
-    for (int j = 1; j < 5; j++)
-      acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, p[j]), __builtin_bit_cast(v2s, u[j]), acc, false);
-    return acc;
-  };
-  auto hpair = [&](int r) -> uint32_t {   // rows r, r+1 packed as i16 x 2
-    if (r + 1 < H + 7) return ashr_pair_rt(hacc(r), hacc(r + 1), hsh);
-    return (uint32_t)(hacc(r) >> hsh);
-  };
-  uint32_t pk[5];
-#pragma unroll
-  for (int j = 0; j < 4; j++) pk[j] = hpair(2 * j);
-#pragma unroll
-  for (int j = 0; j < H / 2; j++) {
-    pk[4] = hpair(2 * j + 8);
-    int32_t a0 = PREP ? dot2_seed64(pk[0], ty[0]) : dot2_seed0(pk[0], ty[0]);
-    int32_t a1 = PREP ? dot2_seed64(pk[0], tz[0]) : dot2_seed0(pk[0], tz[0]);
-#pragma unroll
-    for (int k = 1; k < 4; k++)
-      a0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]), __builtin_bit_cast(v2s, ty[k]), a0, false);
-#pragma unroll
-    for (int k = 1; k < 5; k++)
-      a1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pk[k]), __builtin_bit_cast(v2s, tz[k]), a1, false);
-    if constexpr (PREP) {
-      pred[2 * j] = (a0 >> 7) - 8192;
-      pred[2 * j + 1] = (a1 >> 7) - 8192;
-    } else {
-      a0 >>= vsh;
-      a1 >>= vsh;
-      pred[2 * j] = a0 < 0 ? 0 : (a0 > maxv ? maxv : a0);
-      pred[2 * j + 1] = a1 < 0 ? 0 : (a1 > maxv ? maxv : a1);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) pk[k] = pk[k + 1];
-  }
-}
-
-// SATD contribution of one residual column (TS rows at a time).
-template <int TS, int H, int BD>
-__device__ __forceinline__ uint32_t satd_column(const T *v, int lane) {
-  const LaneSigns sg = lane_signs<TS>(lane);
-  uint32_t acc = 0;
-  if constexpr (TS == 8 && BD <= 10) {
-    const uint32_t m1 = (uint32_t)sg.s1 | 0x00010001u, m2 = (uint32_t)sg.s2 | 0x00010001u;
-    if constexpr (H == 8) {
-      // first vertical stage in i32, then (sum, difference) halves side by side
-      uint32_t a[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) a[k] = pk_pair(v[k] + v[k + 4], v[k] - v[k + 4]);
-      const uint32_t a0 = pk_add(a[0], a[1]), a1 = pk_sub(a[0], a[1]);
-      const uint32_t a2 = pk_add(a[2], a[3]), a3 = pk_sub(a[2], a[3]);
-      acc = habs_lanes_pk(pk_add(a0, a2), m1, m2, acc);
-      acc = habs_lanes_pk(pk_add(a1, a3), m1, m2, acc);
-      acc = habs_lanes_pk(pk_sub(a0, a2), m1, m2, acc);
-      acc = habs_lanes_pk(pk_sub(a1, a3), m1, m2, acc);
-    } else {
-#pragma unroll
-      for (int g = 0; g < H / 16; g++) {   // 8-row groups 2g and 2g+1 side by side
-        uint32_t a[8], b[8], d[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) a[k] = pk_pair(v[g * 16 + k], v[g * 16 + 8 + k]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          b[2 * k] = pk_add(a[2 * k], a[2 * k + 1]);
-          b[2 * k + 1] = pk_sub(a[2 * k], a[2 * k + 1]);
-        }
-        d[0] = pk_add(b[0], b[2]); d[2] = pk_sub(b[0], b[2]);
-        d[1] = pk_add(b[1], b[3]); d[3] = pk_sub(b[1], b[3]);
-        d[4] = pk_add(b[4], b[6]); d[6] = pk_sub(b[4], b[6]);
-        d[5] = pk_add(b[5], b[7]); d[7] = pk_sub(b[5], b[7]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          acc = habs_lanes_pk(pk_add(d[k], d[k + 4]), m1, m2, acc);
-          acc = habs_lanes_pk(pk_sub(d[k], d[k + 4]), m1, m2, acc);
-        }
-      }
-    }
-    return acc;
-  }
-#pragma unroll
-  for (int g = 0; g < H / TS; g++) {
-    int32_t a[TS];
-#pragma unroll
-    for (int k = 0; k < TS; k++) a[k] = v[g * TS + k];
-    // vertical pass on the lane's own TS rows (dist.rs:126-131)
-    if constexpr (TS == 4) {
-      const int32_t a0 = a[0] + a[1], a1 = a[0] - a[1];
-      const int32_t a2 = a[2] + a[3], a3 = a[2] - a[3];
-      a[0] = a0 + a2; a[1] = a1 + a3; a[2] = a0 - a2; a[3] = a1 - a3;
-    } else {
-      int32_t b[8], d[8];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        b[2 * k] = a[2 * k] + a[2 * k + 1];
-        b[2 * k + 1] = a[2 * k] - a[2 * k + 1];
-      }
-      d[0] = b[0] + b[2]; d[2] = b[0] - b[2];
-      d[1] = b[1] + b[3]; d[3] = b[1] - b[3];
-      d[4] = b[4] + b[6]; d[6] = b[4] - b[6];
-      d[5] = b[5] + b[7]; d[7] = b[5] - b[7];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        a[k] = d[k] + d[k + 4];
-        a[k + 4] = d[k] - d[k + 4];
-      }
-    }
-    // horizontal pass across the TS lanes of the tile (dist.rs:132-138)
-#pragma unroll
-    for (int k = 0; k < TS; k++) acc += habs_lanes<TS>(a[k], sg);
-  }
-  return acc;
-}
+#include "cand_helpers.inc"
 
 // QUANT (the "full" candidate): the coefficients do not go to HBM
 // (unless `coeffs` is also given) but through the quantizer in place --
