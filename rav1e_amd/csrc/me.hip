@@ -55,12 +55,12 @@ using r1tx::T;
 // whole search), SATD by the DPP Hadamard (or SAD).  Returns this lane's share; the caller sums the
 // group.  The generic path it replaces for these sizes (scalar taps from byte reads, one lane per
 // 8x8 Hadamard tile = 4 of 16 lanes busy) cost about three times the instructions.
-template <int BPP, int W, int H, int BD>
+template <int BPP, int W, int H, int BD, int NL = 16>
 __device__ __forceinline__ uint32_t subpel_group_dist(uint8_t *win, const R1Plane &ref, int x, int y, int cf,
                                                       int rf, int fm, int gl, int lane, const uint8_t *src /* LDS: the W x H source block, dense */,
                                                       bool satd, int bit_depth) {
   constexpr int WS = (((W + 7) * BPP + 3) >> 2) << 2;
-  r1mc::stage_window_fast<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, 16>(win, WS, ref, x, y, gl);
+  r1mc::stage_window_fast<BPP, BPP == 1 ? 0x80808080u : 0u, W, H, NL>(win, WS, ref, x, y, gl);
   __builtin_amdgcn_wave_barrier();
   T v[H];
 #pragma unroll
@@ -1105,6 +1105,23 @@ struct WgBlock {
   __device__ __forceinline__ uint32_t predict_dist(const R1Plane &ref, uint8_t *win, uint8_t *pred,
                                                    int sx, int sy, int col_frac, int row_frac,
                                                    int mode, bool use_satd) const {
+    // 8-bit 32 / 64-sized blocks: the fused candidate kernel's column filter + DPP SATD, a wave per
+    // candidate (64x64 0.27 -> 0.20 ms, 32x32 0.50 -> 0.42 ms for every block of a 4K frame).  The
+    // 16-bit variant of the same lost at 32x32 (0.56 -> 0.70 ms: 181 VGPRs, spills, 29 k instructions
+    // of code) and stays on the generic path.
+    if constexpr (BPP == 1) {
+      if ((w == 32 || w == 64) && (h == 32 || h == 64)) {
+        uint32_t s = 0;
+#define R1_WP(W_, H_) s = subpel_group_dist<1, W_, H_, 8, 64>(win, ref, sx, sy, col_frac, row_frac, mode, lane, lane, org, use_satd, 8)
+        if (w == 32 && h == 32) R1_WP(32, 32);
+        else if (w == 64 && h == 64) R1_WP(64, 64);
+        else if (w == 64) R1_WP(64, 32);
+        else R1_WP(32, 64);
+#undef R1_WP
+        s = group_sum<64>(s);
+        return use_satd ? (s + 4u) >> 3 : s;
+      }
+    }
     const int ws = (((w + 7) * BPP + 3) >> 2) << 2;
     r1mc::stage_window<BPP>(win, ws, ref, sx, sy, w, h, lane, 64);
     __builtin_amdgcn_wave_barrier();
