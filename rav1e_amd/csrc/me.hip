@@ -37,6 +37,7 @@
 #include <algorithm>
 #include <initializer_list>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -69,10 +70,10 @@ __device__ __forceinline__ uint32_t subpel_group_dist(uint8_t *win, const R1Plan
     int32_t pred[H];
     if constexpr (BPP == 1) {
       const Taps8 tp = load_taps8<W, H>(cf, rf, fm, fm);
-      mc8_column_t<W, H, WS, false>(win, gl, tp, pred);
+      mc8_column_t<W, H, WS, false>(win, gl, tp, pred, taps_six(tp));
     } else {
       const Taps16 tp = load_taps16<W, H>(cf, rf, fm, fm);
-      mc16_column_t<W, H, WS, false>(win, gl, tp, bit_depth, pred);
+      mc16_column_t<W, H, WS, false>(win, gl, tp, bit_depth, pred, taps_six(tp));
     }
 #pragma unroll
     for (int r = 0; r < H; r++) v[r] = ld_px<BPP>(src + (r * W + gl) * BPP) - pred[r];

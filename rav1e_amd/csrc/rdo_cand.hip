@@ -259,6 +259,8 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     if constexpr (BPP == 1) tp = load_taps8<W, H>(cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y);
     else tp = load_taps16<W, H>(cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y);
   }
+  // every filter of the wave with zero outer taps (anything but SHARP): the short column filter
+  const bool six = taps_six(tp);
   // A.2: into LDS
   if constexpr (SRC_LDS) {
     if (live) {
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
         for (int r = 0; r < H; r++) pred[r] = pi[(size_t)r * W];
       } else {
-        mc8_column_t<W, H, WS, false>(win, c, tp, pred);
+        mc8_column_t<W, H, WS, false>(win, c, tp, pred, six);
       }
       if (pred_out && live_st) {
         uint8_t *pp = (uint8_t *)pred_out + (size_t)cand * W * H + c;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
         for (int r = 0; r < H; r++) pred[r] = pi[(size_t)r * W];
       } else {
-        mc16_column_t<W, H, WS, false>(win, c, tp, BD, pred);
+        mc16_column_t<W, H, WS, false>(win, c, tp, BD, pred, six);
       }
       if (pred_out && live_st) {
         uint16_t *pp = (uint16_t *)pred_out + (size_t)cand * W * H + c;
