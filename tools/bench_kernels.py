@@ -41,6 +41,20 @@ def main():
     org = Plane.from_numpy(W.random_plane_array(fw, fh, bd, 1), fw, fh, bd, 88, 88)
     ref = Plane.from_numpy(W.random_plane_array(fw, fh, bd, 2), fw, fh, bd, 88, 88)
     rng = np.random.default_rng(3)
+    # The rows that read PLANES (a1-a5, a8, a9) rotate through NP plane pairs whose footprint exceeds
+    # the 256 MB Infinity Cache, so that a launch finds its planes in HBM, not in L3 (round-2 review:
+    # "scale past L3 before reading them").  Beside the fraction by ALGORITHMIC bytes (every candidate
+    # counted with its own block and window, the contract's figure: > 1 is possible because the K
+    # candidates of a block overlap in L2) the line carries `hbm_frac_unique`: the bytes a launch can
+    # at most pull from HBM (plane footprints + descriptors + outputs) over the same time.
+    plane_bytes = org.data.numel() * org.data.element_size()
+    NP = max(2, int(np.ceil(300e6 / (2 * plane_bytes))))
+    pairs = [(org, ref)]
+    for i in range(1, NP):
+        a = W.random_plane_array(fw, fh, bd, 100 + 2 * i)
+        pairs.append((Plane.from_numpy(a, fw, fh, bd, 88, 88),
+                      Plane.from_numpy(np.roll(a, 7919 * i), fw, fh, bd, 88, 88)))
+    vis_bytes = fw * fh * bpp
 
     def timeit(fn, reps=args.reps):
         for _ in range(3):
@@ -54,11 +68,28 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    def report(name, ms, pixels, abytes, extra=None):
+    def timeit_rot(fn, reps=args.reps):
+        """fn(org_i, ref_i): a different plane pair every launch (see NP above)"""
+        for i in range(3):
+            fn(*pairs[i % NP])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            fn(*pairs[(3 + i) % NP])
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def report(name, ms, pixels, abytes, extra=None, unique=None):
         gbs = abytes / (ms * 1e-3) / 1e9
         d = {"kernel": name, "ms": round(ms, 4), "Mpixels_s": round(pixels / (ms * 1e-3) / 1e6, 1),
              "algorithmic_GB_s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK, 4),
              "bit_depth": bd}
+        if unique is not None:
+            d["unique_GB_s"] = round(unique / (ms * 1e-3) / 1e9, 1)
+            d["hbm_frac_unique"] = round(unique / (ms * 1e-3) / 1e9 / HBM_PEAK, 4)
+            d["planes_rotated"] = NP
         if extra:
             d.update(extra)
         print(json.dumps(d), flush=True)
@@ -81,9 +112,9 @@ def main():
             c = grid_cands(api.DIST_CAND, s, k)
             dc = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
             out = torch.empty(len(c), dtype=torch.int32, device="cuda")
-            ms = timeit(lambda: ctx.dist_batch(kind, org, ref, s, s, dc, n=len(c), out=out))
+            ms = timeit_rot(lambda o, r: ctx.dist_batch(kind, o, r, s, s, dc, n=len(c), out=out))
             report("get_%s %dx%d" % (nm, s, s), ms, len(c) * s * s, len(c) * (2 * s * s * bpp + 4),
-                   {"candidates": len(c)})
+                   {"candidates": len(c)}, unique=2 * vis_bytes + len(c) * 12)
     # ---- a3-a5: weighted SSE / cdef_dist with a scale grid ----
     scales = torch.from_numpy(rng.integers(1 << 12, 1 << 16, ((fh + 7) // 8, (fw + 7) // 8))
                               .astype(np.int32)).cuda()
@@ -92,9 +123,10 @@ def main():
         dc = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
         out = torch.empty(len(c), dtype=torch.int64, device="cuda")
         for kind, nm in ((2, "weighted_sse"), (3, "cdef_dist")):
-            ms = timeit(lambda: ctx.dist_scaled_batch(kind, org, ref, s, s, dc, scales, n=len(c), out=out))
+            ms = timeit_rot(lambda o, r: ctx.dist_scaled_batch(kind, o, r, s, s, dc, scales, n=len(c), out=out))
             report("%s %dx%d" % (nm, s, s), ms, len(c) * s * s,
-                   len(c) * (2 * s * s * bpp + (s // 4) ** 2 * 4 + 8), {"candidates": len(c)})
+                   len(c) * (2 * s * s * bpp + (s // 4) ** 2 * 4 + 8), {"candidates": len(c)},
+                   unique=2 * vis_bytes + scales.numel() * 4 + len(c) * 16)
     # ---- a6 / a13 / a12: transforms and quantizer on every tx block of a frame ----
     for s, tsz in ((64, TxSize.TX_64X64), (32, TxSize.TX_32X32), (16, TxSize.TX_16X16),
                    (8, TxSize.TX_8X8), (4, TxSize.TX_4X4)):
@@ -122,13 +154,15 @@ def main():
         c["row_frac"] = rng.integers(0, 16, len(c))
         dc = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).cuda()
         out = torch.empty((len(c), s, s), dtype=torch.uint8 if bpp == 1 else torch.int16, device="cuda")
-        ms = timeit(lambda: ctx.put_8tap_batch(ref, s, s, dc, n=len(c), out=out))
+        ms = timeit_rot(lambda o, r: ctx.put_8tap_batch(r, s, s, dc, n=len(c), out=out))
         report("put_8tap %dx%d" % (s, s), ms, len(c) * s * s,
-               len(c) * (((s + 7) ** 2 + s * s) * bpp), {"candidates": len(c)})
+               len(c) * (((s + 7) ** 2 + s * s) * bpp), {"candidates": len(c)},
+               unique=vis_bytes + len(c) * (8 + s * s * bpp))
         out16 = torch.empty((len(c), s, s), dtype=torch.int16, device="cuda")
-        ms = timeit(lambda: ctx.prep_8tap_batch(ref, s, s, dc, n=len(c), out=out16))
+        ms = timeit_rot(lambda o, r: ctx.prep_8tap_batch(r, s, s, dc, n=len(c), out=out16))
         report("prep_8tap %dx%d" % (s, s), ms, len(c) * s * s,
-               len(c) * ((s + 7) ** 2 * bpp + 2 * s * s), {"candidates": len(c)})
+               len(c) * ((s + 7) ** 2 * bpp + 2 * s * s), {"candidates": len(c)},
+               unique=vis_bytes + len(c) * (8 + 2 * s * s))
     # ---- a10 / a11: intra edges + prediction on every tx block ----
     for s, tsz in ((32, TxSize.TX_32X32), (16, TxSize.TX_16X16), (8, TxSize.TX_8X8), (4, TxSize.TX_4X4)):
         nx, ny = fw // s, fh // s
