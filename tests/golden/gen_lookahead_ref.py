@@ -135,6 +135,73 @@ def main():
             res = np.array([float(v) for v in acc], np.float32).reshape(hb, wb)
             out["refimp_out_%d_%s" % (ln, k)] = res
     out["keys"] = np.array(keys)
+
+    # ---- adversarial set for update_block_importances (f32, order-of-operation code): reference
+    # positions ON and either side of importance-block boundaries in both axes, negative positions
+    # (-1, -63, -64, -65, -127, -128 in MV units: the `reference < 0` floor terms of
+    # internal.rs:1010-1017), positions at / beyond the right and bottom frame edge (targets partly or
+    # wholly off-frame on each side), len in {1, 2, 7}.  The intra costs are GIVEN (large) so that
+    # every block propagates; the inter costs come from get_satd inside the executed function.
+    adv_keys = []
+    for ci, (bd, w, h, kind) in enumerate([(8, 48, 40, "noise"), (8, 56, 32, "smooth"), (10, 48, 40, "noise"),
+                                           (10, 40, 48, "smooth"), (12, 48, 32, "noise"), (8, 64, 64, "smooth")]):
+        g = L.pixel_type(bd)
+        dt = L.np_dtype(bd)
+        mx = (1 << bd) - 1
+        if kind == "noise":
+            org = rng.integers(0, mx + 1, (h, w))
+            ref = rng.integers(0, mx + 1, (h, w))
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            org = (mx * (0.5 + 0.4 * np.sin(xx / 5.0) * np.cos(yy / 6.0))).astype(np.int64) + rng.integers(-3, 4, (h, w))
+            ref = np.roll(org, (2, -1), (0, 1)) + rng.integers(-2, 3, (h, w))
+        org, ref = np.clip(org, 0, mx).astype(dt), np.clip(ref, 0, mx).astype(dt)
+        k = "%d_%d_%d_adv%d" % (bd, w, h, ci)
+        adv_keys.append(k)
+        pad = 16
+        ref_p = np.pad(ref, pad, mode="edge")
+        out["org_" + k], out["ref_" + k], out["refpad_" + k] = org, ref, ref_p
+        f_org = Obj(planes=R.RSlice([L.plane_from_array(org, bd, pad, pad)]))
+        f_ref = Obj(planes=R.RSlice([L.plane_from_padded(ref_p, bd, pad, pad)]))
+        hb, wb = h // 8, w // 8
+        mv = np.zeros((hb, wb, 2), np.int64)
+
+        def targets(nb, size_px):
+            edge = nb * 64                                       # the frame edge in MV units
+            t = [-128, -127, -65, -64, -63, -1, 0, 1, 63, 64, 65, 127, 128, 129]
+            t += [edge + d for d in (-129, -128, -127, -65, -64, -63, -1, 0, 1, 63, 64)]
+            return [v for v in t if -8 * pad <= v <= (size_px + pad - 8) * 8]
+        tx, ty = targets(wb, w), targets(hb, h)
+        for y in range(hb):
+            for x in range(wb):
+                # a position is reachable from any block: the vector is what it takes to get there
+                rx = tx[(3 * (y * wb + x) + ci) % len(tx)] if rng.random() < 0.85 else int(rng.integers(-8 * pad, (w + pad - 8) * 8 + 1))
+                ry = ty[(5 * (y * wb + x) + 2 * ci + x) % len(ty)] if rng.random() < 0.85 else int(rng.integers(-8 * pad, (h + pad - 8) * 8 + 1))
+                mv[y, x] = (ry - y * 64, rx - x * 64)
+        assert np.abs(mv).max() < 32768
+        out["mv_" + k] = mv.astype(np.int16)
+        cols, rows = (w + 3) // 4, (h + 3) // 4
+        stats = frame_stats(mv, cols, rows)
+        # SATD of an 8x8 block is at most 64 * mx * 8 / 8; intra costs above that always propagate,
+        # a few small ones (0, 1) take the `intra_cost <= inter_cost` arm
+        intra_g = rng.integers(64 * mx, 200 * mx, (hb, wb)).astype(np.uint32)
+        intra_g[rng.random((hb, wb)) < 0.1] = rng.integers(0, 2)
+        out["intra_" + k] = intra_g
+        fut = (rng.random((hb, wb)) * 3000.0).astype(np.float32)
+        fut[rng.random((hb, wb)) < 0.2] = 0.0
+        out["future_" + k] = fut
+        for ln in (1, 2, 7):
+            imp = (rng.random((hb, wb)) * 10.0).astype(np.float32)
+            out["refimp_in_%d_%s" % (ln, k)] = imp
+            acc = R.RSlice([R.F32(float(v)) for v in imp.ravel()])
+            coded = Obj(lookahead_intra_costs=R.RSlice([int(v) for v in intra_g.ravel()]),
+                        block_importances=R.RSlice([R.F32(float(v)) for v in fut.ravel()]),
+                        w_in_imp_b=wb, h_in_imp_b=hb)
+            fi2 = Obj(coded_frame_data=R.Some(coded), cpu_feature_level=None)
+            ubi(g, fi2, stats, f_org, f_ref, bd, bsize8, ln, acc)
+            assert all(type(v) is R.F32 for v in acc), "an f32 operation escaped the F32 model"
+            out["refimp_out_%d_%s" % (ln, k)] = np.array([float(v) for v in acc], np.float32).reshape(hb, wb)
+    out["adv_keys"] = np.array(adv_keys)
     L.save("lookahead_ref.npz", out)
 
 

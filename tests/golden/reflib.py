@@ -18,13 +18,15 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from rustlite import runtime as R  # noqa: E402
 from rustlite.transpile import Crate  # noqa: E402
 
-REF_SRC = "/root/reference/src"
+# R1_REF_SRC: point the generators at a scratch COPY of the reference's src/ (mutation checks:
+# change one constant in the copy, regenerate into a temp dir, see the fixture change)
+REF_SRC = os.environ.get("R1_REF_SRC", "/root/reference/src")
 
 
-def crate(*files):
+def crate(*files, strict=False):
     if not os.path.isdir(REF_SRC):
         raise SystemExit("the reference tree is not present: run this in the build container")
-    c = Crate(REF_SRC)
+    c = Crate(REF_SRC, strict=strict)
     for f in files:
         c.load(f)
     return c
@@ -97,6 +99,6 @@ def struct(c, name):
 
 
 def save(name, out):
-    path = os.path.join(HERE, name)
+    path = os.path.join(os.environ.get("R1_GOLDEN_OUT", HERE), name)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -10,6 +10,7 @@ from rav1e_amd import rdo_glue as RG
 from rav1e_amd.types import BlockSize, TxSize
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "rdo_glue_ref.npz")
+GOLD_PIXEL = os.path.join(os.path.dirname(__file__), "golden", "rdo_pixel_ref.npz")
 TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
 TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
 
@@ -30,6 +31,36 @@ def check_tx_blocks(G, full_cand):
         want = G["tb_out_" + k]
         assert (int(got[0]), int(got[1])) == (int(want[0]), int(want[1])), (k, got, want)
         n += 1
+    return n
+
+
+def check_pixel_blocks(G, pixel_cand):
+    """encode_tx_block's pixel-domain leg + compute_distortion (gen_rdo_pixel_ref.py):
+    pixel_cand(bd, ts, tt, qidx, src_plane, pred_plane, dist_kind, scales, scale_stride) ->
+    (eob, dist, qcoeffs[coded area], rec[h, w]) of the zero-motion candidate at (8, 8);
+    dist_kind 2 = sse_wxh (Tune::Psnr), 3 = cdef_dist_wxh (Tune::Psychovisual); scales = the
+    per-importance-block DistortionScale grid (None: temporal RDO off)."""
+    n = 0
+    for k in G["px_keys"]:
+        k = str(k)
+        bd, ts, tt, qidx = [int(v) for v in k.split("_")]
+        w, h = TX_W[ts], TX_H[ts]
+        src = O.HostPlane(w + 16, h + 16, bd, 16, 16)
+        pred = O.HostPlane(w + 16, h + 16, bd, 16, 16)
+        src.view()[8:8 + h, 8:8 + w] = G["px_src_" + k]
+        pred.view()[8:8 + h, 8:8 + w] = G["px_pred_" + k]
+        sblk = G["px_scales_" + k]
+        gw, gh = (w + 16 + 7) // 8, (h + 16 + 7) // 8
+        grid = np.full((gh, gw), 1 << 14, np.uint32)
+        grid[1:1 + sblk.shape[0], 1:1 + sblk.shape[1]] = sblk
+        want = [int(v) for v in G["px_dist_" + k]]       # [sse, cdef, sse scaled, cdef scaled]
+        for j, (kind, sc) in enumerate(((2, None), (3, None), (2, grid), (3, grid))):
+            eob, dist, qc, rec = pixel_cand(bd, ts, tt, qidx, src, pred, kind, sc, gw)
+            assert int(eob) == int(G["px_eob_" + k][0]), (k, "eob", eob)
+            assert np.array_equal(np.asarray(qc).astype(np.int64).ravel(), G["px_qc_" + k].astype(np.int64)), (k, "qcoeffs")
+            assert np.array_equal(np.asarray(rec).astype(np.int64).reshape(h, w), G["px_rec_" + k].astype(np.int64)), (k, "rec")
+            assert int(dist) == want[j], (k, "dist", j, int(dist), want[j])
+            n += 1
     return n
 
 

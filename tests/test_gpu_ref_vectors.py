@@ -187,6 +187,49 @@ def test_lookahead_ref_maps_and_importances(ctx):
             assert np.array_equal(acc.cpu().numpy().view(np.uint32), want.view(np.uint32)), (k, ln)
 
 
+def test_lookahead_ref_adversarial_importance_positions(ctx):
+    """update_block_importances on the adversarial set of lookahead_ref.npz (negative / boundary /
+    beyond-the-edge reference positions, len in {1, 2, 7}); see test_oracle_lookahead_ref.py"""
+    import torch
+    G = np.load(os.path.join(GOLD, "lookahead_ref.npz"))
+    n = 0
+    for k in G["adv_keys"]:
+        k = str(k)
+        bd, w, h = [int(v) for v in k.split("_")[:3]]
+        hb, wb = h // 8, w // 8
+        org, ref = O.plane_from_image(G["org_" + k], bd, 16, 16), O.plane_from_image(G["ref_" + k], bd, 16, 16)
+        do, dr = dev_plane(org), dev_plane(ref)
+        mvs = torch.from_numpy(np.ascontiguousarray(G["mv_" + k])).cuda()
+        inter = ctx.estimate_inter_costs(do, dr, mvs)
+        intra = torch.from_numpy(np.ascontiguousarray(G["intra_" + k]).view(np.int32)).cuda()
+        fut = torch.from_numpy(np.ascontiguousarray(G["future_" + k])).cuda()
+        for ln in (1, 2, 7):
+            acc = torch.from_numpy(np.ascontiguousarray(G["refimp_in_%d_%s" % (ln, k)]).copy()).cuda()
+            ctx.update_block_importances(intra.reshape(-1), fut.reshape(-1), inter.reshape(-1),
+                                         mvs.reshape(-1, 2), wb, hb, ln, acc.reshape(-1))
+            want = G["refimp_out_%d_%s" % (ln, k)]
+            assert np.array_equal(acc.cpu().numpy().view(np.uint32), want.view(np.uint32)), (k, ln)
+            n += 1
+    assert n == 18
+
+
+# ---- a13: inverse_transform_add, the WHOLE function executed from the text (gen_inv_tx_ref.py) --
+def test_inv_tx_ref_whole_function(ctx):
+    """480 (tx_size, tx_type, bit depth) cases x 3-5 blocks; the 2-D driver of
+    src/transform/inverse.rs:1633-1705 was executed as written (no hand-stated driver)."""
+    import torch
+    G = np.load(os.path.join(GOLD, "inv_tx_ref.npz"))
+    keys = [k for k in G.files if k.endswith("_co")]
+    assert len(keys) == 480
+    for k in keys:
+        _, ts, tt, bd, _ = k.split("_")
+        ts, tt, bd = int(ts), int(tt), int(bd)
+        co, pred, rec = G[k], G[k[:-3] + "_pred"], G[k[:-3] + "_rec"]
+        dp = pred if bd == 8 else pred.view(np.int16)
+        got = ctx.inverse_transform_add_batch(torch.from_numpy(co).cuda(), torch.from_numpy(dp).cuda(), ts, tt, bd)
+        assert np.array_equal(got.cpu().numpy().view(pred.dtype), rec), k
+
+
 # ---- N4 glue against the executed reference text (gen_rdo_glue_ref.py) ----------------------
 def test_rdo_glue_ref_tx_block_rate_and_distortion(ctx):
     """encode_tx_block's TxDistEstRate evaluation (src/encoder.rs:1404-1661) as executed from the
@@ -203,6 +246,35 @@ def test_rdo_glue_ref_tx_block_rate_and_distortion(ctx):
         o = ctx.rdo_full_cand_batch(dev_plane(src), dev_plane(pred), w, h, c, qidx, is_intra=0)
         return int(o["tx_dist"].cpu().numpy().view(np.uint64)[0]), int(o["est_rate"].cpu().numpy().view(np.uint64)[0])
     assert RC.check_tx_blocks(G, full_cand) == 156
+
+
+def test_rdo_pixel_ref_encode_tx_block_pixel_leg(ctx):
+    """rav1e's default tune (BASELINE config 4): encode_tx_block with
+    use_tx_domain_distortion = false (dequantize -> inverse_transform_add into the reconstruction,
+    src/encoder.rs:1588-1614) followed by compute_distortion (src/rdo.rs:254-347), executed from
+    the reference's text (gen_rdo_pixel_ref.py): r1_rdo_pixel_cand_batch reproduces eob, the
+    quantized coefficients, the reconstruction and the distortion (sse_wxh and cdef_dist_wxh,
+    with and without the temporal-RDO scale grid) of all 482 blocks."""
+    import torch
+    import rdo_glue_cases as RC
+    from rav1e_amd.api import RDO_CAND
+    G = np.load(RC.GOLD_PIXEL)
+    cache = {}
+
+    def pixel_cand(bd, ts, tt, qidx, src, pred, kind, scales, stride):
+        w, h = RC.TX_W[ts], RC.TX_H[ts]
+        if cache.get("key") != (id(src), id(pred)):
+            cache.update(key=(id(src), id(pred)), planes=(dev_plane(src), dev_plane(pred)), hold=(src, pred))
+        ds, dp = cache["planes"]
+        c = np.zeros(1, RDO_CAND)
+        c["ox"], c["oy"], c["rx"], c["ry"], c["tx_type"] = 8, 8, 8, 8, tt
+        sc = None if scales is None else torch.from_numpy(scales.view(np.int32)).cuda()
+        o = ctx.rdo_pixel_cand_batch(ds, dp, w, h, c, qidx, kind, scales=sc, is_intra=0, want_qcoeffs=True,
+                                     want_rec=True)
+        pt = np.uint8 if bd == 8 else np.uint16
+        return (int(o["eob"].cpu().numpy().view(np.uint16)[0]), int(o["dist"].cpu().numpy().view(np.uint64)[0]),
+                o["qcoeffs"].cpu().numpy()[0], o["rec"].cpu().numpy().view(pt)[0])
+    assert RC.check_pixel_blocks(G, pixel_cand) == 482 * 4
 
 
 def test_rdo_glue_ref_compute_tx_distortion(ctx):

@@ -1,7 +1,10 @@
 """Pin the inverse-transform oracles (C and rule-based NumPy restatements)
-against vectors produced by executing the reference's own source text
-(tests/golden/gen_inv_tx_golden.py), and against the reference's own
-round-trip test (src/transform/mod.rs:555-603)."""
+against vectors produced by executing the reference's own source text:
+  inv_tx_ref.npz     the WHOLE of inverse_transform_add (inverse.rs:1633-1705, 2-D driver
+                     included) run through tools/rustlite (tests/golden/gen_inv_tx_ref.py)
+  inv_tx_golden.npz  round 1: the 1-D networks executed from the text; its 2-D cases use a
+                     hand-stated driver and are kept only as extra (wrapping-i32) inputs
+and against the reference's own round-trip test (src/transform/mod.rs:555-603)."""
 import os
 
 import numpy as np
@@ -11,6 +14,7 @@ import inv_tx_np as I
 import oracle_lib as O
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "inv_tx_golden.npz"))
+GREF = np.load(os.path.join(os.path.dirname(__file__), "golden", "inv_tx_ref.npz"))
 CLS = {"dct": 0, "adst": 1, "flipadst": 2, "identity": 3, "wht": 4}
 
 
@@ -27,6 +31,37 @@ def test_1d_networks_match_reference_source_vectors(oracle):
         for row in yc:
             assert oracle.r1o_inv_txfm_1d(O.ptr(row), CLS[cls], n, rb) == 0
         assert np.array_equal(yc, want), ("C", k)
+
+
+def test_2d_reference_executed_driver(oracle):
+    """REF-SRC pin of the 2-D driver: every (size, type, bit depth) the reference's
+    INV_TXFM_FNS table implements, T::Coeff-typed coefficients, 3-5 blocks each."""
+    keys = [k for k in GREF.files if k.endswith("_co")]
+    assert len(keys) == 480
+    for j, k in enumerate(keys):
+        _, ts, tt, bd, _ = k.split("_")
+        ts, tt, bd = int(ts), int(tt), int(bd)
+        co, pred, rec = GREF[k], GREF[k[:-3] + "_pred"], GREF[k[:-3] + "_rec"]
+        h, w = pred.shape[1:]
+        hbd = int(bd > 8)
+        assert co.dtype == (np.int32 if hbd else np.int16) and pred.dtype == (np.uint16 if hbd else np.uint8)
+        if j % 5 == 0:
+            got = I.inverse_transform_add(co.astype(np.int32), pred.astype(np.int32), ts, tt, bd)
+            assert np.array_equal(got, rec.astype(np.int32)), ("numpy", k)
+        for i in range(co.shape[0]):
+            d = pred[i].copy()
+            ci = np.ascontiguousarray(co[i])
+            assert oracle.r1o_inverse_transform_add(O.ptr(ci), O.ptr(d), w, ts, tt, bd, hbd, hbd) == 0
+            assert np.array_equal(d, rec[i]), ("C", k, i)
+        # the batch entry the GPU parity tests compare against
+        n = co.shape[0]
+        stride = w * h
+        cb = np.zeros((n, stride), co.dtype)
+        cb[:, :co.shape[1]] = co
+        want = np.zeros_like(pred)
+        assert oracle.r1o_inv_txfm_add_batch(O.ptr(cb), stride, O.ptr(np.ascontiguousarray(pred)), O.ptr(want),
+                                             n, ts, tt, bd, cb.itemsize, 1 + hbd) == 0
+        assert np.array_equal(want, rec), ("C batch", k)
 
 
 def test_2d_all_sizes_types_bitdepths(oracle):

@@ -40,6 +40,29 @@ def test_encode_tx_block_tx_domain(oracle):
     assert RC.check_tx_blocks(G, full_cand) == 156
 
 
+def test_encode_tx_block_pixel_domain_and_compute_distortion(oracle):
+    """rav1e's default tune: dequantize -> inverse_transform_add into the reconstruction
+    (src/encoder.rs:1588-1614), then compute_distortion (src/rdo.rs:254-347) -- the oracle's
+    r1o_rdo_pixel_cand_batch against the executed reference text (gen_rdo_pixel_ref.py)."""
+    G = np.load(RC.GOLD_PIXEL)
+
+    def pixel_cand(bd, ts, tt, qidx, src, pred, kind, scales, stride):
+        w, h = RC.TX_W[ts], RC.TX_H[ts]
+        hbd = int(bd > 8)
+        c = np.zeros(1, O.RDO_CAND)
+        c["ox"], c["oy"], c["rx"], c["ry"], c["tx_type"] = 8, 8, 8, 8, tt
+        pa, pb = src.cstruct(), pred.cstruct()
+        eob, dist = np.zeros(1, np.uint16), np.zeros(1, np.uint64)
+        qc = np.zeros(min(w, 32) * min(h, 32), np.int32 if hbd else np.int16)
+        rec = np.zeros((h, w), np.uint16 if hbd else np.uint8)
+        sc = None if scales is None else O.ptr(np.ascontiguousarray(scales))
+        assert oracle.r1o_rdo_pixel_cand_batch(C.byref(pa), C.byref(pb), w, h, ts, O.ptr(c), 1, qidx, 0, 0, 0, kind,
+                                               sc, stride, 0, 0, None, None, O.ptr(eob), O.ptr(dist), O.ptr(qc),
+                                               O.ptr(rec), None) == 0
+        return int(eob[0]), int(dist[0]), qc, rec
+    assert RC.check_pixel_blocks(G, pixel_cand) == 482 * 4
+
+
 def test_compute_tx_distortion(oracle):
     G = np.load(RC.GOLD)
 

@@ -12,6 +12,9 @@ Runs only where the reference tree is present (the build container); the GPU box
   src/cdef.rs      check_max_element                                (:628-660)
   src/quantize/mod.rs  test_divu_pair, test_tx_log_scale, gen_divu_table  (:159-216)
   src/transform/mod.rs log_tx_ratios                                (:521-552)
+  src/transform/mod.rs roundtrips_u8 / roundtrips_u16               (:479-618; forward_transform ->
+                       inverse_transform_add, 44 (size, type) pairs each, the authors' tolerances;
+                       `rand::random::<u8>()` is a seeded generator, get_func as in gen_rdo_glue_ref.py)
 """
 import os
 import sys
@@ -52,6 +55,71 @@ def test_reference_unit_test_passes_under_rustlite(rel, name):
     # body's literals ([0u8; 16] / vec![0u16; ..]), the transpiler is told
     g = {"T": "u16" if name == "pred_max" else "u8"} if rel == "predict.rs" else {}
     c.get(name)(g)           # a failing assert! / assert_eq! raises rustlite.runtime.Panic
+
+
+TRANSFORM_FILES = ["transform/forward.rs", "transform/forward_shared.rs", "transform/inverse.rs", "context/mod.rs",
+                   "context/block_unit.rs", "tiling/plane_region.rs", "util/mod.rs", "util/uninit.rs", "frame/mod.rs"]
+
+
+def transform_crate(seed, tamper=None):
+    """transform/mod.rs with its test module, the 2-D drivers of forward.rs / inverse.rs as written;
+    get_func (a macro body) = the 1-D networks of the same macro as translated from the text by
+    tests/golden/gen_fwd_tx_golden.py; random() = a seeded stand-in for the rand crate."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gen_fwd_tx_golden as FT
+    from rustlite.transpile import Crate
+    c = Crate(REF)
+    for f in TRANSFORM_FILES:
+        c.load(f)
+    c.load("transform/mod.rs", tests=True)
+    ns, _ = FT.load_reference_1d()
+
+    def get_func(_g, t):
+        idx = t.disc if hasattr(t, "disc") else int(t)
+        name, n = FT.TXFM[idx], FT.TXFM_LEN[idx]
+
+        def run(coeffs):
+            buf = FT.Buf(n)
+            for i in range(n):
+                buf[i] = FT.V(np.array([coeffs[i]], np.int32))
+            ns[name](buf)
+            for i in range(n):
+                coeffs[i] = int(buf[i].v[0])
+        return run
+    c.define_py("get_func", get_func)
+    rng = np.random.default_rng(seed)
+    c.define_py("random", lambda _g: int(rng.integers(0, 256)))
+    return c
+
+
+@pytest.mark.parametrize("name", ["roundtrips_u8", "roundtrips_u16"])
+def test_reference_transform_roundtrips(name):
+    """forward_transform (forward.rs:71-161) -> inverse_transform_add (inverse.rs:1633-1705), both
+    2-D drivers executed as written, meet the tolerances the reference's authors assert."""
+    for seed in (1, 2):
+        transform_crate(seed).get(name)({})
+
+
+def test_roundtrip_harness_catches_a_broken_inverse_driver():
+    """not vacuous: the same test against an inverse driver whose column-pass rounding shift is
+    3 instead of 4 (inverse.rs:1699) panics on the authors' tolerance"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from rustlite import runtime as R
+    src = open(os.path.join(REF, "transform/inverse.rs")).read()
+    a = src.index("pub fn inverse_transform_add<T: Pixel>(")
+    b = src.index("/* From AV1 Spec.", a)
+    body = src[a:b]
+    assert "round_shift(*temp, 4)" in body
+    c = transform_crate(3)
+    c.load_text("<inverse.rs:1633-1705 with the final shift changed to 3>",
+                "pub mod mutated { use super::*; " + body.replace("round_shift(*temp, 4)", "round_shift(*temp, 3)") + "}")
+    # the mutated definition shadows the original for callers resolving `inverse_transform_add`
+    infos = c.fns["inverse_transform_add"]
+    infos.insert(0, infos.pop())
+    with pytest.raises(R.Panic):
+        c.get("roundtrips_u8")({})
 
 
 def test_a_wrong_expectation_is_caught():

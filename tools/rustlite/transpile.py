@@ -63,7 +63,11 @@ class StructInfo:
 
 
 class Crate:
-    def __init__(self, root="/root/reference/src", checks=True):
+    def __init__(self, root="/root/reference/src", checks=True, strict=False):
+        # strict: also range-check UNTYPED `let`s against their inferred integer type (a debug
+        # build of the reference checks every arithmetic result; with this on, a case that runs
+        # to the end overflowed nowhere a `let` could see, so debug == release for it)
+        self.strict = strict
         self.root = root
         self.checks = checks
         self.files = {}
@@ -924,7 +928,7 @@ class FnCompiler:
         if self.needs_copy(s.init, nt):
             val = "_cp(%s)" % val
         st = self.strip(nt)
-        if self.c.checks and s.ty is not None and isinstance(st, str) and st in INT and s.init.k != "int":
+        if self.c.checks and (s.ty is not None or self.c.strict) and isinstance(st, str) and st in INT and s.init.k != "int":
             val = "_chk(%s, %r)" % (val, st)
         self.bind(s.pat, val, nt)
 
@@ -1672,6 +1676,13 @@ class FnCompiler:
             if t in ("f32", "f64") and op == "/":
                 return "(%s / %s)" % (l, r)
             return "%s(%s, %s)" % ("_div" if op == "/" else "_rem", l, r)
+        if self.c.strict and self.c.checks and op in ("+", "-", "*"):
+            # strict: every arithmetic result of a statically known integer type is range-checked,
+            # as a debug build of the reference would
+            lt, rt = self.strip(self.ty(e.l)), self.strip(self.ty(e.r))
+            t = lt if lt is not None else rt
+            if isinstance(t, str) and t in INT:
+                return "_chk((%s %s %s), %r)" % (l, op, r, t)
         return "(%s %s %s)" % (l, op, r)
 
     def x_index(self, e):
@@ -2076,6 +2087,8 @@ class FnCompiler:
             if isinstance(src_t, str) and (src_t == tgt or fits(src_t, tgt)):
                 return v
             return "_cast(%s, %r)" % (v, tgt)
+        if name == "abs" and a in INT and len(argn) == 1:     # i16::abs(x), the UFCS form of x.abs()
+            return "_chk(abs(%s), %r)" % (self.args(argn)[0], a)
         if name == "try_from" and (a in INT):
             return "_try_from(%s, %r)" % (self.args(argn)[0], a)
         if name in ("zero", "one", "max_value", "min_value", "default") and (a in INT or a in self.type_params):
