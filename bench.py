@@ -64,6 +64,12 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps for this long BEFORE the W warm-up steps, so that short runs "
                          "(small W and K) are measured at the clocks a long run settles at; 0 = off")
+    ap.add_argument("--verify-exchange", action="store_true",
+                    help="N = 1: run the tagged-tile self-check of the exchange through the C-ABI communicator "
+                         "(world 1) as the N > 1 runs always do; the result is config.exchange_ok")
+    ap.add_argument("--tiles", type=int, default=0,
+                    help="N = 1 only: cut the frame into this many tiles for --verify-exchange (geometry check of "
+                         "the plan; with one rank every tile is local)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the supplementary workloads (chroma planes, mixed filter pairs, mixed "
                          "transform types) reported under `extra_lines`")
@@ -936,6 +942,39 @@ def main():
     for _ in range(args.warmup):
         step(False)
     fence()
+    # ---- N > 1 (and --verify-exchange at N = 1): did the exchange move the right bytes?  Tagged
+    # tiles through one halo exchange and one tile gather, checked on every rank, before anything
+    # is timed (rav1e_amd/tiles.py verify_exchange).  A wrong rectangle would not slow the
+    # candidates down -- they would read garbage at full speed -- so the number alone cannot tell.
+    exchange_ok = None
+    if world > 1 or args.verify_exchange:
+        vrects = rects if rects is not None else W.tile_rects(world, fw, fh)
+        if world > 1 and comm is None:
+            # the torch.distributed fallback moves row slabs of the allocation, no halo leg: a rank's
+            # slab of the painted plane must arrive as it left (checked through the gathered buffer)
+            rows, lo, hi = tiles.owned_rows(ref.data.shape[0], rank, world)
+            send.fill_(rank + 1)
+            tiles.exchange_rows(send, gathered)
+            torch.cuda.synchronize()
+            ok = all(bool((gathered[r * rows:(r + 1) * rows] == r + 1).all().item()) for r in range(world))
+            send.zero_()
+            send[: hi - lo] = ref.data[lo:hi]
+            mine_ok = {"halo": None, "gather": ok}
+        else:
+            vcomm = comm if comm is not None else tiles.Comm(ctx, rank, world)
+            mine_ok = tiles.verify_exchange(ref, vrects, rank, world,
+                                            lambda: vcomm.exchange_tile_halos(ref, vrects),
+                                            lambda: vcomm.allgather_tiles(ref, vrects))
+            if comm is None:
+                vcomm.close()
+        flags = torch.tensor([1.0 if mine_ok[k] in (True, None) else 0.0 for k in ("halo", "gather")],
+                             dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        exchange_ok = {"halo": None if mine_ok["halo"] is None else bool(flags[0].item() == 1.0),
+                       "gather": None if mine_ok["gather"] is None else bool(flags[1].item() == 1.0),
+                       "checked_on": "every rank (MIN over ranks)" if world > 1 else "rank 0 (world 1: no peers)"}
+        fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -1008,7 +1047,7 @@ def main():
                                    % (fw, fh, bd, args.k),
                        "candidates_per_step": int(sum(len(c) for c in cands.values())) if world == 1
                        else None,
-                       "tiles": world, "exchange": exch_note, "launch_streams": args.streams,
+                       "tiles": world, "exchange": exch_note, "exchange_ok": exchange_ok, "launch_streams": args.streams,
                        "compute_ms": split_ms["compute_ms"] if split_ms else None,
                        "exchange_ms": split_ms["exchange_ms"] if split_ms else None,
                        "step_split": split_ms,

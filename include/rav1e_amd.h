@@ -306,9 +306,10 @@ int r1_cdef_filter_block_batch(r1_ctx *ctx, const R1Plane *in, const R1Plane *ou
 /* cdef_filter_tile for plane p of the whole frame (the reference's only call,
  * src/encoder.rs:3301-3321): skip test over the four 4x4 blocks of every 8x8,
  * direction search on luma, adjust_strength, chroma direction map, edge
- * flags, filter or copy.  skip_mi: Block::skip per 4x4 luma unit (TileBlocks);
+ * flags, filter or copy.  skip_mi: Block::skip per 4x4 luma unit (TileBlocks), a bool per byte
+ * (any non-zero value = skipped; the strength search reads it the same way);
  * cdef_index_sb: per 64x64 superblock; params = the FrameInvariants fields
- * cdef_filter_superblock reads. */
+ * cdef_filter_superblock reads.  luma->bit_depth must equal params->bit_depth (R1_EINVAL). */
 typedef struct R1CdefParams {
   uint8_t y_strengths[8], uv_strengths[8];   /* fi.cdef_y_strengths / cdef_uv_strengths */
   uint8_t damping;                           /* fi.cdef_damping */
@@ -328,7 +329,9 @@ int r1_cdef_filter_frame_plane(r1_ctx *ctx, const R1Plane *luma, const R1Plane *
  * nbx = 8*ceil(tile_w/64) by nby = 8*ceil(tile_h/64) blocks (r1_cdef_analyze_blocks() entries;
  * blocks outside mi_cols x mi_rows are not written; skipped blocks are analysed too, their
  * entries are never read), and three filter calls share it.  r1_cdef_filter_frame_plane is
- * analysis + one plane with stream-ordered scratch.  tile_w / tile_h here = the frame's luma size. */
+ * analysis + one plane with stream-ordered scratch.  tile_w / tile_h here = the luma PLANE size as
+ * v_frame pads it (multiples of 8; r1_cdef_filter_frame_plane_dirs has no luma plane to take the
+ * picture limits from and rejects anything else with R1_EINVAL). */
 long long r1_cdef_analyze_blocks(int tile_w, int tile_h);
 int r1_cdef_analyze_frame(r1_ctx *ctx, const R1Plane *luma, int tile_w, int tile_h,
                           int mi_cols, int mi_rows, uint8_t *dir_out, int32_t *var_out,
@@ -498,8 +501,10 @@ int r1_prescreen_select_batch(r1_ctx *ctx, const uint32_t *keys, int n_groups, i
  * the launch-boundary version (superblock columns + rows + 3 launches replayed as
  * one hipGraph, the three passes skewed inside them), kept as the cross-check.
  * launch_mode 0 takes 2 from 8 jobs on, else 3.  A dependency wait of a persistent
- * launch that runs out of patience is reported as R1_EHIP by the next call on the
- * ring slot, not as a hang.  At most 256 jobs per call (tiles x reference frames of
+ * launch that runs out of patience is not a hang: the call is flagged (r1_me_status,
+ * below), and once a flagged launch has finished every following call of this
+ * function returns R1_ETIMEDOUT -- nothing enqueued -- until r1_me_status has
+ * reported the flag.  At most 256 jobs per call (tiles x reference frames of
  * one frame).  The context keeps one scratch MEStats frame per distinct
  * `stats` array of a call (the refinements of a pass are computed one diagonal
  * ahead of its searches and must stay invisible to them until then). */
@@ -534,8 +539,9 @@ int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, int n_jobs,
  * has returned R1_OK after it: wait != 0 first waits for every launch enqueued so far (wait == 0
  * only looks at launches that have finished).  R1_ETIMEDOUT: *first_failed_call (optional) is the
  * 1-based index, per context, of the first flagged r1_estimate_tile_motion_batch call -- re-issue
- * it with launch_mode = 1 (launch boundaries instead of waits); following calls are unaffected.
- * Flags are consumed by the report.  *calls (optional): calls made on this context so far. */
+ * it with launch_mode = 1 (launch boundaries instead of waits).  Flags are consumed by the report;
+ * while one is pending, r1_estimate_tile_motion_batch refuses with R1_ETIMEDOUT (a caller that never
+ * polls cannot go on consuming non-reference statistics silently).  *calls (optional): calls made on this context so far. */
 int r1_me_status(r1_ctx *ctx, int wait, unsigned long long *first_failed_call,
                  unsigned long long *calls);
 

@@ -177,8 +177,9 @@ void r1o_cdef_filter_tile_plane(const r1o_plane *luma, const r1o_plane *in, cons
           if (bx + 1 >= (xavail >> 3)) edges &= ~HAVE_RIGHT;
           const int mx = fbx * 16 + 2 * bx, my = fby * 16 + 2 * by;
           if (mx < mi_cols && my < mi_rows) {
-            const int skip = skip_mi[my * mi_stride + mx] & skip_mi[my * mi_stride + mx + 1] &
-                             skip_mi[(my + 1) * mi_stride + mx] &
+            /* Block::skip is a bool: any non-zero byte is true */
+            const int skip = skip_mi[my * mi_stride + mx] && skip_mi[my * mi_stride + mx + 1] &&
+                             skip_mi[(my + 1) * mi_stride + mx] &&
                              skip_mi[(my + 1) * mi_stride + mx + 1];
             const int xs = 8 >> xdec, ysz = 8 >> ydec;
             const int px = (in_xoff >> xdec) + bx * xs, py = (in_yoff >> ydec) + by * ysz;
@@ -266,7 +267,7 @@ int r1o_cdef_strength_search(const r1o_plane *rec, const r1o_plane *src, const u
       int all_skip = 1;
       for (int y = 16 * sby; y < 16 * sby + 16 && y < blk_rows; y++)
         for (int x = 16 * sbx; x < 16 * sbx + 16 && x < blk_cols; x++)
-          all_skip &= skip_mi[(size_t)(ay0 * 16 + y) * mi_stride + ax0 * 16 + x] & 1;
+          all_skip &= skip_mi[(size_t)(ay0 * 16 + y) * mi_stride + ax0 * 16 + x] != 0;
       if (all_skip) { *bo = -1; continue; }
       /* cdef_filter_superblock's edge logic on the area frame (cdef.rs:424-459) */
       const int in_xoff = sbx * 64, in_yoff = sby * 64;
@@ -290,7 +291,7 @@ int r1o_cdef_strength_search(const r1o_plane *rec, const r1o_plane *src, const u
             const int mx = sbx * 16 + 2 * bx, my = sby * 16 + 2 * by;   /* area block units */
             if (mx < blk_cols && my < blk_rows) {
               const uint8_t *sk = skip_mi + (size_t)(ay0 * 16 + my) * mi_stride + ax0 * 16 + mx;
-              const int skip = sk[0] & sk[1] & sk[mi_stride] & sk[mi_stride + 1] & 1;
+              const int skip = sk[0] && sk[1] && sk[mi_stride] && sk[mi_stride + 1];
               /* frame position of the block in luma pixels */
               const int flx = ax0 * 64 + in_xoff + 8 * bx, fly = ay0 * 64 + in_yoff + 8 * by;
               uint32_t var = 0;

@@ -638,6 +638,25 @@ class Context:
         self._check(self.lib.r1_estimate_tile_motion_batch(self.h, arr, n, C.byref(p), _stream_ptr()),
                     "r1_estimate_tile_motion_batch")
 
+    def estimate_frame_motion(self, jobs, w_in_b, h_in_b, bit_depth, lambdas, **kw):
+        """The frame-level caller of estimate_tile_motion: enqueue, wait, and acknowledge.  If the
+        persistent launch flagged a timed-out dependency wait (r1_me_status -> R1_ETIMEDOUT) the
+        statistics are recomputed with launch_mode 1 (launch boundaries, no waits) -- the
+        automatic fallback include/rav1e_amd.h describes.  `prev` of the jobs is untouched by a
+        search, and a search overwrites every entry of its tile, so the re-issue is idempotent.
+        -> the launch mode that produced the statistics."""
+        mode = int(kw.pop("launch_mode", 0))
+        self.estimate_tile_motion(jobs, w_in_b, h_in_b, bit_depth, lambdas, launch_mode=mode, **kw)
+        ok, _, _ = self.me_status(wait=True)
+        if ok:
+            return mode
+        if mode == 1:
+            raise R1Error("r1_me_status flagged a launch_mode 1 call: " + self.lib.r1_last_error().decode())
+        self.estimate_tile_motion(jobs, w_in_b, h_in_b, bit_depth, lambdas, launch_mode=1, **kw)
+        ok, _, _ = self.me_status(wait=True)
+        assert ok
+        return 1
+
     def me_status(self, wait=True):
         """r1_me_status: (ok, first_failed_call, calls) -- the statistics of the persistent tile-ME
         launches are valid once this has reported ok after them (include/rav1e_amd.h)."""

@@ -154,8 +154,7 @@ __global__ __launch_bounds__(256) void k_cdef_frame(CdefFrameArgs a) {
       ci = a.cdef_index_sb[(gby >> 3) * a.sb_stride + (gbx >> 3)];
       dir = a.dirs[(size_t)gby * a.nbx + gbx];
       var = a.vars[(size_t)gby * a.nbx + gbx];
-      const uint32_t s01 = s0 & s1;
-      skip = (int)(s01 & (s01 >> 8) & 0xff);
+      skip = r1cdef::skip4(s0, s1);
     }
     // strengths of the superblock's cdef_index out of the argument registers (no dependent load)
     uint32_t st8[2];
@@ -438,6 +437,11 @@ int cdef_frame_plane(r1_ctx *ctx, const R1Plane *luma, const uint8_t *dirs, cons
   R1_REQUIRE(p != 0 || (xdec == 0 && ydec == 0));
   R1_REQUIRE(tile_w > 0 && tile_h > 0 && mi_stride >= mi_cols);
   R1_REQUIRE(params->bit_depth == 8 || params->bit_depth == 10 || params->bit_depth == 12);
+  // the analysis takes its coefficient shift from the luma plane, the filter from params: one value
+  R1_REQUIRE(!luma || luma->bit_depth == params->bit_depth);
+  // without a luma plane the picture limits come from tile_w / tile_h: the plane size as v_frame
+  // pads it (a multiple of 8), not fi.width -- the last 8x8 block column would fall outside
+  R1_REQUIRE(luma || (tile_w % 8 == 0 && tile_h % 8 == 0));
   R1DeviceGuard guard(ctx);
   hipStream_t st = (hipStream_t)stream;
   CdefFrameArgs a;

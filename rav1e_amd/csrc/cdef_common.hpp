@@ -9,6 +9,14 @@
 namespace r1cdef {
 
 constexpr int VERY_LARGE = 0x8000;
+
+// Block::skip of the four 4x4 units of an 8x8 block (src/cdef.rs:443-449: `skip = a.skip && b.skip
+// && ...` on Rust bools).  s0 / s1: the two skip bytes of the upper / lower row as one u16 each.
+// A byte is a bool: any non-zero value is true -- the filter kernel and the strength search must
+// agree on that, whatever the host stores.
+__device__ __forceinline__ int skip4(uint32_t s0, uint32_t s1) {
+  return ((s0 & 0xffu) != 0) & ((s0 & 0xff00u) != 0) & ((s1 & 0xffu) != 0) & ((s1 & 0xff00u) != 0);
+}
 enum { HAVE_LEFT = 1, HAVE_RIGHT = 2, HAVE_TOP = 4, HAVE_BOTTOM = 8 };
 
 template <int BPP>

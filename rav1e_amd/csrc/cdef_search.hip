@@ -67,7 +67,7 @@ __device__ __forceinline__ bool sb_all_skip(const SearchArgs &a, const AreaGeo &
     const uint8_t *sk = a.skip_mi + (size_t)(g.ay0 * 16 + y) * a.mi_stride + g.ax0 * 16 + x0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      if (x0 + k < g.blk_cols) all &= sk[k] & 1;
+      if (x0 + k < g.blk_cols) all &= sk[k] != 0;
   }
   return __all(all);
 }
@@ -148,8 +148,7 @@ __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
       dir = a.dirs[(size_t)gby * a.nbx + gbx];
       var = a.vars[(size_t)gby * a.nbx + gbx];
       if (a.scales) bias = a.scales[(size_t)gby * a.scale_stride + gbx];
-      const uint32_t s01 = s0 & s1;
-      skip = (int)(s01 & (s01 >> 8) & 1);
+      skip = r1cdef::skip4(s0, s1);
     }
     const int own = LUMA ? dir : (XD != YD ? (int)((0x66654207u >> (4 * dir)) & 0xf) : dir);
     uint32_t *r = rec + tid * SR_REC;

@@ -52,6 +52,10 @@ int find_loaded_rccl(struct dl_phdr_info *info, size_t, void *out) {
   return 0;
 }
 
+// why no library could be bound: the loader's message for the LAST candidate that failed, kept from
+// the one attempt (dlerror() is per thread and is cleared by the read: a later call would see nothing)
+std::string g_rccl_why;
+
 RcclApi *rccl_api() {
   static std::mutex mu;
   static RcclApi api;
@@ -71,7 +75,11 @@ RcclApi *rccl_api() {
   }
   for (const std::string &c : cands) {
     void *h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!h) continue;
+    if (!h) {
+      const char *why = dlerror();
+      g_rccl_why = c + ": " + (why ? why : "dlopen failed");
+      continue;
+    }
     RcclApi a;
     a.handle = h;
 #define R1_SYM(field, name) *(void **)(&a.field) = dlsym(h, name)
@@ -94,6 +102,7 @@ RcclApi *rccl_api() {
       api = a;
       return &api;
     }
+    g_rccl_why = c + ": an ncclXxx symbol is missing";
     dlclose(h);
   }
   return nullptr;
@@ -127,9 +136,8 @@ struct r1_comm {
 #define R1_NEED_RCCL(api)                                                          \
   RcclApi *api = rccl_api();                                                       \
   if (!api) {                                                                      \
-    const char *why_ = dlerror();                                                  \
     r1_set_error("no RCCL library could be loaded (R1_RCCL_LIBRARY, a loaded librccl.so, librccl.so.1, " \
-                 "/opt/rocm/lib/librccl.so.1): %s", why_ ? why_ : "symbols missing");                      \
+                 "/opt/rocm/lib/librccl.so.1): %s", g_rccl_why.c_str());                                   \
     return R1_ECOMM;                                                               \
   }
 
@@ -227,6 +235,15 @@ int comm_staging_done(r1_comm *c, hipStream_t st) {
   c->pack_used = true;
   return R1_OK;
 }
+// From the first copy into the staging buffer to the end of the call: whatever way the call is
+// left (an R1_HIP_CHECK return included), pack_done is recorded on the stream, so that a later call
+// on another stream waits for the staging traffic already enqueued.
+struct StagingScope {
+  r1_comm *c;
+  hipStream_t st;
+  StagingScope(r1_comm *c_, hipStream_t st_) : c(c_), st(st_) {}
+  ~StagingScope() { (void)comm_staging_done(c, st); }
+};
 // a rectangle in visible-area coordinates must lie inside the plane's visible area and the rows it
 // touches inside the allocation
 bool rect_in_plane(const R1Plane *p, int x0, int y0, int x1, int y1) {
@@ -270,6 +287,7 @@ extern "C" int r1_comm_exchange_halos(r1_comm *c, const R1Plane *plane, const R1
   }
   CommDeviceGuard guard(c);
   { const int rc = comm_staging(c, off[n], st); if (rc != R1_OK) return rc; }
+  StagingScope staged(c, st);
   uint8_t *base = (uint8_t *)plane->data;
   const size_t pitch = (size_t)plane->stride * bpp;
   auto rect_ptr = [&](const R1HaloXfer &x) {
@@ -295,7 +313,6 @@ extern "C" int r1_comm_exchange_halos(r1_comm *c, const R1Plane *plane, const R1
   const ncclResult_t end = c->api->GroupEnd();
   if (first != ncclSuccess || end != ncclSuccess) {
     r1_set_error("r1_comm_exchange_halos: %s", c->api->GetErrorString(first != ncclSuccess ? first : end));
-    (void)comm_staging_done(c, st);
     return R1_ECOMM;
   }
   for (int i = 0; i < n; i++) {
@@ -305,13 +322,19 @@ extern "C" int r1_comm_exchange_halos(r1_comm *c, const R1Plane *plane, const R1
     R1_HIP_CHECK(hipMemcpy2DAsync(rect_ptr(x), pitch, c->pack + off[i], rb, rb, x.y1 - x.y0,
                                   hipMemcpyDeviceToDevice, st));
   }
-  return comm_staging_done(c, st);
+  return R1_OK;
 }
 
 // The reference-frame all-gather on TILES: rank r owns rects[r] (x0, y0, x1, y1 in plane pixels)
 // of `plane`; afterwards every rank's plane holds every tile.  Tiles are rectangles, so each
-// rank packs its own into a contiguous slot (2-D copy), one ncclAllGather moves the slots
-// (all the size of the largest tile), and the other ranks' tiles are unpacked into place.
+// rank packs its own into a contiguous slot (2-D copy) and the other ranks' tiles are unpacked
+// into place.  What moves the slots:
+//   p2p  (default)  one group of ncclSend (my tile to every peer) + ncclRecv (every peer's tile):
+//        xGMI is point to point -- every GPU has its own link to each of the 7 others -- so the
+//        N - 1 transfers of a rank run on N - 1 links at once, each carrying one tile's exact bytes;
+//   ring ($R1_COMM_GATHER=ring)  one ncclAllGather of equal slots (the size of the largest tile):
+//        RCCL's ring puts the N - 1 hops behind each other on one link per direction.
+// Both orders of operations are the same on every rank (a collective).
 extern "C" int r1_comm_allgather_tiles(r1_comm *c, const R1Plane *plane, const int32_t *rects4, void *stream) {
   R1_REQUIRE(c && plane && plane->data && rects4);
   hipStream_t st = (hipStream_t)stream;
@@ -325,23 +348,45 @@ extern "C" int r1_comm_allgather_tiles(r1_comm *c, const R1Plane *plane, const i
     if (b > slot) slot = b;
   }
   slot = (slot + 255) & ~(size_t)255;
+  static const bool ring = [] {
+    const char *e = getenv("R1_COMM_GATHER");
+    return e && !strcmp(e, "ring");
+  }();
   CommDeviceGuard guard(c);
   { const int rc = comm_staging(c, slot * (c->world + 1), st); if (rc != R1_OK) return rc; }
+  StagingScope staged(c, st);
   uint8_t *base = (uint8_t *)plane->data;
   const size_t pitch = (size_t)plane->stride * bpp;
   auto rect_ptr = [&](const int32_t *q) {
     return base + ((size_t)(plane->yorigin + q[1]) * plane->stride + (size_t)(plane->xorigin + q[0])) * bpp;
   };
+  auto rect_bytes = [&](const int32_t *q) { return (size_t)(q[2] - q[0]) * (q[3] - q[1]) * bpp; };
   const int32_t *mine = rects4 + 4 * c->rank;
   uint8_t *send = c->pack, *recv = c->pack + slot;
   const size_t mrb = (size_t)(mine[2] - mine[0]) * bpp;
   R1_HIP_CHECK(hipMemcpy2DAsync(send, mrb, rect_ptr(mine), pitch, mrb, mine[3] - mine[1],
                                 hipMemcpyDeviceToDevice, st));
-  const ncclResult_t r = c->api->AllGather(send, recv, slot, ncclUint8, c->nccl, st);
-  if (r != ncclSuccess) {
-    r1_set_error("r1_comm_allgather_tiles: %s", c->api->GetErrorString(r));
-    (void)comm_staging_done(c, st);
-    return R1_ECOMM;
+  if (ring) {
+    const ncclResult_t r = c->api->AllGather(send, recv, slot, ncclUint8, c->nccl, st);
+    if (r != ncclSuccess) {
+      r1_set_error("r1_comm_allgather_tiles: %s", c->api->GetErrorString(r));
+      return R1_ECOMM;
+    }
+  } else if (c->world > 1) {
+    // the group is always closed (see r1_comm_exchange_halos)
+    R1_NCCL_CHECK(c->api, c->api->GroupStart());
+    ncclResult_t first = ncclSuccess;
+    for (int rk = 0; rk < c->world && first == ncclSuccess; rk++) {
+      if (rk == c->rank) continue;
+      first = c->api->Send(send, rect_bytes(mine), ncclUint8, rk, c->nccl, st);
+      if (first == ncclSuccess)
+        first = c->api->Recv(recv + slot * rk, rect_bytes(rects4 + 4 * rk), ncclUint8, rk, c->nccl, st);
+    }
+    const ncclResult_t end = c->api->GroupEnd();
+    if (first != ncclSuccess || end != ncclSuccess) {
+      r1_set_error("r1_comm_allgather_tiles: %s", c->api->GetErrorString(first != ncclSuccess ? first : end));
+      return R1_ECOMM;
+    }
   }
   for (int rk = 0; rk < c->world; rk++) {
     if (rk == c->rank) continue;
@@ -350,5 +395,5 @@ extern "C" int r1_comm_allgather_tiles(r1_comm *c, const R1Plane *plane, const i
     R1_HIP_CHECK(hipMemcpy2DAsync(rect_ptr(q), pitch, recv + slot * rk, rb, rb, q[3] - q[1],
                                   hipMemcpyDeviceToDevice, st));
   }
-  return comm_staging_done(c, st);
+  return R1_OK;
 }

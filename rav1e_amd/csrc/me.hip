@@ -1683,14 +1683,30 @@ extern "C" int r1_estimate_tile_motion_batch(r1_ctx *ctx, const R1MeJob *jobs, i
   // per-tile rayon workers share a context) take turns for the enqueue.
   std::lock_guard<std::mutex> ring_lock(ctx->me_mu);
   R1DeviceGuard dev_guard(ctx);
-  ctx->me_calls++;
   const size_t jobs_bytes = ((size_t)n_jobs * sizeof(R1MeJob) + 15) & ~(size_t)15;
   const size_t params_bytes = (sizeof(R1MeParams) + 15) & ~(size_t)15;
   const size_t bytes = jobs_bytes + params_bytes + (size_t)n_jobs * sizeof(R1MeStats *);
   const int slot = ctx->me_next;
-  ctx->me_next = (slot + 1) % r1_ctx::kMeSlots;
   if (ctx->me_done[slot]) R1_HIP_CHECK(hipEventSynchronize(ctx->me_done[slot]));
   else R1_HIP_CHECK(hipEventCreateWithFlags(&ctx->me_done[slot], hipEventDisableTiming));
+  // Fail-safe for callers that never poll r1_me_status: a persistent launch that has FINISHED with a
+  // timed-out dependency wait (stale predictors, non-reference statistics) makes every following call
+  // refuse with R1_ETIMEDOUT until r1_me_status has reported -- and thereby consumed -- the flag.
+  // Nothing is enqueued and the ring does not advance.
+  for (int s = 0; s < r1_ctx::kMeSlots; s++) {
+    MePersistCache *pc = (MePersistCache *)ctx->me_persist[s];
+    if (!pc || !pc->launched || !ctx->me_done[s]) continue;
+    if (s != slot && hipEventQuery(ctx->me_done[s]) != hipSuccess) continue;
+    me_collect_slot(ctx, *pc);
+  }
+  if (ctx->me_failed) {
+    r1_set_error("r1_estimate_tile_motion_batch: %d earlier call(s) (first: call %llu) ran with a timed-out "
+                 "dependency wait and have not been acknowledged; call r1_me_status and re-issue them with "
+                 "launch_mode 1", ctx->me_failed, ctx->me_first_failed);
+    return R1_ETIMEDOUT;
+  }
+  ctx->me_calls++;
+  ctx->me_next = (slot + 1) % r1_ctx::kMeSlots;
   if (ctx->me_jobs_bytes[slot] < bytes) {
     if (ctx->me_graph[slot]) (void)hipGraphExecDestroy(ctx->me_graph[slot]);   // it holds the old pointers
     ctx->me_graph[slot] = nullptr;

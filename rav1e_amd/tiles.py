@@ -105,6 +105,60 @@ class Comm:
         return len(x)
 
 
+def verify_exchange(plane, rects, rank, world, do_halos, do_gather, halo=None):
+    """Self-check of the exchange before a multi-GPU run is timed: did the bytes land where the
+    tile grid says?  Every rank paints its own tile of `plane` with its tag (rank + 1; the rest of
+    the visible area with 0 = nobody), runs the halo exchange and checks that the `halo`-pixel
+    ring of its tile holds the OWNER's tag wherever a neighbour's tile covers it; then runs the
+    tile gather and checks every tile of the frame.  The plane's contents are restored.
+    do_halos / do_gather: callables that run the exchange on the current stream (None: that
+    leg is not part of the path in use, e.g. the torch.distributed fallback has no halo leg).
+    -> dict(halo=bool | None, gather=bool | None) for THIS rank; the caller reduces over ranks."""
+    halo = POSTFILTER_HALO if halo is None else halo
+    saved = plane.data.clone()
+    fw, fh = plane.width, plane.height
+
+    def sync():
+        if plane.data.is_cuda:
+            torch.cuda.synchronize()
+    vis = plane.data[plane.yorigin:plane.yorigin + fh, plane.xorigin:plane.xorigin + fw]
+
+    def paint():
+        vis.zero_()
+        x0, y0, x1, y1 = rects[rank]
+        vis[y0:y1, x0:x1] = rank + 1
+    res = {"halo": None, "gather": None}
+    try:
+        if do_halos is not None:
+            paint()
+            do_halos()
+            sync()
+            _, recvs = tile_halo_plan(rects, rank, halo, fw, fh)
+            ok = True
+            for peer, (x0, y0, x1, y1) in recvs:
+                ok = ok and bool((vis[y0:y1, x0:x1] == peer + 1).all().item())
+            # and nothing beyond the ring was touched: my tile keeps my tag, the rest stays 0
+            x0, y0, x1, y1 = rects[rank]
+            ok = ok and bool((vis[y0:y1, x0:x1] == rank + 1).all().item())
+            ex = expanded_rect(rects[rank], halo, fw, fh)
+            outside = vis.clone()
+            outside[ex[1]:ex[3], ex[0]:ex[2]] = 0
+            ok = ok and not bool(outside.any().item())
+            res["halo"] = ok
+        if do_gather is not None:
+            paint()
+            do_gather()
+            sync()
+            ok = True
+            for r, (x0, y0, x1, y1) in enumerate(rects):
+                ok = ok and bool((vis[y0:y1, x0:x1] == r + 1).all().item())
+            res["gather"] = ok
+    finally:
+        plane.data.copy_(saved)
+        sync()
+    return res
+
+
 def owned_rows(alloc_height, rank, world):
     """Contiguous slab of plane rows rank `rank` contributes: ceil split of the
     padded allocation (every rank sends the same count; the tail is zero-padded)."""

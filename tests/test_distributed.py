@@ -241,6 +241,58 @@ def test_tile_halo_exchange_and_postfilter_gloo():
         assert ns == 3 and nr == 3 and sent < 320 * 256 // 2, (rank, ns, nr, sent)
 
 
+def _verify_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from rav1e_amd import tiles, workload as W
+    fw, fh = 1920, 1080
+    rects = W.tile_rects(world, fw, fh)
+    data = torch.from_numpy(W.random_plane_array(fw, fh, 8, seed=3)).clone()
+    before = data.clone()
+    plane = SimpleNamespace(data=data, width=fw, height=fh, xorigin=88, yorigin=88)
+    vis = data[88:88 + fh, 88:88 + fw]
+
+    def gather(swap=False):
+        for r in range(world):
+            x0, y0, x1, y1 = rects[r]
+            t = vis[y0:y1, x0:x1].contiguous()
+            dist.broadcast(t, src=r)
+            if swap and r != rank and world > 1:
+                t = t + 1            # a tile that arrives with the wrong owner's bytes
+            vis[y0:y1, x0:x1] = t
+    good = tiles.verify_exchange(plane, rects, rank, world,
+                                 lambda: tiles.exchange_tile_halos(vis, rects, rank), gather)
+    restored = torch.equal(data, before)
+    # a halo leg that does nothing and a gather that delivers the wrong bytes are both caught
+    bad = tiles.verify_exchange(plane, rects, rank, world, lambda: None, lambda: gather(swap=True))
+    q.put((rank, good, bad, restored and torch.equal(data, before)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_verify_exchange_self_check_gloo(world):
+    """bench.py's pre-run self-check (tiles.verify_exchange): tagged tiles through the halo exchange
+    and the tile gather; passes on the real exchange, fails on a no-op halo leg and on a gather that
+    lands foreign bytes; the plane is restored either way."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, good, bad, restored in res:
+        assert good == {"halo": True, "gather": True}, (rank, good)
+        assert bad == {"halo": False, "gather": False}, (rank, bad)
+        assert restored, rank
+
+
 def test_tile_halo_plan_is_symmetric():
     """what a rank sends to a peer is exactly what that peer expects to receive from it (4K, 8 tiles)"""
     from rav1e_amd import tiles, workload as W
@@ -286,6 +338,10 @@ def _worker_rccl(rank, world, port, q):
         torch.cuda.synchronize()
         got = dp.data.cpu().numpy()
         ok_all = np.array_equal(got[88:88 + fh, 88:88 + fw], truth[88:88 + fh, 88:88 + fw])
+        # bench.py's pre-run self-check on the same communicator, and the plane back as it was
+        v = tiles.verify_exchange(dp, rects, rank, world, lambda: comm.exchange_tile_halos(dp, rects),
+                                  lambda: comm.allgather_tiles(dp, rects))
+        ok_all = ok_all and v == {"halo": True, "gather": True} and np.array_equal(dp.data.cpu().numpy(), got)
         comm.close()
         ctx.close()
         dist.barrier()

@@ -74,6 +74,7 @@ def main():
     jobs = [dict(org=org, ref=refs[r], stats=stats[r], tile=(x0, y0, x1 - x0, y1 - y0))
             for r in range(len(refs)) for (x0, y0, x1, y1) in rects]
     timed("estimate_tile_motion_8tiles_x_3refs", lambda: ctx.estimate_tile_motion(jobs, cols, rows, bd, lam))
+    assert ctx.me_status(wait=True)[0], "a persistent tile-ME launch flagged a timed-out wait"
     # 2b block importances: update_block_importances over the three references -- SATD map at
     # the ME's vectors (every second MEStats entry), then the f32 propagation
     hb, wb = fh // 8, fw // 8
