@@ -929,22 +929,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    prewarm_steps = 0
-    if args.prewarm_ms > 0:
-        tw = time.perf_counter()
-        while (time.perf_counter() - tw) * 1e3 < args.prewarm_ms:
-            for _ in range(8):
-                step(False, exchange=False)    # ranks leave this loop at different counts: no collectives in it
-            torch.cuda.synchronize()
-            prewarm_steps += 8
-        if world > 1:                      # every rank leaves the pre-warm before anyone warms up
-            fence()
-    for _ in range(args.warmup):
-        step(False)
-    fence()
     # ---- N > 1 (and --verify-exchange at N = 1): did the exchange move the right bytes?  Tagged
-    # tiles through one halo exchange and one tile gather, checked on every rank, before anything
-    # is timed (rav1e_amd/tiles.py verify_exchange).  A wrong rectangle would not slow the
+    # tiles through one halo exchange and one tile gather, checked on every rank, BEFORE the pre-warm and the warm-up (the check's copies and host round trips let
+    # the clocks drop; measured: -12 % on the following 20 steps when it sat after the warm-up) (rav1e_amd/tiles.py verify_exchange).  A wrong rectangle would not slow the
     # candidates down -- they would read garbage at full speed -- so the number alone cannot tell.
     exchange_ok = None
     if world > 1 or args.verify_exchange:
@@ -975,6 +962,19 @@ def main():
                        "gather": None if mine_ok["gather"] is None else bool(flags[1].item() == 1.0),
                        "checked_on": "every rank (MIN over ranks)" if world > 1 else "rank 0 (world 1: no peers)"}
         fence()
+    prewarm_steps = 0
+    if args.prewarm_ms > 0:
+        tw = time.perf_counter()
+        while (time.perf_counter() - tw) * 1e3 < args.prewarm_ms:
+            for _ in range(8):
+                step(False, exchange=False)    # ranks leave this loop at different counts: no collectives in it
+            torch.cuda.synchronize()
+            prewarm_steps += 8
+        if world > 1:                      # every rank leaves the pre-warm before anyone warms up
+            fence()
+    for _ in range(args.warmup):
+        step(False)
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)

@@ -261,6 +261,9 @@ __device__ __forceinline__ void stage_window_fast(uint8_t *win, int ws, const R1
 // kernel can issue EVERYTHING it needs from memory (source block, window, tap tables) before it
 // waits for any of it -- written as one call, the source's LDS write sits between the source's
 // loads and the window's, and the wave pays two dependent round trips instead of one.
+#ifndef R1_WIN_WIDE_STORE
+#define R1_WIN_WIDE_STORE 1   // A/B switch (tools/build_variant.sh)
+#endif
 template <int BPP, uint32_t XORM, int P, int H, int NL>
 struct WindowStage {
   static constexpr int ROW_BYTES = (P + 7) * BPP;
@@ -327,12 +330,22 @@ struct WindowStage {
       uint8_t *w0 = win + r0 * ws + ch * 8;
       const uint32_t sh = 8u * (uint32_t)back;
       const bool second = ch * 8 + 4 < WSR;
+      // every chunk's second dword lies inside the row (P = 8 at either pixel width, P = 4 at 16 bits):
+      // one ds_write_b64 per pass instead of two ds_write_b32 -- half the LDS write instructions of the
+      // staging, and a 16-lane group of a b64 store covers two candidates' chunks instead of four
+      // (the b32 pairs of neighbouring candidates met on the same banks: SQ_LDS_BANK_CONFLICT was
+      // 18 % / 30 % of the LDS cycles of the 8-bit / 10-bit 8x8 launch, all of it here)
+      constexpr bool WIDE = R1_WIN_WIDE_STORE && (CH - 1) * 8 + 4 < WSR;
 #pragma unroll
       for (int u = 0; u < PASSES; u++)
         if (lane_on && r0 + u * RP < NR) {
           const uint64_t q = ((((uint64_t)v[2 * u + 1]) << 32) | v[2 * u]) >> sh;
-          *(uint32_t *)(w0 + u * RP * ws) = (uint32_t)q ^ XORM;
-          if (second) *(uint32_t *)(w0 + u * RP * ws + 4) = (uint32_t)(q >> 32) ^ XORM;
+          if constexpr (WIDE) {
+            *(uint2 *)(w0 + u * RP * ws) = make_uint2((uint32_t)q ^ XORM, (uint32_t)(q >> 32) ^ XORM);
+          } else {
+            *(uint32_t *)(w0 + u * RP * ws) = (uint32_t)q ^ XORM;
+            if (second) *(uint32_t *)(w0 + u * RP * ws + 4) = (uint32_t)(q >> 32) ^ XORM;
+          }
         }
     } else if constexpr (MODE == 4) {
       uint8_t *w0 = win + r0 * ws + ch * 4;

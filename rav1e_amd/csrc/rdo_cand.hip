@@ -81,6 +81,14 @@ __device__ unsigned long long g_phase[4096][8];
 #endif
 
 // which instantiations run their dead candidate slots unmasked (see k_rdo_cand)
+#ifndef R1_TX_TILE_I16
+#define R1_TX_TILE_I16 1
+#endif
+// which instantiations keep the source chunks in registers across the filter and stage them over the
+// dead window afterwards (see k_rdo_cand)
+#ifndef R1_SRC_LATE_POLICY
+#define R1_SRC_LATE_POLICY(BD, P) ((BD) != 8 && (P) == 32)
+#endif
 #ifndef R1_UNMASK_POLICY
 #define R1_UNMASK_POLICY(BD, WL, HL) (!((BD) == 8 && (WL) == 6 && (HL) == 6))
 #endif
@@ -156,14 +164,25 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   constexpr int TS = (W < H ? W : H) == 4 ? 4 : 8;
   constexpr int WS = (((W + 7) * BPP + 3) >> 2) << 2;   // window row stride
   constexpr int WIN_BYTES = NC * (H + 7) * WS;
-  constexpr int LSTRIDE = NC * W + 1;
+  // The transpose tile holds the column pass's outputs after shift[1]: bounded by 16353 at 8-bit
+  // (every size and type) and by 23214 at 10-bit with sides up to 32 (tools/tx_range.py: pixel range,
+  // shift[0], the L1 gain of the column network, shift[1]), so int16 holds them exactly.  Used for
+  // 10-bit 32x32 only, together with SRC_LATE below: tile 8320 -> 4224 B, window + source 10336 ->
+  // 6240 B, 4 -> 5 waves per SIMD, launch 0.252 -> 0.237 ms (profiles/r04_ab_notes.md).  At 8-bit
+  // 32x32 the same change (5 -> 6 waves) made the launch 1.5 % SLOWER -- that kernel is not short of
+  // waves -- and is off.  Row stride 66 int16 = 33 dwords: a candidate's row lanes read 32 banks.
+  constexpr bool TB16 = R1_TX_TILE_I16 && BD == 10 && WL == 5 && HL == 5;
+  typedef typename std::conditional<TB16, int16_t, T>::type TB;
+  constexpr int LSTRIDE = NC * W + (TB16 ? 2 : 1);
+  constexpr int ISTRIDE = NC * W + 1;       // the inverse transform's row buffer (QM == 2): int32
   // 64x64: the transpose goes through LDS in two halves of 32 rows (8.3 KB instead of
   // 16.6 KB per wave).  At 16.6 KB the CU held 9 waves where the registers allow 12, and
   // this kernel lives on occupancy: a wave issues one instruction per ~10 cycles whatever
   // the size, so the SIMD's throughput is proportional to the waves it holds.
   constexpr bool SPLIT_T = W == 64 && H == 64;
   constexpr int TXB_ROWS = SPLIT_T ? 32 : H;
-  constexpr int TXB_BYTES = TXB_ROWS * LSTRIDE * 4;
+  constexpr int TXB_BYTES = TXB_ROWS * LSTRIDE * (int)sizeof(TB);
+  constexpr int IRB_BYTES = QM == 2 ? (H < 32 ? H : 32) * ISTRIDE * 4 : 0;
   constexpr int QT_BYTES = QM != 0 ? NC * (W < 32 ? W : 32) * (H < 32 ? H : 32) * 4 : 0;
   constexpr int REC_BYTES = QM == 2 ? NC * W * H * BPP : 0;
   // The source block is staged in LDS next to the window (16-byte row chunks: H*W*BPP/1024
@@ -171,14 +190,23 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   // column AFTER the motion compensation: the H source registers are not live across the
   // filter any more.  Not for 64-wide 16-bit blocks: + 8 KB of LDS would cost a wave per SIMD.
   constexpr bool SRC_LDS = R1_SRC_LDS_POLICY(BPP, P);
+  // SRC_LATE: the source chunks wait in registers (SPASS x 4 VGPRs) while the window is filtered and
+  // go to LDS afterwards, OVER the dead window -- window + source side by side (10336 B at 10-bit
+  // 32x32) held the CU at 15 waves (4 per SIMD after rounding); with the source over the window the
+  // footprint is the window's 6240 B and the ~93 VGPRs allow 5.
+  constexpr bool SRC_LATE = SRC_LDS && R1_SRC_LATE_POLICY(BD, P);
   constexpr int SRC_ROW = W * BPP;
   constexpr int WIN_PAD = (WIN_BYTES + 15) & ~15;
   constexpr int SRC_BYTES = SRC_LDS ? NC * H * SRC_ROW : 0;
-  constexpr int LDS_A = WIN_PAD + SRC_BYTES > TXB_BYTES ? WIN_PAD + SRC_BYTES : TXB_BYTES;
+  constexpr int SRC_OFF = SRC_LATE ? 0 : WIN_PAD;
+  constexpr int WS_BYTES = SRC_LATE ? (WIN_PAD > SRC_BYTES ? WIN_PAD : SRC_BYTES) : WIN_PAD + SRC_BYTES;
+  constexpr int LDS_A0 = WS_BYTES > TXB_BYTES ? WS_BYTES : TXB_BYTES;
+  constexpr int LDS_A = LDS_A0 > IRB_BYTES ? LDS_A0 : IRB_BYTES;
   constexpr int LDS_B = QT_BYTES > REC_BYTES ? QT_BYTES : REC_BYTES;
   constexpr int LDS_BYTES = LDS_A > LDS_B ? LDS_A : LDS_B;
   __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
   T *buf = (T *)smem;
+  TB *tbuf = (TB *)smem;
 
   R1_PROF_INIT;
   const int lane = threadIdx.x;
@@ -218,7 +246,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
   for (int r = 0; r < H; r++) v[r] = 0;
   const bool col_live = live && c < W;
-  const uint8_t *src_l = smem + WIN_PAD + cl * (H * SRC_ROW) + c * BPP;
+  const uint8_t *src_l = smem + SRC_OFF + cl * (H * SRC_ROW) + c * BPP;
   // A.1: every global load the wave needs goes out before it waits for any of them -- source
   // block, reference window, tap tables depend on the descriptor only (one round trip behind it,
   // not three)
@@ -262,9 +290,9 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   // every filter of the wave with zero outer taps (anything but SHARP): the short column filter
   const bool six = taps_six(tp);
   // A.2: into LDS
-  if constexpr (SRC_LDS) {
+  auto stage_source = [&]() {
     if (live) {
-      uint8_t *sd = smem + WIN_PAD + cl * (H * SRC_ROW) + sch * CHS;
+      uint8_t *sd = smem + SRC_OFF + cl * (H * SRC_ROW) + sch * CHS;
 #pragma unroll
       for (int u = 0; u < SPASS; u++) {
         const int rr = srow + u * RPP;
@@ -275,7 +303,8 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         }
       }
     }
-  }
+  };
+  if constexpr (SRC_LDS && !SRC_LATE) stage_source();
   if (from_ref) wst.store(win, WS);
 #ifdef R1_PHASE_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -318,8 +347,8 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       }
     }
   } else {
+    int32_t pred[H];
     if (col_live) {
-      int32_t pred[H];
       if (qa.pred_in) {
         const uint16_t *pi = (const uint16_t *)qa.pred_in + (size_t)cand_ld * W * H + c;
 #pragma unroll
@@ -336,6 +365,13 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
         for (int r = 0; r < H; r++) ppk[r >> 1] |= (uint32_t)pred[r] << (16 * (r & 1));
       }
+    }
+    if constexpr (SRC_LATE) {
+      __syncthreads();   // every lane has filtered its column: the window is dead
+      stage_source();
+      __syncthreads();
+    }
+    if (col_live) {
       if constexpr (SRC_LDS) {
 #pragma unroll
         for (int r = 0; r < H; r++) {
@@ -388,7 +424,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       const int cc = cl * W + (r1tx::lr_flip(tx_type) ? W - 1 - c : c);
 #pragma unroll
       for (int r = 0; r < H; r++)
-        buf[r * LSTRIDE + cc] = r1tx::shift_fwd_ct<SH1>(v[r]);
+        tbuf[r * LSTRIDE + cc] = (TB)r1tx::shift_fwd_ct<SH1>(v[r]);
     }
   }
   if constexpr (!SPLIT_T) __syncthreads();
@@ -412,12 +448,12 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       if (col_live) {
 #pragma unroll
         for (int rr = 0; rr < 32; rr++)
-          buf[rr * LSTRIDE + cc] = r1tx::shift_fwd_ct<SH1>(v[half * 32 + rr]);
+          tbuf[rr * LSTRIDE + cc] = (TB)r1tx::shift_fwd_ct<SH1>(v[half * 32 + rr]);
       }
       __syncthreads();
       if (row_live && (r >> 5) == half) {
 #pragma unroll
-        for (int k = 0; k < W; k++) u[k] = buf[(r & 31) * LSTRIDE + k];
+        for (int k = 0; k < W; k++) u[k] = tbuf[(r & 31) * LSTRIDE + k];
       }
       __syncthreads();
     }
@@ -425,7 +461,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   if (row_live) {
     if constexpr (!SPLIT_T) {
 #pragma unroll
-      for (int k = 0; k < W; k++) u[k] = buf[r * LSTRIDE + cl2 * W + k];
+      for (int k = 0; k < W; k++) u[k] = tbuf[r * LSTRIDE + cl2 * W + k];
     }
     r1tx::fwd_1d_m24<W>(u, r1tx::htx_1d(tt));
 #pragma unroll
@@ -568,7 +604,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       __syncthreads();   // every coefficient has been read: the tile becomes the row buffer
       if (irow_live) {
 #pragma unroll
-        for (int k = 0; k < W; k++) buf[r * LSTRIDE + cl2 * W + k] = w_[k];
+        for (int k = 0; k < W; k++) buf[r * ISTRIDE + cl2 * W + k] = w_[k];
       }
       __syncthreads();
       // ---- G: inverse column transform, reconstruction (lane = column again) ----
@@ -579,7 +615,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         const T pmax = (T)((1 << BD) - 1);
 #pragma unroll
         for (int rr = 0; rr < HC; rr++) {
-          const T x = buf[rr * LSTRIDE + cl * W + c];
+          const T x = buf[rr * ISTRIDE + cl * W + c];
           rc[rr] = r1itx::clamp3((x + ((1 << qa.inv_shift) >> 1)) >> qa.inv_shift, lo, hi);
         }
 #pragma unroll
