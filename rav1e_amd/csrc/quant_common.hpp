@@ -153,13 +153,15 @@ struct ScanRun {
 // [l*NPL, (l+1)*NPL): gather, eob-1 = max scan index with |c| >= deadzone, DC
 // by lane 0, then the AC loop of mod.rs:311-336.  Its only serial dependence
 // is level_mode (one bit), so every element is a function {0,1} -> {0,1}
-// (reset / keep / set, see pass 1).  A lane composes its run sequentially
-// (two adds and shifts per element), one log2(G)-step scan composes the lanes,
-// and a replay pass picks the level per element.  On return `mine` holds the
-// quantized coefficients, eob the reference's return value and -- DIST -- dist
-// the transform-domain distortion (coded part + `tail` = the caller's partial
-// sum of squares beyond the coded area), already rounded and shifted.
-template <typename CT, int GL, int NPL, bool DIST>
+// (reset / keep / set, see pass 1).  A lane composes its run sequentially, one
+// log2(G)-step scan composes the lanes, and a replay pass picks the level per
+// element.  On return `mine` holds the quantized coefficients, eob the
+// reference's return value and -- DIST -- dist the transform-domain distortion
+// (coded part + `tail` = the caller's partial sum of squares beyond the coded
+// area), already rounded and shifted.
+// LTS: log_tx_scale when the caller knows it at compile time (the fused kernels:
+// it follows from the block size), -1 = qp.lts.
+template <typename CT, int GL, int NPL, bool DIST, int LTS = -1>
 __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, bool live,
                                                const uint16_t *__restrict__ scan,
                                                const QParams &qp, unsigned long long tail,
@@ -170,6 +172,10 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
   // are quarter rate).  The i16 <-> 8-bit coupling is the reference's own
   // (T::Coeff, src/util/mod.rs) and is enforced at the entry points.
   constexpr bool NARROW = sizeof(CT) == 2;
+  // short runs keep pass 1's result of every element in a register (A0 << 1 | dA);
+  // long ones park it in the element's own LDS slot and pass 2 reads it back
+  constexpr bool KEEP = NPL <= 16;
+  const int lts = LTS >= 0 ? LTS : qp.lts;
   // LDS accesses are unconditional: a dead group owns its (unused) slice of
   // the tile all the same and nothing of it reaches HBM
   (void)live;
@@ -192,7 +198,7 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
   // DC (lane 0 of the group holds scan position 0 = coefficient 0)
   int32_t q0 = 0;
   {
-    const int32_t c = (int32_t)((uint32_t)cv[0] << qp.lts);
+    const int32_t c = (int32_t)((uint32_t)cv[0] << lts);
     const uint32_t a = c < 0 ? 0u - (uint32_t)c : (uint32_t)c;
     const uint32_t v = divu_pair(a + qp.dc_offset, qp.dc_a, qp.dc_b, qp.dc_s);
     q0 = (int32_t)(CT)(c < 0 ? -(int32_t)v : (int32_t)v);
@@ -206,17 +212,19 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
   // by case (level0 = 0, 1, >= 2 against level_mode = 0, 1) the whole AC step
   // collapses to
   //     level_mode' = (min(A0, 2) + level_mode) >> 1,   |q| = level_mode' ? A1 : A0
-  // so an element is the pair (A0, A1 - A0) and its transition function is
-  // min(A0, 2): 0 = reset, 1 = keep, 2 = set.  Parked in place as
-  // A0 << 2 | (A1 - A0) << 1 | sign (A0 < 2^30: q >= 4); this lane re-reads it
-  // in pass 2.  Elements at or past eob park 0 (level 0; nothing after them
-  // reads level_mode), the DC slot parks "keep".
+  // so an element is the pair (A0, dA = A1 - A0), kept as pk = A0 << 1 | dA
+  // (A0 < 2^30: q >= 4), and its transition function is min(A0, 2): 0 = reset,
+  // 1 = keep, 2 = set.  A run of elements composes to its LAST element that is
+  // not "keep" (or to "keep"): one compare-and-select per element.  Elements at
+  // or past eob are 0 (level 0; nothing after them reads level_mode), the DC
+  // slot is "keep".  The sign is not carried: pass 2 takes it from cv again.
   const int lim = eob - l * NPL;        // elements k < lim of this run are below eob
   const uint32_t need0 = qp.ac_q - qp.ac_offset0, need1 = qp.ac_q - qp.ac_offset1;
-  uint32_t s0 = 0, s1 = 1;              // level_mode after the run, entering with 0 / 1
+  uint32_t pks[KEEP ? NPL : 1];
+  uint32_t st = 2u;                     // "keep" (A0 = 1)
 #pragma unroll
   for (int k = 0; k < NPL; k++) {
-    const int32_t c = (int32_t)((uint32_t)cv[k] << qp.lts);
+    const int32_t c = (int32_t)((uint32_t)cv[k] << lts);
     const uint32_t a = c < 0 ? 0u - (uint32_t)c : (uint32_t)c;
     uint32_t level0, rem;
     if constexpr (NARROW) {
@@ -228,18 +236,19 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
       rem = a - level0 * qp.ac_q;
     }
     const uint32_t A0 = level0 + (rem >= need0 ? 1u : 0u);
-    const uint32_t dA = (rem - need1 < need0 - need1) ? 2u : 0u;   // need1 <= rem < need0
-    uint32_t park = (A0 << 2) | dA | ((uint32_t)c >> 31);
-    park = (k < lim) ? park : 0u;
-    if (k == 0) park = l == 0 ? 4u : park;
-    const uint32_t t = park >> 2 < 2u ? park >> 2 : 2u;
-    s0 = (t + s0) >> 1;
-    s1 = (t + s1) >> 1;
-    mine[pos.at(k)] = (int32_t)park;
+    const uint32_t dA = (rem - need1 < need0 - need1) ? 1u : 0u;   // need1 <= rem < need0
+    uint32_t pk = (A0 << 1) | dA;
+    pk = (k < lim) ? pk : 0u;
+    if (k == 0) pk = l == 0 ? 2u : pk;
+    st = ((pk | 1u) == 3u) ? st : pk;   // A0 == 1: keep
+    if constexpr (KEEP) pks[k] = pk;
+    else mine[pos.at(k)] = (int32_t)pk;
   }
+  // the run's function as (level_mode after it when entered with 0) | (... with 1) << 1
+  const uint32_t ts = (st >> 1) < 2u ? (st >> 1) : 2u;
+  uint32_t L = (ts >> 1) | (((ts + 1u) >> 1) << 1);
   // the lanes' functions, composed in lane order (inclusive), then the
   // level_mode entering this lane's run (level_mode starts at 1)
-  uint32_t L = s0 | (s1 << 1);
 #pragma unroll
   for (int d = 1; d < G; d <<= 1) {
     const uint32_t p = __shfl_up(L, d, G);
@@ -251,28 +260,33 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
 
   // pass 2: replay
   unsigned long long dist = tail;
-  const int32_t off = (1 << qp.lts) - 1;
+  const int32_t off = (1 << lts) - 1;
 #pragma unroll
   for (int k = 0; k < NPL; k++) {
-    const uint32_t pk = pos.at(k);
-    const uint32_t park = (uint32_t)mine[pk];
-    const uint32_t A0 = park >> 2;
+    const uint32_t pix = pos.at(k);
+    uint32_t pk;
+    if constexpr (KEEP) pk = pks[k];
+    else pk = (uint32_t)mine[pix];
+    const uint32_t A0 = pk >> 1;
     mode = ((A0 < 2u ? A0 : 2u) + mode) >> 1;
-    const uint32_t mag = A0 + ((park >> 1) & mode);
-    int32_t q = (park & 1u) ? -(int32_t)mag : (int32_t)mag;
+    const uint32_t mag = A0 + (pk & mode);        // mode is 0 / 1: picks dA
+    // copysign(abs_qcoeff, coeff): the sign of the SHIFTED coefficient (mod.rs:318,338); an i16
+    // coefficient cannot lose its sign to a shift by <= 2
+    const int32_t sg = NARROW ? cv[k] >> 31 : (int32_t)((uint32_t)cv[k] << lts) >> 31;
+    int32_t q = (int32_t)((mag ^ (uint32_t)sg) - (uint32_t)sg);
     if (k == 0 && l == 0) q = q0;
-    mine[pk] = q;
+    mine[pix] = q;
     if constexpr (DIST) {
       const int32_t qt = (int32_t)(CT)q;
       // scan position 0 is coefficient 0 in every scan order
       const uint32_t quant = (k == 0 && l == 0) ? qp.dc_q : qp.ac_q;
       int32_t r, dd, sq;
       if constexpr (NARROW) {
-        r = (int32_t)(CT)((__mul24(qt, (int32_t)quant) + ((qt >> 31) & off)) >> qp.lts);
+        r = (int32_t)(CT)((__mul24(qt, (int32_t)quant) + ((qt >> 31) & off)) >> lts);
         dd = cv[k] - r;                 // both i16: 17 bits
         sq = mul24_wrap(dd, dd);        // low 32 bits = the wrapping i32 product
       } else {
-        r = (int32_t)((uint32_t)qt * quant + (uint32_t)((qt >> 31) & off)) >> qp.lts;
+        r = (int32_t)((uint32_t)qt * quant + (uint32_t)((qt >> 31) & off)) >> lts;
         dd = (int32_t)((uint32_t)cv[k] - (uint32_t)r);
         sq = (int32_t)((uint32_t)dd * (uint32_t)dd);
       }
@@ -288,7 +302,7 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
       const uint32_t hi = __shfl_xor((uint32_t)(dist >> 32), m, 64);
       dist += ((unsigned long long)hi << 32) | lo;
     }
-    const int bits = 2 * (3 - qp.lts);
+    const int bits = 2 * (3 - lts);
     dist_out = (dist + (1ull << (bits - 1))) >> bits;
   }
 }

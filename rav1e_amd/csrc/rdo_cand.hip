@@ -558,8 +558,10 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     const int kind = tt < 10 ? 0 : ((tt & 1) ? 2 : 1);
     int eob = 0;
     unsigned long long dist = 0;
-    r1q::quantize_group<CT, PL, NPLQ, QM == 1>(tile, cl2 * P, r, live2, qa.scan[kind], qa.qp, tail,
-                                               eob, dist);
+    // log_tx_scale follows from the block size (quantize/mod.rs:get_log_tx_scale): a constant here
+    constexpr int LTS = (W * H > 256) + (W * H > 1024);
+    r1q::quantize_group<CT, PL, NPLQ, QM == 1, LTS>(tile, cl2 * P, r, live2, qa.scan[kind], qa.qp, tail,
+                                                    eob, dist);
     if (live_st && r == 0) {
       qa.eob[cand2] = (uint16_t)eob;
       if constexpr (QM == 1) {
@@ -586,13 +588,13 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       {
         const int range = BD + 8;
         const T hi = (T)((1 << (range - 1)) - 1), lo = -hi - 1;
-        const int32_t off = (1 << qa.qp.lts) - 1;
+        constexpr int32_t off = (1 << LTS) - 1;
         if (irow_live) {
 #pragma unroll
           for (int k = 0; k < WC; k++) {
             const int32_t q = (int32_t)(CT)tile[k * OS + r];
             const uint32_t quant = (k == 0 && r == 0) ? qa.qp.dc_q : qa.qp.ac_q;
-            const T raw = (T)(CT)((int32_t)((uint32_t)q * quant + (uint32_t)((q >> 31) & off)) >> qa.qp.lts);
+            const T raw = (T)(CT)((int32_t)((uint32_t)q * quant + (uint32_t)((q >> 31) & off)) >> LTS);
             const T val = RECT1 ? ((T)((uint32_t)raw * 2896u + 2048u) >> 12) : raw;
             w_[k] = r1itx::clamp3(val, lo, hi);
           }
