@@ -823,13 +823,30 @@ __global__ __launch_bounds__(256, R1_ME_DIAG_WAVES) void k_me_diag(const R1MeJob
 // they stay in that XCD's L2 -- read back with L1-bypassing (agent-scope) loads, and the progress
 // word is a workgroup-scope store behind s_waitcnt(0).  !PIN (launch_mode 3, fewer jobs than XCDs):
 // one list, any wave takes any row; results and progress words are agent-scope stores, written
-// through.  (An __ATOMIC_RELEASE agent-scope store for the progress word hung the kernel on this
-// stack; the explicit s_waitcnt + relaxed store does not.)
+// through.  Why not an __ATOMIC_RELEASE store / fence: at agent scope gfx950 spells it `buffer_wbl2 sc1`
+// + s_waitcnt -- a write-back of the XCD's whole L2 per hand-over (round 2 saw that as a "hang": the
+// waits ran out of patience behind it).  Measured in round 4 with every shared entry an agent-scope
+// atomic, fence(release) before the progress word and fence(acquire) behind each wait (-DR1_ME_FORMAL=1,
+// profiles/r04_me_fence_ab.md): bit-exact, no hang, and 1.3x (1 job) .. 4.1x (64 jobs) SLOWER.  The
+// product keeps the ISA-level argument: the statistics are acknowledged by the memory system
+// (s_waitcnt vmcnt(0)) before the progress word is issued -- written through (sc1) where the
+// readers may sit on another XCD, left in the L2 that all readers share where they are pinned -- and
+// every read of shared data is an L1-bypassing atomic load issued after the wait returned.  The C++
+// model has no scope between "workgroup" and "agent" to say "this XCD", so the pinned mode stays a
+// data race on paper; launch_mode 1 (kernel boundaries) is the formally clean path and the automatic
+// fallback (r1_me_status / Context.estimate_frame_motion).
 // Residency: TWO waves per SIMD (host: grid 2048) -- a searching wave is a dependent instruction
 // chain that wants a VALU slot every ~8 cycles; a third and fourth wave on the SIMD stretch every
 // step of a chain without slack -- so the kernel is not held to k_me_diag's 96
 // registers and keeps three candidate batches in flight at every pixel size.
 // Refined vectors live in the second buffer and are never copied: the samples pick their buffer.
+// R1_ME_FORMAL (A/B build switch, profiles/r04_me_fence_ab.md): the hand-over spelled in the language's memory
+// model -- every shared statistics entry an agent-scope atomic, __builtin_amdgcn_fence(release, "agent")
+// before the progress word, fence(acquire, "agent") behind a successful wait.  On gfx950 the release is
+// `buffer_wbl2 sc1` (write back the XCD's L2) and the acquire `buffer_inv sc1`, per block step.
+#ifndef R1_ME_FORMAL
+#define R1_ME_FORMAL 0
+#endif
 struct MeRow { uint16_t job; uint8_t kind, pad; uint16_t gy, nb; };   // kind 0..2 search, 3 / 4 refine for pass 1 / 2
 struct MePersistArgs {
   const R1MeJob *jobs;
@@ -849,7 +866,12 @@ struct MePersistArgs {
 __device__ __forceinline__ bool me_wait(const unsigned int *f, unsigned int epoch, unsigned int need, int spin) {
   for (int it = 0; it < spin; it++) {
     const unsigned int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((v >> 16) == epoch && (v & 0xFFFFu) >= need) return true;
+    if ((v >> 16) == epoch && (v & 0xFFFFu) >= need) {
+#if R1_ME_FORMAL
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+      return true;
+    }
     if (it > 64) __builtin_amdgcn_s_sleep(8);
     else if (it > 4) __builtin_amdgcn_s_sleep(1);
   }
@@ -871,7 +893,12 @@ __device__ __forceinline__ bool me_wait4(const unsigned int *const *f, const uns
       const unsigned int v = __hip_atomic_load(mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       done = (v >> 16) == epoch && (v & 0xFFFFu) >= mn;
     }
-    if (__all(done)) return true;
+    if (__all(done)) {
+#if R1_ME_FORMAL
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+      return true;
+    }
     if (it > 64) __builtin_amdgcn_s_sleep(8);
     else if (it > 4) __builtin_amdgcn_s_sleep(1);
   }
@@ -939,7 +966,7 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
                                   b.po_y + imin(div8(mvr) + 2, div8(b.mvy_max)), 1);
         TileView tr = t;
         tr.stats = (R1MeStats *)t.rstats;
-        store_result<true, !PIN>(tr, 1 << (log2b + 1), bx, by, r, w, h, ssdec, lane);
+        store_result<true, !PIN || R1_ME_FORMAL>(tr, 1 << (log2b + 1), bx, by, r, w, h, ssdec, lane);
       } else {
         const int sz = MI << log2b;
         const int x = gx * sz, y = row.gy * sz;
@@ -979,9 +1006,14 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
         }
         const int corner = init ? 0 : (1 | ((xin & sz) ? 2 : 0) | ((yin & sz) ? 4 : 0));
         const Msr r = full_pixel_me<Block<BPP, 16, 3>, true>(b, t, p, bx, by, rng, corner, init, ssdec, sh_subsets);
-        store_result<true, !PIN>(t, 1 << log2b, bx, by, r, w, h, ssdec, lane);
+        store_result<true, !PIN || R1_ME_FORMAL>(t, 1 << log2b, bx, by, r, w, h, ssdec, lane);
       }
       // publish: the statistics first (agent-scope stores, acknowledged), then the progress
+#if R1_ME_FORMAL
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0)
+        __hip_atomic_store(mine, (a.epoch << 16) | (unsigned int)(gx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
       asm volatile("" ::: "memory");   // no result store may sink below the wait, no progress store rise above it
       __builtin_amdgcn_s_waitcnt(0);
       asm volatile("" ::: "memory");
@@ -990,6 +1022,7 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
         if constexpr (PIN) __hip_atomic_store(mine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_store(mine, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+#endif
     }
     // the error word is host-mapped pinned memory (one per ring slot): the host reads it where the
     // slot's event is waited for, without a copy (r1_me_status / the slot's reuse)
