@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bit-depth", type=int, default=8)
@@ -67,9 +67,6 @@ def parse():
     ap.add_argument("--verify-exchange", action="store_true",
                     help="N = 1: run the tagged-tile self-check of the exchange through the C-ABI communicator "
                          "(world 1) as the N > 1 runs always do; the result is config.exchange_ok")
-    ap.add_argument("--tiles", type=int, default=0,
-                    help="N = 1 only: cut the frame into this many tiles for --verify-exchange (geometry check of "
-                         "the plan; with one rank every tile is local)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the supplementary workloads (chroma planes, mixed filter pairs, mixed "
                          "transform types) reported under `extra_lines`")
@@ -185,6 +182,9 @@ def cpu_baseline(args, host_org, host_ref, cands, outs):
                 if kind == "scalar":
                     rc = L.r1o_rdo_cand_batch(C.byref(pa), C.byref(pb), s, s, TS[s], O.ptr(sub), len(sub),
                                               O.ptr(sad), O.ptr(satd), O.ptr(co), None)
+                elif kind == "vector512":
+                    rc = L.r1o_fast512_rdo_cand_batch(C.byref(pa), C.byref(pb), s, TS[s], O.ptr(sub), len(sub),
+                                                      threads, O.ptr(sad), O.ptr(satd), O.ptr(co))
                 else:
                     rc = L.r1o_fast_rdo_cand_batch(C.byref(pa), C.byref(pb), s, TS[s], O.ptr(sub), len(sub),
                                                    threads, O.ptr(sad), O.ptr(satd), O.ptr(co))
@@ -216,25 +216,40 @@ def cpu_baseline(args, host_org, host_ref, cands, outs):
         return {"px": px, "dt": dt, "frac": frac, "reps": reps, "n": n_cmp, "bad": bad, "mpx": px / dt / 1e6}
 
     T = args.cpu_seconds
-    sc = sized("scalar", phys, 0.2 * T)
-    vN = sized("vector", phys, 0.4 * T)
-    v1 = sized("vector", 1, 0.3 * T)
-    res = {"value": round(vN["mpx"], 2), "unit": "Mpixels/s", "cores": phys, "kind": "port",
+    wide = bool(L.r1o_fast512_available())
+    sc = sized("scalar", phys, 0.15 * T)
+    vN = sized("vector", phys, (0.25 if wide else 0.45) * T)
+    v1 = sized("vector", 1, (0.15 if wide else 0.3) * T)
+    w_legs = {}
+    if wide:
+        wN = sized("vector512", phys, 0.3 * T)
+        w1 = sized("vector512", 1, 0.15 * T)
+        w_legs = {"avx2_leg": {"value": round(vN["mpx"], 2), "cores": phys, "one_thread": round(v1["mpx"], 2),
+                               "impl": "oracle/fast_cand.c: the same port on 8 x i32 lanes (AVX2, -march=x86-64-v3)"}}
+        top, top1, impl = wN, w1, ("oracle/fast_cand512.c: 16 x i32 lanes (AVX-512 F/BW/DQ/VL, -march=x86-64-v4): gcc vector "
+                                   "extensions over the same generated transform networks as the scalar oracle, the vertical "
+                                   "8-tap pass on vpmaddwd, two 8x8 candidates per vector -- a compiler-vectorised port, NOT "
+                                   "rav1e's avx512icl nasm kernels")
+    else:
+        top, top1, impl = vN, v1, ("oracle/fast_cand.c: gcc vector extensions (AVX2, 8 x i32) over the same generated "
+                                   "transform networks as the scalar oracle -- a compiler-vectorised port, NOT rav1e's "
+                                   "nasm kernels (this host reports no AVX-512)")
+    res = {"value": round(top["mpx"], 2), "unit": "Mpixels/s", "cores": phys, "kind": "port",
            "sample": "%.2f%% of the step's candidates (every ladder size, strided) x %d, %.1f s, one "
-                     "OpenMP thread per core" % (100 * vN["frac"], vN["reps"], vN["dt"]),
-           "impl": "oracle/fast_cand.c: gcc vector extensions (AVX2, 8 x i32) over the same generated "
-                   "transform networks as the scalar oracle -- a compiler-vectorised port, NOT rav1e's "
-                   "nasm kernels",
-           "one_thread": {"value": round(v1["mpx"], 2),
-                          "sample": "%.2f%% of the candidates x %d, %.1f s" % (100 * v1["frac"], v1["reps"], v1["dt"])},
+                     "OpenMP thread per core" % (100 * top["frac"], top["reps"], top["dt"]),
+           "impl": impl,
+           "one_thread": {"value": round(top1["mpx"], 2),
+                          "sample": "%.2f%% of the candidates x %d, %.1f s" % (100 * top1["frac"], top1["reps"], top1["dt"])},
+           **w_legs,
            "scalar_port": {"value": round(sc["mpx"], 2), "threads": phys,
                            "sample": "%.3f%% of the candidates x %d, %.1f s; oracle/batch.c, the parity checker"
                                      % (100 * sc["frac"], sc["reps"], sc["dt"])},
            "logical_cpus": logical, "cores_note": cores_note,
            "reference_probe": reference_probe()}
-    parity = {"parity_checked": sc["n"], "parity_checked_vector_leg": vN["n"] + v1["n"],
-              "parity_ok": not (sc["bad"] or vN["bad"] or v1["bad"]),
-              "bad": sorted(set(sc["bad"] + vN["bad"] + v1["bad"]))}
+    legs = [sc, vN, v1] + ([wN, w1] if wide else [])
+    parity = {"parity_checked": sc["n"], "parity_checked_vector_leg": sum(l["n"] for l in legs[1:]),
+              "parity_ok": not any(l["bad"] for l in legs),
+              "bad": sorted(set(sum((l["bad"] for l in legs), [])))}
     return res, parity
 
 
@@ -281,43 +296,108 @@ N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
 NOMINAL_GHZ = 2.4         # the clock tools/ubench/valu_rate.hip's cycle counts are expressed in
 
 
-def build_roofline(kname, abytes, launch_ms, pmc, pmc_src, mix):
-    """Both roofs of the dominant kernel.  VALU: wave64 instructions issued per second (PMC count
-    per launch / live launch time) against SIMDs x clock / (issue cycles per instruction of this
-    kernel's mix).  HBM: algorithmic bytes, and the PMC traffic, per live launch time against
-    8 TB/s.  The larger fraction names the bound."""
+INFINITY_CACHE_BYTES = 256 << 20   # MI355X_MICROARCH.md: 256 MiB memory-side cache in front of HBM
+
+
+def launch_pmc(key):
+    """FETCH_SIZE / WRITE_SIZE of one launch of an extra / config line.  key = (kernel name prefix as
+    tools/pmc_summary.py shortens it, grid size in work-items): the counter pass (tools/gpu_pmc_lines.sh:
+    this bench with its lines under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes) is
+    summarised per (kernel, grid) under profiles/ -- a counter pass cannot run inside a timed bench."""
+    f = _latest("r*_pmc_launches.json")
+    if not f or not key:
+        return None, None
+    d = json.load(open(f))
+    prefix, grid = key
+    for k, v in d.items():
+        if k.startswith(prefix) and k.endswith("@%d" % grid) and "hbm_traffic_bytes" in v:
+            return {"dominant_traffic_bytes": v["hbm_traffic_bytes"], "kernel": k,
+                    "FETCH_SIZE_KiB": v.get("FETCH_SIZE"), "WRITE_SIZE_KiB": v.get("WRITE_SIZE"),
+                    "dispatches_averaged": v.get("n")}, os.path.basename(f)
+    return None, None
+
+
+def rdo_launch_key(bd, size, qm, n):
+    lg = {64: 6, 32: 5, 16: 4, 8: 3, 4: 2}[size]
+    nc = 64 // size
+    return ("k_rdo_cand<%d,%d,%d,%s,%d>" % (bd, lg, lg, "short" if bd == 8 else "int", qm), ((n + nc - 1) // nc) * 64)
+
+
+def build_roofline(kname, abytes, launch_ms, pmc, pmc_src, mix, working_set=None, write_bytes=None,
+                   line_counters=None, line_src=None):
+    """The dominant launch against its roofs.
+    Top level = the bench contract's HBM roofline: `achieved` = ALGORITHMIC bytes per launch (SURVEY 8(d)
+    per-candidate bytes x candidates) / the launch's live time, `peak` = 8 TB/s, `traffic` = HBM bytes per
+    launch by the PMC counters (2 x FETCH_SIZE + WRITE_SIZE KiB, MI355X_MICROARCH.md), or null.
+    `binding_roof` says which roof actually limits the launch; for the fused kernels that is VALU issue
+    (`valu`: three yardsticks), so `frac` -- kept as the contract defines it -- is NOT how close the
+    kernel is to its limit.
+    working_set / write_bytes: bytes of the input planes the launch reads from / bytes it writes.  A
+    read working set below the 256 MiB Infinity Cache is served from that cache from the second step
+    on: `hbm.reads_cache_resident`, and `hbm.frac_unique` prices only what must move (each input byte
+    once + the writes)."""
     sec = launch_ms * 1e-3
     hbm_ach = abytes / sec / 1e9
-    traffic = int(pmc["hbm_traffic_bytes"]) if pmc and "hbm_traffic_bytes" in pmc else None
+    traffic, traffic_src = None, None
+    if pmc and "hbm_traffic_bytes" in pmc:
+        traffic, traffic_src = int(pmc["hbm_traffic_bytes"]), pmc_src
+    elif line_counters and line_counters.get("dominant_traffic_bytes") is not None:
+        traffic, traffic_src = int(line_counters["dominant_traffic_bytes"]), line_src
     hbm = {"achieved": round(hbm_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(hbm_ach / HBM_PEAK_GBS, 4), "traffic": traffic,
            "frac_by_counters": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
            "traffic_note": ("%s: 2*FETCH_SIZE + WRITE_SIZE KiB per dispatch (gfx950 FETCH_SIZE correction, "
-                            "MI355X_MICROARCH.md); below the algorithmic bytes because the K candidates of a "
-                            "block share window rows in L2/MALL" % pmc_src) if traffic else None,
+                            "MI355X_MICROARCH.md); below the algorithmic bytes where the K candidates of a "
+                            "block share window rows in L2 / Infinity Cache" % traffic_src) if traffic else None,
            "algorithmic_bytes_per_launch": int(abytes)}
-    common = {"kernel": kname, "avg_launch_ms": round(launch_ms, 4), "traffic": traffic, "hbm": hbm,
+    if line_counters:
+        hbm["counters_of_the_line"] = {k: line_counters[k] for k in line_counters if k != "dominant_traffic_bytes"}
+    if working_set is not None:
+        uniq = min(int(abytes), int(working_set)) if write_bytes is None else \
+            min(int(abytes) - int(write_bytes), int(working_set)) + int(write_bytes)
+        hbm.update({"read_working_set_bytes": int(working_set),
+                    "reads_cache_resident": bool(working_set < INFINITY_CACHE_BYTES),
+                    "unique_bytes_per_launch": int(uniq),
+                    "frac_unique": round(uniq / sec / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_note": ("the input planes (%.1f MB) stay in the 256 MiB Infinity Cache between steps: "
+                                  "`frac` is algorithmic bytes over time, served mostly by that cache, NOT an HBM "
+                                  "fraction; `frac_unique` counts each input byte once plus the writes"
+                                  % (working_set / 1e6)) if working_set < INFINITY_CACHE_BYTES else
+                                 "the read working set exceeds the Infinity Cache"})
+    common = {"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": hbm["frac"], "traffic": traffic,
+              "kernel": kname, "avg_launch_ms": round(launch_ms, 4), "hbm": hbm,
               "algorithmic_bytes_per_launch": int(abytes)}
+    valu = None
     if pmc and mix and "SQ_INSTS_VALU" in pmc:
         cost = mix["issue_cycles_per_valu"]
         ach = pmc["SQ_INSTS_VALU"] / sec / 1e9
-        peak = N_SIMD * NOMINAL_GHZ / cost
-        # two yardsticks: `peak` prices this kernel's instruction mix with the issue cycles measured on the
-        # chip (tools/ubench/valu_rate{,2}.hip: 2.5 / 4.5 cycles per wave64 instruction); `peak_guide` is
-        # MI355X_MICROARCH.md's constant (a wave64 VALU instruction issues in 2 cycles on a SIMD-32)
+        # clock the chip held during the counter pass: GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        # (tools/pmc_summary.py divides by the dispatch's own duration in that pass)
+        clk = pmc.get("clock_ghz_by_counters")
+        peak_ubench = N_SIMD * NOMINAL_GHZ / cost
         peak_guide = N_SIMD * NOMINAL_GHZ / 2.0
-        valu = {"achieved": round(ach, 2), "peak": round(peak, 2), "unit": "G wave64-instr/s",
-                "frac": round(ach / peak, 4), "peak_guide": round(peak_guide, 2),
-                "frac_guide": round(ach / peak_guide, 4), "insts_per_launch": int(pmc["SQ_INSTS_VALU"]),
+        valu = {"achieved": round(ach, 2), "unit": "G wave64-instr/s",
+                "insts_per_launch": int(pmc["SQ_INSTS_VALU"]),
+                # 1: this kernel's static mix priced with the issue cycles measured on the chip
+                #    (tools/ubench/valu_rate{,2}.hip: add / sub / shifts / logic 2.5, everything else 4.5)
+                "peak_ubench_mix": round(peak_ubench, 2), "frac_ubench_mix": round(ach / peak_ubench, 4),
                 "issue_cycles_per_inst": cost, "fast_slow_static": [mix["fast"], mix["slow"]],
+                # 2: MI355X_MICROARCH.md's constant -- every wave64 VALU instruction in 2 cycles at 2.4 GHz
+                "peak_guide": round(peak_guide, 2), "frac_guide": round(ach / peak_guide, 4),
+                # 3: the same 2-cycle rate at the clock the counters say the chip held
+                "clock_ghz_by_counters": round(clk, 3) if clk else None,
+                "frac_guide_at_measured_clock": round(ach / (N_SIMD * clk / 2.0), 4) if clk else None,
                 "sources": [pmc_src, mix["source"], "tools/ubench/valu_rate.hip", "tools/ubench/valu_rate2.hip"]}
-        if valu["frac"] >= hbm["frac"]:
-            return dict(common, bound="valu", achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"],
-                        frac=valu["frac"], valu=valu)
-        return dict(common, bound="hbm", achieved=hbm["achieved"], peak=hbm["peak"], unit="GB/s",
-                    frac=hbm["frac"], valu=valu)
-    return dict(common, bound="hbm", achieved=hbm["achieved"], peak=hbm["peak"], unit="GB/s", frac=hbm["frac"],
-                valu=None)
+    binding = "hbm"
+    if valu and valu["frac_ubench_mix"] >= (hbm["frac_by_counters"] or hbm["frac"]):
+        binding = "valu"
+    elif launch_ms < 0.02:
+        binding = "launch"        # a launch of a few microseconds: neither roof is in sight
+    return dict(common, binding_roof=binding, valu=valu,
+                binding_note={"valu": "VALU issue bound: see valu.frac_ubench_mix / frac_guide; HBM is not the limit",
+                              "launch": "the launch lasts microseconds: launch-bound, neither roof applies",
+                              "hbm": "HBM / cache bandwidth"}[binding])
 
 
 def extra_lines(ctx, args):
@@ -406,8 +486,12 @@ def extra_lines(ctx, args):
             n_chk += len(idx)
             if not ok:
                 bad.append("plane %d %dx%d" % (p, s, s))
+        lc, lsrc = launch_pmc(rdo_launch_key(bd, dom, 0, len(cands[dom])))
         roof = build_roofline("k_rdo_cand<bd=%d,%dx%d> (%s)" % (bd, dom, dom, name), abytes,
-                              per[dom], None, None, None)
+                              per[dom], None, None, None,
+                              working_set=planes[0][0].nbytes + planes[0][1].nbytes,
+                              write_bytes=len(cands[dom]) * (8 + dom * dom * (2 if bpp == 1 else 4)),
+                              line_counters=lc, line_src=lsrc)
         lines.append({"name": name, "metric": "RDO-candidate Mpixels/s (dist+fwd_tx+mc)",
                       "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "steps": STEPS,
                       "ms_per_step": round(dt * 1e3, 4),
@@ -499,9 +583,13 @@ def config_lines(ctx, args):
         launch_how.append(how)
         return per, dt
 
-    def line(name, desc, px, per, step_ms, abytes_by_tag, n_chk, bad, extra=None):
+    def line(name, desc, px, per, step_ms, abytes_by_tag, n_chk, bad, extra=None, working_set=None, wbytes=None,
+             kkeys=None):
         dom = max(per, key=lambda t: per[t])
-        roof = build_roofline("%s: %s" % (name, dom), abytes_by_tag[dom], per[dom], None, None, None)
+        lc, lsrc = launch_pmc((kkeys or {}).get(dom))
+        roof = build_roofline("%s: %s" % (name, dom), abytes_by_tag[dom], per[dom], None, None, None,
+                              working_set=working_set, write_bytes=(wbytes or {}).get(dom),
+                              line_counters=lc, line_src=lsrc)
         d = {"name": name, "metric": "Mpixels/s", "value": round(px / (step_ms * 1e-3) / 1e6, 2), "unit": "Mpixels/s",
              "steps": REPS, "ms_per_step": round(step_ms, 4),
              "config": {"workload": desc, "launch": launch_how[-1] if launch_how else None},
@@ -521,8 +609,9 @@ def config_lines(ctx, args):
     a, b = O.HostPlane(w, h, bd), O.HostPlane(w, h, bd)
     a.data, b.data = ho, hr
     pa, pb = a.cstruct(), b.cstruct()
+    ws_1080 = ho.nbytes + hr.nbytes
     # config 2: SAD K = 32, SATD K = 8
-    fns, abytes, px, chk = [], {}, 0, []
+    fns, abytes, px, chk, wbytes, kkeys = [], {}, 0, [], {}, {}
     for kind, k, nm in ((0, 32, "sad"), (1, 8, "satd")):
         cands = W.speed6_ladder(w, h, k, seed=3, mv_range=32)
         for sz, c in cands.items():
@@ -534,6 +623,8 @@ def config_lines(ctx, args):
             tag = "%s %dx%d" % (nm, sz, sz)
             fns.append((tag, lambda kind=kind, sz=sz, dev=dev, n=len(c), out=out: ctx.dist_batch(kind, po, pr, sz, sz, dev, n=n, out=out)))
             abytes[tag] = (2 * sz * sz + 4) * len(c)
+            wbytes[tag] = 4 * len(c)
+            kkeys[tag] = ("k_dist<1,8,%s>" % ("true" if kind else "false"), ((len(c) * (sz // 8) ** 2 + 255) // 256) * 256)
             px += len(c) * sz * sz
             chk.append((kind, sz, dcand, out))
     per, step = timed(fns)
@@ -548,9 +639,9 @@ def config_lines(ctx, args):
         if not np.array_equal(got, want):
             bad.append("%s %d" % ("satd" if kind else "sad", sz))
     line("config2_dist_1080p", "1920x1080 8-bit luma, speed-6 ladder 64/32/16/8: get_sad K=32 + get_satd K=8 per block, "
-         "MV +-32 px (benches/dist.rs)", px, per, step, abytes, n_chk, bad)
+         "MV +-32 px (benches/dist.rs)", px, per, step, abytes, n_chk, bad, working_set=ws_1080, wbytes=wbytes, kkeys=kkeys)
     # config 2: forward DCT of every transform block of the frame
-    fns, abytes, px, chk = [], {}, 0, []
+    fns, abytes, px, chk, wbytes, kkeys = [], {}, 0, [], {}, {}
     from rav1e_amd.types import TxSize
     rng = np.random.default_rng(5)
     for sz in W.LADDER:
@@ -562,6 +653,9 @@ def config_lines(ctx, args):
         tag = "fdct %dx%d" % (sz, sz)
         fns.append((tag, lambda dres=dres, ts=ts, out=out: ctx.forward_transform_batch(dres, ts, 0, 8, out=out)))
         abytes[tag] = nb * (2 * sz * sz + 2 * sz * sz)
+        wbytes[tag] = nb * 2 * sz * sz
+        lg_ = sz.bit_length() - 1
+        kkeys[tag] = ("k_fwd_tx<%d,%d,short>" % (lg_, lg_), ((nb + 64 // sz - 1) // (64 // sz)) * 64)
         px += nb * sz * sz
         chk.append((sz, ts, res, out))
     per, step = timed(fns)
@@ -576,9 +670,11 @@ def config_lines(ctx, args):
         if not np.array_equal(got, want):
             bad.append("fdct %d" % sz)
     line("config2_fwd_dct_1080p", "every transform block of a 1920x1080 frame at 64/32/16/8, DCT_DCT, residual uniform "
-         "[-255, 255] (benches/transform.rs)", px, per, step, abytes, n_chk, bad)
+         "[-255, 255] (benches/transform.rs)", px, per, step, abytes, n_chk, bad,
+         # the residual blocks ARE the input here: every byte is read once per pass
+         working_set=sum(v for v in wbytes.values()), wbytes=wbytes, kkeys=kkeys)
     # config 3: put_8tap / prep_8tap
-    fns, abytes, px, chk = [], {}, 0, []
+    fns, abytes, px, chk, wbytes, kkeys = [], {}, 0, [], {}, {}
     cands = W.speed6_ladder(w, h, 8, seed=4, mv_range=32)
     for sz, c in cands.items():
         mc = np.zeros(len(c), MC_CAND)
@@ -591,6 +687,11 @@ def config_lines(ctx, args):
         fns.append(("prep %dx%d" % (sz, sz), lambda sz=sz, dev=dev, n=len(c), o=o_prep: ctx.prep_8tap_batch(pr, sz, sz, dev, n=n, out=o)))
         abytes["put %dx%d" % (sz, sz)] = len(c) * ((sz + 7) * (sz + 7) + sz * sz)
         abytes["prep %dx%d" % (sz, sz)] = len(c) * ((sz + 7) * (sz + 7) + 2 * sz * sz)
+        wbytes["put %dx%d" % (sz, sz)], wbytes["prep %dx%d" % (sz, sz)] = len(c) * sz * sz, 2 * len(c) * sz * sz
+        lg_ = sz.bit_length() - 1
+        for nm_, pf_ in (("put", "false"), ("prep", "true")):
+            kkeys["%s %dx%d" % (nm_, sz, sz)] = ("k_mc_fast<1,%d,%d,%s>" % (lg_, lg_, pf_),
+                                                ((len(c) + 64 // sz - 1) // (64 // sz)) * 64)
         px += 2 * len(c) * sz * sz
         chk.append((sz, mc, o_put, o_prep))
     per, step = timed(fns)
@@ -607,7 +708,8 @@ def config_lines(ctx, args):
                 np.array_equal(o_prep.index_select(0, ix).cpu().numpy(), w_prep)):
             bad.append("mc %d" % sz)
     line("config3_mc_1080p", "1920x1080 8-bit luma, ladder 64/32/16/8, K=8: put_8tap + prep_8tap REGULAR with random "
-         "1/16-pel fractions, MV +-32 px (benches/mc.rs)", px, per, step, abytes, n_chk, bad)
+         "1/16-pel fractions, MV +-32 px (benches/mc.rs)", px, per, step, abytes, n_chk, bad,
+         working_set=hr.nbytes, wbytes=wbytes, kkeys=kkeys)
     del po, pr, fns, chk
     torch.cuda.empty_cache()
 
@@ -645,7 +747,10 @@ def config_lines(ctx, args):
                 np.array_equal(outs[s]["coeffs"].index_select(0, ix).cpu().numpy(), co)):
             bad.append("fused %d" % s)
     line("fused_4k_10bit", "%dx%d 10-bit luma, speed-6 ladder, K=%d fused candidates (the headline step at the config-4 "
-         "pixel format)" % (w, h, k), px, per, step, abytes, n_chk, bad, {"dtype": "u16"})
+         "pixel format)" % (w, h, k), px, per, step, abytes, n_chk, bad, {"dtype": "u16"},
+         working_set=ho.nbytes + hr.nbytes,
+         wbytes={"%dx%d" % (s_, s_): len(c_) * (8 + 4 * s_ * s_) for s_, c_ in cands.items()},
+         kkeys={"%dx%d" % (s_, s_): rdo_launch_key(10, s_, 0, len(c_)) for s_, c_ in cands.items()})
     del outs, fns
     torch.cuda.empty_cache()
     # config-4 proxy: pixel-domain chain + CDEF luma pass + CDEF strength search
@@ -726,7 +831,10 @@ def config_lines(ctx, args):
     line("config4_proxy_4k_10bit", "%dx%d 10-bit: pixel-domain candidate chain over the ladder (K=%d: mc -> dist -> fwd -> quantize "
          "-> inverse -> cdef_dist) + CDEF luma pass + CDEF strength search over rav1e's 8 presets (4:2:0)" % (w, h, k),
          px, per, step, abytes, n_chk, bad, {"dtype": "u16", "px_note": "Mpixels/s counts the candidate pixels of the chain; the "
-                                             "two CDEF launches are inside the step time"})
+                                             "two CDEF launches are inside the step time"},
+         working_set=ho.nbytes + hr.nbytes,
+         wbytes={"pixel %dx%d" % (s_, s_): 18 * len(c_) for s_, c_ in cands.items()},
+         kkeys={"pixel %dx%d" % (s_, s_): rdo_launch_key(10, s_, 2, len(c_)) for s_, c_ in cands.items()})
     return lines
 
 
@@ -1019,8 +1127,10 @@ def main():
             abytes = abytes_per_cand(dom) * n_dom
             kname = "k_rdo_cand<bd=%d,%dx%d%s>" % (bd, dom, dom, ",pixel" if pixel else (",quant" if full else ""))
             pmc, pmc_src = (None, None) if full else pmc_counters(bd, dom, fw, fh, args.k)
+            wr = n_dom * ((8 + dom * dom * (2 if bpp == 1 else 4)) if not full else (18 if pixel else 26))
             roof = build_roofline(kname, abytes, per[dom], pmc, pmc_src,
-                                  None if full else valu_issue_model(bd, dom))
+                                  None if full else valu_issue_model(bd, dom),
+                                  working_set=host_org.nbytes + host_ref.nbytes, write_bytes=wr)
         else:
             dom, per = None, {}
             abytes = sum(abytes_per_cand(s) * len(c) for s, c in cands.items())

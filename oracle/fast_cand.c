@@ -166,7 +166,10 @@ typedef uint16_t pixv_u16 __attribute__((vector_size(16), aligned(2)));
 
 /* Mirrors r1o_rdo_cand_batch for square blocks 8..64 with tx_type DCT_DCT; `threads` OpenMP
  * threads over candidates (1 = the single-thread figure). */
-int r1o_fast_rdo_cand_batch(const r1o_plane *org, const r1o_plane *ref, int n_px, int tx_size,
+#ifndef R1_FAST_ENTRY   /* fast_cand512.c compiles this file once more under its own ISA and name */
+#define R1_FAST_ENTRY r1o_fast_rdo_cand_batch
+#endif
+int R1_FAST_ENTRY(const r1o_plane *org, const r1o_plane *ref, int n_px, int tx_size,
                             const r1o_rdo_cand *c, int n, int threads, uint32_t *sad_out,
                             uint32_t *satd_out, void *coeffs) {
   if (n_px != 8 && n_px != 16 && n_px != 32 && n_px != 64) return -1;

@@ -106,6 +106,8 @@ def lib():
         "r1o_plane_pad": (None, [vp, i, i, i, i]),
         "r1o_plane_downsample": (i, [vp, vp, i, i, i, i]),
         "r1o_fast_rdo_cand_batch": (i, [vp, vp, i, i, vp, i, i, vp, vp, vp]),
+        "r1o_fast512_rdo_cand_batch": (i, [vp, vp, i, i, vp, i, i, vp, vp, vp]),
+        "r1o_fast512_available": (i, []),
         "r1o_estimate_tile_motion": (i, [vp, vp, vp, vp, vp]),
         "r1o_rdo_pixel_cand_batch": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i, vp, i, i, i,
                                          vp, vp, vp, vp, vp, vp, vp]),

@@ -34,13 +34,24 @@ def test_fast_leg_equals_scalar_oracle(size, bd):
     got = [np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros((n, size * size), ct)]
     assert L.r1o_rdo_cand_batch(C.byref(pa), C.byref(pb), size, size, ts, O.ptr(c), n,
                                 O.ptr(ref[0]), O.ptr(ref[1]), O.ptr(ref[2]), None) == 0
-    for threads in (1, 3):
-        for g in got:
-            g[...] = 0
-        assert L.r1o_fast_rdo_cand_batch(C.byref(pa), C.byref(pb), size, ts, O.ptr(c), n, threads,
-                                         O.ptr(got[0]), O.ptr(got[1]), O.ptr(got[2])) == 0
-        for r, g, name in zip(ref, got, ("sad", "satd", "coeffs")):
-            assert np.array_equal(r, g), name
+    legs = [L.r1o_fast_rdo_cand_batch]
+    if L.r1o_fast512_available():      # the AVX-512 leg (oracle/fast_cand512.c) where the host has it
+        legs.append(L.r1o_fast512_rdo_cand_batch)
+    for leg in legs:
+        for threads in (1, 3):
+            for g in got:
+                g[...] = 0
+            assert leg(C.byref(pa), C.byref(pb), size, ts, O.ptr(c), n, threads,
+                       O.ptr(got[0]), O.ptr(got[1]), O.ptr(got[2])) == 0
+            for r, g, name in zip(ref, got, ("sad", "satd", "coeffs")):
+                assert np.array_equal(r, g), (name, leg.__name__ if hasattr(leg, "__name__") else leg)
+
+
+def test_avx512_leg_ran_here_or_says_so():
+    """this container's CPU has AVX-512: the wide leg must actually be exercised by the test above"""
+    L = O.lib()
+    flags = open("/proc/cpuinfo").read()
+    assert bool(L.r1o_fast512_available()) == all(f in flags for f in ("avx512f", "avx512bw", "avx512dq", "avx512vl"))
 
 
 def test_fast_leg_rejects_what_it_does_not_cover():
