@@ -389,15 +389,22 @@ def build_roofline(kname, abytes, launch_ms, pmc, pmc_src, mix, working_set=None
                 "clock_ghz_by_counters": round(clk, 3) if clk else None,
                 "frac_guide_at_measured_clock": round(ach / (N_SIMD * clk / 2.0), 4) if clk else None,
                 "sources": [pmc_src, mix["source"], "tools/ubench/valu_rate.hip", "tools/ubench/valu_rate2.hip"]}
-    binding = "hbm"
-    if valu and valu["frac_ubench_mix"] >= (hbm["frac_by_counters"] or hbm["frac"]):
-        binding = "valu"
+    if valu:
+        binding = "valu" if valu["frac_ubench_mix"] >= (hbm["frac_by_counters"] or hbm["frac"]) else "hbm"
     elif launch_ms < 0.02:
         binding = "launch"        # a launch of a few microseconds: neither roof is in sight
+    elif "k_rdo_cand" in kname or "pixel" in kname or "x" in kname.split(":")[-1] and "fused" in kname:
+        binding = "valu (not measured for this launch)"
+    else:
+        binding = "not measured"
     return dict(common, binding_roof=binding, valu=valu,
                 binding_note={"valu": "VALU issue bound: see valu.frac_ubench_mix / frac_guide; HBM is not the limit",
+                              "hbm": "HBM / cache bandwidth",
                               "launch": "the launch lasts microseconds: launch-bound, neither roof applies",
-                              "hbm": "HBM / cache bandwidth"}[binding])
+                              "valu (not measured for this launch)": "a fused-candidate launch: the headline's instruction counters say "
+                              "this kernel family is VALU issue bound; no instruction counters were taken for this launch",
+                              "not measured": "no instruction counters for this launch; `frac` / `frac_unique` / `traffic` are what "
+                              "is known"}[binding])
 
 
 def extra_lines(ctx, args):
