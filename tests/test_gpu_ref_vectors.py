@@ -362,6 +362,49 @@ def _me_stats_tensor(a):
     return torch.from_numpy(s.view(np.int32).reshape(s.shape[0], s.shape[1], 2).copy()).cuda(), s
 
 
+def test_lookahead_chain_search_to_cost_to_importance(ctx):
+    """lookahead_chain_ref.npz (gen_lookahead_chain_ref.py): the reference's motion search feeding its cost
+    loop and update_block_importances.  The device runs the whole chain on its own: r1_estimate_tile_motion_batch
+    writes the statistics, a strided VIEW of that very buffer is what r1_estimate_inter_costs /
+    r1_update_block_importances take as vectors -- no host round trip -- and the mean inter cost and the
+    importances equal the reference's."""
+    import torch
+    M = np.load(os.path.join(GOLD, "me_ref.npz"))
+    CH = np.load(os.path.join(GOLD, "lookahead_chain_ref.npz"))
+    pads = (88, 44, 22)
+    n = 0
+    for name in CH["keys"]:
+        name = str(name)
+        w, h, bd, tx, ty, tw, th, hp, full, scale, n_refs, _ = [int(v) for v in M[name + "_meta"]]
+        lam = [int(v) for v in M[name + "_lambda"]]
+        org = [dev_plane(O.plane_from_image(M["%s_org%d" % (name, s)].astype(np.int64), bd, pads[s], pads[s]))
+               for s in range(3)]
+        ref = [dev_plane(O.plane_from_image(M["%s_ref0_%d" % (name, s)].astype(np.int64), bd, pads[s], pads[s]))
+               for s in range(3)]
+        prev_t, _ = _me_stats_tensor(M["%s_prev0" % name])
+        st, _ = _me_stats_tensor(np.zeros_like(M["%s_stats0" % name]))
+        cols, rows = (w + 3) // 4, (h + 3) // 4
+        mode = ctx.estimate_frame_motion([dict(org=org, ref=ref, stats=st, prev=prev_t, tile=(tx, ty, tw, th))], cols, rows,
+                                         bd, lam, allow_hp=bool(hp), allow_full_search=bool(full), me_range_scale=scale)
+        assert mode in (0, 1)
+        hb, wb = h // 8, w // 8
+        # MEStats = (row | col << 16, normalized_sad): the first int32 of every second entry, as int16 pairs
+        mvs = st[0:2 * hb:2, 0:2 * wb:2, 0].contiguous().view(torch.int16).reshape(hb, wb, 2)
+        inter = ctx.estimate_inter_costs(org[0], ref[0], mvs)
+        tot = int(inter.cpu().numpy().view(np.uint32).astype(np.uint64).sum())
+        assert tot / (wb * hb) == float(CH["inter_mean_" + name][0]), name
+        intra = ctx.estimate_intra_costs(org[0])
+        assert np.array_equal(intra.cpu().numpy().view(np.uint32), CH["intra_" + name]), name
+        fut = torch.from_numpy(np.ascontiguousarray(CH["future_" + name])).cuda()
+        for ln in (1, 3):
+            acc = torch.from_numpy(np.ascontiguousarray(CH["imp_in_%d_%s" % (ln, name)]).copy()).cuda()
+            ctx.update_block_importances(intra.reshape(-1), fut.reshape(-1), inter.reshape(-1), mvs.reshape(-1, 2),
+                                         wb, hb, ln, acc.reshape(-1))
+            assert np.array_equal(acc.cpu().numpy().view(np.uint32), CH["imp_out_%d_%s" % (ln, name)].view(np.uint32)), (name, ln)
+            n += 1
+    assert n == 16
+
+
 @pytest.mark.parametrize("launch_mode", [1, 2, 3])
 @pytest.mark.parametrize("name", _me_ref_cases())
 def test_me_ref_tile_motion_and_block_searches(ctx, name, launch_mode):

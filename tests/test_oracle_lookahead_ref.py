@@ -82,3 +82,38 @@ def test_update_block_importances_adversarial_positions(oracle):
             assert np.array_equal(acc.view(np.uint32), want.view(np.uint32).ravel().reshape(acc.shape)), (k, ln)
             n += 1
     assert n == 18
+
+
+def test_search_to_cost_to_importance_chain_reproduces_the_reference(oracle):
+    """lookahead_chain_ref.npz: the reference's motion search (me_ref.npz statistics, executed) feeding
+    its cost loop and update_block_importances (executed by gen_lookahead_chain_ref.py).  The oracle runs
+    the WHOLE chain itself -- its own search, its statistics into its cost loop -- and must land on the
+    same mean inter cost and importances."""
+    import test_oracle_me_ref as MR
+    CH = np.load(os.path.join(os.path.dirname(__file__), "golden", "lookahead_chain_ref.npz"))
+    n = 0
+    for name in CH["keys"]:
+        name = str(name)
+        c = MR.load_case(name)
+        pyr, prev, want = c["refs"][0]
+        stats = np.zeros_like(want)
+        O.me_oracle(oracle, c["org"], pyr, (c["w"] + 3) // 4, (c["h"] + 3) // 4, c["tile"], c["bd"], c["lam"], stats,
+                    prev, allow_hp=c["hp"], allow_full_search=c["full"], me_range_scale=c["scale"])
+        hb, wb = c["h"] // 8, c["w"] // 8
+        # the importance blocks' vectors: every second MEStats entry in both directions (lookahead.rs:236-244)
+        mvs = np.ascontiguousarray(np.stack([stats["row"][0:2 * hb:2, 0:2 * wb:2], stats["col"][0:2 * hb:2, 0:2 * wb:2]],
+                                            axis=-1).astype(np.int16))
+        po, pr = c["org"][0].cstruct(), pyr[0].cstruct()
+        inter = np.zeros(hb * wb, np.uint32)
+        oracle.r1o_estimate_inter_costs(C.byref(po), C.byref(pr), O.ptr(mvs), O.ptr(inter))
+        assert int(inter.astype(np.uint64).sum()) / (wb * hb) == float(CH["inter_mean_" + name][0]), name
+        intra = np.zeros(hb * wb, np.uint32)
+        oracle.r1o_estimate_intra_costs(C.byref(po), c["bd"], O.ptr(intra))
+        assert np.array_equal(intra.reshape(hb, wb), CH["intra_" + name]), name
+        fut = np.ascontiguousarray(CH["future_" + name])
+        for ln in (1, 3):
+            acc = np.ascontiguousarray(CH["imp_in_%d_%s" % (ln, name)]).copy()
+            oracle.r1o_update_block_importances(O.ptr(intra), O.ptr(fut), O.ptr(inter), O.ptr(mvs), wb, hb, ln, O.ptr(acc))
+            assert np.array_equal(acc.view(np.uint32), CH["imp_out_%d_%s" % (ln, name)].view(np.uint32)), (name, ln)
+            n += 1
+    assert n == 16
