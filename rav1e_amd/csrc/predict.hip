@@ -191,25 +191,48 @@ __device__ __forceinline__ int32_t filt5(const uint16_t *src, int i, int size, i
 // `group` consecutive candidates (the modes of one block) share one edge set
 // and one source position; the prediction goes to LDS and only get_satd of it
 // against the source block leaves the CU.
-template <int BPP, bool SATD_OUT>
+// WLT / HLT >= 0 (the pre-screen's square sizes): block size known at compile time -- every row loop
+// unrolls, and with SATD_OUT the prediction column never leaves the lane's registers (it used to go
+// through LDS and back: one ds_write + one ds_read per pixel, plus the address arithmetic of loops
+// with a runtime trip count).
+#ifndef R1_PRESCREEN_LOOPED
+#define R1_PRESCREEN_LOOPED 1   // A/B switch
+#endif
+template <int BPP, bool SATD_OUT, int WLT = -1, int HLT = -1>
 __global__ __launch_bounds__(64) void k_intra_predict(
     int wl, int hl, const R1IntraCand *__restrict__ cands, int n,
     const void *__restrict__ edges, int edge_stride, const uint8_t *__restrict__ lens,
     const int16_t *__restrict__ ac, int bit_depth, void *__restrict__ dst, R1Plane src,
     const int16_t *__restrict__ pos_xy, int group, uint32_t *__restrict__ satd_out) {
   extern __shared__ uint16_t smem[];
+  constexpr bool FIXED = WLT >= 0 && HLT >= 0;
+  if constexpr (FIXED) { wl = WLT; hl = HLT; }
   const int W = 1 << wl, H = 1 << hl;
   const int NC = 64 >> wl;
+  constexpr bool IN_REGS = SATD_OUT && FIXED;
+  int32_t pv[IN_REGS ? (1 << (HLT < 0 ? 0 : HLT)) : 1];   // IN_REGS: the lane's prediction column
   const int FL = 2 * (W + H) + 1;
   const int lane = threadIdx.x;
   const int cl = lane >> wl, c = lane & (W - 1);
   // SATD_OUT: a wave takes ONE member of the group (one mode of the pre-screen) for NC
   // consecutive blocks, so every lane runs the same predictor; with the candidates in
   // list order a 16x16 wave held four different modes and paid for all four branches.
+  // LOOPED (the fixed-size pre-screen instantiations): a wave takes ALL the members of the group, one
+  // after the other, for its NC blocks -- the blocks' edges are loaded once (they were loaded once per
+  // mode: 13 times) and the source columns stay in registers across the modes (8 / 16 rows).
+  // 8x8 only: at 16x16 / 32x32 the loop costs registers (131 / 157 VGPRs, 3 waves per SIMD) and the
+  // launch gets 15-25 % slower than one wave per (blocks, member); at 8x8 it is 24 % faster
+  // (gpurun_out/r04_f: 0.243 -> 0.185 ms for 129600 blocks x 13 modes)
+  constexpr bool LOOPED = IN_REGS && R1_PRESCREEN_LOOPED && HLT == 3;
+  constexpr bool SRC_REGS = LOOPED && HLT >= 0 && HLT <= 4;
   long long cand = (long long)blockIdx.x * NC + cl;
   bool live = cand < n;
   long long ecand = cand;             // edge set / block of this candidate
-  if constexpr (SATD_OUT) {
+  if constexpr (LOOPED) {
+    ecand = (long long)blockIdx.x * NC + cl;
+    live = ecand < n / group;
+    cand = ecand * group;
+  } else if constexpr (SATD_OUT) {
     const unsigned bg = blockIdx.x / (unsigned)group, mi = blockIdx.x - bg * (unsigned)group;
     ecand = (long long)bg * NC + cl;
     live = ecand < n / group;
@@ -217,10 +240,19 @@ __global__ __launch_bounds__(64) void k_intra_predict(
   }
   uint16_t *raw = smem + cl * EDGE_LEN;
   uint16_t *work = smem + NC * EDGE_LEN + cl * (4 * FL);   // af0 af1 lf0 lf1
-  R1IntraCand cd = {};
   int left_len = 0, above_len = 0;
+  int32_t sv[SRC_REGS ? (1 << (HLT < 0 ? 0 : HLT)) : 1];   // SRC_REGS: the lane's source column
+  if constexpr (SRC_REGS) {
+#pragma unroll
+    for (int r = 0; r < (1 << (HLT < 0 ? 0 : HLT)); r++) sv[r] = 0;
+    if (live) {
+      const uint8_t *ps = px_addr<BPP>(src, pos_xy[2 * ecand] + c, pos_xy[2 * ecand + 1]);
+      const size_t ss = (size_t)src.stride * BPP;
+#pragma unroll
+      for (int r = 0; r < (1 << (HLT < 0 ? 0 : HLT)); r++) sv[r] = ldp<BPP>(ps + (size_t)r * ss, 0);
+    }
+  }
   if (live) {
-    cd = cands[cand];
     left_len = lens[2 * ecand];
     above_len = lens[2 * ecand + 1];
     const void *e = (const uint8_t *)edges + (size_t)ecand * edge_stride * BPP;
@@ -229,6 +261,14 @@ __global__ __launch_bounds__(64) void k_intra_predict(
       raw[k] = (uint16_t)ldp<BPP>(e, k);
   }
   __syncthreads();
+  const long long cand0 = cand;
+  for (int it = 0; it < (LOOPED ? group : 1); it++) {
+  if constexpr (LOOPED) {
+    cand = cand0 + it;
+    if (it) __syncthreads();     // the previous member's readers of the work arrays are done
+  }
+  R1IntraCand cd = {};
+  if (live) cd = cands[cand];
   const int mode = cd.mode, variant = cd.variant, angle = cd.angle;
   const int32_t smax = (1 << bit_depth) - 1;
   const uint16_t *above = raw + 2 * MAXTX + 1;
@@ -239,6 +279,12 @@ __global__ __launch_bounds__(64) void k_intra_predict(
                                   (size_t)cl * W * H * BPP)
                        : (void *)((uint8_t *)dst + (size_t)cand * W * H * BPP);
 
+  // one predicted pixel of this lane's column (row `i_`)
+#define R1_PUT(i_, v_)                                                   \
+  do {                                                                   \
+    if constexpr (IN_REGS) pv[i_] = (v_);                                \
+    else stp<BPP>(out, (size_t)(i_) * W + c, (v_));                      \
+  } while (0)
   const bool directional = live && mode >= V_PRED && mode <= D67_PRED &&
                            !(mode == V_PRED && angle == 90) && !(mode == H_PRED && angle == 180);
   const bool enable = directional && cd.ief != 0;
@@ -302,7 +348,10 @@ __global__ __launch_bounds__(64) void k_intra_predict(
     __syncthreads();
     if (enable) aedge = af0;
   }
-  if (!live) return;
+  if (!live) {
+    if constexpr (LOOPED) continue;
+    else return;
+  }
 
   // left_edge[k] of the reference (after left_filtered.reverse()) = lf0[FL-1-k];
   // raw case: left_and_left_below_slice[k] = raw[128 - lb_len + k]
@@ -319,6 +368,7 @@ __global__ __launch_bounds__(64) void k_intra_predict(
     else if (angle > 180) dy = kR1DrIntraDerivative[270 - angle];
     const int oa = (enable ? 1 : 0) << up_a, ol = (enable ? 1 : 0) << up_l;
     const int j = c;
+#pragma unroll
     for (int i = 0; i < H; i++) {
       int32_t v;
       if (angle < 90) {
@@ -359,7 +409,7 @@ __global__ __launch_bounds__(64) void k_intra_predict(
         ib = ib < 0 ? 0 : ib;
         v = (ledge(ia) * (32 - shift) + ledge(ib) * shift + 16) >> 5;
       }
-      stp<BPP>(out, (size_t)i * W + j, v < 0 ? 0 : (v > smax ? smax : v));
+      R1_PUT(i, v < 0 ? 0 : (v > smax ? smax : v));
     }
   }
   // ---- non-directional ----
@@ -367,20 +417,24 @@ __global__ __launch_bounds__(64) void k_intra_predict(
   if (directional) {
   } else if (mode == V_PRED) {
     const int32_t a = above[c];
-    for (int r = 0; r < H; r++) stp<BPP>(out, (size_t)r * W + c, a);
+#pragma unroll
+    for (int r = 0; r < H; r++) R1_PUT(r, a);
   } else if (mode == H_PRED) {
-    for (int r = 0; r < H; r++) stp<BPP>(out, (size_t)r * W + c, left_row(r));
+#pragma unroll
+    for (int r = 0; r < H; r++) R1_PUT(r, left_row(r));
   } else if (mode == PAETH_PRED) {
     const int32_t rt = above[c];
+#pragma unroll
     for (int r = 0; r < H; r++) {
       const int32_t rl = left_row(r);
       const int32_t base = rt + rl - top_left;
       const int32_t pl = iabs(base - rl), pt = iabs(base - rt), ptl = iabs(base - top_left);
-      stp<BPP>(out, (size_t)r * W + c, (pl <= pt && pl <= ptl) ? rl : (pt <= ptl ? rt : top_left));
+      R1_PUT(r, (pl <= pt && pl <= ptl) ? rl : (pt <= ptl ? rt : top_left));
     }
   } else if (mode == SMOOTH_PRED || mode == SMOOTH_V_PRED || mode == SMOOTH_H_PRED) {
     const uint32_t below_pred = raw[2 * MAXTX - ls_len], right_pred = above[W - 1];
     const uint32_t a = above[c], wc = kR1SmWeights[W + c];
+#pragma unroll
     for (int r = 0; r < H; r++) {
       const uint32_t lft = (uint32_t)left_row(r), wr = kR1SmWeights[H + r];
       uint32_t p;
@@ -390,7 +444,7 @@ __global__ __launch_bounds__(64) void k_intra_predict(
         p = (wc * lft + (256 - wc) * right_pred + 128) >> 8;
       else
         p = (wr * a + (256 - wr) * below_pred + 128) >> 8;
-      stp<BPP>(out, (size_t)r * W + c, (int32_t)p);
+      R1_PUT(r, (int32_t)p);
     }
   } else {   // DC_PRED / UV_CFL_PRED
     uint32_t avg;
@@ -412,16 +466,19 @@ __global__ __launch_bounds__(64) void k_intra_predict(
     }
     if (mode == UV_CFL_PRED && angle != 0) {
       const int16_t *acb = ac + cand * (W * H);
+#pragma unroll
       for (int r = 0; r < H; r++) {
         const int32_t q6 = (int32_t)(int16_t)angle * (int32_t)acb[r * W + c];
         const int32_t q0 = (iabs(q6) + 32) >> 6;
         const int32_t v = (int32_t)avg + (q6 < 0 ? -q0 : q0);
-        stp<BPP>(out, (size_t)r * W + c, v < 0 ? 0 : (v > smax ? smax : v));
+        R1_PUT(r, v < 0 ? 0 : (v > smax ? smax : v));
       }
     } else {
-      for (int r = 0; r < H; r++) stp<BPP>(out, (size_t)r * W + c, (int32_t)avg);
+#pragma unroll
+      for (int r = 0; r < H; r++) R1_PUT(r, (int32_t)avg);
     }
   }
+#undef R1_PUT
   if constexpr (SATD_OUT) {
     __builtin_amdgcn_wave_barrier();
     const bool small = (W < H ? W : H) == 4;
@@ -438,11 +495,17 @@ __global__ __launch_bounds__(64) void k_intra_predict(
       const int bx = pos_xy[2 * ecand], by = pos_xy[2 * ecand + 1];
       const uint8_t *ps = px_addr<BPP>(src, bx + c, by);
       const size_t ss = (size_t)src.stride * BPP;
+#pragma unroll
       for (int g = 0; g < H; g += 8) {
         int32_t a[8], b[8], d[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-          a[k] = ldp<BPP>(ps + (size_t)(g + k) * ss, 0) - ldp<BPP>(out, (size_t)(g + k) * W + c);
+        for (int k = 0; k < 8; k++) {
+          int32_t pp;
+          if constexpr (IN_REGS) pp = pv[g + k];
+          else pp = ldp<BPP>(out, (size_t)(g + k) * W + c);
+          if constexpr (SRC_REGS) a[k] = sv[g + k] - pp;
+          else a[k] = ldp<BPP>(ps + (size_t)(g + k) * ss, 0) - pp;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           b[2 * k] = a[2 * k] + a[2 * k + 1];
@@ -477,6 +540,7 @@ __global__ __launch_bounds__(64) void k_intra_predict(
     const int ln = small ? 2 : 3;
     if (c == 0) satd_out[cand] = (sum + ((1u << ln) >> 1)) >> ln;
   }
+  }   // members of the group (LOOPED), else one pass
 }
 
 // r1_prescreen_select_batch: one thread per (group, element).  An element's place in the
@@ -693,16 +757,28 @@ extern "C" int r1_intra_satd_batch(r1_ctx *ctx, const R1Plane *src, int tx_size,
   const int NC = 64 / W, FL = 2 * (W + H) + 1;
   const size_t lds = (((size_t)NC * (EDGE_LEN + 4 * FL) * sizeof(uint16_t) + 15) & ~(size_t)15) +
                      (size_t)NC * W * H * src->bytes_per_px;
-  const unsigned grid = (unsigned)((n / group + NC - 1) / NC) * (unsigned)group;   // (block group, member)
+  unsigned grid = (unsigned)((n / group + NC - 1) / NC) * (unsigned)group;   // (block group, member)
+  // the pre-screen's sizes (luma transform blocks 8x8 .. 32x32) with the block size as a constant; at 8x8 a
+  // wave walks the members of its blocks' groups itself
+  const int sq = wl[tx_size] == hl[tx_size] ? wl[tx_size] : 0;
+  if (R1_PRESCREEN_LOOPED && sq == 3) grid /= (unsigned)group;
   hipStream_t st = (hipStream_t)stream;
-  if (src->bytes_per_px == 1)
-    hipLaunchKernelGGL((k_intra_predict<1, true>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
-                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, src->bit_depth,
-                       (void *)nullptr, *src, pos_xy, group, satd_out);
-  else
-    hipLaunchKernelGGL((k_intra_predict<2, true>), dim3(grid), dim3(64), lds, st, (int)wl[tx_size],
-                       (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac, src->bit_depth,
-                       (void *)nullptr, *src, pos_xy, group, satd_out);
+#define R1_SATD_LAUNCH(B, ...)                                                                            \
+  hipLaunchKernelGGL((k_intra_predict<B, true, ##__VA_ARGS__>), dim3(grid), dim3(64), lds, st,            \
+                     (int)wl[tx_size], (int)hl[tx_size], cands, n, edges, edge_stride, lens, ac,          \
+                     src->bit_depth, (void *)nullptr, *src, pos_xy, group, satd_out)
+  if (src->bytes_per_px == 1) {
+    if (sq == 3) R1_SATD_LAUNCH(1, 3, 3);
+    else if (sq == 4) R1_SATD_LAUNCH(1, 4, 4);
+    else if (sq == 5) R1_SATD_LAUNCH(1, 5, 5);
+    else R1_SATD_LAUNCH(1);
+  } else {
+    if (sq == 3) R1_SATD_LAUNCH(2, 3, 3);
+    else if (sq == 4) R1_SATD_LAUNCH(2, 4, 4);
+    else if (sq == 5) R1_SATD_LAUNCH(2, 5, 5);
+    else R1_SATD_LAUNCH(2);
+  }
+#undef R1_SATD_LAUNCH
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }

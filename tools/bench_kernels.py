@@ -271,13 +271,21 @@ def main():
         b = Plane.from_numpy(W.random_plane_array(cw_, ch_, bd, 20 + pli, 44, 44), cw_, ch_, bd, 44, 44)
         planes3.append((a, b, pli, 1, 1))
 
-    def run_filter():
+    rec3, src3 = [a for (a, b, pli, xd, yd) in planes3], [b for (a, b, pli, xd, yd) in planes3]
+
+    def run_filter():          # the frame entry point (one call, what tools/frame_pipeline.py times)
+        ctx.deblock_frame(state, rec3, 1, 1, dblocks, fw, fh)
+
+    def run_filter_planes():   # the per-plane entry point, three calls (what this row timed up to round 3)
         for (a, b, pli, xd, yd) in planes3:
             ctx.deblock_plane(state, a, pli, xd, yd, dblocks, fw, fh)
 
     tall = torch.zeros((3, 2, 65), dtype=torch.int64, device="cuda")
 
     def run_sse():
+        ctx.deblock_sse_frame(rec3, src3, 1, 1, dblocks, fw, fh, tallies=tall)
+
+    def run_sse_planes():
         for (a, b, pli, xd, yd) in planes3:
             ctx.deblock_sse_plane(a, b, pli, xd, yd, dblocks, fw, fh, tallies=tall[pli])
     npx = fw * fh * 3 // 2
@@ -289,9 +297,15 @@ def main():
     ms = timeit_fresh(run_filter, restore)
     report("deblock_filter_frame 4:2:0 (3 planes, in place; fresh pixels every rep)", ms, npx,
            2 * npx * bpp + blocks.size * 8)
+    ms = timeit_fresh(run_filter_planes, restore)
+    report("deblock_filter_frame 4:2:0 through the per-plane entry point (3 calls)", ms, npx,
+           2 * npx * bpp + blocks.size * 8)
     restore()
     ms = timeit(run_sse)
-    report("deblock sse_optimize tallies 4:2:0 (3 planes)", ms, npx, 2 * npx * bpp + blocks.size * 8)
+    report("deblock sse_optimize tallies 4:2:0 (3 planes, frame entry point)", ms, npx, 2 * npx * bpp + blocks.size * 8)
+    ms = timeit(run_sse_planes)
+    report("deblock sse_optimize tallies 4:2:0 through the per-plane entry point (3 calls)", ms, npx,
+           2 * npx * bpp + blocks.size * 8)
     # ---- N3 (last stage): self-guided loop restoration, luma plane, every unit filtered ----
     us = 64
     ucols, urows = max((fw + us // 2) // us, 1), max((fh + us // 2) // us, 1)
