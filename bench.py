@@ -1175,6 +1175,34 @@ def main():
             "kernel_ms_note": "HIP events around each launch of every %dth timed step "
                               "(%d samples per size)" % (EV_EVERY, max([len(v) for v in ev.values()] + [0])),
         }
+        if pixel and world == 1:
+            # The same chain as rav1e's RDO runs it: rdo_tx_size_type -> encode_tx_block -> compute_distortion
+            # (src/rdo.rs:1073, src/encoder.rs:1404-1661, src/rdo.rs:254-347) never takes SAD or SATD of a
+            # candidate -- those belong to the motion search (compute_mv_rd, src/me.rs:1445-1463).  `value` keeps
+            # them (the step the previous rounds timed: the headline candidate carried through the quantizer);
+            # this is the step without them, NULL sad / satd outputs, same launches otherwise.
+            lo = {}
+            for s_, c_ in cands.items():
+                n_ = len(c_)
+                o_ = {"eob": outs[s_]["eob"], "dist": outs[s_]["dist"]}
+                lo[s_] = (lambda s_=s_, n_=n_, o_=o_: ctx.rdo_pixel_cand_batch(
+                    org, ref, s_, s_, dcands[s_], args.qindex, 3, scales=scales, n=n_, outs=o_, want_sad=False,
+                    want_satd=False))
+            for _ in range(args.warmup):
+                for s_ in W.LADDER:
+                    lo[s_]()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                for s_ in W.LADDER:
+                    lo[s_]()
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            res["rdo_only"] = {"value": round(total_px * args.steps / dt1 / 1e6, 2), "unit": "Mpixels/s",
+                               "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                               "note": "the pixel-domain chain without SAD / SATD of the candidate (NULL outputs): what "
+                                       "rdo_tx_size_type -> encode_tx_block -> compute_distortion compute per candidate; "
+                                       "`value` above keeps both (the motion search's distortions ride along)"}
         bad = []
         if world == 1 and not full and not args.no_extra:
             res["extra_lines"] = extra_lines(ctx, args)

@@ -101,17 +101,38 @@ __device__ __forceinline__ void load_row(const uint8_t *p, int kw, int32_t *out)
 // cdef_dist_kernel's fixed-point tail (dist.rs:350-372) + the ssim boost + the
 // DistortionScale of the 8x8 importance block at (px, py), from the five sums
 // of a tile of `area` pixels.
+// BDT: the bit depth when the caller knows it at compile time (8 / 10: sum^2 fits 32 bits), 0 otherwise.
+template <int BDT = 0>
 __device__ __forceinline__ unsigned long long cdef_tile_tail(
     uint32_t sum_s, uint32_t sum_d, uint32_t sum_s2, uint32_t sum_d2, uint32_t sum_sd, int area, int px,
     int py, const uint32_t *__restrict__ scales, int scale_stride, int bit_depth) {
   const uint32_t sse = sum_d2 + sum_s2 - 2 * sum_sd;
-  const unsigned long long div = area_divisor(area);
-  const uint32_t ms = (uint32_t)(((unsigned long long)sum_s * sum_s * div + 8192) >> 14);
-  const uint32_t md = (uint32_t)(((unsigned long long)sum_d * sum_d * div + 8192) >> 14);
-  uint32_t svar = sum_s2 > ms ? sum_s2 - ms : 0;
-  uint32_t dvar = sum_d2 > md ? sum_d2 - md : 0;
-  svar = (uint32_t)(((unsigned long long)svar * div + 128) >> 8);
-  dvar = (uint32_t)(((unsigned long long)dvar * div + 128) >> 8);
+  uint32_t svar, dvar;
+  if ((area & (area - 1)) == 0) {
+    // area = 2^la (every tile of 4 / 8 pixel sides): AREA_DIVISORS[area - 1] = 2^(14 - la) exactly, so
+    //   (x * div + 2^13) >> 14 = (x + area / 2) >> la        and        (v * div + 128) >> 8 = v << (6 - la)
+    // (dist.rs:352-367; "when w and h are powers of two, this can be done via shifting", the reference says)
+    // -- six 64-bit multiplies of the general form become shifts
+    const int la = 31 - __builtin_clz((unsigned)area);
+    uint32_t ms, md;
+    if constexpr (BDT == 8 || BDT == 10) {        // sum <= 64 * 1023: the square fits 32 bits
+      ms = (sum_s * sum_s + (uint32_t)(area >> 1)) >> la;
+      md = (sum_d * sum_d + (uint32_t)(area >> 1)) >> la;
+    } else {
+      ms = (uint32_t)(((unsigned long long)sum_s * sum_s + (unsigned long long)(area >> 1)) >> la);
+      md = (uint32_t)(((unsigned long long)sum_d * sum_d + (unsigned long long)(area >> 1)) >> la);
+    }
+    svar = (sum_s2 > ms ? sum_s2 - ms : 0) << (6 - la);
+    dvar = (sum_d2 > md ? sum_d2 - md : 0) << (6 - la);
+  } else {
+    const unsigned long long div = area_divisor(area);
+    const uint32_t ms = (uint32_t)(((unsigned long long)sum_s * sum_s * div + 8192) >> 14);
+    const uint32_t md = (uint32_t)(((unsigned long long)sum_d * sum_d * div + 8192) >> 14);
+    svar = sum_s2 > ms ? sum_s2 - ms : 0;
+    dvar = sum_d2 > md ? sum_d2 - md : 0;
+    svar = (uint32_t)(((unsigned long long)svar * div + 128) >> 8);
+    dvar = (uint32_t)(((unsigned long long)dvar * div + 128) >> 8);
+  }
   const unsigned long long v = apply_ssim_boost(sse, svar, dvar, bit_depth);
   const unsigned long long sc =
       scales ? scales[(size_t)(py >> 3) * scale_stride + (px >> 3)] : (1u << 14);

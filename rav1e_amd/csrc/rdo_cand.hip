@@ -600,7 +600,9 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
           }
 #pragma unroll
           for (int k = WC; k < W; k++) w_[k] = 0;
+#ifndef R1_STUB_INVR
           r1itx::inv_1d<W, true>(w_, r1tx::htx_1d(tt), lo, hi);
+#endif
         }
       }
       __syncthreads();   // every coefficient has been read: the tile becomes the row buffer
@@ -622,7 +624,9 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         }
 #pragma unroll
         for (int rr = HC; rr < H; rr++) rc[rr] = 0;
+#ifndef R1_STUB_INVC
         r1itx::inv_1d<H, true>(rc, r1tx::vtx_1d(tx_type), lo, hi);
+#endif
 #pragma unroll
         for (int rr = 0; rr < H; rr++) {
           const T pr = BPP == 1 ? (T)((ppk[rr >> 2] >> (8 * (rr & 3))) & 0xFF)
@@ -643,6 +647,9 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         }
       }
       unsigned long long acc = 0;
+#ifdef R1_STUB_DIST   /* timing experiments only (tools/gpu_r4_h.sh): results are wrong */
+      acc = (unsigned long long)(uint32_t)rc[0] + (uint32_t)rc[H - 1];
+#else
       constexpr bool COL_DIST = H <= 16;
       if constexpr (COL_DIST) {
         // ---- H (blocks up to 32 rows): sse_wxh / cdef_dist_wxh with lane = column.  The
@@ -654,8 +661,16 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         const uint8_t *po = px_addr<BPP>(org, cd.ox + (col_live ? c : 0), cd.oy);
         const size_t so = (size_t)org.stride * BPP;
         if (qa.dist_kind == R1_DIST_CDEF) {
+          // the five sums of every tile row first, ONE fixed-point tail afterwards: after the xor-shuffles
+          // all KW lanes of a tile hold its sums, so lane j of the group takes tile row j (16-row blocks have
+          // two) -- the tail (ssim boost in 64-bit arithmetic) used to run once per tile row with one lane
+          // of the group alive
+          constexpr int NR = H / KH;
+          static_assert(NR <= KW, "a tile group has a lane for every tile row");
+          uint32_t S[NR][5];
 #pragma unroll
-          for (int y0 = 0; y0 < H; y0 += KH) {
+          for (int t = 0; t < NR; t++) {
+            const int y0 = t * KH;
             uint32_t sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
             if (col_live) {
 #pragma unroll
@@ -671,10 +686,19 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
               sum_s2 += __shfl_xor(sum_s2, m, 64); sum_d2 += __shfl_xor(sum_d2, m, 64);
               sum_sd += __shfl_xor(sum_sd, m, 64);
             }
-            if (col_live && (c & (KW - 1)) == 0)
-              acc += r1dist::cdef_tile_tail(sum_s, sum_d, sum_s2, sum_d2, sum_sd, KW * KH, cd.ox + c,
-                                            cd.oy + y0, qa.scales, qa.scale_stride, BD);
+            S[t][0] = sum_s; S[t][1] = sum_d; S[t][2] = sum_s2; S[t][3] = sum_d2; S[t][4] = sum_sd;
           }
+          const int j = c & (KW - 1);
+          uint32_t P5[5];
+#pragma unroll
+          for (int q5 = 0; q5 < 5; q5++) {
+            P5[q5] = S[0][q5];
+#pragma unroll
+            for (int t = 1; t < NR; t++) P5[q5] = j == t ? S[t][q5] : P5[q5];
+          }
+          if (col_live && j < NR)
+            acc += r1dist::cdef_tile_tail<BD>(P5[0], P5[1], P5[2], P5[3], P5[4], KW * KH, cd.ox + c - j,
+                                              cd.oy + j * KH, qa.scales, qa.scale_stride, BD);
         } else {
 #pragma unroll
           for (int y0 = 0; y0 < H; y0 += 4) {
@@ -725,6 +749,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
                                                  qa.xdec, qa.ydec, BD);
       }
       }
+#endif
 #pragma unroll
       for (int m = 1; m < P; m <<= 1) {
         const uint32_t lo = __shfl_xor((uint32_t)acc, m, 64);
