@@ -100,7 +100,11 @@ typedef struct r1_ctx r1_ctx;
 int r1_ctx_create(int device, r1_ctx **out);
 void r1_ctx_destroy(r1_ctx *ctx);
 const char *r1_last_error(void);
-/* ABI version, bumped on any incompatible change */
+/* ABI version, bumped on any incompatible change.
+ * 4 (round 4): r1_estimate_tile_motion_batch refuses with R1_ETIMEDOUT while a flagged persistent launch
+ *    has not been acknowledged through r1_me_status; r1_cdef_filter_frame_plane checks luma->bit_depth
+ *    against params->bit_depth and the _dirs variant wants 8-aligned tile_w / tile_h; skip_mi bytes are
+ *    bools (any non-zero value) in the CDEF filter and the strength search alike. */
 int r1_abi_version(void);
 
 /* ---- dist:: (reference: src/dist.rs get_sad 31, get_satd 156; dispatch
