@@ -84,6 +84,9 @@ __device__ unsigned long long g_phase[4096][8];
 #ifndef R1_TX_TILE_I16
 #define R1_TX_TILE_I16 1
 #endif
+#ifndef R1_SRC_PAD
+#define R1_SRC_PAD 1   // A/B switch: the padded source-block stride in LDS (see k_rdo_cand)
+#endif
 // which instantiations keep the source chunks in registers across the filter and stage them over the
 // dead window afterwards (see k_rdo_cand)
 #ifndef R1_SRC_LATE_POLICY
@@ -197,7 +200,12 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   constexpr bool SRC_LATE = SRC_LDS && R1_SRC_LATE_POLICY(BD, P);
   constexpr int SRC_ROW = W * BPP;
   constexpr int WIN_PAD = (WIN_BYTES + 15) & ~15;
-  constexpr int SRC_BYTES = SRC_LDS ? NC * H * SRC_ROW : 0;
+  // A candidate's source block starts max(16, row bytes) past a multiple of its own size: with the bare
+  // stride (16 / 32 / 64 / 128 dwords) the column reads of the NC candidates of a lane group hit the SAME
+  // banks with different addresses -- 2-way at 8-bit 8x8 and at 16x16, 4-way at 10-bit 8x8: this, not the
+  // window staging, was the SQ_LDS_BANK_CONFLICT of those launches (0.18 / 0.30 of the LDS cycles)
+  constexpr int SRC_CSTRIDE = H * SRC_ROW + (NC > 1 && R1_SRC_PAD ? (SRC_ROW > 16 ? SRC_ROW : 16) : 0);
+  constexpr int SRC_BYTES = SRC_LDS ? NC * SRC_CSTRIDE : 0;
   constexpr int SRC_OFF = SRC_LATE ? 0 : WIN_PAD;
   constexpr int WS_BYTES = SRC_LATE ? (WIN_PAD > SRC_BYTES ? WIN_PAD : SRC_BYTES) : WIN_PAD + SRC_BYTES;
   constexpr int LDS_A0 = WS_BYTES > TXB_BYTES ? WS_BYTES : TXB_BYTES;
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
   for (int r = 0; r < H; r++) v[r] = 0;
   const bool col_live = live && c < W;
-  const uint8_t *src_l = smem + SRC_OFF + cl * (H * SRC_ROW) + c * BPP;
+  const uint8_t *src_l = smem + SRC_OFF + cl * SRC_CSTRIDE + c * BPP;
   // A.1: every global load the wave needs goes out before it waits for any of them -- source
   // block, reference window, tap tables depend on the descriptor only (one round trip behind it,
   // not three)
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   // A.2: into LDS
   auto stage_source = [&]() {
     if (live) {
-      uint8_t *sd = smem + SRC_OFF + cl * (H * SRC_ROW) + sch * CHS;
+      uint8_t *sd = smem + SRC_OFF + cl * SRC_CSTRIDE + sch * CHS;
 #pragma unroll
       for (int u = 0; u < SPASS; u++) {
         const int rr = srow + u * RPP;
