@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_fwd_tx(const int16_t *__restrict__ in,
     for (int cg = 0; cg < W; cg += 32)
 #pragma unroll
       for (int k = 0; k < WC; k++)
-        dst[H * cg + k * OS] = (CT)r1tx::shift_fwd(u[k + cg], sh.s[2]);
+        __builtin_nontemporal_store((CT)r1tx::shift_fwd(u[k + cg], sh.s[2]), &dst[H * cg + k * OS]);   // streamed out, never re-read here
   }
 }
 

@@ -84,6 +84,10 @@ __device__ unsigned long long g_phase[4096][8];
 #ifndef R1_TX_TILE_I16
 #define R1_TX_TILE_I16 1
 #endif
+// the coefficient blocks leave with non-temporal stores (see the store loops of k_rdo_cand)
+#ifndef R1_NT_STORE
+#define R1_NT_STORE 1
+#endif
 #ifndef R1_SRC_PAD
 #define R1_SRC_PAD 1   // A/B switch: the padded source-block stride in LDS (see k_rdo_cand)
 #endif
@@ -488,7 +492,13 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
 #pragma unroll
       for (int cg = 0; cg < W; cg += 32)
 #pragma unroll
-        for (int k = 0; k < WC; k++) dst[H * cg + k * OS] = (CT)u[k + cg];
+        for (int k = 0; k < WC; k++) {
+#if R1_NT_STORE
+          __builtin_nontemporal_store((CT)u[k + cg], &dst[H * cg + k * OS]);
+#else
+          dst[H * cg + k * OS] = (CT)u[k + cg];
+#endif
+        }
     }
   } else
   if (coeffs) {   // wave-uniform: kernel argument
@@ -534,9 +544,26 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         uint8_t *dst = gdst + p * CBY + r * CH;
 #pragma unroll
         for (int j = 0; j < NCH; j++) {
+#if R1_NT_STORE
+          // The coefficients are not read again by this launch, and a step writes 0.26 GB (8-bit) / 0.53 GB
+          // (10-bit) of them per ladder size: written through the L2 as ordinary stores they evict the window
+          // rows the K candidates of a block share.  Non-temporal stores (same-box A/B, gpurun_out/r04_ab3):
+          // 8-bit 8x8 launch 0.226 -> 0.206 ms, 10-bit 8x8 0.308 -> 0.232, 10-bit 16x16 0.252 -> 0.221; step
+          // +3.3 % / +11 %.
+          if constexpr (CH == 16) {
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*(const u32x4_t *)(src + j * P * CH), (u32x4_t *)(dst + j * P * CH));
+          } else if constexpr (CH == 8) {
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store(*(const u32x2_t *)(src + j * P * CH), (u32x2_t *)(dst + j * P * CH));
+          } else {
+            __builtin_nontemporal_store(*(const uint32_t *)(src + j * P * CH), (uint32_t *)(dst + j * P * CH));
+          }
+#else
           if constexpr (CH == 16) *(uint4 *)(dst + j * P * CH) = *(const uint4 *)(src + j * P * CH);
           else if constexpr (CH == 8) *(uint2 *)(dst + j * P * CH) = *(const uint2 *)(src + j * P * CH);
           else *(uint32_t *)(dst + j * P * CH) = *(const uint32_t *)(src + j * P * CH);
+#endif
         }
       }
     }
@@ -797,14 +824,15 @@ __global__ __launch_bounds__(64) void k_mc_fast(R1Plane ref, const R1McCand *__r
   else
     mc16_column<W, H, WS, PREP>(win, c, cd.col_frac, cd.row_frac, cd.mode_x, cd.mode_y,
                                 ref.bit_depth, pred);
+  // the predictions stream out (non-temporal: they would only push the reference rows out of the L2)
   if constexpr (PREP || BPP == 2) {
     uint16_t *pp = (uint16_t *)dst + (size_t)cand * W * H + c;
 #pragma unroll
-    for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint16_t)pred[r];
+    for (int r = 0; r < H; r++) __builtin_nontemporal_store((uint16_t)pred[r], &pp[(size_t)r * W]);
   } else {
     uint8_t *pp = (uint8_t *)dst + (size_t)cand * W * H + c;
 #pragma unroll
-    for (int r = 0; r < H; r++) pp[(size_t)r * W] = (uint8_t)pred[r];
+    for (int r = 0; r < H; r++) __builtin_nontemporal_store((uint8_t)pred[r], &pp[(size_t)r * W]);
   }
 }
 
