@@ -405,6 +405,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       for (int r = 0; r < H; r++) sad += (uint32_t)iabs32(v[r]);
     }
     const uint32_t s = group_sum<P>(sad);
+    // (non-temporal here too was tried: no difference, gpurun_out/r04_ab4 -- 8 bytes per candidate)
     if (live_st && c == 0) (sad_out + (size_t)blockIdx.x * NC)[cl] = s;
   }
   if (satd_out) {
