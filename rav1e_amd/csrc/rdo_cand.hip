@@ -88,6 +88,9 @@ __device__ unsigned long long g_phase[4096][8];
 #ifndef R1_NT_STORE
 #define R1_NT_STORE 1
 #endif
+#ifndef R1_SRC_KEEP
+#define R1_SRC_KEEP 1   // A/B switch (see k_rdo_cand)
+#endif
 #ifndef R1_SRC_PAD
 #define R1_SRC_PAD 1   // A/B switch: the padded source-block stride in LDS (see k_rdo_cand)
 #endif
@@ -210,12 +213,18 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   // window staging, was the SQ_LDS_BANK_CONFLICT of those launches (0.18 / 0.30 of the LDS cycles)
   constexpr int SRC_CSTRIDE = H * SRC_ROW + (NC > 1 && R1_SRC_PAD ? (SRC_ROW > 16 ? SRC_ROW : 16) : 0);
   constexpr int SRC_BYTES = SRC_LDS ? NC * SRC_CSTRIDE : 0;
-  constexpr int SRC_OFF = SRC_LATE ? 0 : WIN_PAD;
-  constexpr int WS_BYTES = SRC_LATE ? (WIN_PAD > SRC_BYTES ? WIN_PAD : SRC_BYTES) : WIN_PAD + SRC_BYTES;
+  // SRC_KEEP (pixel-domain chain, blocks up to 16 rows): the staged source block sits BEHIND the work area
+  // that the later phases alias (transpose tile, quantizer tile, row buffer), so the distortion at the end of
+  // the chain reads its source column from LDS again instead of issuing H more global loads per lane
+  constexpr bool SRC_KEEP = R1_SRC_KEEP && QM == 2 && H <= 16 && SRC_LDS && !SRC_LATE;
+  constexpr int WS_BYTES = SRC_KEEP ? WIN_PAD
+                                    : (SRC_LATE ? (WIN_PAD > SRC_BYTES ? WIN_PAD : SRC_BYTES) : WIN_PAD + SRC_BYTES);
   constexpr int LDS_A0 = WS_BYTES > TXB_BYTES ? WS_BYTES : TXB_BYTES;
   constexpr int LDS_A = LDS_A0 > IRB_BYTES ? LDS_A0 : IRB_BYTES;
   constexpr int LDS_B = QT_BYTES > REC_BYTES ? QT_BYTES : REC_BYTES;
-  constexpr int LDS_BYTES = LDS_A > LDS_B ? LDS_A : LDS_B;
+  constexpr int LDS_WORK = ((LDS_A > LDS_B ? LDS_A : LDS_B) + 15) & ~15;
+  constexpr int SRC_OFF = SRC_KEEP ? LDS_WORK : (SRC_LATE ? 0 : WIN_PAD);
+  constexpr int LDS_BYTES = LDS_WORK + (SRC_KEEP ? SRC_BYTES : 0);
   __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
   T *buf = (T *)smem;
   TB *tbuf = (TB *)smem;
@@ -512,9 +521,9 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     // per wave.  64x64 32-bit coefficients (16 KB) go in two halves (k < 32, k >= 32), which
     // are contiguous halves of the output.
     constexpr int ESZ = (int)sizeof(CT);
-    constexpr int NP = NC * W * H * ESZ > LDS_BYTES ? 2 : 1;
+    constexpr int NP = NC * W * H * ESZ > LDS_WORK ? 2 : 1;
     static_assert(NP == 1 || W == 64, "only the 64-wide blocks are split");
-    static_assert(NC * W * H * ESZ / NP <= LDS_BYTES, "a pass fits the LDS of the kernel");
+    static_assert(NC * W * H * ESZ / NP <= LDS_WORK, "a pass fits the LDS of the kernel");
     constexpr int EPP = W * H / NP;                 // elements of one candidate per pass
     constexpr int CBY = EPP * ESZ;                  // bytes of one candidate per pass
     constexpr int CH = CBY / P >= 16 ? 16 : CBY / P;   // bytes a lane moves per step
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     // 8x8 / 16x16) the NC candidates of a lane group hit the same banks with their element
     // writes (4-way at 8x8: SQ_LDS_BANK_CONFLICT 4.1 M -> 20.7 M per launch when this path came in)
     constexpr int TPAD = NC > 1 ? ((P * ESZ + 15) & ~15) / ESZ : 0;
-    static_assert(NC * (EPP + TPAD) * ESZ <= LDS_BYTES, "the padded tiles fit the LDS of the kernel");
+    static_assert(NC * (EPP + TPAD) * ESZ <= LDS_WORK, "the padded tiles fit the LDS of the kernel");
     static_assert(((EPP + TPAD) * ESZ) % 16 == 0, "16-byte reads stay aligned");
     CT *tile = (CT *)smem + cl2 * (EPP + TPAD);
     uint8_t *gdst = (uint8_t *)(coeffs + (size_t)blockIdx.x * (NC * W * H)) + cl2 * (W * H * ESZ);
@@ -711,7 +720,11 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
             if (col_live) {
 #pragma unroll
               for (int rr = 0; rr < KH; rr++) {
-                const uint32_t sv = (uint32_t)ld_px<BPP>(po + (y0 + rr) * so), dv = (uint32_t)rc[y0 + rr];
+                uint32_t sv;
+                if constexpr (SRC_KEEP) sv = BPP == 1 ? (uint32_t)src_l[(y0 + rr) * SRC_ROW]
+                                                      : (uint32_t) * (const uint16_t *)(src_l + (y0 + rr) * SRC_ROW);
+                else sv = (uint32_t)ld_px<BPP>(po + (y0 + rr) * so);
+                const uint32_t dv = (uint32_t)rc[y0 + rr];
                 sum_s += sv; sum_d += dv;
                 sum_s2 += sv * sv; sum_d2 += dv * dv; sum_sd += sv * dv;
               }
@@ -742,7 +755,11 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
             if (col_live) {
 #pragma unroll
               for (int rr = 0; rr < 4; rr++) {
-                const int32_t d = ld_px<BPP>(po + (y0 + rr) * so) - (int32_t)rc[y0 + rr];
+                int32_t sv;
+                if constexpr (SRC_KEEP) sv = BPP == 1 ? (int32_t)src_l[(y0 + rr) * SRC_ROW]
+                                                      : (int32_t) * (const uint16_t *)(src_l + (y0 + rr) * SRC_ROW);
+                else sv = ld_px<BPP>(po + (y0 + rr) * so);
+                const int32_t d = sv - (int32_t)rc[y0 + rr];
                 cell += (uint32_t)(d * d);
               }
             }
