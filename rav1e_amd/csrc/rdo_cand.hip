@@ -88,6 +88,9 @@ __device__ unsigned long long g_phase[4096][8];
 #ifndef R1_NT_STORE
 #define R1_NT_STORE 1
 #endif
+#ifndef R1_XCD_REMAP
+#define R1_XCD_REMAP 1   // A/B switch (see k_rdo_cand)
+#endif
 #ifndef R1_SRC_KEEP
 #define R1_SRC_KEEP 1   // A/B switch (see k_rdo_cand)
 #endif
@@ -230,12 +233,25 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   TB *tbuf = (TB *)smem;
 
   R1_PROF_INIT;
+  // Workgroup -> candidate group, XCD-aware.  The dispatcher deals workgroups round-robin over the 8 XCDs
+  // (workgroup i runs on XCD i % 8), each with its own L2.  Consecutive candidate groups belong to the same
+  // block (the K candidates of a block sit next to each other in the list and share the source block and
+  // most of their reference windows): in dispatch order they would land on 8 different L2s and each would
+  // fetch the window rows again.  So XCD x takes the x-th contiguous eighth of the list: workgroup i works on
+  // group (i % 8) * (grid / 8) + i / 8 (the host rounds the grid up to a multiple of 8; groups past the
+  // list end return).  Same-box A/B: profiles/r04_ab_notes.md, ab5.
+#if R1_XCD_REMAP
+  const unsigned wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if ((long long)wg * NC >= (long long)n) return;
+#else
+  const unsigned wg = blockIdx.x;
+#endif
   const int lane = threadIdx.x;
   const int cl = lane / P, c = lane % P;
   // n < 2^31 candidates: the liveness test and the lane-local parts of every address are 32-bit;
-  // what is 64-bit is the workgroup's base (blockIdx.x * per-workgroup bytes), which the scalar
+  // what is 64-bit is the workgroup's base (wg * per-workgroup bytes), which the scalar
   // unit computes
-  const int cand_i = (int)blockIdx.x * NC + cl;
+  const int cand_i = (int)wg * NC + cl;
   const long long cand = cand_i;
   // Only STORES look at whether this lane's candidate exists (live_st).  The dead slots of the
   // launch's last wave load and compute the launch's last candidate once more: no masked regions,
@@ -247,10 +263,10 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   constexpr bool UNMASK = R1_UNMASK_POLICY(BD, WL, HL);
   const bool live_st = cand_i < n;
   const bool live = UNMASK || live_st;
-  const int cl_ld = live_st ? cl : n - 1 - (int)blockIdx.x * NC;     // >= 0: the wave's first candidate exists
+  const int cl_ld = live_st ? cl : n - 1 - (int)wg * NC;     // >= 0: the wave's first candidate exists
   const long long cand_ld = live_st ? cand : (long long)n - 1;
   R1RdoCand cd = {};
-  if (live) cd = (cands + (size_t)blockIdx.x * NC)[cl_ld];
+  if (live) cd = (cands + (size_t)wg * NC)[cl_ld];
 #ifdef R1_PHASE_PROF
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   R1_PROF(5);   // A0: descriptor round trip
@@ -415,12 +431,12 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     }
     const uint32_t s = group_sum<P>(sad);
     // (non-temporal here too was tried: no difference, gpurun_out/r04_ab4 -- 8 bytes per candidate)
-    if (live_st && c == 0) (sad_out + (size_t)blockIdx.x * NC)[cl] = s;
+    if (live_st && c == 0) (sad_out + (size_t)wg * NC)[cl] = s;
   }
   if (satd_out) {
     const uint32_t s = group_sum<P>(satd_column<TS, H, BD>(v, lane));
     constexpr int LN = TS == 4 ? 2 : 3;
-    if (live_st && c == 0) (satd_out + (size_t)blockIdx.x * NC)[cl] = (s + ((1u << LN) >> 1)) >> LN;
+    if (live_st && c == 0) (satd_out + (size_t)wg * NC)[cl] = (s + ((1u << LN) >> 1)) >> LN;
   }
   R1_PROF(2);   // B2: SAD + SATD
   if (!QUANT && !coeffs) return;   // wave-uniform: kernel argument
@@ -498,7 +514,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     // large blocks: direct element stores (measured: the LDS detour costs more than the
     // 16-byte stores save at 32x32 and 64x64, profiles/r02_wide_store_ab.log)
     if (coeffs && row_live && live_st) {
-      CT *dst = coeffs + (size_t)blockIdx.x * (NC * W * H) + (cl2 * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31));
+      CT *dst = coeffs + (size_t)wg * (NC * W * H) + (cl2 * (W * H) + (r >= 32 ? OS * WC : 0) + (r & 31));
 #pragma unroll
       for (int cg = 0; cg < W; cg += 32)
 #pragma unroll
@@ -536,7 +552,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     static_assert(NC * (EPP + TPAD) * ESZ <= LDS_WORK, "the padded tiles fit the LDS of the kernel");
     static_assert(((EPP + TPAD) * ESZ) % 16 == 0, "16-byte reads stay aligned");
     CT *tile = (CT *)smem + cl2 * (EPP + TPAD);
-    uint8_t *gdst = (uint8_t *)(coeffs + (size_t)blockIdx.x * (NC * W * H)) + cl2 * (W * H * ESZ);
+    uint8_t *gdst = (uint8_t *)(coeffs + (size_t)wg * (NC * W * H)) + cl2 * (W * H * ESZ);
 #pragma unroll
     for (int p = 0; p < NP; p++) {
       __syncthreads();   // rows are in registers (pass 0) / the previous half has been copied out
@@ -877,7 +893,11 @@ int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n
   constexpr int W = 1 << WL, H = 1 << HL, P = W > H ? W : H, NC = 64 / P;
   typedef typename std::conditional<BD == 8, int16_t, int32_t>::type CT;
   const unsigned groups = (unsigned)((n + NC - 1) / NC);
+#if R1_XCD_REMAP
+  const unsigned grid = (groups + 7u) & ~7u;     // whole rounds over the 8 XCDs (see the kernel's `wg`)
+#else
   const unsigned grid = groups;
+#endif
   hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, QM>), dim3(grid), dim3(64), 0, st,
                      org, ref, cands, n, sad, satd, (CT *)coeffs, pred, qa ? *qa : RdoQuantArgs{});
   R1_HIP_CHECK(hipGetLastError());
