@@ -12,6 +12,8 @@ Runs only where the reference tree is present (the build container); the GPU box
   src/cdef.rs      check_max_element                                (:628-660)
   src/quantize/mod.rs  test_divu_pair, test_tx_log_scale, gen_divu_table  (:159-216)
   src/transform/mod.rs log_tx_ratios                                (:521-552)
+  src/activity.rs  overflow_test (ssim_boost, :193-216);  src/partition.rs from_wh_matches_naive
+  src/tiling/tiler.rs  test_tiling_info_from_tile_count, from_target_tiles_422, tile_log2_overflow (:277-860)
   src/transform/mod.rs roundtrips_u8 / roundtrips_u16               (:479-618; forward_transform ->
                        inverse_transform_add, 44 (size, type) pairs each, the authors' tolerances;
                        `rand::random::<u8>()` is a seeded generator, get_func as in gen_rdo_glue_ref.py)
@@ -34,6 +36,10 @@ CASES = [
     ("quantize/mod.rs", "test_divu_pair"), ("quantize/mod.rs+transform/mod.rs", "test_tx_log_scale"),
     ("quantize/mod.rs", "gen_divu_table"),
     ("transform/mod.rs", "log_tx_ratios"),
+    ("activity.rs", "overflow_test"),
+    ("partition.rs", "from_wh_matches_naive"),
+    ("tiling/tiler.rs", "test_tiling_info_from_tile_count"), ("tiling/tiler.rs", "from_target_tiles_422"),
+    ("tiling/tiler.rs", "tile_log2_overflow"),
 ]
 
 
@@ -120,6 +126,49 @@ def test_roundtrip_harness_catches_a_broken_inverse_driver():
     infos.insert(0, infos.pop())
     with pytest.raises(R.Panic):
         c.get("roundtrips_u8")({})
+
+
+def test_tile_rects_equal_the_executed_tiling_info():
+    """rav1e_amd/workload.py::tile_rects (what shards the frame over the GPUs, SURVEY 8e) against the
+    reference's TilingInfo::from_target_tiles EXECUTED (src/tiling/tiler.rs:56-150) inside the tile-count
+    loop of Sequence::new (src/encoder.rs:248-277, eight lines, restated here): same grid, same tile
+    sizes in superblocks, for the frame sizes and tile counts of BASELINE.json and a sweep around them."""
+    sys.path.insert(0, ROOT)
+    from rav1e_amd import workload as W
+    c = crate_with_tests("tiling/tiler.rs")
+    ftt = c.get("from_target_tiles", owner="TilingInfo")
+
+    def reference_tiling(w, h, tiles):
+        rl = cl = 0
+        while True:
+            t = ftt({}, 6, w, h, 60.0, cl, rl, False)
+            if t.rows * t.cols >= tiles:
+                return t
+            if not (rl < t.max_tile_rows_log2 or cl < t.max_tile_cols_log2):
+                return t
+            if (t.tile_height_sb >= t.tile_width_sb and t.tile_rows_log2 < t.max_tile_rows_log2) or \
+                    cl >= t.max_tile_cols_log2:
+                rl += 1
+            else:
+                cl += 1
+    n = 0
+    for (w, h) in ((3840, 2160), (1920, 1080), (1280, 720), (4096, 2304), (640, 360), (3840, 2176), (1000, 600)):
+        for tiles in (1, 2, 4, 8, 16):
+            t = reference_tiling(w, h, tiles)
+            try:
+                rects = W.tile_rects(tiles, w, h)
+            except ValueError:
+                assert t.rows * t.cols != tiles, (w, h, tiles)      # the reference lands on another count too
+                continue
+            assert t.rows * t.cols == tiles, (w, h, tiles, t.cols, t.rows)
+            want = []
+            for r in range(t.rows):
+                for cc in range(t.cols):
+                    x0, y0 = cc * t.tile_width_sb * 64, r * t.tile_height_sb * 64
+                    want.append((x0, y0, min(x0 + t.tile_width_sb * 64, w), min(y0 + t.tile_height_sb * 64, h)))
+            assert rects == want, (w, h, tiles, rects[:3], want[:3])
+            n += 1
+    assert n >= 25, n
 
 
 def test_a_wrong_expectation_is_caught():

@@ -704,6 +704,9 @@ class FnCompiler:
                      "wrapping_shr", "rem_euclid", "div_euclid", "align_power_of_two",
                      "align_power_of_two_and_shift", "to_owned", "copied", "isqrt"):
                 return rt
+            if n in ("unwrap", "expect", "unwrap_or", "unwrap_or_default", "unwrap_unchecked") and \
+                    isinstance(rt, tuple) and rt[0] == "opt":
+                return rt[1]                                   # Option<T>::unwrap() -> T
             if n in ("get_unchecked", "get_unchecked_mut") and isinstance(rt, tuple) and rt[0] == "arr" and \
                     e.args and self.strip(self.ty(e.args[0])) in INT:
                 return ("ref", rt[1], n.endswith("mut"))     # slice.get_unchecked(i) -> &T
