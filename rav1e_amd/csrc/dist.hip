@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void k_dist(R1Plane org, R1Plane ref,
                                               int n, uint32_t *__restrict__ out) {
   __shared__ uint32_t wave_part[4];
   const int tid = threadIdx.x;
-  const long long gt = (long long)blockIdx.x * 256 + tid;  // global tile id
+  // XCD-aware: workgroup i runs on XCD i % 8; XCD x takes the x-th contiguous eighth of the tile list, so the
+  // K candidates of a block (same source tile, overlapping reference tiles) meet in ONE L2 (grid = multiple of 8)
+  const unsigned wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long long gt = (long long)wg * 256 + tid;  // global tile id
   const int cand = (int)(gt >> tpc_log2);
   const int t = (int)(gt & ((1 << tpc_log2) - 1));
   const bool live = cand < n;
@@ -63,7 +66,7 @@ int launch_dist(int kind, const R1Plane &org, const R1Plane &ref, int w, int h,
                 const R1DistCand *cands, int n, uint32_t *out, hipStream_t st) {
   const int wt_log2 = r1_ilog2(w / TS), tpc_log2 = wt_log2 + r1_ilog2(h / TS);
   const long long tiles = (long long)n << tpc_log2;
-  const unsigned grid = (unsigned)((tiles + 255) / 256);
+  const unsigned grid = ((unsigned)((tiles + 255) / 256) + 7u) & ~7u;   // whole rounds over the 8 XCDs
   if (kind == R1_DIST_SAD)
     hipLaunchKernelGGL((k_dist<BPP, TS, false>), dim3(grid), dim3(256), 0, st,
                        org, ref, wt_log2, tpc_log2, cands, n, out);

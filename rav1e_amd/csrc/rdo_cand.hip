@@ -842,7 +842,9 @@ __global__ __launch_bounds__(64) void k_mc_fast(R1Plane ref, const R1McCand *__r
   __shared__ __attribute__((aligned(16))) uint8_t smem[NC * (H + 7) * WS];
   const int lane = threadIdx.x;
   const int cl = lane / P, c = lane % P;
-  const long long cand = (long long)blockIdx.x * NC + cl;
+  // XCD-aware like k_rdo_cand: XCD x takes the x-th contiguous eighth of the list (grid = multiple of 8)
+  const unsigned wg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long long cand = (long long)wg * NC + cl;
   const bool live = cand < n;
   R1McCand cd = {};
   if (live) cd = cands[cand];
@@ -874,7 +876,7 @@ template <int BPP, int WL, int HL>
 int launch_mc_fast(bool prep, const R1Plane &ref, const R1McCand *cands, int n, void *dst,
                    hipStream_t st) {
   constexpr int W = 1 << WL, H = 1 << HL, P = W > H ? W : H, NC = 64 / P;
-  const unsigned grid = (unsigned)((n + NC - 1) / NC);
+  const unsigned grid = ((unsigned)((n + NC - 1) / NC) + 7u) & ~7u;
   if (prep)
     hipLaunchKernelGGL((k_mc_fast<BPP, WL, HL, true>), dim3(grid), dim3(64), 0, st, ref, cands, n, dst);
   else
