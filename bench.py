@@ -320,7 +320,9 @@ def launch_pmc(key):
 def rdo_launch_key(bd, size, qm, n):
     lg = {64: 6, 32: 5, 16: 4, 8: 3, 4: 2}[size]
     nc = 64 // size
-    return ("k_rdo_cand<%d,%d,%d,%s,%d>" % (bd, lg, lg, "short" if bd == 8 else "int", qm), ((n + nc - 1) // nc) * 64)
+    # the grid is rounded up to a multiple of 8 workgroups (XCD-aware mapping, csrc/rdo_cand.hip)
+    return ("k_rdo_cand<%d,%d,%d,%s,%d>" % (bd, lg, lg, "short" if bd == 8 else "int", qm),
+            ((((n + nc - 1) // nc) + 7) & ~7) * 64)
 
 
 def build_roofline(kname, abytes, launch_ms, pmc, pmc_src, mix, working_set=None, write_bytes=None,
@@ -631,7 +633,8 @@ def config_lines(ctx, args):
             fns.append((tag, lambda kind=kind, sz=sz, dev=dev, n=len(c), out=out: ctx.dist_batch(kind, po, pr, sz, sz, dev, n=n, out=out)))
             abytes[tag] = (2 * sz * sz + 4) * len(c)
             wbytes[tag] = 4 * len(c)
-            kkeys[tag] = ("k_dist<1,8,%s>" % ("true" if kind else "false"), ((len(c) * (sz // 8) ** 2 + 255) // 256) * 256)
+            kkeys[tag] = ("k_dist<1,8,%s>" % ("true" if kind else "false"),
+                          ((((len(c) * (sz // 8) ** 2 + 255) // 256) + 7) & ~7) * 256)
             px += len(c) * sz * sz
             chk.append((kind, sz, dcand, out))
     per, step = timed(fns)
@@ -698,7 +701,7 @@ def config_lines(ctx, args):
         lg_ = sz.bit_length() - 1
         for nm_, pf_ in (("put", "false"), ("prep", "true")):
             kkeys["%s %dx%d" % (nm_, sz, sz)] = ("k_mc_fast<1,%d,%d,%s>" % (lg_, lg_, pf_),
-                                                ((len(c) + 64 // sz - 1) // (64 // sz)) * 64)
+                                                ((((len(c) + 64 // sz - 1) // (64 // sz)) + 7) & ~7) * 64)
         px += 2 * len(c) * sz * sz
         chk.append((sz, mc, o_put, o_prep))
     per, step = timed(fns)
