@@ -64,6 +64,11 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps for this long BEFORE the W warm-up steps, so that short runs "
                          "(small W and K) are measured at the clocks a long run settles at; 0 = off")
+    ap.add_argument("--exchange", choices=("auto", "push", "p2p"), default="auto",
+                    help="N > 1: how tiles travel.  push = direct peer stores into IPC-mapped planes "
+                         "(r1_comm_push_*), p2p = grouped RCCL send / receive (r1_comm_exchange_halos + "
+                         "r1_comm_allgather_tiles); auto = push if every rank can map its peers' planes and "
+                         "the tagged-tile check passes through it, else p2p")
     ap.add_argument("--verify-exchange", action="store_true",
                     help="N = 1: run the tagged-tile self-check of the exchange through the C-ABI communicator "
                          "(world 1) as the N > 1 runs always do; the result is config.exchange_ok")
@@ -930,35 +935,41 @@ def main():
         except Exception as e:   # keep the scaling run alive; the JSON says which path ran
             exch_note = "torch.distributed all_gather_into_tensor (C-ABI comm failed: %s)" % (str(e)[:80],)
             send, gathered = tiles.make_exchange_buffers(ref.data, rank, world)
+    push_why = None   # why the peer-store exchange is not the one in use (None: it is, or N = 1)
 
     full = args.chain != "cand"
     pixel = args.chain == "pixel"
     if pixel:
         scales = torch.from_numpy(np.random.default_rng(9).integers(
             1 << 12, 1 << 16, ((fh + 7) // 8, (fw + 7) // 8)).astype(np.int32)).cuda()
-        launches = {}
-        for s, c in cands.items():
-            n = len(c)
-            if not n:
-                continue
+    for s, c in cands.items():
+        n = len(c)
+        if pixel and n:
             del outs[s]["coeffs"]
             outs[s].update(eob=torch.empty(n, dtype=torch.int16, device="cuda"),
                            dist=torch.empty(n, dtype=torch.int64, device="cuda"))
-            launches[s] = (lambda s=s, n=n: ctx.rdo_pixel_cand_batch(
-                org, ref, s, s, dcands[s], args.qindex, 3, scales=scales, n=n, outs=outs[s]))
-    elif full:
-        for s, c in cands.items():
-            n = len(c)
+        elif full and not pixel:
             del outs[s]["coeffs"]
             outs[s].update(eob=torch.empty(n, dtype=torch.int16, device="cuda"),
                            tx_dist=torch.empty(n, dtype=torch.int64, device="cuda"),
                            est_rate=torch.empty(n, dtype=torch.int64, device="cuda"))
-        launches = {s: ctx.prepare_rdo_full_cand(org, ref, s, s, dcands[s], len(cands[s]),
-                                                 args.qindex, outs[s])
+
+    def build_launches(refp):
+        """one callable per ladder size: the step's launch of that size reading reference plane `refp`"""
+        if pixel:
+            return {s: (lambda s=s, n=len(c): ctx.rdo_pixel_cand_batch(
+                        org, refp, s, s, dcands[s], args.qindex, 3, scales=scales, n=n, outs=outs[s]))
+                    for s, c in cands.items() if len(c)}
+        if full:
+            return {s: ctx.prepare_rdo_full_cand(org, refp, s, s, dcands[s], len(cands[s]), args.qindex, outs[s])
                     for s in cands if len(cands[s])}
-    else:
-        launches = {s: ctx.prepare_rdo_cand(org, ref, s, s, dcands[s], len(cands[s]), outs[s])
-                    for s in cands if len(cands[s])}
+        return {s: ctx.prepare_rdo_cand(org, refp, s, s, dcands[s], len(cands[s]), outs[s])
+                for s in cands if len(cands[s])}
+    launches = build_launches(ref)
+    # N > 1 with the exchange as peer stores: the reconstruction of a step goes into the OTHER plane of
+    # a two-plane ring (a new buffer per frame, as in the reference), so nobody stores into a plane
+    # a peer may still be reading; ring[cur[0]] is the plane the step's launches read
+    ring, ring_launches, ring_peers, cur = [ref], [launches], [], [0]
 
     def abytes_per_cand(s):
         if pixel:  # window + source (read twice: residual, distortion) + sad/satd/eob/dist
@@ -998,7 +1009,7 @@ def main():
             for s in W.LADDER:
                 if len(cands[s]):
                     with torch.cuda.stream(size_streams[s]):
-                        launches[s]()
+                        ring_launches[cur[0]][s]()
         else:
             for st in size_streams.values():
                 main.wait_stream(st)
@@ -1012,7 +1023,7 @@ def main():
                 if mark:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                launches[s]()
+                ring_launches[cur[0]][s]()
                 if mark:
                     e1.record()
                     ev[s].append((e0, e1))
@@ -1025,11 +1036,20 @@ def main():
                 main.wait_stream(st)
             # stand-in for the reconstruction write: this rank's tile of the plane differs every
             # step, so the exchange never moves bytes the peers already hold
-            my_tile.bitwise_xor_(1)
-            if comm is not None:
+            if ring_peers:
+                # peer stores: the new tile goes into the other plane of the ring, its borders and
+                # then the whole tile straight into the peers' copies of that plane
+                nxt = cur[0] ^ 1
+                torch.bitwise_xor(ring_tiles[cur[0]], 1, out=ring_tiles[nxt])
+                ring_peers[nxt].push_halos(rects)
+                ring_peers[nxt].push_tile(rects)
+                cur[0] = nxt
+            elif comm is not None:
+                my_tile.bitwise_xor_(1)
                 comm.exchange_tile_halos(ref, rects)
                 comm.allgather_tiles(ref, rects)
             else:
+                my_tile.bitwise_xor_(1)
                 tiles.exchange_rows(send, gathered)
             if split:
                 xe[2].record()
@@ -1054,7 +1074,78 @@ def main():
     exchange_ok = None
     if world > 1 or args.verify_exchange:
         vrects = rects if rects is not None else W.tile_rects(world, fw, fh)
-        if world > 1 and comm is None:
+        # the communicator the exchange goes through: the run's own; at N = 1 one made for the check;
+        # None when the C-ABI communicator could not be made at N > 1 (RCCL missing, or the dry run
+        # with every rank on one GPU) -- peer stores then hand-shake through the host
+        vcomm = comm if comm is not None else (tiles.Comm(ctx, rank, world) if world == 1 else None)
+        mine_ok = None
+        if args.exchange in ("auto", "push"):
+            # the exchange as direct peer stores (csrc/comm.hip r1_comm_push_*): both planes of the
+            # ring mapped on every rank, then the same tagged-tile check through the stores.  In
+            # use only if EVERY rank mapped and verified; otherwise the RCCL p2p exchange below.
+            def host_barrier():
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+
+            def all_agree(ok):
+                flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda")
+                if world > 1:
+                    torch.cuda.synchronize()
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return flag.item() == 1.0
+            push_ok = None
+            ring.append(Plane.from_numpy(host_ref, fw, fh, bd, 88, 88))
+            # mapping is a collective per plane: every rank learns whether everybody mapped before
+            # anyone enters the next one (a rank that failed alone would leave the others inside it)
+            for pl in ring:
+                try:
+                    ring_peers.append(tiles.PeerPlanes(ctx, pl, rank, world, comm=vcomm))
+                except Exception as e:   # noqa: BLE001 -- keep the run alive on the other exchange
+                    push_why = "%s" % (str(e)[:120],)
+                if not all_agree(push_why is None):
+                    push_why = push_why or "another rank could not map its peers' planes"
+                    break
+            try:
+                if push_why is not None:
+                    raise RuntimeError(push_why)
+                push_ok = {"halo": True, "gather": True}
+                for pl, pp in zip(ring, ring_peers):
+                    v = tiles.verify_exchange(pl, vrects, rank, world, lambda: pp.push_halos(vrects),
+                                              lambda: pp.push_tile(vrects), pre=host_barrier)
+                    push_ok = {k: push_ok[k] and v[k] for k in push_ok}
+                if not all(push_ok.values()):
+                    push_why = "tagged tiles did not arrive: %s" % (push_ok,)
+            except Exception as e:   # noqa: BLE001
+                push_why = "%s" % (str(e)[:120],)
+                push_ok = None
+            if all_agree(push_why is None):
+                mine_ok = push_ok
+                through = "peer stores (r1_comm_push_*), both planes of the ring"
+                ring_launches.append(build_launches(ring[1]))
+                ring_tiles = [pl.data[pl.yorigin + vrects[rank][1]:pl.yorigin + vrects[rank][3],
+                                      pl.xorigin + vrects[rank][0]:pl.xorigin + vrects[rank][2]] for pl in ring]
+                exch_note = None if world == 1 else (
+                             "r1_comm_push_halos (64 px) + r1_comm_push_tile per step: peer stores into "
+                             "IPC-mapped planes (two-plane ring) + %s" %
+                             ("r1_comm_barrier, in stream order" if vcomm is not None else
+                              "a host hand-shake (stream synchronize + torch.distributed barrier: no C-ABI communicator)"))
+            else:
+                push_why = push_why or "another rank could not use it"
+                host_barrier()                   # nobody unmaps while a peer may still store
+                for pp in ring_peers:
+                    pp.close()
+                del ring_peers[:], ring[1:]
+        if (mine_ok is None or world == 1) and vcomm is not None:
+            p2p_ok = tiles.verify_exchange(ref, vrects, rank, world,
+                                           lambda: vcomm.exchange_tile_halos(ref, vrects),
+                                           lambda: vcomm.allgather_tiles(ref, vrects))
+            if mine_ok is None:
+                mine_ok, through = p2p_ok, "RCCL p2p (r1_comm_exchange_halos + r1_comm_allgather_tiles)"
+            else:   # world 1: both sets of entry points go through their (peerless) motions
+                mine_ok = {k: mine_ok[k] and p2p_ok[k] for k in mine_ok}
+                through += " and RCCL p2p"
+        elif mine_ok is None:
             # the torch.distributed fallback moves row slabs of the allocation, no halo leg: a rank's
             # slab of the painted plane must arrive as it left (checked through the gathered buffer)
             rows, lo, hi = tiles.owned_rows(ref.data.shape[0], rank, world)
@@ -1065,20 +1156,21 @@ def main():
             send.zero_()
             send[: hi - lo] = ref.data[lo:hi]
             mine_ok = {"halo": None, "gather": ok}
-        else:
-            vcomm = comm if comm is not None else tiles.Comm(ctx, rank, world)
-            mine_ok = tiles.verify_exchange(ref, vrects, rank, world,
-                                            lambda: vcomm.exchange_tile_halos(ref, vrects),
-                                            lambda: vcomm.allgather_tiles(ref, vrects))
-            if comm is None:
-                vcomm.close()
+            through = "torch.distributed row slabs"
+        if world == 1:
+            for pp in ring_peers:
+                pp.close()
+            del ring_peers[:], ring[1:], ring_launches[1:]
+            vcomm.close()
         flags = torch.tensor([1.0 if mine_ok[k] in (True, None) else 0.0 for k in ("halo", "gather")],
                              dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(flags, op=dist.ReduceOp.MIN)
         exchange_ok = {"halo": None if mine_ok["halo"] is None else bool(flags[0].item() == 1.0),
                        "gather": None if mine_ok["gather"] is None else bool(flags[1].item() == 1.0),
-                       "checked_on": "every rank (MIN over ranks)" if world > 1 else "rank 0 (world 1: no peers)"}
+                       "checked_on": "every rank (MIN over ranks)" if world > 1 else "rank 0 (world 1: no peers)",
+                       "through": through,
+                       "peer_stores_not_used_because": push_why}
         fence()
     prewarm_steps = 0
     if args.prewarm_ms > 0:
@@ -1123,7 +1215,7 @@ def main():
                     "samples": len(xev),
                     "note": "HIP events on every %dth timed step (launches on one stream in those steps): "
                             "compute = the step's launches, exchange = stand-in reconstruction write + "
-                            "r1_comm_exchange_halos + r1_comm_allgather_tiles; max over ranks" % EV_EVERY}
+                            "the exchange config.exchange names; max over ranks" % EV_EVERY}
 
     if rank == 0:
         per = {}
@@ -1223,6 +1315,11 @@ def main():
         if bad:
             print("PARITY FAILURE at block sizes %s" % bad, file=sys.stderr)
             sys.exit(3)
+    if ring_peers:
+        torch.cuda.synchronize()
+        dist.barrier()                       # nobody unmaps a plane a peer may still store into
+        for pp in ring_peers:
+            pp.close()
     if comm is not None:
         comm.close()
     if world > 1:

@@ -788,6 +788,43 @@ int r1_comm_allgather_tiles(r1_comm *comm, const R1Plane *plane, const int32_t *
 int r1_comm_exchange_halos(r1_comm *comm, const R1Plane *plane, const R1HaloXfer *xfers, int n,
                            void *stream);
 
+/* ---- the same exchange as direct peer stores (an addition: the ABI version stays 4).  xGMI is a load / store fabric: once a
+ * peer's plane is mapped into this process, a kernel stores this rank's rectangles straight into
+ * it -- N - 1 links at once, no staging copy, nothing to unpack.  Planes have the same geometry on
+ * every rank.  The destination must not be a plane a peer may still be reading: the
+ * reconstruction of a frame is a new buffer (src/encoder.rs:3322), so rotate two. */
+typedef struct R1IpcMem {
+  uint8_t handle[64];      /* hipIpcMemHandle_t of the allocation */
+  uint64_t offset;         /* of the exported range inside it */
+  uint64_t bytes;
+} R1IpcMem;
+typedef struct R1PushRect {
+  int32_t peer;            /* index into peer_data */
+  int32_t x0, y0, x1, y1;  /* plane pixels, visible-area coordinates, half-open */
+} R1PushRect;
+/* device memory of this process (any offset inside a hipMalloc allocation) as 80 bytes another
+ * process maps with r1_ipc_open; the bytes travel by whatever channel the host has */
+int r1_ipc_export(r1_ctx *ctx, const void *ptr, size_t bytes, R1IpcMem *out);
+int r1_ipc_open(r1_ctx *ctx, const R1IpcMem *mem, void **ptr);
+int r1_ipc_close(r1_ctx *ctx, void *ptr);
+/* stores rects[i] of `plane` into the same rectangle of the plane at peer_data[rects[i].peer]
+ * (one launch per 16 rectangles, enqueued on `stream`; no hand-shake) */
+int r1_push_rects(r1_ctx *ctx, const R1Plane *plane, void *const *peer_data, int n_peers,
+                  const R1PushRect *rects, int n, void *stream);
+/* with a communicator: every rank's plane mapped on every rank (peer_data: `world` entries,
+ * [rank] = plane->data; the exports travel in one all-gather; blocking, once per plane) */
+int r1_comm_open_peer_planes(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void **peer_data);
+int r1_comm_close_peer_planes(r1_comm *comm, r1_ctx *ctx, void **peer_data);
+/* stream-ordered hand-shake (a 4-byte all-reduce): what follows on `stream` starts after every
+ * rank's stream reached this call */
+int r1_comm_barrier(r1_comm *comm, void *stream);
+/* r1_comm_allgather_tiles / r1_comm_exchange_halos as peer stores + r1_comm_barrier (of the
+ * xfers list only the dir == 0 entries are used: a rank's receives are its peers' stores) */
+int r1_comm_push_tile(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
+                      const int32_t *rects4, void *stream);
+int r1_comm_push_halos(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
+                       const R1HaloXfer *xfers, int n, void *stream);
+
 /* ---- per-call compat shims: reference asm signatures, HOST pointers ----
  * SadFn / SatdFn (src/asm/x86/dist/mod.rs:21-43): strides in BYTES. */
 uint32_t rav1e_sad_hip(const uint8_t *src, ptrdiff_t src_stride,

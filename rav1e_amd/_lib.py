@@ -96,6 +96,15 @@ SYMBOLS = {
     "r1_comm_allgather": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "r1_comm_exchange_halos": (_i, [_vp, _PP, _vp, _i, _vp]),
     "r1_comm_allgather_tiles": (_i, [_vp, _PP, _vp, _vp]),
+    "r1_ipc_export": (_i, [_vp, _vp, _sz, _vp]),
+    "r1_ipc_open": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "r1_ipc_close": (_i, [_vp, _vp]),
+    "r1_push_rects": (_i, [_vp, _PP, _vp, _i, _vp, _i, _vp]),
+    "r1_comm_open_peer_planes": (_i, [_vp, _vp, _PP, _vp]),
+    "r1_comm_close_peer_planes": (_i, [_vp, _vp, _vp]),
+    "r1_comm_barrier": (_i, [_vp, _vp]),
+    "r1_comm_push_tile": (_i, [_vp, _vp, _PP, _vp, _vp, _vp]),
+    "r1_comm_push_halos": (_i, [_vp, _vp, _PP, _vp, _vp, _i, _vp]),
     "r1_rdo_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "r1_rdo_full_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, C.POINTER(R1QuantParams),
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -41,6 +41,8 @@ struct RcclApi {
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  // optional (r1_comm_barrier): a library without it still serves the exchange entry points
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   bool ok = false;
 };
 
@@ -92,6 +94,7 @@ RcclApi *rccl_api() {
     R1_SYM(Recv, "ncclRecv");
     R1_SYM(GroupStart, "ncclGroupStart");
     R1_SYM(GroupEnd, "ncclGroupEnd");
+    R1_SYM(AllReduce, "ncclAllReduce");
 #undef R1_SYM
     if (a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GetErrorString && a.AllGather && a.Send && a.Recv &&
         a.GroupStart && a.GroupEnd) {
@@ -122,6 +125,7 @@ struct r1_comm {
   hipEvent_t pack_done;
   hipStream_t pack_stream;
   bool pack_used;
+  int32_t *flag;   // r1_comm_barrier's two words
 };
 
 #define R1_NCCL_CHECK(api, expr)                                                   \
@@ -173,6 +177,7 @@ extern "C" int r1_comm_create(r1_ctx *ctx, int rank, int world, const uint8_t *i
   c->pack_done = nullptr;
   c->pack_stream = nullptr;
   c->pack_used = false;
+  c->flag = nullptr;
   if (hipEventCreateWithFlags(&c->pack_done, hipEventDisableTiming) != hipSuccess) {
     r1_set_error("r1_comm_create: hipEventCreate failed");
     delete c;
@@ -195,6 +200,7 @@ extern "C" void r1_comm_destroy(r1_comm *c) {
   if (hipGetDevice(&prev) == hipSuccess && prev != c->device) (void)hipSetDevice(c->device);
   (void)c->api->CommDestroy(c->nccl);
   if (c->pack) (void)hipFree(c->pack);
+  if (c->flag) (void)hipFree(c->flag);
   if (c->pack_done) (void)hipEventDestroy(c->pack_done);
   if (prev >= 0 && prev != c->device) (void)hipSetDevice(prev);
   delete c;
@@ -396,4 +402,268 @@ extern "C" int r1_comm_allgather_tiles(r1_comm *c, const R1Plane *plane, const i
                                   hipMemcpyDeviceToDevice, st));
   }
   return R1_OK;
+}
+
+// ---- direct peer stores: a rank writes its rectangles straight into the peers' planes --------
+// xGMI is a load / store fabric: a kernel on GPU a can store into GPU b's HBM once b's allocation
+// is mapped here (hipIpcOpenMemHandle).  With every rank's plane mapped on every other rank, the
+// tile gather is ONE kernel per rank that stores the finished tile into the N - 1 peers' planes
+// (N - 1 links at once, no staging copy on either side, nothing to unpack), and the halo exchange
+// is the same kernel on the border rectangles.  What RCCL keeps is the hand-shake: a 4-byte
+// all-reduce (r1_comm_barrier) behind the stores -- it completes on a rank only after every rank's
+// stream reached it, i.e. after every rank's store kernel finished, and the kernels a rank enqueues
+// behind it start with the plane complete (kernel boundaries are where a GPU's L2s are written
+// back and invalidated).  The DESTINATION must not be a plane a peer may still be reading: the
+// reconstruction of frame k is a new buffer in the reference (src/encoder.rs:3322 hands it to the
+// reference slots afterwards), so the host rotates two planes and needs no barrier before the stores
+// (rav1e_amd/tiles.py PeerPlanes; bench.py).
+namespace {
+constexpr int R1_PUSH_MAX = 16;      // rectangles per launch (the kernel argument carries them)
+constexpr uint32_t R1_PUSH_ROWS = 4; // rows of a rectangle per workgroup
+struct PushRect {
+  uint8_t *dst;
+  const uint8_t *src;
+  uint32_t row_bytes, rows, head, first_wg;
+};
+struct PushArgs {
+  PushRect r[R1_PUSH_MAX];
+  int n;
+  uint32_t pitch;
+};
+
+__global__ __launch_bounds__(256) void k_push_rects(const PushArgs a) {
+  int ri = 0;
+  while (ri + 1 < a.n && blockIdx.x >= a.r[ri + 1].first_wg) ri++;
+  const PushRect r = a.r[ri];
+  const uint32_t row0 = (blockIdx.x - r.first_wg) * R1_PUSH_ROWS;
+  const uint32_t nrows = min(R1_PUSH_ROWS, r.rows - row0);
+  const uint8_t *src = r.src + (size_t)row0 * a.pitch;
+  uint8_t *dst = r.dst + (size_t)row0 * a.pitch;
+  // a row = `head` bytes up to the first 16-byte boundary (source and destination have the same
+  // phase, the host checked), 16-byte words, the remaining bytes
+  const uint32_t body = (r.row_bytes - r.head) >> 4;
+  const uint32_t edge = r.row_bytes - (body << 4);   // head + tail bytes of a row
+  for (uint32_t i = threadIdx.x; i < nrows * body; i += 256) {
+    const uint32_t y = i / body, v = i - y * body;
+    const size_t o = (size_t)y * a.pitch + r.head + ((size_t)v << 4);
+    *(uint4 *)(dst + o) = *(const uint4 *)(src + o);
+  }
+  for (uint32_t i = threadIdx.x; i < nrows * edge; i += 256) {
+    const uint32_t y = i / edge, e = i - y * edge;
+    const size_t o = (size_t)y * a.pitch + (e < r.head ? e : (body << 4) + e);
+    dst[o] = src[o];
+  }
+}
+
+// peer mappings of this process: pointer handed out -> base of the mapping (what hipIpcCloseMemHandle wants)
+std::mutex g_ipc_mu;
+std::vector<std::pair<void *, void *>> g_ipc_open;
+}  // namespace
+
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "R1IpcMem carries the handle as 64 bytes");
+
+// `ptr` .. ptr + bytes (device memory of this process, any offset inside a hipMalloc allocation, a
+// PyTorch caching-allocator block for instance) as 80 bytes another process can map.
+extern "C" int r1_ipc_export(r1_ctx *ctx, const void *ptr, size_t bytes, R1IpcMem *out) {
+  R1_REQUIRE(ctx && ptr && bytes && out);
+  R1DeviceGuard guard(ctx);
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  R1_HIP_CHECK(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr));
+  const size_t off = (const uint8_t *)ptr - (const uint8_t *)base;
+  R1_REQUIRE(off + bytes <= size);
+  hipIpcMemHandle_t h;
+  R1_HIP_CHECK(hipIpcGetMemHandle(&h, base));
+  memcpy(out->handle, &h, 64);
+  out->offset = off;
+  out->bytes = bytes;
+  return R1_OK;
+}
+
+// Maps a peer process's exported memory on the context's device; *ptr addresses the exported
+// range.  (Not for memory of the calling process: HIP refuses to open its own handles.)
+extern "C" int r1_ipc_open(r1_ctx *ctx, const R1IpcMem *mem, void **ptr) {
+  R1_REQUIRE(ctx && mem && ptr);
+  R1DeviceGuard guard(ctx);
+  hipIpcMemHandle_t h;
+  memcpy(&h, mem->handle, 64);
+  void *base = nullptr;
+  R1_HIP_CHECK(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+  *ptr = (uint8_t *)base + mem->offset;
+  std::lock_guard<std::mutex> lk(g_ipc_mu);
+  g_ipc_open.emplace_back(*ptr, base);
+  return R1_OK;
+}
+
+extern "C" int r1_ipc_close(r1_ctx *ctx, void *ptr) {
+  R1_REQUIRE(ctx && ptr);
+  void *base = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_ipc_mu);
+    for (size_t i = 0; i < g_ipc_open.size(); i++)
+      if (g_ipc_open[i].first == ptr) {
+        base = g_ipc_open[i].second;
+        g_ipc_open.erase(g_ipc_open.begin() + i);
+        break;
+      }
+  }
+  if (!base) {
+    r1_set_error("r1_ipc_close: %p was not returned by r1_ipc_open", ptr);
+    return R1_EINVAL;
+  }
+  R1DeviceGuard guard(ctx);
+  R1_HIP_CHECK(hipIpcCloseMemHandle(base));
+  return R1_OK;
+}
+
+// rects[i]: the rectangle (visible-area pixels) of `plane` to store into peer_data[rects[i].peer]
+// -- the data pointer of a plane with the SAME geometry (stride, origins, pixel size) on a peer,
+// mapped with r1_ipc_open (or a second plane of this process).  One launch per 16 rectangles.
+extern "C" int r1_push_rects(r1_ctx *ctx, const R1Plane *plane, void *const *peer_data, int n_peers,
+                             const R1PushRect *rects, int n, void *stream) {
+  R1_REQUIRE(ctx && plane && plane->data && (n == 0 || (rects && peer_data)) && n >= 0);
+  const int bpp = plane->bytes_per_px;
+  R1_REQUIRE(bpp == 1 || bpp == 2);
+  const size_t pitch = (size_t)plane->stride * bpp;
+  R1_REQUIRE(pitch < (1ull << 32));
+  for (int i = 0; i < n; i++) {
+    const R1PushRect &q = rects[i];
+    R1_REQUIRE(q.peer >= 0 && q.peer < n_peers && peer_data[q.peer]);
+    R1_REQUIRE(peer_data[q.peer] != plane->data);
+    R1_REQUIRE(rect_in_plane(plane, q.x0, q.y0, q.x1, q.y1));
+  }
+  R1DeviceGuard guard(ctx);
+  for (int i0 = 0; i0 < n; i0 += R1_PUSH_MAX) {
+    PushArgs a;
+    a.n = n - i0 < R1_PUSH_MAX ? n - i0 : R1_PUSH_MAX;
+    a.pitch = (uint32_t)pitch;
+    uint32_t wgs = 0;
+    for (int j = 0; j < a.n; j++) {
+      const R1PushRect &q = rects[i0 + j];
+      const size_t o = ((size_t)(plane->yorigin + q.y0) * plane->stride + (size_t)(plane->xorigin + q.x0)) * bpp;
+      PushRect &r = a.r[j];
+      r.src = (const uint8_t *)plane->data + o;
+      r.dst = (uint8_t *)peer_data[q.peer] + o;
+      r.row_bytes = (uint32_t)(q.x1 - q.x0) * bpp;
+      r.rows = (uint32_t)(q.y1 - q.y0);
+      const bool same_phase = (((uintptr_t)r.src ^ (uintptr_t)r.dst) & 15) == 0 && (pitch & 15) == 0;
+      const uint32_t to16 = (uint32_t)(-(intptr_t)(uintptr_t)r.src & 15);
+      r.head = (!same_phase || to16 > r.row_bytes) ? r.row_bytes : to16;
+      r.first_wg = wgs;
+      wgs += (r.rows + R1_PUSH_ROWS - 1) / R1_PUSH_ROWS;
+    }
+    hipLaunchKernelGGL(k_push_rects, dim3(wgs), dim3(256), 0, (hipStream_t)stream, a);
+    R1_HIP_CHECK(hipGetLastError());
+  }
+  return R1_OK;
+}
+
+// Every rank's `plane` (same geometry everywhere) mapped on every rank: peer_data[r] = rank r's
+// plane as this rank addresses it (peer_data[rank] = plane->data itself).  The 80-byte exports
+// travel in one all-gather.  Blocking (done once per plane, not per frame).
+extern "C" int r1_comm_open_peer_planes(r1_comm *c, r1_ctx *ctx, const R1Plane *plane, void **peer_data) {
+  R1_REQUIRE(c && ctx && plane && plane->data && peer_data && ctx->device == c->device);
+  for (int r = 0; r < c->world; r++) peer_data[r] = nullptr;
+  peer_data[c->rank] = plane->data;
+  if (c->world == 1) return R1_OK;
+  const size_t bytes = (size_t)plane->stride * plane->alloc_height * plane->bytes_per_px;
+  // every rank takes part in the all-gather whatever failed locally (a rank that returned early
+  // would leave the others inside the collective); a failed export travels as bytes == 0
+  R1IpcMem mine;
+  memset(&mine, 0, sizeof(mine));
+  int rc = r1_ipc_export(ctx, plane->data, bytes, &mine);
+  if (rc != R1_OK) memset(&mine, 0, sizeof(mine));
+  CommDeviceGuard guard(c);
+  R1IpcMem *dev = nullptr;
+  std::vector<R1IpcMem> all(c->world);
+  R1_HIP_CHECK(hipMalloc((void **)&dev, sizeof(R1IpcMem) * (c->world + 1)));
+  hipError_t he = hipMemcpy(dev + c->world, &mine, sizeof(mine), hipMemcpyHostToDevice);
+  ncclResult_t nr = ncclSuccess;
+  if (he == hipSuccess) {
+    nr = c->api->AllGather(dev + c->world, dev, sizeof(R1IpcMem), ncclUint8, c->nccl, (hipStream_t) nullptr);
+    if (nr == ncclSuccess) he = hipStreamSynchronize(nullptr);
+    if (nr == ncclSuccess && he == hipSuccess)
+      he = hipMemcpy(all.data(), dev, sizeof(R1IpcMem) * c->world, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(dev);
+  if (nr != ncclSuccess) {
+    r1_set_error("r1_comm_open_peer_planes: %s", c->api->GetErrorString(nr));
+    return R1_ECOMM;
+  }
+  if (he != hipSuccess) {
+    r1_set_error("r1_comm_open_peer_planes: %s", hipGetErrorString(he));
+    return R1_EHIP;
+  }
+  for (int r = 0; r < c->world && rc == R1_OK; r++) {
+    if (r == c->rank) continue;
+    if (all[r].bytes != bytes) {
+      r1_set_error("r1_comm_open_peer_planes: rank %d exported %llu bytes, this rank's plane has %llu", r,
+                   (unsigned long long)all[r].bytes, (unsigned long long)bytes);
+      rc = R1_ECOMM;
+    } else {
+      rc = r1_ipc_open(ctx, &all[r], &peer_data[r]);
+    }
+  }
+  if (rc != R1_OK) (void)r1_comm_close_peer_planes(c, ctx, peer_data);
+  return rc;
+}
+
+extern "C" int r1_comm_close_peer_planes(r1_comm *c, r1_ctx *ctx, void **peer_data) {
+  R1_REQUIRE(c && ctx && peer_data);
+  int rc = R1_OK;
+  for (int r = 0; r < c->world; r++) {
+    if (r != c->rank && peer_data[r]) {
+      const int e = r1_ipc_close(ctx, peer_data[r]);
+      if (e != R1_OK) rc = e;
+    }
+    peer_data[r] = nullptr;
+  }
+  return rc;
+}
+
+// Stream-ordered hand-shake: returns at once; the work enqueued on `stream` behind it starts only
+// after every rank's stream reached its r1_comm_barrier (a 4-byte all-reduce).
+extern "C" int r1_comm_barrier(r1_comm *c, void *stream) {
+  R1_REQUIRE(c);
+  if (c->world == 1) return R1_OK;
+  if (!c->api->AllReduce) {
+    r1_set_error("r1_comm_barrier: %s has no ncclAllReduce", c->api->path.c_str());
+    return R1_ECOMM;
+  }
+  CommDeviceGuard guard(c);
+  if (!c->flag) {
+    R1_HIP_CHECK(hipMalloc((void **)&c->flag, 8));
+    R1_HIP_CHECK(hipMemset(c->flag, 0, 8));
+  }
+  R1_NCCL_CHECK(c->api, c->api->AllReduce(c->flag, c->flag + 1, 1, ncclInt32, ncclSum, c->nccl, (hipStream_t)stream));
+  return R1_OK;
+}
+
+// The tile gather by peer stores: this rank's tile (rects4[4 rank ..]) into every peer's plane,
+// then the hand-shake.  peer_data from r1_comm_open_peer_planes for THIS plane.
+extern "C" int r1_comm_push_tile(r1_comm *c, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
+                                 const int32_t *rects4, void *stream) {
+  R1_REQUIRE(c && ctx && plane && peer_data && rects4);
+  const int32_t *q = rects4 + 4 * c->rank;
+  std::vector<R1PushRect> rects;
+  for (int r = 0; r < c->world; r++)
+    if (r != c->rank) rects.push_back(R1PushRect{r, q[0], q[1], q[2], q[3]});
+  const int rc = r1_push_rects(ctx, plane, peer_data, c->world, rects.data(), (int)rects.size(), stream);
+  return rc != R1_OK ? rc : r1_comm_barrier(c, stream);
+}
+
+// The halo exchange by peer stores: the dir == 0 (send) entries of the same list
+// r1_comm_exchange_halos takes are stored into the peers' planes (the receives are the peers'
+// sends), then the hand-shake.
+extern "C" int r1_comm_push_halos(r1_comm *c, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
+                                  const R1HaloXfer *xfers, int n, void *stream) {
+  R1_REQUIRE(c && ctx && plane && peer_data && (n == 0 || xfers));
+  std::vector<R1PushRect> rects;
+  for (int i = 0; i < n; i++) {
+    R1_REQUIRE(xfers[i].dir == 0 || xfers[i].dir == 1);
+    R1_REQUIRE(xfers[i].peer >= 0 && xfers[i].peer < c->world && xfers[i].peer != c->rank);
+    if (xfers[i].dir == 0) rects.push_back(R1PushRect{xfers[i].peer, xfers[i].x0, xfers[i].y0, xfers[i].x1, xfers[i].y1});
+  }
+  const int rc = r1_push_rects(ctx, plane, peer_data, c->world, rects.data(), (int)rects.size(), stream);
+  return rc != R1_OK ? rc : r1_comm_barrier(c, stream);
 }

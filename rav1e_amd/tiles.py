@@ -105,7 +105,123 @@ class Comm:
         return len(x)
 
 
-def verify_exchange(plane, rects, rank, world, do_halos, do_gather, halo=None):
+IPC_MEM = np.dtype([("handle", "u1", (64,)), ("offset", "<u8"), ("bytes", "<u8")])
+PUSH_RECT = np.dtype([("peer", "<i4"), ("x0", "<i4"), ("y0", "<i4"), ("x1", "<i4"), ("y1", "<i4")])
+assert IPC_MEM.itemsize == 80 and PUSH_RECT.itemsize == 20
+
+
+class PeerPlanes:
+    """Every rank's copy of one plane (same geometry everywhere) mapped into this process, for the
+    exchange as direct peer stores (csrc/comm.hip: r1_push_rects and friends): push_tile stores
+    this rank's tile into every peer's plane, push_halos the border rectangles of tile_halo_plan,
+    each followed by the hand-shake.
+
+    comm given: the exports travel through the C ABI's communicator and the hand-shake is
+    r1_comm_barrier (stream-ordered, RCCL).  comm None: the exports travel through
+    torch.distributed (`group`; any backend) and the hand-shake is a stream synchronize + a
+    torch.distributed barrier -- the form the tests use to drive the stores between two processes
+    that share ONE GPU, where RCCL refuses to form a communicator."""
+
+    def __init__(self, ctx, plane, rank, world, comm=None, group=None):
+        from . import _lib
+        self.lib = _lib.load()
+        self.ctx, self.plane, self.rank, self.world, self.comm, self.group = ctx, plane, rank, world, comm, group
+        self.ptrs = (C.c_void_p * world)()
+        p = plane.cstruct()
+        if comm is not None:
+            self._check(self.lib.r1_comm_open_peer_planes(comm.h, ctx.h, C.byref(p), self.ptrs),
+                        "r1_comm_open_peer_planes")
+        else:
+            mine = np.zeros(1, IPC_MEM)
+            nbytes = plane.data.numel() * plane.data.element_size()
+            rc = self.lib.r1_ipc_export(ctx.h, plane.data.data_ptr(), nbytes, mine.ctypes.data)
+            err = None if rc == 0 else "r1_ipc_export: " + self.lib.r1_last_error().decode()
+            box = [None] * world
+            if world > 1:
+                dist.all_gather_object(box, None if err else mine.tobytes(), group=group)
+            else:
+                box[0] = None if err else mine.tobytes()
+            if any(b is None for b in box):
+                raise RuntimeError(err or "r1_ipc_export failed on rank(s) %s"
+                                   % [i for i, b in enumerate(box) if b is None])
+            self.ptrs[rank] = plane.data.data_ptr()
+            for r in range(world):
+                if r == rank:
+                    continue
+                m = np.frombuffer(box[r], IPC_MEM).copy()
+                if int(m["bytes"][0]) != nbytes:
+                    err = err or "rank %d exported %d bytes, this rank's plane has %d" % (r, int(m["bytes"][0]), nbytes)
+                    continue
+                out = C.c_void_p()
+                if self.lib.r1_ipc_open(ctx.h, m.ctypes.data, C.byref(out)) != 0:
+                    err = err or "r1_ipc_open(rank %d): %s" % (r, self.lib.r1_last_error().decode())
+                    continue
+                self.ptrs[r] = out.value
+            if err:
+                self.close()
+                raise RuntimeError(err)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.r1_last_error().decode()))
+
+    def close(self):
+        if self.ptrs is None:
+            return
+        if self.comm is not None:
+            self.lib.r1_comm_close_peer_planes(self.comm.h, self.ctx.h, self.ptrs)
+        else:
+            for r in range(self.world):
+                if r != self.rank and self.ptrs[r]:
+                    self.lib.r1_ipc_close(self.ctx.h, self.ptrs[r])
+                self.ptrs[r] = None
+        self.ptrs = None
+
+    def _handshake(self):
+        torch.cuda.current_stream().synchronize()
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    def push_tile(self, rects):
+        """this rank's tile into every peer's plane; afterwards (in stream order with comm, on
+        return without) every rank's plane holds every tile"""
+        st = torch.cuda.current_stream().cuda_stream
+        p = self.plane.cstruct()
+        if self.comm is not None:
+            r4 = np.ascontiguousarray(np.array(rects, np.int32).reshape(-1))
+            self._check(self.lib.r1_comm_push_tile(self.comm.h, self.ctx.h, C.byref(p), self.ptrs,
+                                                   r4.ctypes.data, st), "r1_comm_push_tile")
+            return
+        x = np.zeros(self.world - 1, PUSH_RECT)
+        for i, r in enumerate(q for q in range(self.world) if q != self.rank):
+            x[i] = (r,) + tuple(int(v) for v in rects[self.rank])
+        self._check(self.lib.r1_push_rects(self.ctx.h, C.byref(p), self.ptrs, self.world,
+                                           x.ctypes.data, len(x), st), "r1_push_rects")
+        self._handshake()
+
+    def push_halos(self, rects, halo=None):
+        """the border rectangles of tile_halo_plan into the neighbours' planes"""
+        halo = POSTFILTER_HALO if halo is None else halo
+        st = torch.cuda.current_stream().cuda_stream
+        p = self.plane.cstruct()
+        sends, _ = tile_halo_plan(rects, self.rank, halo, self.plane.width, self.plane.height)
+        if self.comm is not None:
+            x = np.zeros(len(sends), HALO_XFER)
+            for i, (peer, r) in enumerate(sends):
+                x[i] = (peer, 0, r[0], r[1], r[2], r[3])
+            self._check(self.lib.r1_comm_push_halos(self.comm.h, self.ctx.h, C.byref(p), self.ptrs,
+                                                    x.ctypes.data, len(x), st), "r1_comm_push_halos")
+            return len(x)
+        x = np.zeros(len(sends), PUSH_RECT)
+        for i, (peer, r) in enumerate(sends):
+            x[i] = (peer, r[0], r[1], r[2], r[3])
+        self._check(self.lib.r1_push_rects(self.ctx.h, C.byref(p), self.ptrs, self.world,
+                                           x.ctypes.data, len(x), st), "r1_push_rects")
+        self._handshake()
+        return len(x)
+
+
+def verify_exchange(plane, rects, rank, world, do_halos, do_gather, halo=None, pre=None):
     """Self-check of the exchange before a multi-GPU run is timed: did the bytes land where the
     tile grid says?  Every rank paints its own tile of `plane` with its tag (rank + 1; the rest of
     the visible area with 0 = nobody), runs the halo exchange and checks that the `halo`-pixel
@@ -113,6 +229,8 @@ def verify_exchange(plane, rects, rank, world, do_halos, do_gather, halo=None):
     tile gather and checks every tile of the frame.  The plane's contents are restored.
     do_halos / do_gather: callables that run the exchange on the current stream (None: that
     leg is not part of the path in use, e.g. the torch.distributed fallback has no halo leg).
+    pre: called after painting, before the exchange (a host barrier when the exchange is peer
+    stores: a rank's paint must not run over what a faster peer already stored into its plane).
     -> dict(halo=bool | None, gather=bool | None) for THIS rank; the caller reduces over ranks."""
     halo = POSTFILTER_HALO if halo is None else halo
     saved = plane.data.clone()
@@ -127,6 +245,10 @@ def verify_exchange(plane, rects, rank, world, do_halos, do_gather, halo=None):
         vis.zero_()
         x0, y0, x1, y1 = rects[rank]
         vis[y0:y1, x0:x1] = rank + 1
+        if pre is not None:
+            # peer stores write into OTHER ranks' planes: nobody stores before everybody painted
+            sync()
+            pre()
     res = {"halo": None, "gather": None}
     try:
         if do_halos is not None:

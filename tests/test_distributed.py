@@ -323,7 +323,9 @@ def _worker_rccl(rank, world, port, q):
         truth = W.random_plane_array(fw, fh, 8, 77)               # what every rank must end up with
         mine = np.zeros_like(truth)
         x0, y0, x1, y1 = rects[rank]
-        mine[88 + y0:88 + y1, 88 + x0:88 + x1] = truth[88 + y0:88 + y1, 88 + x0:88 + x1]
+        geo = Plane(fw, fh, 8, 88, 88, device="cpu")
+        xo, yo = geo.xorigin, geo.yorigin          # the visible area's origin inside the allocation
+        mine[yo + y0:yo + y1, xo + x0:xo + x1] = truth[yo + y0:yo + y1, xo + x0:xo + x1]
         ctx = Context(rank)
         dp = Plane.from_numpy(mine, fw, fh, 8, 88, 88)
         comm = tiles.Comm(ctx, rank, world)
@@ -332,16 +334,24 @@ def _worker_rccl(rank, world, port, q):
         torch.cuda.synchronize()
         got = dp.data.cpu().numpy()
         ex = tiles.expanded_rect(rects[rank], tiles.POSTFILTER_HALO, fw, fh)
-        ok_halo = np.array_equal(got[88 + ex[1]:88 + ex[3], 88 + ex[0]:88 + ex[2]],
-                                 truth[88 + ex[1]:88 + ex[3], 88 + ex[0]:88 + ex[2]])
+        ok_halo = np.array_equal(got[yo + ex[1]:yo + ex[3], xo + ex[0]:xo + ex[2]],
+                                 truth[yo + ex[1]:yo + ex[3], xo + ex[0]:xo + ex[2]])
         comm.allgather_tiles(dp, rects)
         torch.cuda.synchronize()
         got = dp.data.cpu().numpy()
-        ok_all = np.array_equal(got[88:88 + fh, 88:88 + fw], truth[88:88 + fh, 88:88 + fw])
+        ok_all = np.array_equal(got[yo:yo + fh, xo:xo + fw], truth[yo:yo + fh, xo:xo + fw])
         # bench.py's pre-run self-check on the same communicator, and the plane back as it was
         v = tiles.verify_exchange(dp, rects, rank, world, lambda: comm.exchange_tile_halos(dp, rects),
                                   lambda: comm.allgather_tiles(dp, rects))
         ok_all = ok_all and v == {"halo": True, "gather": True} and np.array_equal(dp.data.cpu().numpy(), got)
+        # the same exchange as direct peer stores through the communicator (planes mapped over IPC,
+        # r1_comm_barrier as the hand-shake)
+        pp = tiles.PeerPlanes(ctx, dp, rank, world, comm=comm)
+        v = tiles.verify_exchange(dp, rects, rank, world, lambda: pp.push_halos(rects),
+                                  lambda: pp.push_tile(rects), pre=dist.barrier)
+        ok_all = ok_all and v == {"halo": True, "gather": True} and np.array_equal(dp.data.cpu().numpy(), got)
+        dist.barrier()
+        pp.close()
         comm.close()
         ctx.close()
         dist.barrier()
@@ -373,3 +383,131 @@ def test_rccl_halo_exchange_and_tile_allgather_two_gpus():
         assert err is None, "rank %d: %s" % (rank, err)
         assert n == 2 and ok_halo and ok_all, (rank, n, ok_halo, ok_all)
         assert "librccl" in lib
+
+
+# ---- direct peer stores: two processes sharing ONE GPU map each other's plane over IPC ----------
+def _worker_peer_stores(rank, world, port, q, bd):
+    try:
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from rav1e_amd import tiles
+        from rav1e_amd import workload as W
+        from rav1e_amd.api import Context, Plane
+        fw, fh = 650, 333                        # odd sizes: rows with unaligned heads and tails
+        rects = W.tile_rects(world, fw, fh) if world > 2 else [(0, 0, 323, 333), (323, 0, 650, 333)]
+        truth = W.random_plane_array(fw, fh, bd, 78)
+        mine = np.zeros_like(truth)
+        x0, y0, x1, y1 = rects[rank]
+        geo = Plane(fw, fh, bd, 88, 88, device="cpu")
+        xo, yo = geo.xorigin, geo.yorigin          # the visible area's origin inside the allocation
+        mine[yo + y0:yo + y1, xo + x0:xo + x1] = truth[yo + y0:yo + y1, xo + x0:xo + x1]
+        ctx = Context(0)
+        # a filler of a rank-dependent size first: the planes sit at different offsets of their
+        # allocator blocks in the two processes
+        filler = torch.empty(4096 * (1 + 3 * rank), dtype=torch.uint8, device="cuda")
+        dp = Plane.from_numpy(mine, fw, fh, bd, 88, 88)
+        pp = tiles.PeerPlanes(ctx, dp, rank, world, comm=None)
+        dist.barrier()                            # both planes filled before anybody stores
+        n = pp.push_halos(rects, halo=37)
+        got = dp.data.cpu().numpy()
+        ex = tiles.expanded_rect(rects[rank], 37, fw, fh)
+        ok_halo = np.array_equal(got[yo + ex[1]:yo + ex[3], xo + ex[0]:xo + ex[2]],
+                                 truth[yo + ex[1]:yo + ex[3], xo + ex[0]:xo + ex[2]])
+        # and nothing outside the ring arrived
+        outside = got[yo:yo + fh, xo:xo + fw].copy()
+        outside[ex[1]:ex[3], ex[0]:ex[2]] = 0
+        ok_halo = ok_halo and not outside.any()
+        dist.barrier()
+        pp.push_tile(rects)
+        got = dp.data.cpu().numpy()
+        ok_all = np.array_equal(got[yo:yo + fh, xo:xo + fw], truth[yo:yo + fh, xo:xo + fw])
+        # the padding around the visible area is nobody's tile: untouched
+        pad = got.copy()
+        pad[yo:yo + fh, xo:xo + fw] = 0
+        ok_all = ok_all and not pad.any()
+        v = tiles.verify_exchange(dp, rects, rank, world, lambda: pp.push_halos(rects),
+                                  lambda: pp.push_tile(rects), pre=dist.barrier)
+        ok_all = ok_all and v == {"halo": True, "gather": True} and np.array_equal(dp.data.cpu().numpy(), got)
+        dist.barrier()
+        pp.close()
+        del filler
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, n, ok_halo, ok_all, None))
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put((rank, 0, False, False, traceback.format_exc()[-1500:]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bd", [8, 10])
+def test_peer_stores_two_processes_one_gpu(bd):
+    """r1_ipc_export / r1_ipc_open / r1_push_rects: two processes on the SAME GPU (RCCL would refuse
+    the pair; the mapping and the store kernel do not care which GPU the peer's memory is on) map
+    each other's plane and store their halo rectangles, then their tiles, into it.  Odd sizes and
+    different allocator offsets exercise the unaligned row edges."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_worker_peer_stores, args=(r, 2, port, q, bd)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(60)
+    for rank, n, ok_halo, ok_all, err in res:
+        assert err is None, "rank %d: %s" % (rank, err)
+        assert n == 1 and ok_halo and ok_all, (rank, n, ok_halo, ok_all)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bd", [8, 10])
+def test_push_rects_into_a_second_plane(bd):
+    """r1_push_rects inside one process: 40 random rectangles (three launches of <= 16) of one plane
+    stored into two other planes of the same geometry; everything outside the rectangles stays."""
+    import ctypes as C
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from rav1e_amd import tiles, workload as W
+    from rav1e_amd.api import Context, Plane
+    fw, fh = 777, 211
+    rng = np.random.default_rng(5)
+    src = W.random_plane_array(fw, fh, bd, 3)
+    ctx = Context(0)
+    sp = Plane.from_numpy(src, fw, fh, bd, 88, 88)
+    dsts = [Plane.from_numpy(np.zeros_like(src), fw, fh, bd, 88, 88) for _ in range(2)]
+    xo, yo = sp.xorigin, sp.yorigin
+    ptrs = (C.c_void_p * 2)(*[d.data.data_ptr() for d in dsts])
+    x = np.zeros(40, tiles.PUSH_RECT)
+    want = [np.zeros_like(src), np.zeros_like(src)]
+    for i in range(40):
+        x0, y0 = int(rng.integers(0, fw - 1)), int(rng.integers(0, fh - 1))
+        x1, y1 = int(rng.integers(x0 + 1, min(fw, x0 + 300) + 1)), int(rng.integers(y0 + 1, min(fh, y0 + 40) + 1))
+        peer = int(rng.integers(0, 2))
+        x[i] = (peer, x0, y0, x1, y1)
+        want[peer][yo + y0:yo + y1, xo + x0:xo + x1] = src[yo + y0:yo + y1, xo + x0:xo + x1]
+    p = sp.cstruct()
+    lib = ctx.lib
+    rc = lib.r1_push_rects(ctx.h, C.byref(p), ptrs, 2, x.ctypes.data, 40, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.r1_last_error()
+    torch.cuda.synchronize()
+    for d, w in zip(dsts, want):
+        assert np.array_equal(d.data.cpu().numpy(), w)
+    # a rectangle outside the visible area, an unknown peer, the plane itself as its own peer: refused
+    bad = x[:1].copy()
+    bad["x1"] = fw + 1
+    assert lib.r1_push_rects(ctx.h, C.byref(p), ptrs, 2, bad.ctypes.data, 1, None) == -1
+    bad = x[:1].copy()
+    bad["peer"] = 2
+    assert lib.r1_push_rects(ctx.h, C.byref(p), ptrs, 2, bad.ctypes.data, 1, None) == -1
+    own = (C.c_void_p * 2)(sp.data.data_ptr(), sp.data.data_ptr())
+    assert lib.r1_push_rects(ctx.h, C.byref(p), own, 2, x.ctypes.data, 1, None) == -1
+    ctx.close()
