@@ -455,9 +455,18 @@ __global__ __launch_bounds__(256) void k_push_rects(const PushArgs a) {
   }
 }
 
-// peer mappings of this process: pointer handed out -> base of the mapping (what hipIpcCloseMemHandle wants)
+// peer mappings of this process.  An allocation is mapped ONCE however many exported ranges lie in
+// it (two planes of a peer often share one allocator block, and a second hipIpcOpenMemHandle of the
+// same handle is not something to rely on): `maps` holds handle -> base with a use count, `ptrs`
+// the pointers handed out -> their map entry.
+struct IpcMap {
+  uint8_t handle[64];
+  void *base;
+  int device, uses;
+};
 std::mutex g_ipc_mu;
-std::vector<std::pair<void *, void *>> g_ipc_open;
+std::vector<IpcMap> g_ipc_maps;
+std::vector<std::pair<void *, void *>> g_ipc_ptrs;   // (pointer handed out, base of its mapping)
 }  // namespace
 
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "R1IpcMem carries the handle as 64 bytes");
@@ -487,23 +496,43 @@ extern "C" int r1_ipc_open(r1_ctx *ctx, const R1IpcMem *mem, void **ptr) {
   R1DeviceGuard guard(ctx);
   hipIpcMemHandle_t h;
   memcpy(&h, mem->handle, 64);
-  void *base = nullptr;
-  R1_HIP_CHECK(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
-  *ptr = (uint8_t *)base + mem->offset;
   std::lock_guard<std::mutex> lk(g_ipc_mu);
-  g_ipc_open.emplace_back(*ptr, base);
+  IpcMap *m = nullptr;
+  for (IpcMap &e : g_ipc_maps)
+    if (e.device == ctx->device && !memcmp(e.handle, mem->handle, 64)) m = &e;
+  if (!m) {
+    void *base = nullptr;
+    R1_HIP_CHECK(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+    IpcMap e;
+    memcpy(e.handle, mem->handle, 64);
+    e.base = base;
+    e.device = ctx->device;
+    e.uses = 0;
+    g_ipc_maps.push_back(e);
+    m = &g_ipc_maps.back();
+  }
+  m->uses++;
+  *ptr = (uint8_t *)m->base + mem->offset;
+  g_ipc_ptrs.emplace_back(*ptr, m->base);
   return R1_OK;
 }
 
 extern "C" int r1_ipc_close(r1_ctx *ctx, void *ptr) {
   R1_REQUIRE(ctx && ptr);
   void *base = nullptr;
+  bool unmap = false;
   {
     std::lock_guard<std::mutex> lk(g_ipc_mu);
-    for (size_t i = 0; i < g_ipc_open.size(); i++)
-      if (g_ipc_open[i].first == ptr) {
-        base = g_ipc_open[i].second;
-        g_ipc_open.erase(g_ipc_open.begin() + i);
+    for (size_t i = 0; i < g_ipc_ptrs.size(); i++)
+      if (g_ipc_ptrs[i].first == ptr) {
+        base = g_ipc_ptrs[i].second;
+        g_ipc_ptrs.erase(g_ipc_ptrs.begin() + i);
+        break;
+      }
+    for (size_t i = 0; base && i < g_ipc_maps.size(); i++)
+      if (g_ipc_maps[i].base == base) {
+        unmap = --g_ipc_maps[i].uses == 0;
+        if (unmap) g_ipc_maps.erase(g_ipc_maps.begin() + i);
         break;
       }
   }
@@ -511,6 +540,7 @@ extern "C" int r1_ipc_close(r1_ctx *ctx, void *ptr) {
     r1_set_error("r1_ipc_close: %p was not returned by r1_ipc_open", ptr);
     return R1_EINVAL;
   }
+  if (!unmap) return R1_OK;
   R1DeviceGuard guard(ctx);
   R1_HIP_CHECK(hipIpcCloseMemHandle(base));
   return R1_OK;

@@ -432,8 +432,25 @@ def _worker_peer_stores(rank, world, port, q, bd):
         v = tiles.verify_exchange(dp, rects, rank, world, lambda: pp.push_halos(rects),
                                   lambda: pp.push_tile(rects), pre=dist.barrier)
         ok_all = ok_all and v == {"halo": True, "gather": True} and np.array_equal(dp.data.cpu().numpy(), got)
+        # a second plane while the first is still mapped: small planes share an allocator block, so
+        # the peer's allocation is already mapped here (the library maps an allocation once)
+        truth2 = W.random_plane_array(fw, fh, bd, 79)
+        mine2 = np.zeros_like(truth2)
+        mine2[yo + y0:yo + y1, xo + x0:xo + x1] = truth2[yo + y0:yo + y1, xo + x0:xo + x1]
+        dq = Plane.from_numpy(mine2, fw, fh, bd, 88, 88)
+        pq = tiles.PeerPlanes(ctx, dq, rank, world, comm=None)
+        dist.barrier()
+        pq.push_tile(rects)
+        got2 = dq.data.cpu().numpy()
+        ok_all = ok_all and np.array_equal(got2[yo:yo + fh, xo:xo + fw], truth2[yo:yo + fh, xo:xo + fw])
+        ok_all = ok_all and np.array_equal(dp.data.cpu().numpy(), got)       # the first plane: untouched
         dist.barrier()
         pp.close()
+        # the shared mapping outlives the first close
+        pq.push_tile(rects)
+        ok_all = ok_all and np.array_equal(dq.data.cpu().numpy(), got2)
+        dist.barrier()
+        pq.close()
         del filler
         ctx.close()
         dist.barrier()
