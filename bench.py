@@ -1095,10 +1095,15 @@ def main():
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 return flag.item() == 1.0
             push_ok = None
+            if world > 1 and not args.single_device and ctx.lib.r1_ipc_peer_access(ctx.h) == 0:
+                push_why = "hipDeviceCanAccessPeer refuses a GPU of this node"   # do not map, do not store
             ring.append(Plane.from_numpy(host_ref, fw, fh, bd, 88, 88))
             # mapping is a collective per plane: every rank learns whether everybody mapped before
             # anyone enters the next one (a rank that failed alone would leave the others inside it)
             for pl in ring:
+                if not all_agree(push_why is None):   # before the collective: nobody enters it alone
+                    push_why = push_why or "another rank has no peer access"
+                    break
                 try:
                     ring_peers.append(tiles.PeerPlanes(ctx, pl, rank, world, comm=vcomm))
                 except Exception as e:   # noqa: BLE001 -- keep the run alive on the other exchange

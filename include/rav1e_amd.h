@@ -805,6 +805,10 @@ typedef struct R1PushRect {
 /* device memory of this process (any offset inside a hipMalloc allocation) as 80 bytes another
  * process maps with r1_ipc_open; the bytes travel by whatever channel the host has */
 int r1_ipc_export(r1_ctx *ctx, const void *ptr, size_t bytes, R1IpcMem *out);
+/* before mapping anything: 1 = the context's device can address every other GPU this process
+ * sees (hipDeviceCanAccessPeer), 0 = some GPU refuses (stay on r1_comm_exchange_halos /
+ * r1_comm_allgather_tiles), -1 = unknown (the process sees one GPU only) */
+int r1_ipc_peer_access(r1_ctx *ctx);
 int r1_ipc_open(r1_ctx *ctx, const R1IpcMem *mem, void **ptr);
 int r1_ipc_close(r1_ctx *ctx, void *ptr);
 /* stores rects[i] of `plane` into the same rectangle of the plane at peer_data[rects[i].peer]

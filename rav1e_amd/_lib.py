@@ -97,6 +97,7 @@ SYMBOLS = {
     "r1_comm_exchange_halos": (_i, [_vp, _PP, _vp, _i, _vp]),
     "r1_comm_allgather_tiles": (_i, [_vp, _PP, _vp, _vp]),
     "r1_ipc_export": (_i, [_vp, _vp, _sz, _vp]),
+    "r1_ipc_peer_access": (_i, [_vp]),
     "r1_ipc_open": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "r1_ipc_close": (_i, [_vp, _vp]),
     "r1_push_rects": (_i, [_vp, _PP, _vp, _i, _vp, _i, _vp]),

@@ -489,6 +489,22 @@ extern "C" int r1_ipc_export(r1_ctx *ctx, const void *ptr, size_t bytes, R1IpcMe
   return R1_OK;
 }
 
+// Can kernels of the context's device address the memory of every other GPU this process sees?
+// 1 yes, 0 no (hipDeviceCanAccessPeer said no for some device: do not map its memory), -1 unknown
+// (this process sees one GPU only -- the peers' ordinals are not visible from here).
+extern "C" int r1_ipc_peer_access(r1_ctx *ctx) {
+  if (!ctx) return -1;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 2) return -1;
+  for (int d = 0; d < n; d++) {
+    if (d == ctx->device) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, ctx->device, d) != hipSuccess) return -1;
+    if (!can) return 0;
+  }
+  return 1;
+}
+
 // Maps a peer process's exported memory on the context's device; *ptr addresses the exported
 // range.  (Not for memory of the calling process: HIP refuses to open its own handles.)
 extern "C" int r1_ipc_open(r1_ctx *ctx, const R1IpcMem *mem, void **ptr) {
