@@ -61,6 +61,13 @@ def parse():
                          "> 1: the launches of a step (one per block size, independent of each other) "
                          "go to one HIP stream per size, so that a launch fills the CUs the previous "
                          "one is draining; the steps that carry timing events stay on one stream")
+    ap.add_argument("--stream-plan", default="",
+                    help="with --streams > 1: which stream runs which sizes, e.g. 64h/32l/16l/8l ('/' separates "
+                         "streams, ',' sizes on one stream in order, h / l = high / low queue priority)")
+    ap.add_argument("--step-join", action="store_true",
+                    help="with --streams > 1: the size streams fork from / join the main stream every step")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="every n-th timed step carries the per-launch timing events (and runs on one stream)")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps for this long BEFORE the W warm-up steps, so that short runs "
                          "(small W and K) are measured at the clocks a long run settles at; 0 = off")
@@ -853,6 +860,12 @@ def config_lines(ctx, args):
     return lines
 
 
+# N = 1: one stream per block size, the 64x64 launch (the longest workgroups) at high queue priority;
+# the streams free-run, so the launches of consecutive steps overlap and the CUs / register files a
+# draining launch leaves idle are filled by the other sizes (same-box A/B: profiles/r04_ab_notes.md, ab6)
+PIPELINE_PLAN = "64h/32l/16l/8l"
+
+
 def respawn_under_launcher(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: re-exec this very command
     line under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1, a free port) --
@@ -989,13 +1002,28 @@ def main():
 
     # A timing-event pair costs ~0.5 % of a step (the event drains the stream), so every
     # EV_EVERY-th timed step carries them (around each size's launch), the others run bare.
-    EV_EVERY = 4
+    EV_EVERY = max(1, args.event_every)
     nstep = [0]
 
     if args.streams <= 0:
         args.streams = 4 if world > 1 else 1
     fan = args.streams > 1
-    size_streams = {s: torch.cuda.Stream() for s in W.LADDER} if fan else {}
+    fan_order = list(W.LADDER)
+    if fan and args.stream_plan:
+        # "64h/32l/16l/8l": streams separated by "/", the sizes a stream runs in order, h / l = the
+        # stream's queue priority.  The launch with the long workgroups goes out first at high
+        # priority; the other sizes' workgroups fill the CUs it leaves idle while it drains.
+        least, greatest = torch.cuda.Stream.priority_range()
+        size_streams, fan_order = {}, []
+        for grp in args.stream_plan.split("/"):
+            items = grp.split(",")
+            st = torch.cuda.Stream(priority=greatest if items[0].endswith("h") else least)
+            for it in items:
+                size_streams[int(it.rstrip("hl"))] = st
+                fan_order.append(int(it.rstrip("hl")))
+        assert sorted(fan_order) == sorted(W.LADDER), args.stream_plan
+    else:
+        size_streams = {s: torch.cuda.Stream() for s in W.LADDER} if fan else {}
 
     def step(timed, exchange=True):
         mark = timed and use_events and nstep[0] % EV_EVERY == 0
@@ -1003,13 +1031,28 @@ def main():
         if timed:
             nstep[0] += 1
         main = torch.cuda.current_stream()
-        if fan and not mark and not split:
+        if fan and not split and (not mark or args.step_join):
             # independent launches, one stream per block size (each stream is in order with the
-            # same size's launch of the previous step, which wrote the same output buffers)
-            for s in W.LADDER:
+            # same size's launch of the previous step, which wrote the same output buffers).
+            # --step-join: the streams fork from and join the main stream every step (a step is
+            # finished before the next one starts) and the timing events of a marked step bracket
+            # each launch ON ITS OWN STREAM -- co-scheduled durations, what rocprofv3 sees too
+            for s in fan_order:
                 if len(cands[s]):
-                    with torch.cuda.stream(size_streams[s]):
+                    st = size_streams[s]
+                    if args.step_join:
+                        st.wait_stream(main)
+                    with torch.cuda.stream(st):
+                        if mark:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
                         ring_launches[cur[0]][s]()
+                        if mark:
+                            e1.record()
+                            ev[s].append((e0, e1))
+            if args.step_join:
+                for st in set(size_streams.values()):
+                    main.wait_stream(st)
         else:
             for st in size_streams.values():
                 main.wait_stream(st)
@@ -1275,6 +1318,35 @@ def main():
             "kernel_ms_note": "HIP events around each launch of every %dth timed step "
                               "(%d samples per size)" % (EV_EVERY, max([len(v) for v in ev.values()] + [0])),
         }
+        if world == 1 and not fan and not args.no_extra:
+            # The same K steps with the four launches of a step on four FREE-RUNNING streams (no join
+            # between steps: the launches of consecutive steps overlap, as independent batches in
+            # flight do -- the tiles of a frame are encoded independently), the 64x64 launch at high
+            # queue priority.  The CUs and register files a draining launch leaves idle are filled by
+            # the other sizes.  Reported beside `value`, which stays the serialized step: per-launch
+            # durations (and with them `roofline`) are not separable once launches share the GPU.
+            least, greatest = torch.cuda.Stream.priority_range()
+            pst = {s_: torch.cuda.Stream(priority=greatest if s_ == max(W.LADDER) else least) for s_ in W.LADDER}
+
+            def pipe_steps(n_):
+                for _ in range(n_):
+                    for s_ in sorted(W.LADDER, reverse=True):
+                        if len(cands[s_]):
+                            with torch.cuda.stream(pst[s_]):
+                                launches[s_]()
+            torch.cuda.synchronize()
+            pipe_steps(args.warmup)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            pipe_steps(args.steps)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - tp
+            res["pipelined"] = {"value": round(total_px * args.steps / dtp / 1e6, 2), "unit": "Mpixels/s",
+                                "ms_per_step": round(dtp / args.steps * 1e3, 4), "steps": args.steps,
+                                "plan": PIPELINE_PLAN,
+                                "note": "the same steps, one free-running stream per block size ('/' separates streams, "
+                                        "h / l = queue priority), no join between steps; outputs checked like the "
+                                        "serialized steps' (the parity legs below run on what these launches left)"}
         if pixel and world == 1:
             # The same chain as rav1e's RDO runs it: rdo_tx_size_type -> encode_tx_block -> compute_distortion
             # (src/rdo.rs:1073, src/encoder.rs:1404-1661, src/rdo.rs:254-347) never takes SAD or SATD of a
