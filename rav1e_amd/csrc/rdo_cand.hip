@@ -81,6 +81,9 @@ __device__ unsigned long long g_phase[4096][8];
 #endif
 
 // which instantiations run their dead candidate slots unmasked (see k_rdo_cand)
+#ifndef R1_TB16_POLICY
+#define R1_TB16_POLICY(BD, WL, HL) ((BD) == 10 && (WL) == 5 && (HL) == 5)
+#endif
 #ifndef R1_TX_TILE_I16
 #define R1_TX_TILE_I16 1
 #endif
@@ -100,7 +103,7 @@ __device__ unsigned long long g_phase[4096][8];
 // which instantiations keep the source chunks in registers across the filter and stage them over the
 // dead window afterwards (see k_rdo_cand)
 #ifndef R1_SRC_LATE_POLICY
-#define R1_SRC_LATE_POLICY(BD, P) ((BD) != 8 && (P) == 32)
+#define R1_SRC_LATE_POLICY(BD, P, QM) ((BD) != 8 && ((P) == 32 || ((P) == 16 && (QM) == 0)))
 #endif
 #ifndef R1_UNMASK_POLICY
 #define R1_UNMASK_POLICY(BD, WL, HL) (!((BD) == 8 && (WL) == 6 && (HL) == 6))
@@ -157,8 +160,23 @@ constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm) {
 #ifdef R1_HINT_16X16
   if (wl == 4 && hl == 4 && qm == 0) return R1_HINT_16X16;
 #endif
-  if (wl == 5 && hl == 5 && qm == 2 && bd == 8) return 4;   // 132 VGPRs -> 128 (10-bit: 149, spills)
-  if (wl == 5 && hl == 5 && qm == 1 && bd == 8) return 5;   // 97 -> 96
+#ifdef R1_HINT_64_HBD
+  if (wl == 6 && hl == 6 && qm == 0 && bd != 8) return R1_HINT_64_HBD;   // A/B: 10-bit 64x64 sits at 165 (3 waves); 4 = 152 B of spills, launch 0.281 -> 0.365 ms
+#endif
+  if (wl == 5 && hl == 5 && qm == 0 && bd != 8) return 6;   // 89 -> 80 VGPRs, no spill: 5 -> 6 waves, launch -1.7 % (ab7)
+#ifdef R1_HINT_X   /* A/B: -DR1_HINT_X=5 '-DR1_HINT_X_COND=(bd==8&&wl==6&&hl==6&&qm==0)' */
+  if (R1_HINT_X_COND) return R1_HINT_X;
+#endif
+#ifdef R1_HINT_Y
+  if (R1_HINT_Y_COND) return R1_HINT_Y;
+#endif
+  // the pixel-domain chain sat a few registers above an allocation step at three sizes; asked for the
+  // step, the allocator gets there without a spill worth mentioning (same-box, r04_ab_notes.md ab8:
+  // 8-bit 290.3 -> 295.0 k, 10-bit 274.2 -> 283.5 k)
+  if (wl == 3 && hl == 3 && qm == 2) return 7;              // 73 / 74 VGPRs -> 58 / 72: 6 -> 8 / 7 waves, launch -2.2 / -1.6 %
+  if (wl == 4 && hl == 4 && qm == 2) return 5;              // 105 / 107 -> 91 / 94: 4 -> 5 waves, -4.0 / -5.1 %
+  if (wl == 5 && hl == 5 && qm == 2) return 4;              // 8-bit 132 -> 128; 10-bit 131 -> 128 (8 B of scratch): 3 -> 4 waves, -5.4 %
+  if (wl == 5 && hl == 5 && qm == 1) return 5;              // 8-bit 97 -> 96; 10-bit 120 -> 96 (20 B of scratch): 4 -> 5 waves, launch -4 % (ab10)
   if (wl == 6 && hl == 6 && qm == 2) return 3;              // 176 / 181 -> 168
   return 1;
 }
@@ -184,7 +202,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   // 6240 B, 4 -> 5 waves per SIMD, launch 0.252 -> 0.237 ms (profiles/r04_ab_notes.md).  At 8-bit
   // 32x32 the same change (5 -> 6 waves) made the launch 1.5 % SLOWER -- that kernel is not short of
   // waves -- and is off.  Row stride 66 int16 = 33 dwords: a candidate's row lanes read 32 banks.
-  constexpr bool TB16 = R1_TX_TILE_I16 && BD == 10 && WL == 5 && HL == 5;
+  constexpr bool TB16 = R1_TX_TILE_I16 && R1_TB16_POLICY(BD, WL, HL);
   typedef typename std::conditional<TB16, int16_t, T>::type TB;
   constexpr int LSTRIDE = NC * W + (TB16 ? 2 : 1);
   constexpr int ISTRIDE = NC * W + 1;       // the inverse transform's row buffer (QM == 2): int32
@@ -207,7 +225,9 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   // go to LDS afterwards, OVER the dead window -- window + source side by side (10336 B at 10-bit
   // 32x32) held the CU at 15 waves (4 per SIMD after rounding); with the source over the window the
   // footprint is the window's 6240 B and the ~93 VGPRs allow 5.
-  constexpr bool SRC_LATE = SRC_LDS && R1_SRC_LATE_POLICY(BD, P);
+  // 16-bit 16x16, headline only (the pixel chain keeps its source block in LDS for the distortion,
+  // SRC_KEEP below): 6592 -> 4416 B, 6 -> 8 waves, launch 0.2255 -> 0.217 ms (r04_ab_notes.md, ab7)
+  constexpr bool SRC_LATE = SRC_LDS && R1_SRC_LATE_POLICY(BD, P, QM);
   constexpr int SRC_ROW = W * BPP;
   constexpr int WIN_PAD = (WIN_BYTES + 15) & ~15;
   // A candidate's source block starts max(16, row bytes) past a multiple of its own size: with the bare
