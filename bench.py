@@ -265,6 +265,19 @@ def cpu_baseline(args, host_org, host_ref, cands, outs):
     return res, parity
 
 
+def sustain(one_pass, ms):
+    """untimed passes for `ms` milliseconds: a line is timed at the clocks a long run settles at, not at
+    what the host work before it (candidate lists, the previous line's CPU parity leg) left"""
+    import torch
+    if ms <= 0:
+        return
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(4):
+            one_pass()
+        torch.cuda.synchronize()
+
+
 def _latest(pattern):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
@@ -446,7 +459,7 @@ def extra_lines(ctx, args):
                      "candidate (7 up to 16x16, DCT/IDTX at 32, DCT at 64)",
          dict(planes=1, w=fw, h=fh, pad=88, sizes=W.LADDER, mv=32, kw={"mix_tx_types": True})),
     ]
-    STEPS, WARM, NCHK = 6, 2, 48
+    STEPS, WARM, NCHK = 20, 2, 48
     lines = []
     for name, desc, sp in specs:
         w, h, pad = sp["w"], sp["h"], sp["pad"]
@@ -470,6 +483,9 @@ def extra_lines(ctx, args):
             for _, f in launches:
                 f()
         torch.cuda.synchronize()
+        # the CPU parity leg of the line before let the clocks drop: without this the 64x64 launch of the
+        # tx_types line (DCT only at that size -- the headline's own launch) read 0.277 ms instead of 0.233
+        sustain(lambda: [f() for _, f in launches], args.prewarm_ms)
         t0 = time.perf_counter()
         for _ in range(STEPS):
             for s, f in launches:
@@ -558,6 +574,7 @@ def config_lines(ctx, args):
             for _, f in fns:
                 f()
         torch.cuda.synchronize()
+        sustain(lambda: [f() for _, f in fns], args.prewarm_ms)
         ev = []
         t0 = time.perf_counter()
         for _ in range(REPS):
