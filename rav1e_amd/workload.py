@@ -129,3 +129,19 @@ def random_plane_array(width, height, bit_depth, seed, xpad=88, ypad=88):
     rng = np.random.default_rng(seed)
     dt = np.uint8 if lay["bpp"] == 1 else np.uint16
     return rng.integers(0, 1 << bit_depth, size=(lay["alloc_height"], lay["stride"]), dtype=dt)
+
+
+def sustain_clocks(one_pass, ms=150.0):
+    """Untimed passes of `one_pass` for `ms` milliseconds before a benchmark row is timed: the GPU is
+    then at the clocks a continuously running encoder holds, not at what the host-side preparation of
+    the row (candidate lists, oracle legs) let them fall to -- short rows read 10-20 % slow otherwise
+    (bench.py::sustain has the measurement)."""
+    import time
+    import torch
+    if ms <= 0:
+        return
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(4):
+            one_pass()
+        torch.cuda.synchronize()

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--sustain-ms", type=float, default=100.0,
+                    help="untimed launches for this long before a row is timed (sustained clocks); 0 = off")
     args = ap.parse_args()
     import torch
     from rav1e_amd import api, workload as W
@@ -60,6 +62,7 @@ def main():
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
+        W.sustain_clocks(fn, args.sustain_ms)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -75,6 +78,7 @@ def main():
         the row read 0.195 ms where a fresh frame takes ~0.10 (the frame pipeline's figure)."""
         restore()
         fn()
+        W.sustain_clocks(lambda: (restore(), fn()), args.sustain_ms)
         ms = []
         for _ in range(reps):
             restore()
@@ -91,6 +95,12 @@ def main():
         for i in range(3):
             fn(*pairs[i % NP])
         torch.cuda.synchronize()
+        rot = [0]
+
+        def one():
+            fn(*pairs[rot[0] % NP])
+            rot[0] += 1
+        W.sustain_clocks(one, args.sustain_ms)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(reps):

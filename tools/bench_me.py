@@ -32,13 +32,16 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bit-depth", type=int, default=8)
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--sustain-ms", type=float, default=100.0,
+                    help="untimed runs of a row for this long before it is timed (sustained clocks); 0 = off")
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (tens of seconds)")
     ap.add_argument("--only", type=int, default=-1, help="run only tile-ME configuration i (for profiling)")
     ap.add_argument("--tile-only", action="store_true", help="stop after the tile-ME configurations")
     args = ap.parse_args()
     import torch
     import oracle_lib as O
+    from rav1e_amd import workload as W
     from rav1e_amd.api import Context, Plane, me_lambdas
     w, h, bd = args.width, args.height, args.bit_depth
     f = texture(w, h, bd, 1)
@@ -81,6 +84,7 @@ def main():
             ctx.estimate_tile_motion(jobs, cols, rows, bd, lam)
         run()
         torch.cuda.synchronize()
+        W.sustain_clocks(run, args.sustain_ms)
         t0 = time.perf_counter()
         for _ in range(args.reps):
             run()
@@ -145,6 +149,7 @@ def main():
         f = lambda: ctx.estimate_motion_batch(job, dc, cols, rows, bd, lam, max_w=s, max_h=s, n=len(c))
         f()
         torch.cuda.synchronize()
+        W.sustain_clocks(f, args.sustain_ms)
         t0 = time.perf_counter()
         for _ in range(args.reps):
             f()

@@ -28,7 +28,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bit-depth", type=int, default=8)
-    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--sustain-ms", type=float, default=100.0,
+                    help="untimed passes of a stage for this long before it is timed (sustained clocks); 0 = off")
     args = ap.parse_args()
     import torch
     import deblock_util as D
@@ -58,6 +60,7 @@ def main():
     def timed(name, fn):
         fn()
         torch.cuda.synchronize()
+        W.sustain_clocks(fn, args.sustain_ms)
         t0 = time.perf_counter()
         for _ in range(args.reps):
             fn()
@@ -160,6 +163,7 @@ def main():
     for _ in range(2):
         cdef_search()
     torch.cuda.synchronize()
+    W.sustain_clocks(cdef_search, args.sustain_ms)
     t0 = time.perf_counter()
     for _ in range(args.reps):
         cdef_search()
@@ -196,6 +200,7 @@ def main():
     torch.cuda.synchronize()
     overlapped()
     torch.cuda.synchronize()
+    W.sustain_clocks(overlapped, args.sustain_ms)
     t0 = time.perf_counter()
     for _ in range(args.reps):
         overlapped()
