@@ -675,6 +675,27 @@ typedef struct R1SgrSolveUnit {
 int r1_sgrproj_solve_batch(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *input,
                            const R1SgrSolveUnit *units, int n, int max_w, int max_h,
                            int64_t *moments_scratch, int8_t *xqd_out, void *stream);
+/* The restoration-filter leg of rdo_loop_decision for ONE plane, everything but the entropy coder's
+ * rate (src/rdo.rs:2575-2763).  For each (restoration unit, parameter set) pair:
+ *   xqd = sgrproj_solve on the unit (as above);
+ *   the unit filtered with those weights -- sgrproj_stripe_filter on the unit's own integral image
+ *   (setup_integral_image with crop = the unit, rdo.rs:2651-2666, 2688-2702), never stored;
+ *   err = rdo_loop_plane_error of that against `src` (rdo.rs:2027-2093): over the 8x8-luma blocks
+ *   of the unit  cdef_dist_kernel * bias  (luma, is_chroma 0)  or  sse_wxh with |_, _| bias on
+ *   (8 >> xdec) x (8 >> ydec) pixels (is_chroma 1), bias = scales[(luma y >> 3) * scale_stride +
+ *   (luma x >> 3)] (NULL: the default scale), summed and multiplied by dist_scale (fi.dist_scale[pli],
+ *   Q14).
+ * units[i].set = 255: the "no filter option" (rdo.rs:2617-2643): err of lrf_in itself, xqd (0, 0).
+ * Units start on superblock boundaries; w % (8 >> xdec) == 0 and h % (8 >> ydec) == 0 (a visible
+ * frame that is a multiple of 8 luma pixels: the reference's last blocks otherwise read its working
+ * copy beyond what the filter wrote; partial blocks are left out here).  scratch: 6 int64 per pair
+ * (device).  The host adds cw.fc.count_lrf_switchable's rate to err and keeps the cheapest choice
+ * (compute_rd_cost, rdo.rs:718-723). */
+int r1_lrf_search_batch(r1_ctx *ctx, const R1Plane *lrf_in, const R1Plane *src,
+                        const R1SgrSolveUnit *units, int n, int max_w, int max_h, int is_chroma,
+                        int xdec, int ydec, const uint32_t *scales, int scale_stride,
+                        uint32_t dist_scale, int64_t *scratch, int8_t *xqd_out, uint64_t *err_out,
+                        void *stream);
 
 /* ---- fused RDO candidate: the headline path.  For each candidate:
  *   pred   = put_8tap(ref @ (rx,ry), fracs, modes)              (src/mc.rs:250)

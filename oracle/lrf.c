@@ -299,3 +299,72 @@ void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0,
   xqd_out[0] = (int8_t)xqd0;
   xqd_out[1] = (int8_t)xqd1;
 }
+
+/* The restoration leg of rdo_loop_decision for ONE plane, one (restoration unit, parameter set)
+ * pair -- everything but the entropy coder's rate (src/rdo.rs:2575-2763):
+ *   set < 16: sgrproj_solve on the unit (above), then the unit filtered with the weights it
+ *             returned -- sgrproj_stripe_filter on the unit's OWN integral image
+ *             (setup_integral_image with crop = the unit: "hard-clipping to the superblock
+ *             boundary", rdo.rs:2651-2666, 2688-2702), the whole unit as one stripe;
+ *   set = 255: the "no filter option" (rdo.rs:2617-2643): the unit of lrf_in as it is;
+ *   err = rdo_loop_plane_error (rdo.rs:2027-2093) of that against the source: over the
+ *         8x8-luma blocks of the unit  cdef_dist_kernel * bias (luma)  /  sse_wxh with |_, _| bias
+ *         on (8 >> xdec) x (8 >> ydec) pixels (chroma), bias = the DistortionScale of the block's
+ *         8x8 luma position, summed, * fi.dist_scale[pli].
+ * (x0, y0, w, h): the unit in pixels of THIS plane, w % (8 >> xdec) == 0 and h % (8 >> ydec) == 0
+ * (the visible frame a multiple of 8 luma pixels: otherwise the reference's last blocks read the
+ * working copy beyond what the filter wrote).  scales: one per 8x8 luma block of the frame (NULL:
+ * the default scale).  Returns -1 on geometry it does not take. */
+int r1o_lrf_search_unit(const r1o_plane *lrf_in, const r1o_plane *src, int x0, int y0, int w, int h,
+                        int set, int is_chroma, int xdec, int ydec, const uint32_t *scales,
+                        int scale_stride, uint32_t dist_scale, int bd, int8_t *xqd_out,
+                        uint64_t *err_out) {
+  const int bw = 8 >> xdec, bh = 8 >> ydec, hbd = lrf_in->bytes_per_px == 2;
+  if (w <= 0 || h <= 0 || w > IMG_MAX || w % bw || h % bh || (set != 255 && (set < 0 || set > 15))) return -1;
+  if (!is_chroma && (xdec || ydec)) return -1;
+  const size_t bpp = (size_t)lrf_in->bytes_per_px;
+  uint8_t *tmp = (uint8_t *)malloc((size_t)w * h * bpp);
+  xqd_out[0] = xqd_out[1] = 0;
+  if (set == 255) {
+    for (int y = 0; y < h; y++)
+      memcpy(tmp + (size_t)y * w * bpp,
+             (const uint8_t *)lrf_in->data +
+                 ((size_t)(lrf_in->yorigin + y0 + y) * lrf_in->stride + lrf_in->xorigin + x0) * bpp,
+             (size_t)w * bpp);
+  } else {
+    r1o_sgrproj_solve(lrf_in, src, x0, y0, w, h, set, bd, xqd_out);
+    const int rows = h + (h & 1) + 6;
+    uint32_t *ii = (uint32_t *)calloc((size_t)IMG_STRIDE * rows * 2, sizeof(uint32_t));
+    uint32_t *sq = ii + (size_t)IMG_STRIDE * rows;
+    setup_integral_image(ii, sq, x0 + w, y0 + h, w, h, lrf_in, lrf_in, x0, y0);
+    /* a plane whose pixel (x0, y0) is tmp[0] */
+    r1o_plane out = *lrf_in;
+    out.data = tmp;
+    out.stride = w;
+    out.xorigin = -x0;
+    out.yorigin = -y0;
+    stripe_filter(set, xqd_out, bd, ii, sq, lrf_in, &out, x0, y0, w, h);
+    free(ii);
+  }
+  uint64_t plane_sum = 0;
+  for (int by = 0; by < h / bh; by++)
+    for (int bx = 0; bx < w / bw; bx++) {
+      const int px_ = x0 + bx * bw, py_ = y0 + by * bh;
+      const uint8_t *spx = (const uint8_t *)src->data +
+                           ((size_t)(src->yorigin + py_) * src->stride + src->xorigin + px_) * bpp;
+      const uint8_t *tpx = tmp + ((size_t)by * bh * w + (size_t)bx * bw) * bpp;
+      const uint32_t bias = scales ? scales[(size_t)((py_ << ydec) >> 3) * scale_stride + ((px_ << xdec) >> 3)]
+                                   : (1u << 14);
+      if (!is_chroma) {
+        const uint64_t raw = r1o_cdef_dist_kernel(spx, src->stride, tpx, w, 8, 8, bd, hbd);
+        plane_sum += ((uint64_t)bias * raw + 8192) >> 14;               /* RawDistortion * bias */
+      } else {
+        uint32_t cell[4] = {bias, bias, bias, bias};                      /* sse_wxh: |_, _| bias */
+        plane_sum += r1o_get_weighted_sse(spx, src->stride, tpx, w, cell, 2, bw, bh, hbd);
+      }
+    }
+  free(tmp);
+  *err_out = ((uint64_t)dist_scale * plane_sum + 8192) >> 14;            /* Distortion * dist_scale */
+  return 0;
+}
+

@@ -128,6 +128,7 @@ SYMBOLS = {
                                     _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "r1_lrf_sgrproj_plane": (_i, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "r1_sgrproj_solve_batch": (_i, [_vp, _PP, _PP, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "r1_lrf_search_batch": (_i, [_vp, _PP, _PP, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, C.c_uint32, _vp, _vp, _vp, _vp]),
     "r1_activity_scales": (_i, [_vp, _PP, _vp, _vp, _vp]),
     "r1_cfl_alpha_search_batch": (_i, [_vp, _PP, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rav1e_sad_hip": (C.c_uint32, [_vp, _pd, _vp, _pd, _i, _i]),

@@ -814,6 +814,25 @@ class Context:
                                                     _stream_ptr()), "r1_sgrproj_solve_batch")
         return out
 
+    def lrf_search_batch(self, lrf_in, src, units, is_chroma=False, xdec=0, ydec=0, scales=None, dist_scale=1 << 14,
+                         max_w=256, max_h=256):
+        """the restoration leg of rdo_loop_decision for one plane (src/rdo.rs:2575-2763) but the rate:
+        units: SGR_SOLVE_UNIT array (set 255 = the no-filter option); scales: 2-D int32/uint32 device
+        tensor (one DistortionScale per 8x8 luma block) or None -> ((n, 2) int8 xqd, (n,) int64 err)"""
+        dc = _dev_cands(units, SGR_SOLVE_UNIT)
+        n = dc.numel() // SGR_SOLVE_UNIT.itemsize
+        scratch = torch.empty(n * 6, dtype=torch.int64, device="cuda")
+        xqd = torch.empty((n, 2), dtype=torch.int8, device="cuda")
+        err = torch.empty(n, dtype=torch.int64, device="cuda")
+        pc, ps = lrf_in.cstruct(), src.cstruct()
+        self._check(self.lib.r1_lrf_search_batch(self.h, C.byref(pc), C.byref(ps), dc.data_ptr(), n, max_w, max_h,
+                                                 int(bool(is_chroma)), xdec, ydec,
+                                                 scales.data_ptr() if scales is not None else None,
+                                                 scales.shape[1] if scales is not None else 0, int(dist_scale),
+                                                 scratch.data_ptr(), xqd.data_ptr(), err.data_ptr(), _stream_ptr()),
+                    "r1_lrf_search_batch")
+        return xqd, err
+
     # ---- fused candidate ----
     def rdo_cand_batch(self, org, ref, w, h, cands, n=None, want_sad=True, want_satd=True,
                        want_coeffs=True, want_pred=False, outs=None):

@@ -23,6 +23,7 @@
 //     projection with xqd, clamp, store.
 // u32 arithmetic wraps where the reference's release build wraps (p * s).
 #include "common.hpp"
+#include "dist_common.hpp"
 
 namespace {
 
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void k_sgr_moments(R1Plane cdeffed, R1Plane in
   __shared__ long long part[4][5];
   const R1SgrSolveUnit u = units[blockIdx.y];
   const int ntx = (u.w + TW - 1) / TW, nty = (u.h + 63) / 64;
-  if ((int)blockIdx.x >= ntx * nty) return;   // workgroup-uniform
+  if ((int)blockIdx.x >= ntx * nty || u.set > 15) return;   // workgroup-uniform (set 255: r1_lrf_search_batch's "no filter")
   SgrTile t;
   t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
   t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the unit (rdo.rs:2651-2666)
@@ -275,18 +276,19 @@ __global__ __launch_bounds__(256) void k_sgr_moments(R1Plane cdeffed, R1Plane in
   }
 }
 
-// the 2x2 solve in IEEE doubles, operation for operation (lrf.rs:1057-1095)
-__global__ void k_sgr_solve(const R1SgrSolveUnit *__restrict__ units, const long long *__restrict__ acc,
-                            int n, int8_t *__restrict__ xqd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const R1SgrSolveUnit u = units[i];
-  const uint32_t s2 = kSgrS[u.set & 15][0], s1 = kSgrS[u.set & 15][1];
-  const double nn = __dmul_rn((double)u.w, (double)u.h);
-  const double h00 = __ddiv_rn((double)acc[i * 5 + 0], nn), h11 = __ddiv_rn((double)acc[i * 5 + 1], nn);
-  const double h01 = __ddiv_rn((double)acc[i * 5 + 2], nn);
+// the 2x2 solve in IEEE doubles, operation for operation (lrf.rs:1057-1095): m = the five moments
+// (h00, h11, h01, c0, c1) of a w x h unit
+__device__ __forceinline__ void sgr_solve_xqd(const long long *m, int w, int h, int set, int8_t *xqd) {
+  if (set > 15) {   // no parameter set: no weights
+    xqd[0] = xqd[1] = 0;
+    return;
+  }
+  const uint32_t s2 = kSgrS[set & 15][0], s1 = kSgrS[set & 15][1];
+  const double nn = __dmul_rn((double)w, (double)h);
+  const double h00 = __ddiv_rn((double)m[0], nn), h11 = __ddiv_rn((double)m[1], nn);
+  const double h01 = __ddiv_rn((double)m[2], nn);
   const double sc = __ddiv_rn(128.0, nn);
-  const double c0 = __dmul_rn((double)acc[i * 5 + 3], sc), c1 = __dmul_rn((double)acc[i * 5 + 4], sc);
+  const double c0 = __dmul_rn((double)m[3], sc), c1 = __dmul_rn((double)m[4], sc);
   double xq0 = 0., xq1 = 0.;
   if (s2 == 0) {
     if (h11 != 0.) xq1 = round(__ddiv_rn(c1, h11));
@@ -306,8 +308,237 @@ __global__ void k_sgr_solve(const R1SgrSolveUnit *__restrict__ units, const long
   const long long q0 = sat(xq0), q1 = sat(xq1);
   const long long x0 = q0 < -96 ? -96 : (q0 > 31 ? 31 : q0);
   const long long t = 128 - x0 - q1;
-  xqd[2 * i] = (int8_t)x0;
-  xqd[2 * i + 1] = (int8_t)(t < -32 ? -32 : (t > 95 ? 95 : t));
+  xqd[0] = (int8_t)x0;
+  xqd[1] = (int8_t)(t < -32 ? -32 : (t > 95 ? 95 : t));
+}
+
+__global__ void k_sgr_solve(const R1SgrSolveUnit *__restrict__ units, const long long *__restrict__ acc,
+                            int n, int8_t *__restrict__ xqd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const R1SgrSolveUnit u = units[i];
+  sgr_solve_xqd(acc + (size_t)i * 5, u.w, u.h, u.set, xqd + 2 * i);
+}
+
+// rdo_loop_plane_error's term for one block of the unit (rdo.rs:2060-2088): `test` = the filtered unit
+// in LDS (row stride TS pixels), (px, py) = the block's position in the plane
+template <int BPP, bool CHROMA, int TS>
+__device__ __forceinline__ unsigned long long lrf_block_err(const R1Plane &src, const uint16_t *test, int px, int py,
+                                                            int bw, int bh, int xdec, int ydec,
+                                                            const uint32_t *__restrict__ scales, int scale_stride,
+                                                            int bd) {
+  const uint8_t *po = px_addr<BPP>(src, px, py);
+  const size_t so = (size_t)src.stride * BPP;
+  if constexpr (!CHROMA) {
+    uint32_t sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
+    for (int r = 0; r < 8; r++)
+      for (int i = 0; i < 8; i++) {
+        const uint32_t sv = (uint32_t)ld_px<BPP>(po + r * so + (size_t)i * BPP), dv = test[r * TS + i];
+        sum_s += sv; sum_d += dv;
+        sum_s2 += sv * sv; sum_d2 += dv * dv; sum_sd += sv * dv;
+      }
+    // RawDistortion(cdef_dist_kernel) * bias: the tail multiplies by the block's DistortionScale
+    return r1dist::cdef_tile_tail<0>(sum_s, sum_d, sum_s2, sum_d2, sum_sd, 64, px, py, scales, scale_stride, bd);
+  } else {
+    // sse_wxh with one bias for the block: get_weighted_sse over its 4x4 cells (dist.rs:234-283)
+    const uint32_t sc = scales ? scales[(size_t)((py << ydec) >> 3) * scale_stride + ((px << xdec) >> 3)]
+                               : (1u << 14);
+    unsigned long long sum = 0;
+    for (int cy = 0; cy < bh; cy += 4)
+      for (int cx = 0; cx < bw; cx += 4) {
+        uint32_t cell = 0;
+        for (int r = 0; r < 4; r++)
+          for (int i = 0; i < 4; i++) {
+            const int32_t d = (int32_t)ld_px<BPP>(po + (cy + r) * so + (size_t)(cx + i) * BPP) -
+                              (int32_t)test[(cy + r) * TS + cx + i];
+            cell += (uint32_t)(d * d);
+          }
+        sum += ((unsigned long long)cell * sc + 128) >> 8;
+      }
+    return (sum + 32) >> 6;
+  }
+}
+
+// sum of a 64-bit value over the workgroup (256 threads); valid in thread 0
+__device__ __forceinline__ unsigned long long wg_sum_u64(unsigned long long v, unsigned long long *part4) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+  for (int sft = 1; sft < 64; sft <<= 1) {
+    const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)hi, sft, 64) << 32) |
+                                 (uint32_t)__shfl_xor((int)lo, sft, 64);
+    const unsigned long long t = (((unsigned long long)hi << 32) | lo) + o;
+    lo = (uint32_t)t;
+    hi = (uint32_t)(t >> 32);
+  }
+  __syncthreads();   // part4 may still be read from a previous use
+  if ((threadIdx.x & 63) == 0) part4[threadIdx.x >> 6] = ((unsigned long long)hi << 32) | lo;
+  __syncthreads();
+  return part4[0] + part4[1] + part4[2] + part4[3];
+}
+
+// The restoration leg of rdo_loop_decision, per (unit, set) pair (src/rdo.rs:2575-2763): the unit
+// filtered with the weights k_sgr_solve just wrote -- sgrproj_stripe_filter on the unit's OWN padded
+// image (hard-clipped like the solve), never stored -- and rdo_loop_plane_error of the result against
+// the source (rdo.rs:2027-2093): per 8x8-luma block cdef_dist_kernel * bias (luma) or sse_wxh with
+// |_, _| bias on (8 >> xdec) x (8 >> ydec) pixels (chroma).  Same tiling as k_sgr_moments; a tile's
+// filtered pixels go to LDS, one thread per block sums its block, the workgroup's total is added to
+// the pair's plane sum.  set = 255: the "no filter option" (the unit of lrf_in as it is).
+template <int BPP, bool CHROMA>
+__global__ __launch_bounds__(256) void k_sgr_unit_err(R1Plane lrf_in, R1Plane src,
+                                                      const R1SgrSolveUnit *__restrict__ units,
+                                                      const int8_t *__restrict__ xqd, int xdec, int ydec,
+                                                      const uint32_t *__restrict__ scales, int scale_stride,
+                                                      unsigned long long *__restrict__ acc) {
+  __shared__ uint16_t F[64][TW];
+  __shared__ unsigned long long part[4];
+  const R1SgrSolveUnit u = units[blockIdx.y];
+  const int ntx = (u.w + TW - 1) / TW, nty = (u.h + 63) / 64;
+  if ((int)blockIdx.x >= ntx * nty) return;   // workgroup-uniform
+  SgrTile t;
+  t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
+  t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the unit (rdo.rs:2651-2666)
+  const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+  t.cx0 = u.x + tx * TW;
+  t.ty0 = ty * 64;
+  t.tw = (u.w - tx * TW) < TW ? (u.w - tx * TW) : TW;
+  t.th = (u.h - ty * 64) < 64 ? (u.h - ty * 64) : 64;
+  const int bd = lrf_in.bit_depth;
+  if (u.set > 15) {
+    for (int e = threadIdx.x; e < t.th * t.tw; e += 256) {
+      const int y = e / t.tw, x = e - y * t.tw;
+      F[y][x] = (uint16_t)ld_px<BPP>(px_addr<BPP>(lrf_in, t.cx0 + x, u.y + t.ty0 + y));
+    }
+  } else {
+    const int w0 = xqd[2 * blockIdx.y], w1 = xqd[2 * blockIdx.y + 1], w2 = 128 - w0 - w1;
+    const int32_t pmax = (1 << bd) - 1;
+    sgr_tile<BPP>(lrf_in, lrf_in, t, u.set, bd, [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2) {
+      // apply_filter (lrf.rs:796-815)
+      const int32_t v = w0 * (int32_t)f2 + w1 * (int32_t)(p << 4) + w2 * (int32_t)f1;
+      const int32_t sft = (v + (1 << 10)) >> 11;
+      F[y][x] = (uint16_t)(sft < 0 ? 0 : (sft > pmax ? pmax : sft));
+    });
+  }
+  __syncthreads();
+  const int bw = CHROMA ? 8 >> xdec : 8, bh = CHROMA ? 8 >> ydec : 8;
+  const int nbx = t.tw / bw, nby = t.th / bh;
+  unsigned long long mine = 0;
+  if ((int)threadIdx.x < nbx * nby) {
+    const int by = (int)threadIdx.x / nbx, bx = (int)threadIdx.x - by * nbx;
+    mine = lrf_block_err<BPP, CHROMA, TW>(src, &F[by * bh][bx * bw], t.cx0 + bx * bw, u.y + t.ty0 + by * bh, bw, bh,
+                                          xdec, ydec, scales, scale_stride, bd);
+  }
+  const unsigned long long v = wg_sum_u64(mine, part);
+  if (threadIdx.x == 0 && v) atomicAdd(acc + blockIdx.y, v);
+}
+
+// The same leg in ONE launch for units up to 64 x 64 pixels (the 64x64 luma / 32x32 chroma units of the
+// speed settings the encoder ships): a workgroup owns a (unit, set) pair, the two filter outputs of every
+// pixel stay in LDS between the moments and the projection, so the box filters run once.
+template <int BPP, bool CHROMA>
+__global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane src,
+                                                         const R1SgrSolveUnit *__restrict__ units, int xdec, int ydec,
+                                                         const uint32_t *__restrict__ scales, int scale_stride,
+                                                         uint32_t dist_scale, int8_t *__restrict__ xqd_out,
+                                                         unsigned long long *__restrict__ err_out) {
+  __shared__ uint32_t F1[64][64];
+  __shared__ uint32_t F2[BPP == 2 ? 64 : 1][64];   // 8-bit: f1 | f2 << 16 in F1 (f <= 255 * 16 + rounding)
+  __shared__ uint16_t P[64][64];                     // the unit's pixels, then the filtered unit
+  __shared__ long long mpart[4][5];
+  __shared__ unsigned long long epart[4];
+  __shared__ int8_t xq[2];
+  const R1SgrSolveUnit u = units[blockIdx.x];
+  const int bd = lrf_in.bit_depth;
+  if (u.w > 64 || u.h > 64 || u.w <= 0 || u.h <= 0) {   // not what max_w / max_h promised: no result
+    if (threadIdx.x == 0) {
+      err_out[blockIdx.x] = ~0ull;
+      xqd_out[2 * blockIdx.x] = xqd_out[2 * blockIdx.x + 1] = 0;
+    }
+    return;
+  }
+  if (u.set > 15) {
+    for (int e = threadIdx.x; e < u.w * u.h; e += 256) {
+      const int y = e / u.w, x = e - y * u.w;
+      P[y][x] = (uint16_t)ld_px<BPP>(px_addr<BPP>(lrf_in, u.x + x, u.y + y));
+    }
+    if (threadIdx.x == 0) xqd_out[2 * blockIdx.x] = xqd_out[2 * blockIdx.x + 1] = 0;
+  } else {
+    long long m[5] = {0, 0, 0, 0, 0};
+    const int ntx = (u.w + TW - 1) / TW;
+    for (int tx = 0; tx < ntx; tx++) {
+      SgrTile t;
+      t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
+      t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the unit (rdo.rs:2651-2666)
+      t.cx0 = u.x + tx * TW;
+      t.ty0 = 0;
+      t.tw = (u.w - tx * TW) < TW ? (u.w - tx * TW) : TW;
+      t.th = u.h;
+      sgr_tile<BPP>(lrf_in, lrf_in, t, u.set, bd, [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2) {
+        const int X = tx * TW + x;
+        if constexpr (BPP == 2) { F1[y][X] = f1; F2[y][X] = f2; }
+        else F1[y][X] = f1 | (f2 << 16);
+        P[y][X] = (uint16_t)p;
+        const int32_t uu = (int32_t)(p << 4);
+        const long long sv = ((int32_t)ld_px<BPP>(px_addr<BPP>(src, u.x + X, u.y + y)) << 4) - uu;
+        const long long g2 = (int32_t)f2 - uu, g1 = (int32_t)f1 - uu;
+        m[0] += g2 * g2; m[1] += g1 * g1; m[2] += g1 * g2; m[3] += g2 * sv; m[4] += g1 * sv;
+      });
+      __syncthreads();   // the tile's LDS is staged again by the next one
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      uint32_t lo = (uint32_t)m[k], hi = (uint32_t)((unsigned long long)m[k] >> 32);
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) {
+        const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)hi, sft, 64) << 32) |
+                                     (uint32_t)__shfl_xor((int)lo, sft, 64);
+        const unsigned long long v = (((unsigned long long)hi << 32) | lo) + o;
+        lo = (uint32_t)v;
+        hi = (uint32_t)(v >> 32);
+      }
+      if (lane == 0) mpart[wave][k] = (long long)(((unsigned long long)hi << 32) | lo);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long tot[5];
+      for (int k = 0; k < 5; k++) tot[k] = mpart[0][k] + mpart[1][k] + mpart[2][k] + mpart[3][k];
+      sgr_solve_xqd(tot, u.w, u.h, u.set, xq);
+      xqd_out[2 * blockIdx.x] = xq[0];
+      xqd_out[2 * blockIdx.x + 1] = xq[1];
+    }
+    __syncthreads();
+    const int w0 = xq[0], w1 = xq[1], w2 = 128 - w0 - w1;
+    const int32_t pmax = (1 << bd) - 1;
+    for (int e = threadIdx.x; e < u.w * u.h; e += 256) {
+      const int y = e / u.w, x = e - y * u.w;
+      uint32_t f1, f2;
+      if constexpr (BPP == 2) { f1 = F1[y][x]; f2 = F2[y][x]; }
+      else { f1 = F1[y][x] & 0xFFFFu; f2 = F1[y][x] >> 16; }
+      // apply_filter (lrf.rs:796-815)
+      const int32_t v = w0 * (int32_t)f2 + w1 * (int32_t)((uint32_t)P[y][x] << 4) + w2 * (int32_t)f1;
+      const int32_t sft = (v + (1 << 10)) >> 11;
+      P[y][x] = (uint16_t)(sft < 0 ? 0 : (sft > pmax ? pmax : sft));
+    }
+  }
+  __syncthreads();
+  const int bw = CHROMA ? 8 >> xdec : 8, bh = CHROMA ? 8 >> ydec : 8;
+  const int nbx = u.w / bw, nby = u.h / bh;
+  unsigned long long mine = 0;
+  for (int b = threadIdx.x; b < nbx * nby; b += 256) {
+    const int by = b / nbx, bx = b - by * nbx;
+    mine += lrf_block_err<BPP, CHROMA, 64>(src, &P[by * bh][bx * bw], u.x + bx * bw, u.y + by * bh, bw, bh, xdec, ydec,
+                                           scales, scale_stride, bd);
+  }
+  const unsigned long long v = wg_sum_u64(mine, epart);
+  // Distortion * fi.dist_scale[pli] (rdo.rs:2092; DistortionScale::mul_u64, rdo.rs:613-615)
+  if (threadIdx.x == 0) err_out[blockIdx.x] = ((unsigned long long)dist_scale * v + 8192) >> 14;
+}
+
+// Distortion * fi.dist_scale[pli] (rdo.rs:2092; DistortionScale::mul_u64, rdo.rs:613-615)
+__global__ void k_lrf_err_finish(const unsigned long long *__restrict__ acc, int n, uint32_t dist_scale,
+                                 unsigned long long *__restrict__ err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) err[i] = ((unsigned long long)dist_scale * acc[i] + 8192) >> 14;
 }
 
 }  // namespace
@@ -371,3 +602,61 @@ extern "C" int r1_sgrproj_solve_batch(r1_ctx *ctx, const R1Plane *cdeffed, const
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }
+
+// The restoration leg of rdo_loop_decision for one plane, everything but the rate (see
+// k_sgr_unit_err): units as for r1_sgrproj_solve_batch, plus set = 255 for the "no filter option".
+extern "C" int r1_lrf_search_batch(r1_ctx *ctx, const R1Plane *lrf_in, const R1Plane *src,
+                                   const R1SgrSolveUnit *units, int n, int max_w, int max_h, int is_chroma,
+                                   int xdec, int ydec, const uint32_t *scales, int scale_stride,
+                                   uint32_t dist_scale, int64_t *scratch, int8_t *xqd_out,
+                                   uint64_t *err_out, void *stream) {
+  R1_REQUIRE(ctx && lrf_in && src);
+  R1_REQUIRE(lrf_in->bytes_per_px == src->bytes_per_px && lrf_in->bit_depth == src->bit_depth);
+  R1_REQUIRE(lrf_in->bytes_per_px == 1 || lrf_in->bytes_per_px == 2);
+  R1_REQUIRE((lrf_in->bytes_per_px == 1) == (lrf_in->bit_depth == 8));
+  R1_REQUIRE(max_w > 0 && max_h > 0 && max_w <= 384 && max_h <= 384);
+  R1_REQUIRE(xdec >= 0 && xdec <= 1 && ydec >= 0 && ydec <= 1 && (is_chroma || (!xdec && !ydec)));
+  R1_REQUIRE(!scales || scale_stride > 0);
+  if (n <= 0) return R1_OK;
+  R1_REQUIRE(units && scratch && xqd_out && err_out);
+  hipStream_t st = (hipStream_t)stream;
+  if (max_w <= 64 && max_h <= 64) {
+    // one launch: a workgroup per pair keeps the filter outputs in LDS between the solve and the projection
+#define R1_LRF_UNIT(BPP, CH)                                                                                  \
+  hipLaunchKernelGGL((k_lrf_search_unit<BPP, CH>), dim3(n), dim3(256), 0, st, *lrf_in, *src, units, xdec, ydec, \
+                     scales, scale_stride, dist_scale, xqd_out, (unsigned long long *)err_out)
+    if (lrf_in->bytes_per_px == 1) {
+      if (is_chroma) R1_LRF_UNIT(1, true); else R1_LRF_UNIT(1, false);
+    } else {
+      if (is_chroma) R1_LRF_UNIT(2, true); else R1_LRF_UNIT(2, false);
+    }
+#undef R1_LRF_UNIT
+    R1_HIP_CHECK(hipGetLastError());
+    return R1_OK;
+  }
+  // larger units: moments, solve, then the box filters again for the error
+  // scratch: 5 moments per pair, then the pair's plane sum
+  R1_HIP_CHECK(hipMemsetAsync(scratch, 0, (size_t)n * 6 * sizeof(int64_t), st));
+  unsigned long long *acc = (unsigned long long *)scratch + (size_t)n * 5;
+  const dim3 grid(((max_w + TW - 1) / TW) * ((max_h + 63) / 64), n);
+  if (lrf_in->bytes_per_px == 1)
+    hipLaunchKernelGGL(k_sgr_moments<1>, grid, dim3(256), 0, st, *lrf_in, *src, units, (long long *)scratch);
+  else
+    hipLaunchKernelGGL(k_sgr_moments<2>, grid, dim3(256), 0, st, *lrf_in, *src, units, (long long *)scratch);
+  hipLaunchKernelGGL(k_sgr_solve, dim3((n + 127) / 128), dim3(128), 0, st, units, (const long long *)scratch, n,
+                     xqd_out);
+#define R1_LRF_ERR(BPP, CH)                                                                                  \
+  hipLaunchKernelGGL((k_sgr_unit_err<BPP, CH>), grid, dim3(256), 0, st, *lrf_in, *src, units,              \
+                     (const int8_t *)xqd_out, xdec, ydec, scales, scale_stride, acc)
+  if (lrf_in->bytes_per_px == 1) {
+    if (is_chroma) R1_LRF_ERR(1, true); else R1_LRF_ERR(1, false);
+  } else {
+    if (is_chroma) R1_LRF_ERR(2, true); else R1_LRF_ERR(2, false);
+  }
+#undef R1_LRF_ERR
+  hipLaunchKernelGGL(k_lrf_err_finish, dim3((n + 127) / 128), dim3(128), 0, st, acc, n, dist_scale,
+                     (unsigned long long *)err_out);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+

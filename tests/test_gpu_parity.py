@@ -1462,6 +1462,79 @@ def test_sgrproj_solve_ref(ctx, bd):
     assert np.array_equal(got.astype(np.int64), cases[:, 5:7].astype(np.int64)), (bd, got[:4], cases[:4])
 
 
+@pytest.mark.parametrize("case", ["s0", "s1", "s2", "s3"])
+def test_lrf_search_ref(ctx, case):
+    """r1_lrf_search_batch (the restoration leg of rdo_loop_decision but the rate) on what
+    setup_integral_image + sgrproj_solve + sgrproj_stripe_filter + rdo_loop_plane_error of the
+    reference's own text returned: (xqd, err) per (unit, set) and the no-filter error, three planes
+    (lrf_search_ref.npz)"""
+    import torch
+    from rav1e_amd.api import SGR_SOLVE_UNIT
+    REF = np.load(os.path.join(GOLD, "lrf_search_ref.npz"))
+    W, H, xdec, ydec, bd, lru_sb = [int(v) for v in REF[case + "_meta"]]
+    rows, want = REF[case + "_rows"], REF[case + "_err"]
+    scales = torch.from_numpy(REF[case + "_scales"].astype(np.int64).astype(np.int32)).cuda()
+    for pli in range(3):
+        hi = O.plane_from_image(REF[case + "_in%d" % pli].astype(np.int64), bd, 16, 16)
+        hs = O.plane_from_image(REF[case + "_src%d" % pli].astype(np.int64), bd, 16, 16)
+        sel = rows[:, 0] == pli
+        r = rows[sel]
+        u = np.zeros(len(r), SGR_SOLVE_UNIT)
+        for i, (_, x, y, w, h, set_, q0, q1) in enumerate(r.tolist()):
+            u[i] = (x, y, w, h, set_, (0, 0, 0))
+        xd, yd = (0, 0) if pli == 0 else (xdec, ydec)
+        # units up to 64 x 64: the one-launch kernel; max 256: moments / solve / filter-and-error launches
+        for mx in ([64, 256] if r[:, 3:5].max() <= 64 else [256]):
+            xqd, err = ctx.lrf_search_batch(dev_plane(hi), dev_plane(hs), u, is_chroma=pli != 0, xdec=xd, ydec=yd,
+                                            scales=scales, dist_scale=int(REF[case + "_dscale"][pli]), max_w=mx, max_h=mx)
+            assert np.array_equal(xqd.cpu().numpy().astype(np.int64), r[:, 6:8].astype(np.int64)), (case, pli, mx)
+            got = err.cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, want[sel]), (case, pli, mx, np.argwhere(got != want[sel])[:4].ravel(), got[:4],
+                                                    want[sel][:4])
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_lrf_search_vs_oracle_frame_units(ctx, oracle, bd):
+    """every 64x64 luma unit (and the 32x32 units of a 4:2:0 chroma plane) of a 520x264 frame -- the last
+    column of units 8 wide, the last row 8 high -- x {no filter, four parameter sets}, against
+    oracle/lrf.c::r1o_lrf_search_unit"""
+    import ctypes as C
+    import torch
+    from rav1e_amd.api import SGR_SOLVE_UNIT
+    rng = np.random.default_rng(77 + bd)
+    W, H = 520, 264
+    yy, xx = np.mgrid[0:H, 0:W]
+    srcY = np.clip((np.sin(xx / 7.0) + np.cos(yy / 5.0) + 2) / 4 * ((1 << bd) - 1), 0, (1 << bd) - 1).astype(np.int64)
+    inY = np.clip(srcY + rng.integers(-8, 9, (H, W)) * (1 << (bd - 8)), 0, (1 << bd) - 1)
+    grid = rng.integers(1 << 12, 1 << 16, ((H + 7) // 8, (W + 7) // 8)).astype(np.uint32)
+    dscales = torch.from_numpy(grid.astype(np.int64).astype(np.int32)).cuda()
+    for chroma in (False, True):
+        xd = yd = 1 if chroma else 0
+        s_, i_ = (srcY[::2, ::2], inY[::2, ::2]) if chroma else (srcY, inY)
+        hi, hs = O.plane_from_image(i_, bd, 16, 16), O.plane_from_image(s_, bd, 16, 16)
+        us = 64 >> xd
+        u = []
+        for y in range(0, s_.shape[0], us):
+            for x in range(0, s_.shape[1], us):
+                for set_ in (255, 2, 11, 14, 9):
+                    u.append((x, y, min(us, s_.shape[1] - x), min(us, s_.shape[0] - y), set_, (0, 0, 0)))
+        u = np.array(u, SGR_SOLVE_UNIT)
+        xqd, err = ctx.lrf_search_batch(dev_plane(hi), dev_plane(hs), u, is_chroma=chroma, xdec=xd, ydec=yd,
+                                        scales=dscales, dist_scale=21000, max_w=64, max_h=64)
+        x2, e2 = ctx.lrf_search_batch(dev_plane(hi), dev_plane(hs), u, is_chroma=chroma, xdec=xd, ydec=yd,
+                                      scales=dscales, dist_scale=21000, max_w=128, max_h=128)
+        assert torch.equal(xqd, x2) and torch.equal(err, e2)            # the two launch plans agree
+        xqd, err = xqd.cpu().numpy(), err.cpu().numpy().view(np.uint64)
+        ci, cs = hi.cstruct(), hs.cstruct()
+        wx, we = np.zeros((len(u), 2), np.int8), np.zeros(len(u), np.uint64)
+        for i in range(len(u)):
+            assert oracle.r1o_lrf_search_unit(C.byref(ci), C.byref(cs), int(u["x"][i]), int(u["y"][i]), int(u["w"][i]),
+                                              int(u["h"][i]), int(u["set"][i]), int(chroma), xd, yd, grid.ctypes.data,
+                                              grid.shape[1], 21000, bd, wx[i].ctypes.data, we[i:].ctypes.data) == 0
+        assert np.array_equal(xqd, wx), (bd, chroma)
+        assert np.array_equal(err, we), (bd, chroma, np.argwhere(err != we)[:4].ravel())
+
+
 @pytest.mark.parametrize("bd", [8, 10, 12])
 def test_activity_scales_vs_oracle(ctx, oracle, bd):
     """r1_activity_scales (ActivityMask::from_plane + fill_scales) on a frame whose size is not a

@@ -91,3 +91,46 @@ def test_sgrproj_solve_equals_the_executed_reference(oracle, bd):
         got = np.zeros(2, np.int8)
         oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), x0, y0, uw, uh, set_, bd, got.ctypes.data)
         assert (int(got[0]), int(got[1])) == (q0, q1), (bd, x0, y0, uw, uh, set_, got, (q0, q1))
+
+
+# ---- the restoration leg of rdo_loop_decision (everything but the rate) -------------------------
+SEARCH = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lrf_search_ref.npz"))
+
+
+def search_cases():
+    return sorted({k.split("_")[0] for k in SEARCH.files})
+
+
+@pytest.mark.parametrize("case", search_cases())
+def test_lrf_search_units_equal_the_executed_reference(oracle, case):
+    """oracle/lrf.c::r1o_lrf_search_unit against setup_integral_image + sgrproj_solve +
+    sgrproj_stripe_filter + rdo_loop_plane_error of the reference's own text, unit by unit and set by
+    set (and the "no filter option"), luma and both chroma planes (lrf_search_ref.npz)"""
+    W, H, xdec, ydec, bd, lru_sb = [int(v) for v in SEARCH[case + "_meta"]]
+    pin = [O.plane_from_image(SEARCH[case + "_in%d" % p].astype(np.int64), bd, 16, 16) for p in range(3)]
+    psrc = [O.plane_from_image(SEARCH[case + "_src%d" % p].astype(np.int64), bd, 16, 16) for p in range(3)]
+    scales = np.ascontiguousarray(SEARCH[case + "_scales"])
+    dscale = SEARCH[case + "_dscale"]
+    rows, errs = SEARCH[case + "_rows"], SEARCH[case + "_err"]
+    for (pli, x, y, w, h, set_, q0, q1), want in zip(rows, errs):
+        xd, yd = (0, 0) if pli == 0 else (xdec, ydec)
+        ci, cs = pin[pli].cstruct(), psrc[pli].cstruct()
+        xqd, err = np.zeros(2, np.int8), np.zeros(1, np.uint64)
+        rc = oracle.r1o_lrf_search_unit(C.byref(ci), C.byref(cs), int(x), int(y), int(w), int(h), int(set_),
+                                        int(pli != 0), xd, yd, scales.ctypes.data, scales.shape[1],
+                                        int(dscale[pli]), bd, xqd.ctypes.data, err.ctypes.data)
+        assert rc == 0
+        assert (int(xqd[0]), int(xqd[1])) == (int(q0), int(q1)), (case, pli, x, y, set_)
+        assert int(err[0]) == int(want), (case, pli, x, y, w, h, set_, int(err[0]), int(want))
+
+
+def test_lrf_search_rejects_partial_blocks(oracle):
+    a = np.full((64, 64), 100, np.int64)
+    p = O.plane_from_image(a, 8, 16, 16)
+    c = p.cstruct()
+    xqd, err = np.zeros(2, np.int8), np.zeros(1, np.uint64)
+    args = lambda w, h, s: (C.byref(c), C.byref(c), 0, 0, w, h, s, 0, 0, 0, None, 0, 1 << 14, 8, xqd.ctypes.data,
+                            err.ctypes.data)
+    assert oracle.r1o_lrf_search_unit(*args(60, 64, 3)) == -1      # a width that cuts an 8x8 block
+    assert oracle.r1o_lrf_search_unit(*args(64, 64, 16)) == -1     # no such parameter set
+    assert oracle.r1o_lrf_search_unit(*args(64, 64, 255)) == 0 and int(err[0]) == 0   # identical planes

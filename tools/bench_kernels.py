@@ -329,6 +329,29 @@ def main():
     lrf_out.data.copy_(ref.data)
     ms = timeit(lambda: ctx.lrf_sgrproj_plane(ref, org, lrf_out, 0, fw, fh, fh, us, dunits, 64))
     report("lrf sgrproj luma (all units, mixed sets)", ms, fw * fh, 3 * fw * fh * bpp)
+    # ---- N3: the restoration leg of rdo_loop_decision but the rate (rdo.rs:2575-2763): per 64x64 luma /
+    # 32x32 chroma unit of a 4:2:0 frame the no-filter error + (solve, filter, error) for the speed-6 list of
+    # parameter sets (SGRPROJ_REDUCED_SETS, lrf.rs:86; speed >= 5, speedsettings.rs:143-144) ----
+    sets = [255, 1, 3, 5, 7, 9, 11, 13, 15]
+    scl = torch.from_numpy(np.random.default_rng(9).integers(1 << 12, 1 << 16, ((fh + 7) // 8, (fw + 7) // 8))
+                           .astype(np.int32)).cuda()
+    cw, ch = fw // 2, fh // 2
+    cin = [Plane.from_numpy(W.random_plane_array(cw, ch, bd, 40 + i, 44, 44), cw, ch, bd, 44, 44) for i in range(4)]
+
+    def unit_list(pw, ph, us_):
+        u = [(x, y, min(us_, pw - x), min(us_, ph - y), s_, (0, 0, 0))
+             for y in range(0, ph, us_) for x in range(0, pw, us_) for s_ in sets]
+        return torch.from_numpy(np.array(u, api.SGR_SOLVE_UNIT).view(np.uint8).reshape(-1).copy()).cuda()
+    ul, uc = unit_list(fw, fh, 64), unit_list(cw, ch, 32)
+
+    def lrf_search():
+        ctx.lrf_search_batch(ref, org, ul, scales=scl, max_w=64, max_h=64)
+        ctx.lrf_search_batch(cin[0], cin[1], uc, is_chroma=True, xdec=1, ydec=1, scales=scl, max_w=32, max_h=32)
+        ctx.lrf_search_batch(cin[2], cin[3], uc, is_chroma=True, xdec=1, ydec=1, scales=scl, max_w=32, max_h=32)
+    ms = timeit(lrf_search)
+    npairs = (ul.numel() + 2 * uc.numel()) // api.SGR_SOLVE_UNIT.itemsize
+    report("lrf search 4:2:0 (no filter + 8 parameter sets per unit: solve, filter, error)", ms,
+           (fw * fh + 2 * cw * ch) * len(sets), (fw * fh + 2 * cw * ch) * 2 * bpp + npairs * 10, {"pairs": npairs})
     ctx.close()
 
 
