@@ -169,6 +169,29 @@ def main():
         cdef_search()
     torch.cuda.synchronize()
     cdef_search_ms = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
+    # the restoration search of rdo_loop_decision (rdo.rs:2575-2763) but the rate: per 64x64 luma / 32x32
+    # chroma unit the no-filter error + (solve, filter, error) for the 8 parameter sets of speed >= 5
+    sets = [255, 1, 3, 5, 7, 9, 11, 13, 15]
+
+    def unit_list(pw, ph, us_):
+        u = [(x, y, min(us_, pw - x), min(us_, ph - y), s_, (0, 0, 0))
+             for y in range(0, ph, us_) for x in range(0, pw, us_) for s_ in sets]
+        return torch.from_numpy(np.array(u, api.SGR_SOLVE_UNIT).view(np.uint8).reshape(-1).copy()).cuda()
+    ul, uc = unit_list(fw, fh, 64), unit_list(fw // 2, fh // 2, 32)
+
+    def lrf_search():
+        ctx.lrf_search_batch(rec3[0], src3[0], ul, scales=scales, max_w=64, max_h=64)
+        for pl in (1, 2):
+            ctx.lrf_search_batch(rec3[pl], src3[pl], uc, is_chroma=True, xdec=1, ydec=1, scales=scales, max_w=32,
+                                 max_h=32)
+    lrf_search()
+    torch.cuda.synchronize()
+    W.sustain_clocks(lrf_search, args.sustain_ms)
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        lrf_search()
+    torch.cuda.synchronize()
+    lrf_search_ms = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
     # 9 loop restoration (self-guided), luma, every 64x64 unit
     us = 64
     units = np.zeros((max((fh + 32) // us, 1), max((fw + 32) // us, 1), 4), np.uint8)
@@ -209,6 +232,7 @@ def main():
     print(json.dumps({"frame": "%dx%d %d-bit" % (fw, fh, bd), "stage_ms": stages, "sum_ms": total,
                       "frames_per_s_if_serial": round(1e3 / total, 1),
                       "cdef_strength_search_8_presets_420_ms (optional stage, not in the sum)": cdef_search_ms,
+                      "lrf_search_8_sets_420_ms (optional stage, not in the sum)": lrf_search_ms,
                       "two_stream_ms (ME of the next frame beside the other stages)": ov,
                       "frames_per_s_two_streams": round(1e3 / ov, 1)}))
     ctx.close()
