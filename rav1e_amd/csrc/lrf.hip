@@ -22,6 +22,8 @@
 //   * every thread then finishes 8 pixels: the weighted (a, b) stencils, the
 //     projection with xqd, clamp, store.
 // u32 arithmetic wraps where the reference's release build wraps (p * s).
+#include <type_traits>
+
 #include "common.hpp"
 #include "dist_common.hpp"
 
@@ -332,8 +334,8 @@ __global__ void k_sgr_solve(const R1SgrSolveUnit *__restrict__ units, const long
 
 // rdo_loop_plane_error's term for one block of the unit (rdo.rs:2060-2088): `test` = the filtered unit
 // in LDS (row stride TS pixels), (px, py) = the block's position in the plane
-template <int BPP, bool CHROMA, int TS>
-__device__ __forceinline__ unsigned long long lrf_block_err(const R1Plane &src, const uint16_t *test, int px, int py,
+template <int BPP, bool CHROMA, int TS, typename PT>
+__device__ __forceinline__ unsigned long long lrf_block_err(const R1Plane &src, const PT *test, int px, int py,
                                                             int bw, int bh, int xdec, int ydec,
                                                             const uint32_t *__restrict__ scales, int scale_stride,
                                                             int bd) {
@@ -414,9 +416,9 @@ __global__ __launch_bounds__(256) void k_sgr_unit_err(R1Plane lrf_in, R1Plane sr
   t.th = (u.h - ty * 64) < 64 ? (u.h - ty * 64) : 64;
   const int bd = lrf_in.bit_depth;
   if (u.set > 15) {
-    for (int e = threadIdx.x; e < t.th * t.tw; e += 256) {
-      const int y = e / t.tw, x = e - y * t.tw;
-      F[y][x] = (uint16_t)ld_px<BPP>(px_addr<BPP>(lrf_in, t.cx0 + x, u.y + t.ty0 + y));
+    for (int e = threadIdx.x; e < t.th * TW; e += 256) {
+      const int y = e / TW, x = e % TW;   // TW is a constant: no runtime division
+      if (x < t.tw) F[y][x] = (uint16_t)ld_px<BPP>(px_addr<BPP>(lrf_in, t.cx0 + x, u.y + t.ty0 + y));
     }
   } else {
     const int w0 = xqd[2 * blockIdx.y], w1 = xqd[2 * blockIdx.y + 1], w2 = 128 - w0 - w1;
@@ -444,15 +446,18 @@ __global__ __launch_bounds__(256) void k_sgr_unit_err(R1Plane lrf_in, R1Plane sr
 // The same leg in ONE launch for units up to 64 x 64 pixels (the 64x64 luma / 32x32 chroma units of the
 // speed settings the encoder ships): a workgroup owns a (unit, set) pair, the two filter outputs of every
 // pixel stay in LDS between the moments and the projection, so the box filters run once.
-template <int BPP, bool CHROMA>
+// PACK: both filter outputs of a pixel in one dword (f <= 16 * 1023 + rounding: up to 10 bits; at 12 bits an
+// all-white unit reaches 65588)
+template <int BPP, bool CHROMA, bool PACK>
 __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane src,
                                                          const R1SgrSolveUnit *__restrict__ units, int xdec, int ydec,
                                                          const uint32_t *__restrict__ scales, int scale_stride,
                                                          uint32_t dist_scale, int8_t *__restrict__ xqd_out,
                                                          unsigned long long *__restrict__ err_out) {
+  typedef typename std::conditional<BPP == 1, uint8_t, uint16_t>::type PT;
   __shared__ uint32_t F1[64][64];
-  __shared__ uint32_t F2[BPP == 2 ? 64 : 1][64];   // 8-bit: f1 | f2 << 16 in F1 (f <= 255 * 16 + rounding)
-  __shared__ uint16_t P[64][64];                     // the unit's pixels, then the filtered unit
+  __shared__ uint32_t F2[PACK ? 1 : 64][64];         // PACK: f1 | f2 << 16 in F1
+  __shared__ PT P[64][64];                           // the unit's pixels, then the filtered unit
   __shared__ long long mpart[4][5];
   __shared__ unsigned long long epart[4];
   __shared__ int8_t xq[2];
@@ -466,9 +471,9 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
     return;
   }
   if (u.set > 15) {
-    for (int e = threadIdx.x; e < u.w * u.h; e += 256) {
-      const int y = e / u.w, x = e - y * u.w;
-      P[y][x] = (uint16_t)ld_px<BPP>(px_addr<BPP>(lrf_in, u.x + x, u.y + y));
+    for (int e = threadIdx.x; e < 64 * u.h; e += 256) {
+      const int y = e >> 6, x = e & 63;   // rows of 64: no runtime division
+      if (x < u.w) P[y][x] = (PT)ld_px<BPP>(px_addr<BPP>(lrf_in, u.x + x, u.y + y));
     }
     if (threadIdx.x == 0) xqd_out[2 * blockIdx.x] = xqd_out[2 * blockIdx.x + 1] = 0;
   } else {
@@ -484,9 +489,9 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
       t.th = u.h;
       sgr_tile<BPP>(lrf_in, lrf_in, t, u.set, bd, [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2) {
         const int X = tx * TW + x;
-        if constexpr (BPP == 2) { F1[y][X] = f1; F2[y][X] = f2; }
+        if constexpr (!PACK) { F1[y][X] = f1; F2[y][X] = f2; }
         else F1[y][X] = f1 | (f2 << 16);
-        P[y][X] = (uint16_t)p;
+        P[y][X] = (PT)p;
         const int32_t uu = (int32_t)(p << 4);
         const long long sv = ((int32_t)ld_px<BPP>(px_addr<BPP>(src, u.x + X, u.y + y)) << 4) - uu;
         const long long g2 = (int32_t)f2 - uu, g1 = (int32_t)f1 - uu;
@@ -519,23 +524,25 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
     __syncthreads();
     const int w0 = xq[0], w1 = xq[1], w2 = 128 - w0 - w1;
     const int32_t pmax = (1 << bd) - 1;
-    for (int e = threadIdx.x; e < u.w * u.h; e += 256) {
-      const int y = e / u.w, x = e - y * u.w;
+    for (int e = threadIdx.x; e < 64 * u.h; e += 256) {
+      const int y = e >> 6, x = e & 63;
+      if (x >= u.w) continue;
       uint32_t f1, f2;
-      if constexpr (BPP == 2) { f1 = F1[y][x]; f2 = F2[y][x]; }
+      if constexpr (!PACK) { f1 = F1[y][x]; f2 = F2[y][x]; }
       else { f1 = F1[y][x] & 0xFFFFu; f2 = F1[y][x] >> 16; }
       // apply_filter (lrf.rs:796-815)
       const int32_t v = w0 * (int32_t)f2 + w1 * (int32_t)((uint32_t)P[y][x] << 4) + w2 * (int32_t)f1;
       const int32_t sft = (v + (1 << 10)) >> 11;
-      P[y][x] = (uint16_t)(sft < 0 ? 0 : (sft > pmax ? pmax : sft));
+      P[y][x] = (PT)(sft < 0 ? 0 : (sft > pmax ? pmax : sft));
     }
   }
   __syncthreads();
   const int bw = CHROMA ? 8 >> xdec : 8, bh = CHROMA ? 8 >> ydec : 8;
   const int nbx = u.w / bw, nby = u.h / bh;
   unsigned long long mine = 0;
-  for (int b = threadIdx.x; b < nbx * nby; b += 256) {
-    const int by = b / nbx, bx = b - by * nbx;
+  for (int b = threadIdx.x; b < 16 * nby; b += 256) {   // rows of 16 block slots (a unit is at most 16 blocks wide)
+    const int by = b >> 4, bx = b & 15;
+    if (bx >= nbx) continue;
     mine += lrf_block_err<BPP, CHROMA, 64>(src, &P[by * bh][bx * bw], u.x + bx * bw, u.y + by * bh, bw, bh, xdec, ydec,
                                            scales, scale_stride, bd);
   }
@@ -632,13 +639,15 @@ extern "C" int r1_lrf_search_batch(r1_ctx *ctx, const R1Plane *lrf_in, const R1P
   hipStream_t st = (hipStream_t)stream;
   if (max_w <= 64 && max_h <= 64) {
     // one launch: a workgroup per pair keeps the filter outputs in LDS between the solve and the projection
-#define R1_LRF_UNIT(BPP, CH)                                                                                  \
-  hipLaunchKernelGGL((k_lrf_search_unit<BPP, CH>), dim3(n), dim3(256), 0, st, *lrf_in, *src, units, xdec, ydec, \
+#define R1_LRF_UNIT(BPP, CH, PK)                                                                                  \
+  hipLaunchKernelGGL((k_lrf_search_unit<BPP, CH, PK>), dim3(n), dim3(256), 0, st, *lrf_in, *src, units, xdec, ydec, \
                      scales, scale_stride, dist_scale, xqd_out, (unsigned long long *)err_out)
     if (lrf_in->bytes_per_px == 1) {
-      if (is_chroma) R1_LRF_UNIT(1, true); else R1_LRF_UNIT(1, false);
+      if (is_chroma) R1_LRF_UNIT(1, true, true); else R1_LRF_UNIT(1, false, true);
+    } else if (lrf_in->bit_depth <= 10) {
+      if (is_chroma) R1_LRF_UNIT(2, true, true); else R1_LRF_UNIT(2, false, true);
     } else {
-      if (is_chroma) R1_LRF_UNIT(2, true); else R1_LRF_UNIT(2, false);
+      if (is_chroma) R1_LRF_UNIT(2, true, false); else R1_LRF_UNIT(2, false, false);
     }
 #undef R1_LRF_UNIT
     R1_HIP_CHECK(hipGetLastError());
