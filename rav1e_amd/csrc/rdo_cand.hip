@@ -177,7 +177,7 @@ constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm) {
   if (wl == 4 && hl == 4 && qm == 2) return 5;              // 105 / 107 -> 91 / 94: 4 -> 5 waves, -4.0 / -5.1 %
   if (wl == 5 && hl == 5 && qm == 2) return 4;              // 8-bit 132 -> 128; 10-bit 131 -> 128 (8 B of scratch): 3 -> 4 waves, -5.4 %
   if (wl == 5 && hl == 5 && qm == 1) return 5;              // 8-bit 97 -> 96; 10-bit 120 -> 96 (20 B of scratch): 4 -> 5 waves, launch -4 % (ab10)
-  if (wl == 6 && hl == 6 && qm == 2) return 3;              // 176 / 181 -> 168
+  if (wl == 6 && hl == 6 && qm == 2) return bd == 8 ? 4 : 3;   // 8-bit: 168 -> 128 + 64 B of scratch, launch -2.9 %; 10-bit at 4: +14 % (ab12) -> 3: 181 -> 168
   return 1;
 }
 
