@@ -107,37 +107,57 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
   }
   __syncthreads();
   // ---- 2: (a, b) of both passes ----
-  if (s1 > 0) {
-    for (int e = tid; e < (t.th + 2) * AW; e += 256) {
-      const int r = e / AW, c = e - r * AW;   // centre (c - 1, r - 1) -> S[r + 3][c + 3]
-      if (c > t.tw + 1) continue;
-      uint32_t sum = 0, ssq = 0;
-#pragma unroll
-      for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-        for (int dx = 0; dx < 3; dx++) {
-          const uint32_t v = S[r + 2 + dy][c + 2 + dx];
-          sum += v;
-          ssq += v * v;
+  // A thread owns a COLUMN of (a, b) centres over a segment of rows and slides the box down: per new
+  // centre three (five) pixels of one new row (two new rows for the radius-2 pass, whose centres sit on
+  // every other row) instead of the whole 3x3 (5x5) box -- 9 -> 3 and 25 -> 10 LDS reads per centre.
+  {
+    constexpr int NSEG = 256 / AW;          // row segments per column
+    const int c = tid % AW, seg = tid / AW;
+    if (seg < NSEG && c <= t.tw + 1) {
+      if (s1 > 0) {
+        const int rows1 = t.th + 2, per = (rows1 + NSEG - 1) / NSEG;
+        const int r0 = seg * per, r1 = r0 + per < rows1 ? r0 + per : rows1;
+        auto row3 = [&](int j, uint32_t &sm, uint32_t &sq) {   // S[j][c + 2 .. c + 4]
+          const uint32_t v0 = S[j][c + 2], v1 = S[j][c + 3], v2 = S[j][c + 4];
+          sm = v0 + v1 + v2;
+          sq = v0 * v0 + v1 * v1 + v2 * v2;
+        };
+        if (r0 < r1) {
+          uint32_t sa, qa, sb, qb, sc, qc;
+          row3(r0 + 2, sa, qa);
+          row3(r0 + 3, sb, qb);
+          for (int r = r0; r < r1; r++) {   // centre (c - 1, r - 1): S rows r + 2 .. r + 4
+            row3(r + 4, sc, qc);
+            ab1[r][c] = sum_finish(qa + qb + qc, sa + sb + sc, 9, 455, s1, bd);
+            sa = sb; qa = qb; sb = sc; qb = qc;
+          }
         }
-      ab1[r][c] = sum_finish(ssq, sum, 9, 455, s1, bd);
-    }
-  }
-  if (s2 > 0) {
-    const int nr = th2 / 2 + 1;
-    for (int e = tid; e < nr * AW; e += 256) {
-      const int r = e / AW, c = e - r * AW;   // centre (c - 1, 2 r - 1) -> S[2 r + 3][c + 3]
-      if (c > t.tw + 1) continue;
-      uint32_t sum = 0, ssq = 0;
+      }
+      if (s2 > 0) {
+        const int nr = th2 / 2 + 1, per = (nr + NSEG - 1) / NSEG;
+        const int r0 = seg * per, r1 = r0 + per < nr ? r0 + per : nr;
+        auto row5 = [&](int j, uint32_t &sm, uint32_t &sq) {   // S[j][c + 1 .. c + 5]
+          sm = 0; sq = 0;
 #pragma unroll
-      for (int dy = 0; dy < 5; dy++)
-#pragma unroll
-        for (int dx = 0; dx < 5; dx++) {
-          const uint32_t v = S[2 * r + 1 + dy][c + 1 + dx];
-          sum += v;
-          ssq += v * v;
+          for (int dx = 0; dx < 5; dx++) {
+            const uint32_t v = S[j][c + 1 + dx];
+            sm += v;
+            sq += v * v;
+          }
+        };
+        if (r0 < r1) {
+          uint32_t m1, q1, m2, q2, m3, q3, m4, q4, m5, q5;
+          row5(2 * r0 + 1, m1, q1);
+          row5(2 * r0 + 2, m2, q2);
+          row5(2 * r0 + 3, m3, q3);
+          for (int r = r0; r < r1; r++) {   // centre (c - 1, 2 r - 1): S rows 2 r + 1 .. 2 r + 5
+            row5(2 * r + 4, m4, q4);
+            row5(2 * r + 5, m5, q5);
+            ab2[r][c] = sum_finish(q1 + q2 + q3 + q4 + q5, m1 + m2 + m3 + m4 + m5, 25, 164, s2, bd);
+            m1 = m3; q1 = q3; m2 = m4; q2 = q4; m3 = m5; q3 = q5;
+          }
         }
-      ab2[r][c] = sum_finish(ssq, sum, 25, 164, s2, bd);
+      }
     }
   }
   __syncthreads();
