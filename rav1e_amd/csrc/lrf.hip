@@ -162,54 +162,64 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
   }
   __syncthreads();
   // ---- 3: the weighted stencils ----
-  for (int e = tid; e < t.th * TW; e += 256) {
-    const int y = e / TW, x = e - y * TW;
-    if (x >= t.tw) continue;
-    const uint32_t p = S[y + 4][x + 4];
-    uint32_t f1, f2;
-    if (s1 > 0) {
-      uint32_t A = 0, B = 0;
-#pragma unroll
-      for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-        for (int dx = 0; dx < 3; dx++) {
-          const uint32_t v = ab1[y + dy][x + dx];
-          const uint32_t wt = (dx != 1 && dy != 1) ? 3u : 4u;
-          A += wt * (v & 511u);
-          B += wt * (v >> 9);
-        }
-      f1 = (A * p + B + (1u << 8)) >> 9;
-    } else {
-      f1 = p << 4;
-    }
-    if (s2 > 0) {
-      uint32_t A = 0, B = 0;
-      if ((y & 1) == 0) {
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-#pragma unroll
-          for (int dx = 0; dx < 3; dx++) {
-            const uint32_t v = ab2[y / 2 + k][x + dx];
-            const uint32_t wt = dx == 1 ? 6u : 5u;
-            A += wt * (v & 511u);
-            B += wt * (v >> 9);
-          }
-        f2 = (A * p + B + (1u << 8)) >> 9;
-      } else {
-#pragma unroll
-        for (int dx = 0; dx < 3; dx++) {
-          const uint32_t v = ab2[(y + 1) / 2][x + dx];
-          const uint32_t wt = dx == 1 ? 6u : 5u;
-          A += wt * (v & 511u);
-          B += wt * (v >> 9);
-        }
-        f2 = (A * p + B + (1u << 7)) >> 8;
+  // A thread owns a pixel COLUMN over a segment of rows (an even number of them: the radius-2 pass pairs
+  // rows) and slides down: the 3x3 stencil of the radius-1 pass is (3 4 3) on its outer rows and (4 4 4)
+  // on the middle one, so a row of (a, b) pairs is read once and its two horizontal forms kept; the
+  // radius-2 pass reads one row of pairs per TWO pixel rows.
+  {
+    static_assert(TW == 32, "column = tid & 31");
+    const int x = tid & (TW - 1), seg = tid >> 5;               // 8 segments
+    const int per = (((t.th + 7) >> 3) + 1) & ~1;
+    const int y0 = seg * per, y1 = y0 + per < t.th ? y0 + per : t.th;
+    if (x < t.tw && y0 < y1) {
+      auto row1 = [&](int j, uint32_t &oa, uint32_t &ob, uint32_t &ma, uint32_t &mb) {   // ab1 row j at x .. x + 2
+        const uint32_t v0 = ab1[j][x], v1 = ab1[j][x + 1], v2 = ab1[j][x + 2];
+        const uint32_t a0 = v0 & 511u, a1 = v1 & 511u, a2 = v2 & 511u;
+        const uint32_t b0 = v0 >> 9, b1 = v1 >> 9, b2 = v2 >> 9;
+        oa = 3u * (a0 + a2) + 4u * a1;
+        ob = 3u * (b0 + b2) + 4u * b1;
+        ma = 4u * (a0 + a1 + a2);
+        mb = 4u * (b0 + b1 + b2);
+      };
+      auto row2 = [&](int r, uint32_t &ha, uint32_t &hb) {   // ab2 row r at x .. x + 2: (5 6 5)
+        const uint32_t v0 = ab2[r][x], v1 = ab2[r][x + 1], v2 = ab2[r][x + 2];
+        ha = 5u * ((v0 & 511u) + (v2 & 511u)) + 6u * (v1 & 511u);
+        hb = 5u * ((v0 >> 9) + (v2 >> 9)) + 6u * (v1 >> 9);
+      };
+      uint32_t oa0 = 0, ob0 = 0, oa1 = 0, ob1 = 0, ma1 = 0, mb1 = 0, oa2, ob2, ma2, mb2, dump_a, dump_b;
+      if (s1 > 0) {
+        row1(y0, oa0, ob0, dump_a, dump_b);
+        row1(y0 + 1, oa1, ob1, ma1, mb1);
       }
-    } else {
-      // sgrproj_box_f_r0 once per row pair: the odd row reuses the even row's value
-      f2 = (uint32_t)S[(y & ~1) + 4][x + 4] << 4;
+      uint32_t ha0 = 0, hb0 = 0, ha1 = 0, hb1 = 0;
+      if (s2 > 0) row2(y0 / 2, ha0, hb0);
+      for (int y = y0; y < y1; y++) {
+        const uint32_t p = S[y + 4][x + 4];
+        uint32_t f1, f2;
+        if (s1 > 0) {
+          row1(y + 2, oa2, ob2, ma2, mb2);
+          const uint32_t A = oa0 + ma1 + oa2, B = ob0 + mb1 + ob2;
+          f1 = (A * p + B + (1u << 8)) >> 9;
+          oa0 = oa1; ob0 = ob1;
+          oa1 = oa2; ob1 = ob2; ma1 = ma2; mb1 = mb2;
+        } else {
+          f1 = p << 4;
+        }
+        if (s2 > 0) {
+          if ((y & 1) == 0) {
+            row2(y / 2 + 1, ha1, hb1);
+            f2 = ((ha0 + ha1) * p + hb0 + hb1 + (1u << 8)) >> 9;
+          } else {
+            f2 = (ha1 * p + hb1 + (1u << 7)) >> 8;
+            ha0 = ha1; hb0 = hb1;
+          }
+        } else {
+          // sgrproj_box_f_r0 once per row pair: the odd row reuses the even row's value
+          f2 = (uint32_t)S[(y & ~1) + 4][x + 4] << 4;
+        }
+        emit(x, y, p, f1, f2);
+      }
     }
-    emit(x, y, p, f1, f2);
   }
 }
 
