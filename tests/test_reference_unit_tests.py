@@ -21,6 +21,7 @@ Runs only where the reference tree is present (the build container); the GPU box
 import os
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -187,3 +188,35 @@ def test_a_wrong_expectation_is_caught():
                 body.replace("fn get_satd_same_inner", "fn mutated_satd_inner").replace("(4, 4, 1408)", "(4, 4, 1409)") + "}")
     with pytest.raises(R.Panic):
         c.get("mutated_satd_inner")({"T": "u8"})
+
+
+def test_lrf_search_fixture_follows_the_reference_text(tmp_path):
+    """lrf_search_ref.npz is what the reference's text computes, not what the generator assumes: the
+    generator run on a scratch copy of src/ with (a) `err * fi.dist_scale[pli]` of rdo_loop_plane_error
+    (rdo.rs:2092) reduced to `err` changes every error and no weight; (b) the second weight's clamp
+    bound of sgrproj_solve (lrf.rs:1091) moved changes weights.  One small case each."""
+    import shutil
+    import subprocess
+    src = tmp_path / "src"
+    shutil.copytree(REF, src)
+    gen = os.path.join(ROOT, "tests", "golden", "gen_lrf_search_ref.py")
+    base = np.load(os.path.join(ROOT, "tests", "golden", "lrf_search_ref.npz"))
+
+    def run(rel, old, new, tag):
+        text = open(os.path.join(REF, rel)).read()
+        assert text.count(old) == 1, (rel, old)
+        (src / rel).write_text(text.replace(old, new))
+        out = tmp_path / tag
+        out.mkdir()
+        env = dict(os.environ, R1_REF_SRC=str(src), R1_GOLDEN_OUT=str(out), R1_LRF_SEARCH_CASES="2")
+        subprocess.run([sys.executable, gen], check=True, env=env, cwd=os.path.dirname(gen),
+                       stdout=subprocess.DEVNULL, timeout=600)
+        (src / rel).write_text(text)
+        return np.load(out / "lrf_search_ref.npz")
+    m = run("rdo.rs", "  err * fi.dist_scale[pli]\n}", "  err\n}", "a")
+    assert np.array_equal(m["s2_rows"], base["s2_rows"])                     # same units, sets, weights
+    assert (m["s2_err"] != base["s2_err"]).mean() > 0.9                      # (nearly) every error moved
+    m = run("lrf.rs", "      SGRPROJ_XQD_MAX[1] as i32,\n    );\n    (xqd0 as i8, xqd1 as i8)",
+            "      SGRPROJ_XQD_MAX[1] as i32 - 60,\n    );\n    (xqd0 as i8, xqd1 as i8)", "b")
+    assert not np.array_equal(m["s2_rows"], base["s2_rows"])                 # weights moved
+
