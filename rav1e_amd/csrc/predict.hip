@@ -198,8 +198,15 @@ __device__ __forceinline__ int32_t filt5(const uint16_t *src, int i, int size, i
 #ifndef R1_PRESCREEN_LOOPED
 #define R1_PRESCREEN_LOOPED 1   // A/B switch
 #endif
+// waves per SIMD the register allocator is asked to make room for in the fixed-size pre-screen
+// instantiations: left alone it takes 79 / 113 VGPRs (16x16 / 32x32); asked, 44 / 68 without a spill
+// (tools/kres.py): launches 0.136 -> 0.133 and 0.126 -> 0.103 ms
+constexpr int intra_waves_hint(bool satd, int wlt) {
+  return !satd ? 1 : (wlt == 4 ? 7 : (wlt == 5 ? 5 : 1));   // 8x8 at 6 waves (79 VGPRs): +1.7 % on the launch, left alone
+}
+
 template <int BPP, bool SATD_OUT, int WLT = -1, int HLT = -1>
-__global__ __launch_bounds__(64) void k_intra_predict(
+__global__ __launch_bounds__(64, intra_waves_hint(SATD_OUT, WLT)) void k_intra_predict(
     int wl, int hl, const R1IntraCand *__restrict__ cands, int n,
     const void *__restrict__ edges, int edge_stride, const uint8_t *__restrict__ lens,
     const int16_t *__restrict__ ac, int bit_depth, void *__restrict__ dst, R1Plane src,
