@@ -173,8 +173,8 @@ constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm) {
   // the pixel-domain chain sat a few registers above an allocation step at three sizes; asked for the
   // step, the allocator gets there without a spill worth mentioning (same-box, r04_ab_notes.md ab8:
   // 8-bit 290.3 -> 295.0 k, 10-bit 274.2 -> 283.5 k)
-  if (wl == 3 && hl == 3 && qm == 2) return 7;              // 73 / 74 VGPRs -> 58 / 72: 6 -> 8 / 7 waves, launch -2.2 / -1.6 %
-  if (wl == 4 && hl == 4 && qm == 2) return 5;              // 105 / 107 -> 91 / 94: 4 -> 5 waves, -4.0 / -5.1 %
+  if (wl == 3 && hl == 3 && qm == 2) return bd == 8 ? 7 : 8;   // 73 / 74 VGPRs -> 58 / 62: 6 -> 8 waves, launch -2.2 / -3.7 % (10-bit at 7: 72 VGPRs, -1.6 %; ab13)
+  if (wl == 4 && hl == 4 && qm == 2) return bd == 8 ? 6 : 5;   // 105 / 107 -> 80 + 44 B scratch / 94: 4 -> 6 / 5 waves, -6 / -5.1 % (10-bit at 6: 68 B of scratch, +1 %; ab13)
   if (wl == 5 && hl == 5 && qm == 2) return 4;              // 8-bit 132 -> 128; 10-bit 131 -> 128 (8 B of scratch): 3 -> 4 waves, -5.4 %
   if (wl == 5 && hl == 5 && qm == 1) return 5;              // 8-bit 97 -> 96; 10-bit 120 -> 96 (20 B of scratch): 4 -> 5 waves, launch -4 % (ab10)
   if (wl == 6 && hl == 6 && qm == 2) return bd == 8 ? 4 : 3;   // 8-bit: 168 -> 128 + 64 B of scratch, launch -2.9 %; 10-bit at 4: +14 % (ab12) -> 3: 181 -> 168
