@@ -144,6 +144,11 @@ struct RdoQuantArgs {
   // prediction from a dense buffer (n x h x w pixels: intra predictions, compound
   // averages) instead of put_8tap of the reference plane
   const void *pred_in;
+  // MT (transform-type search fan-out, rdo_tx_type_decision src/rdo.rs:1701-1817): every candidate is
+  // carried through the chain once per set bit of tx_mask (bit t = TxType t, ascending), on ONE
+  // prediction / residual; result slot of (candidate i, j-th set bit) = i * nt + j, nt = popcount
+  uint32_t tx_mask;
+  int nt;
 };
 namespace {
 using r1tx::T;
@@ -153,7 +158,16 @@ using r1tx::T;
 // Waves per SIMD the register allocator is asked to make room for (0 = no request).  Only
 // where the kernel sits a few registers above an allocation step (512 / n, in eights) and
 // the step costs no spill worth mentioning -- measured, see DESIGN.md 5.1 "occupancy".
-constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm) {
+constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm, bool mt = false) {
+  // the type-search instantiations (see the MT loop of k_rdo_cand): their own steps
+  if (mt) {
+#ifdef R1_HINT_MT
+    if (R1_HINT_MT_COND) return R1_HINT_MT;
+#endif
+    if (wl <= 3 && hl <= 3) return qm == 2 ? (bd == 8 ? 7 : 8) : 1;
+    if (wl <= 4 && hl <= 4) return qm == 2 ? (bd == 8 ? 6 : 5) : 1;
+    return qm == 2 ? 3 : 1;
+  }
 #ifdef R1_HINT_8X8
   if (wl == 3 && hl == 3 && qm == 0) return R1_HINT_8X8;   // A/B: the pipelined 8x8 kernel sits at 69 (8-bit)
 #endif
@@ -181,8 +195,8 @@ constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm) {
   return 1;
 }
 
-template <int BD, int WL, int HL, typename CT, int QM>
-__global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand(
+template <int BD, int WL, int HL, typename CT, int QM, bool MT = false>
+__global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_cand(
     R1Plane org, R1Plane ref, const R1RdoCand *__restrict__ cands, int n,
     uint32_t *__restrict__ sad_out, uint32_t *__restrict__ satd_out,
     CT *__restrict__ coeffs, void *__restrict__ pred_out, RdoQuantArgs qa) {
@@ -461,9 +475,44 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   R1_PROF(2);   // B2: SAD + SATD
   if (!QUANT && !coeffs) return;   // wave-uniform: kernel argument
 
+  // ---- MT: the transform-type fan-out (rdo_tx_type_decision, src/rdo.rs:1701-1817).  The reference runs
+  // motion_compensate + write_tx_tree + compute_distortion once per type of RAV1E_TX_TYPES
+  // (src/transform/mod.rs:28-44) that the block's tx set allows, on the SAME prediction; here phases A / B ran
+  // once and C .. H loop over the set bits of the launch's mask (a kernel argument: wave-uniform, every
+  // 1-D kernel switch below is a scalar branch).  What an iteration needs again is the residual column: where
+  // the source block stays in LDS (SRC_KEEP) it is re-formed from there and the packed prediction the
+  // reconstruction keeps anyway -- no register is live across the loop for it; elsewhere a register copy.
+  constexpr bool MT_RECOMP = MT && SRC_KEEP;
+  T vkeep[MT && !MT_RECOMP ? H : 1];
+  if constexpr (MT && !MT_RECOMP) {
+#pragma unroll
+    for (int r = 0; r < H; r++) vkeep[r] = v[r];
+  }
+  uint32_t tmask = MT ? qa.tx_mask : 1u;
+  int slot = 0;
+  do {
+  if constexpr (MT) {
+    if (slot != 0) {   // wave-uniform
+      if constexpr (MT_RECOMP) {
+        if (col_live) {
+#pragma unroll
+          for (int r = 0; r < H; r++) {
+            const T sp = BPP == 1 ? (T)src_l[r * SRC_ROW] : (T) * (const uint16_t *)(src_l + r * SRC_ROW);
+            const T pr = BPP == 1 ? (T)((ppk[r >> 2] >> (8 * (r & 3))) & 0xFF)
+                                  : (T)((ppk[r >> 1] >> (16 * (r & 1))) & 0xFFFF);
+            v[r] = sp - pr;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < H; r++) v[r] = vkeep[r];
+      }
+    }
+  }
   // ---- C: column transform on the residual registers ----
-  __syncthreads();  // every lane is done reading the window; LDS becomes buf
-  const int tx_type = cd.tx_type;
+  __syncthreads();  // every lane is done reading the window (MT: the previous type's last phase); LDS becomes buf
+  const int tx_type = MT ? (int)__builtin_ctz(tmask) : (int)cd.tx_type;
+  const long long oslot = MT ? cand * (long long)qa.nt + slot : cand;   // result slot of (candidate, type)
   const bool any_ud = __any(live && r1tx::ud_flip(tx_type));
   if (col_live) {
     if (any_ud) {   // wave-uniform: skipped when no candidate of the wave flips
@@ -491,7 +540,6 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
   // P lanes per candidate again: the lane that filtered column c of candidate cl now owns row c
   // of the same candidate -- its descriptor is still in registers
   const int cl2 = cl, r = c;
-  const long long cand2 = cand;
   const bool live2 = live;
   const bool row_live = live2 && r < H;
   const int tt = tx_type;
@@ -530,6 +578,9 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       if constexpr (QUANT) u[k] = (T)(CT)u[k];
     }
   }
+  if constexpr (MT) {
+    // the type search keeps its coefficients on the CU
+  } else
   if constexpr (!R1_WIDE_STORE_POLICY(P)) {
     // large blocks: direct element stores (measured: the LDS detour costs more than the
     // 16-byte stores save at 32x32 and 64x64, profiles/r02_wide_store_ab.log)
@@ -644,16 +695,16 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
     r1q::quantize_group<CT, PL, NPLQ, QM == 1, LTS>(tile, cl2 * P, r, live2, qa.scan[kind], qa.qp, tail,
                                                     eob, dist);
     if (live_st && r == 0) {
-      qa.eob[cand2] = (uint16_t)eob;
+      qa.eob[oslot] = (uint16_t)eob;
       if constexpr (QM == 1) {
-        qa.tx_dist[cand2] = dist;
-        if (qa.est_rate) qa.est_rate[cand2] = r1q::estimate_rate(qa.q_bin, qa.tx_size, dist);
+        qa.tx_dist[oslot] = dist;
+        if (qa.est_rate) qa.est_rate[oslot] = r1q::estimate_rate(qa.q_bin, qa.tx_size, dist);
       }
     }
     if (qa.qcoeffs) {
       __syncthreads();
       if (live_st) {
-        CT *qd = (CT *)qa.qcoeffs + cand2 * CODED;
+        CT *qd = (CT *)qa.qcoeffs + oslot * CODED;
 #pragma unroll
         for (int k = 0; k < NPLQ; k++) qd[k * P + r] = (CT)tile[k * P + r];
       }
@@ -718,11 +769,11 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
       }
       if (col_live && live_st && qa.rec) {
         if constexpr (BPP == 1) {
-          uint8_t *d = (uint8_t *)qa.rec + (size_t)cand * W * H + c;
+          uint8_t *d = (uint8_t *)qa.rec + (size_t)oslot * W * H + c;
 #pragma unroll
           for (int rr = 0; rr < H; rr++) d[(size_t)rr * W] = (uint8_t)rc[rr];
         } else {
-          uint16_t *d = (uint16_t *)qa.rec + (size_t)cand * W * H + c;
+          uint16_t *d = (uint16_t *)qa.rec + (size_t)oslot * W * H + c;
 #pragma unroll
           for (int rr = 0; rr < H; rr++) d[(size_t)rr * W] = (uint16_t)rc[rr];
         }
@@ -845,9 +896,13 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM)) void k_rdo_cand
         const uint32_t hi = __shfl_xor((uint32_t)(acc >> 32), m, 64);
         acc += ((unsigned long long)hi << 32) | lo;
       }
-      if (live_st && c == 0) qa.pix_dist[cand] = qa.dist_kind == R1_DIST_WSSE ? (acc + 32) / 64 : acc;
+      if (live_st && c == 0) qa.pix_dist[oslot] = qa.dist_kind == R1_DIST_WSSE ? (acc + 32) / 64 : acc;
     }
   }
+  if constexpr (!MT) break;
+  tmask &= tmask - 1;
+  slot++;
+  } while (tmask != 0);
 }
 
 #ifdef R1_RDO_DISPATCH_TU
@@ -908,7 +963,7 @@ int launch_mc_fast(bool prep, const R1Plane &ref, const R1McCand *cands, int n, 
 #endif   // R1_RDO_DISPATCH_TU
 
 #ifdef R1_RDO_SLICE_TU
-template <int BD, int WL, int HL, int QM>
+template <int BD, int WL, int HL, int QM, bool MT>
 int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n,
            uint32_t *sad, uint32_t *satd, void *coeffs, void *pred, const RdoQuantArgs *qa,
            hipStream_t st) {
@@ -920,14 +975,14 @@ int launch(const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n
 #else
   const unsigned grid = groups;
 #endif
-  hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, QM>), dim3(grid), dim3(64), 0, st,
+  hipLaunchKernelGGL((k_rdo_cand<BD, WL, HL, CT, QM, MT>), dim3(grid), dim3(64), 0, st,
                      org, ref, cands, n, sad, satd, (CT *)coeffs, pred, qa ? *qa : RdoQuantArgs{});
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
 }
 
 // one (bit depth, QM) slice: tx_size -> instantiation
-template <int BD, int QM>
+template <int BD, int QM, bool MT>
 int slice(int tx_size, const R1Plane &org, const R1Plane &ref, const R1RdoCand *cands, int n,
           uint32_t *sad, uint32_t *satd, void *coeffs, void *pred, const RdoQuantArgs *qa,
           hipStream_t st) {
@@ -936,10 +991,14 @@ int slice(int tx_size, const R1Plane &org, const R1Plane &ref, const R1RdoCand *
 #ifndef R1_RDO_TU_TSMASK
 #define R1_RDO_TU_TSMASK 0x7ffff
 #endif
+  // the type-search slices: sizes up to 32 x 32 (a 64-point side has TX_SET_DCTONLY, get_tx_set
+  // src/context/transform_unit.rs:123-131: one type, the plain kernel)
+  constexpr unsigned TSM = MT ? ((R1_RDO_TU_TSMASK) & ~((1u << 4) | (1u << 11) | (1u << 12) | (1u << 17) | (1u << 18)))
+                              : (unsigned)(R1_RDO_TU_TSMASK);
 #define R1_RC_CASE(ID, WL, HL)                                                                   \
   case ID:                                                                                       \
-    if constexpr (((R1_RDO_TU_TSMASK) >> ID) & 1)                                                \
-      return launch<BD, WL, HL, QM>(org, ref, cands, n, sad, satd, coeffs, pred, qa, st);        \
+    if constexpr ((TSM >> ID) & 1)                                                               \
+      return launch<BD, WL, HL, QM, MT>(org, ref, cands, n, sad, satd, coeffs, pred, qa, st);    \
     else                                                                                         \
       break;
   switch (tx_size) {
@@ -980,8 +1039,10 @@ extern "C" int r1_debug_phase_prof(unsigned long long *out, int reset) {   /* ou
 #define R1_SLICE_NAME2(B, Q) r1_rdo_slice_b##B##_q##Q
 #define R1_SLICE_NAME(B, Q) R1_SLICE_NAME2(B, Q)
 #if defined(R1_RDO_TU_BD) && !defined(R1_HEADLINE_ONLY)
+// slice numbers 0..2 = QM; 3 / 4 = the type-search (MT) instantiations of QM 1 / 2
 int R1_SLICE_NAME(R1_RDO_TU_BD, R1_RDO_TU_QM)(R1_SLICE_ARGS) {
-  return slice<R1_RDO_TU_BD, R1_RDO_TU_QM>(tx_size, org, ref, cands, n, sad, satd, coeffs, pred, qa, st);
+  return slice<R1_RDO_TU_BD, (R1_RDO_TU_QM >= 3 ? R1_RDO_TU_QM - 2 : R1_RDO_TU_QM), (R1_RDO_TU_QM >= 3)>(
+      tx_size, org, ref, cands, n, sad, satd, coeffs, pred, qa, st);
 }
 #endif
 
@@ -990,6 +1051,9 @@ int R1_SLICE_NAME(R1_RDO_TU_BD, R1_RDO_TU_QM)(R1_SLICE_ARGS) {
 int r1_rdo_slice_b8_q0(R1_SLICE_ARGS);  int r1_rdo_slice_b8_q1(R1_SLICE_ARGS);  int r1_rdo_slice_b8_q2(R1_SLICE_ARGS);
 int r1_rdo_slice_b10_q0(R1_SLICE_ARGS); int r1_rdo_slice_b10_q1(R1_SLICE_ARGS); int r1_rdo_slice_b10_q2(R1_SLICE_ARGS);
 int r1_rdo_slice_b12_q0(R1_SLICE_ARGS); int r1_rdo_slice_b12_q1(R1_SLICE_ARGS); int r1_rdo_slice_b12_q2(R1_SLICE_ARGS);
+int r1_rdo_slice_b8_q3(R1_SLICE_ARGS);  int r1_rdo_slice_b8_q4(R1_SLICE_ARGS);
+int r1_rdo_slice_b10_q3(R1_SLICE_ARGS); int r1_rdo_slice_b10_q4(R1_SLICE_ARGS);
+int r1_rdo_slice_b12_q3(R1_SLICE_ARGS); int r1_rdo_slice_b12_q4(R1_SLICE_ARGS);
 #endif
 // Used by r1_mc_put_batch / r1_mc_prep_batch (mc.hip) for block sizes that are
 // transform sizes; returns 1 when (w, h) is not one of them.
@@ -1046,15 +1110,18 @@ int rdo_dispatch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w, int
   const int qm = !qa ? 0 : (qa->pix_dist ? 2 : 1);
 #ifdef R1_HEADLINE_ONLY
   if (qm != 0 || bd == 12) return R1_EINVAL;
-  return bd == 8 ? slice<8, 0>(tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out, nullptr, st)
-                 : slice<10, 0>(tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out, nullptr, st);
+  return bd == 8 ? slice<8, 0, false>(tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out, nullptr, st)
+                 : slice<10, 0, false>(tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out, nullptr, st);
 #else
   typedef int (*SliceFn)(R1_SLICE_ARGS);
-  static const SliceFn kSlices[3][3] = {
-      {r1_rdo_slice_b8_q0, r1_rdo_slice_b8_q1, r1_rdo_slice_b8_q2},
-      {r1_rdo_slice_b10_q0, r1_rdo_slice_b10_q1, r1_rdo_slice_b10_q2},
-      {r1_rdo_slice_b12_q0, r1_rdo_slice_b12_q1, r1_rdo_slice_b12_q2}};
-  return kSlices[(bd - 8) / 2][qm](tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out, qa, st);
+  static const SliceFn kSlices[3][5] = {
+      {r1_rdo_slice_b8_q0, r1_rdo_slice_b8_q1, r1_rdo_slice_b8_q2, r1_rdo_slice_b8_q3, r1_rdo_slice_b8_q4},
+      {r1_rdo_slice_b10_q0, r1_rdo_slice_b10_q1, r1_rdo_slice_b10_q2, r1_rdo_slice_b10_q3, r1_rdo_slice_b10_q4},
+      {r1_rdo_slice_b12_q0, r1_rdo_slice_b12_q1, r1_rdo_slice_b12_q2, r1_rdo_slice_b12_q3, r1_rdo_slice_b12_q4}};
+  const bool mt = qa && qa->tx_mask != 0;
+  R1_REQUIRE(!mt || (qm != 0 && !coeffs));
+  return kSlices[(bd - 8) / 2][mt ? qm + 2 : qm](tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out,
+                                                 qa, st);
 #endif
 }
 }  // namespace
@@ -1160,5 +1227,71 @@ extern "C" int r1_rdo_pred_cand_batch(r1_ctx *ctx, const R1Plane *org, const voi
   }
   return rdo_dispatch(ctx, org, nullptr, w, h, tx_size, cands, n, sad_out, satd_out, nullptr, nullptr,
                       &qa, stream);
+}
+// av1_tx_used[get_tx_set(tx_size, is_inter, use_reduced_set)] (src/context/transform_unit.rs:37-44,
+// 123-148) as a bit mask over TxType, optionally cut down to RAV1E_TX_TYPES (src/transform/mod.rs:28-44):
+// the types the loop of rdo_tx_type_decision (src/rdo.rs:1732-1736) does not skip.
+extern "C" uint32_t r1_tx_type_mask(int tx_size, int is_inter, int use_reduced_set, int rav1e_types_only) {
+  if (tx_size < 0 || tx_size >= 19) return 0;
+  const int wl = r1tx::kTxWLog2[tx_size], hl = r1tx::kTxHLog2[tx_size];
+  const int up = wl > hl ? wl : hl, dn = wl < hl ? wl : hl;   // sqr_up / sqr as log2 of the side
+  // TxSet rows of av1_tx_used
+  constexpr uint32_t DCTONLY = 0x0001, INTER_3 = 0x0201, INTRA_2 = 0x020F, INTRA_1 = 0x0E0F, INTER_2 = 0x0FFF,
+                     INTER_1 = 0xFFFF;
+  uint32_t m;
+  if (up > 5) m = DCTONLY;
+  else if (is_inter) m = (use_reduced_set || up == 5) ? INTER_3 : (dn == 4 ? INTER_2 : INTER_1);
+  else m = up == 5 ? DCTONLY : ((use_reduced_set || dn == 4) ? INTRA_2 : INTRA_1);
+  return rav1e_types_only ? (m & 0x0E0Fu) : m;
+}
+
+extern "C" int r1_rdo_txsearch_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, const void *pred,
+                                     int w, int h, int tx_size, const R1RdoCand *cands, int n,
+                                     uint32_t tx_type_mask, const R1QuantParams *params, int dist_kind,
+                                     const uint32_t *scales, int scale_stride, int xdec, int ydec,
+                                     uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
+                                     uint64_t *dist_out, uint64_t *est_rate_out, void *qcoeffs_out,
+                                     void *rec_out, void *stream) {
+  R1_REQUIRE(ctx && org && params && eob_out && dist_out);
+  R1_REQUIRE((ref != nullptr) != (pred != nullptr));
+  R1_REQUIRE(tx_size >= 0 && tx_size < 19);
+  R1_REQUIRE(params->bit_depth == org->bit_depth);
+  R1_REQUIRE(dist_kind == 0 || dist_kind == R1_DIST_WSSE || dist_kind == R1_DIST_CDEF);
+  R1_REQUIRE(xdec >= 0 && xdec <= 1 && ydec >= 0 && ydec <= 1);
+  R1_REQUIRE(dist_kind != R1_DIST_CDEF || (xdec == 0 && ydec == 0));
+  R1_REQUIRE(!scales || scale_stride > 0);
+  R1_REQUIRE(dist_kind != 0 || !rec_out);
+  R1_REQUIRE(dist_kind == 0 || !est_rate_out);
+  // WHT (16) has no scan order; the mask is over the 16 TxTypes of the tx sets
+  R1_REQUIRE(tx_type_mask != 0 && tx_type_mask <= 0xFFFFu);
+  const bool side64 = r1tx::kTxWLog2[tx_size] > 5 || r1tx::kTxHLog2[tx_size] > 5;
+  // a 64-point side codes DCT_DCT only (TX_SET_DCTONLY): the plain kernel, which reads the candidates' tx_type
+  R1_REQUIRE(!side64 || tx_type_mask == 1u);
+  RdoQuantArgs qa = {};
+  qa.qp = r1q::make_qparams(*params, tx_size, org->bytes_per_px == 1 ? 2 : 4);
+  for (int k = 0; k < 3; k++) qa.scan[k] = ctx->scan_dev + ctx->scan_off[tx_size][k];
+  qa.tx_size = tx_size;
+  qa.q_bin = params->qindex / 32;
+  qa.eob = eob_out;
+  qa.qcoeffs = qcoeffs_out;
+  qa.pred_in = pred;
+  if (!side64) {
+    qa.tx_mask = tx_type_mask;
+    qa.nt = __builtin_popcount(tx_type_mask);
+  }
+  if (dist_kind == 0) {
+    qa.tx_dist = (unsigned long long *)dist_out;
+    qa.est_rate = (unsigned long long *)est_rate_out;
+  } else {
+    qa.dist_kind = dist_kind;
+    qa.inv_shift = r1itx::kInvShift[tx_size];
+    qa.scales = scales;
+    qa.scale_stride = scale_stride;
+    qa.xdec = xdec;
+    qa.ydec = ydec;
+    qa.pix_dist = (unsigned long long *)dist_out;
+    qa.rec = rec_out;
+  }
+  return rdo_dispatch(ctx, org, ref, w, h, tx_size, cands, n, sad_out, satd_out, nullptr, nullptr, &qa, stream);
 }
 #endif   // R1_RDO_DISPATCH_TU
