@@ -874,6 +874,66 @@ def config_lines(ctx, args):
          working_set=ho.nbytes + hr.nbytes,
          wbytes={"pixel %dx%d" % (s_, s_): 18 * len(c_) for s_, c_ in cands.items()},
          kkeys={"pixel %dx%d" % (s_, s_): rdo_launch_key(10, s_, 2, len(c_)) for s_, c_ in cands.items()})
+    del pouts, fns
+    torch.cuda.empty_cache()
+    # ---------------- the transform-type search (rdo_tx_type_decision): one prediction per block, every TxType of
+    # RAV1E_TX_TYPES the tx set allows, pixel-domain distortion (rav1e's default) -- the fan-out launch, and beside it
+    # the same evaluations as independent single-type candidates (what r1_rdo_pixel_cand_batch alone would cost)
+    from rav1e_amd import rdo_glue as RG
+    fns, fns_ind, abytes, px, touts, tcands = [], [], {}, 0, {}, {}
+    for s in (32, 16, 8):
+        c1 = np.ascontiguousarray(cands[s][::k])               # one prediction per block of the size
+        n = len(c1)
+        mask = ctx.tx_type_mask(TS[s], True)
+        types = RG.tx_type_slots(mask)
+        nt = len(types)
+        tcands[s] = (c1, mask, types)
+        dev1 = torch.from_numpy(c1.view(np.uint8).reshape(-1).copy()).cuda()
+        touts[s] = {"eob": torch.empty((n, nt), dtype=torch.int16, device="cuda"),
+                    "dist": torch.empty((n, nt), dtype=torch.int64, device="cuda")}
+        tag = "txsearch %dx%d x%d" % (s, s, nt)
+        fns.append((tag, lambda s=s, n=n, dev1=dev1, mask=mask: ctx.rdo_txsearch_batch(
+            po, pr, s, s, dev1, mask, args.qindex, 3, scales=scales, n=n, outs=touts[s])))
+        abytes[tag] = (2 * ((s + 7) * (s + 7) + s * s) + 16 + 10 * nt) * n
+        px += n * nt * s * s
+        for t in types:
+            ct_ = c1.copy()
+            ct_["tx_type"] = t
+            devt = torch.from_numpy(ct_.view(np.uint8).reshape(-1).copy()).cuda()
+            o1 = {"eob": torch.empty(n, dtype=torch.int16, device="cuda"), "dist": torch.empty(n, dtype=torch.int64, device="cuda")}
+            fns_ind.append(("single %dx%d" % (s, s), lambda s=s, n=n, devt=devt, o1=o1: ctx.rdo_pixel_cand_batch(
+                po, pr, s, s, devt, args.qindex, 3, scales=scales, n=n, outs=o1, want_sad=False, want_satd=False)))
+    per_ind, step_ind = timed(fns_ind)
+    per, step = timed(fns)
+    n_chk, bad = 0, []
+    hs = scales.cpu().numpy().view(np.uint32)
+    for s, (c1, mask, types) in tcands.items():
+        idx = sample(len(c1))[:16]
+        sub = np.ascontiguousarray(c1[idx])
+        nt = len(types)
+        eob, dist = np.zeros((len(sub), nt), np.uint16), np.zeros((len(sub), nt), np.uint64)
+        assert L.r1o_rdo_txsearch_batch(C.byref(pa), C.byref(pb), None, s, s, TS[s], O.ptr(sub), len(sub), mask, args.qindex, 0, 0, 0,
+                                        3, O.ptr(hs), hs.shape[1], 0, 0, None, None, O.ptr(eob), O.ptr(dist), None, None, None) == 0
+        ix = torch.from_numpy(idx.astype(np.int64)).cuda()
+        n_chk += len(idx) * nt
+        if not (np.array_equal(touts[s]["dist"].index_select(0, ix).cpu().numpy().view(np.uint64), dist) and
+                np.array_equal(touts[s]["eob"].index_select(0, ix).cpu().numpy().view(np.uint16), eob)):
+            bad.append("txsearch %d" % s)
+    ratio = {}
+    for s, (c1, mask, types) in tcands.items():
+        tag = "txsearch %dx%d x%d" % (s, s, len(types))
+        # the events of the independent launches are averaged per launch: the search costs len(types) of them
+        ratio["%dx%d" % (s, s)] = round(per[tag] / (per_ind["single %dx%d" % (s, s)] * len(types)), 4)
+    line("tx_search_4k_10bit", "%dx%d 10-bit luma: transform-type search of ONE inter prediction per block, 32x32 (DCT_DCT, IDTX), "
+         "16x16 and 8x8 (the 7 RAV1E_TX_TYPES): mc -> diff once, then fwd -> quantize -> dequantize -> inverse -> cdef_dist per "
+         "type (r1_rdo_txsearch_batch)" % (w, h), px, per, step, abytes, n_chk, bad,
+         {"dtype": "u16", "px_note": "Mpixels/s counts (block, type) evaluations",
+          "independent_single_type_launches": {"ms_per_launch": {t: round(v, 4) for t, v in per_ind.items()},
+                                               "ms_per_pass": round(step_ind, 4),
+                                               "fanout_over_independent": ratio,
+                                               "pass_ratio": round(step / step_ind, 4)}},
+         working_set=ho.nbytes + hr.nbytes,
+         wbytes={"txsearch %dx%d x%d" % (s_, s_, len(t_[2])): 10 * len(t_[2]) * len(t_[0]) for s_, t_ in tcands.items()})
     return lines
 
 

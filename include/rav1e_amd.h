@@ -104,7 +104,8 @@ const char *r1_last_error(void);
  * 4 (round 4): r1_estimate_tile_motion_batch refuses with R1_ETIMEDOUT while a flagged persistent launch
  *    has not been acknowledged through r1_me_status; r1_cdef_filter_frame_plane checks luma->bit_depth
  *    against params->bit_depth and the _dirs variant wants 8-aligned tile_w / tile_h; skip_mi bytes are
- *    bools (any non-zero value) in the CDEF filter and the strength search alike. */
+ *    bools (any non-zero value) in the CDEF filter and the strength search alike.
+ * 5 (round 5): + r1_rdo_txsearch_batch, r1_tx_type_mask (additions only; nothing of 4 changed). */
 int r1_abi_version(void);
 
 /* ---- dist:: (reference: src/dist.rs get_sad 31, get_satd 156; dispatch
@@ -126,8 +127,9 @@ int r1_dist_batch(r1_ctx *ctx, int kind, const R1Plane *org,
  * 8x8 kernel (CDEF) -- exactly what the compute_bias closure at
  * src/rdo.rs:283-303 looks up.  NULL = DistortionScale::default() (1 << 14).
  * out[i] = the reference's Distortion (u64), before `* fi.dist_scale[p]`.
- * w, h <= 128: the visible block size after frame clipping.  R1_DIST_CDEF: multiples of 4.
- * R1_DIST_WSSE: any size >= 1 -- like get_weighted_sse, only whole 4x4 cells are measured (a
+ * w, h <= 128: the visible block size after frame clipping (clip_visible_bsize, src/rdo.rs:228-251),
+ * any size >= 1.  R1_DIST_CDEF: the last kernel of a row / column is kernel_w x kernel_h < 8x8.
+ * R1_DIST_WSSE: -- like get_weighted_sse, only whole 4x4 cells are measured (a
  * clipped chroma block may be 2 wide: its distortion is 0, as in the reference). */
 int r1_dist_scaled_batch(r1_ctx *ctx, int kind, const R1Plane *org,
                          const R1Plane *ref, int w, int h,
@@ -772,6 +774,38 @@ int r1_rdo_pred_cand_batch(r1_ctx *ctx, const R1Plane *org, const void *pred, in
                            int scale_stride, int xdec, int ydec, uint32_t *sad_out,
                            uint32_t *satd_out, uint16_t *eob_out, uint64_t *dist_out,
                            void *qcoeffs_out, void *rec_out, void *stream);
+
+/* ---- the transform-type search of one prediction in ONE launch (ABI 5): rdo_tx_type_decision
+ * (src/rdo.rs:1701-1817) evaluates every TxType of RAV1E_TX_TYPES (src/transform/mod.rs:28-44) that the
+ * block's tx set allows (av1_tx_used[get_tx_set(..)], src/context/transform_unit.rs:37-44, 123-148) on the
+ * SAME prediction -- it even re-runs motion_compensate per type (rdo.rs:1738-1742) -- through
+ * write_tx_tree / write_tx_blocks -> encode_tx_block (src/encoder.rs:1404-1661) and compute_distortion /
+ * compute_tx_distortion.  Here the prediction (put_8tap of `ref`, or the dense `pred` buffer of
+ * r1_rdo_pred_cand_batch: exactly one of the two is non-NULL), the residual, SAD / SATD and the staged
+ * source block are made ONCE per candidate; then, for every set bit t of tx_type_mask in ascending order
+ * (slot j = the j-th set bit; nt = popcount(tx_type_mask)):
+ *   forward_transform(t) -> quantize -> dequantize -> [inverse_transform_add(t) -> sse_wxh / cdef_dist_wxh]
+ * with the residual re-formed on the CU.  The candidates' own tx_type field is ignored.
+ *   dist_kind 0:                 dist_out = transform-domain distortion, est_rate_out (optional) as
+ *                                r1_rdo_full_cand_batch; rec_out must be NULL
+ *   R1_DIST_WSSE / R1_DIST_CDEF: the pixel-domain leg of r1_rdo_pixel_cand_batch; est_rate_out must be NULL
+ * Outputs: sad_out / satd_out (optional): n words; eob_out, dist_out (, est_rate_out): n * nt entries,
+ * entry [i * nt + j] = candidate i, slot j; qcoeffs_out (optional): n * nt dense coded-area blocks;
+ * rec_out (optional): n * nt dense w*h reconstructions.  The host adds the rate of each slot's qcoeffs
+ * and keeps the cheapest (compute_rd_cost, rdo.rs:718-723), applying the reference's early exit after the
+ * first type itself (rdo.rs:1793-1802: a pure saving there, it changes no result).
+ * Sizes with a 64-point side code DCT_DCT only (TX_SET_DCTONLY): tx_type_mask must be 1 and the call is
+ * r1_rdo_pixel_cand_batch / r1_rdo_full_cand_batch (the candidates' tx_type must then be 0). */
+int r1_rdo_txsearch_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, const void *pred, int w,
+                          int h, int tx_size, const R1RdoCand *cands, int n, uint32_t tx_type_mask,
+                          const R1QuantParams *params, int dist_kind, const uint32_t *scales,
+                          int scale_stride, int xdec, int ydec, uint32_t *sad_out, uint32_t *satd_out,
+                          uint16_t *eob_out, uint64_t *dist_out, uint64_t *est_rate_out,
+                          void *qcoeffs_out, void *rec_out, void *stream);
+/* The mask of that loop: bit t set = TxType t is in av1_tx_used[get_tx_set(tx_size, is_inter,
+ * use_reduced_set)]; rav1e_types_only != 0 keeps only RAV1E_TX_TYPES (DCT_DCT, ADST_DCT, DCT_ADST,
+ * ADST_ADST, IDTX, V_DCT, H_DCT = 0x0E0F).  0 for an invalid tx_size.  Host arithmetic, no device work. */
+uint32_t r1_tx_type_mask(int tx_size, int is_inter, int use_reduced_set, int rav1e_types_only);
 
 /* ---- multi-GPU: the tile-boundary exchange and the reference-frame all-gather (RCCL over
  * xGMI), SURVEY.md 8(e).  One process (or host thread) per GPU, tile r on rank r.  Rendezvous:

@@ -9,6 +9,7 @@
  * timed as bench.py's cpu_baseline.
  */
 #include <omp.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "r1_oracle.h"
@@ -229,6 +230,88 @@ int r1o_rdo_pixel_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, 
     r1o_dist_scaled_batch(kind, org, &rp, w, h, &dc, 1, scales, scale_stride, xdec, ydec,
                           &dist_out[i]);
     if (rec_out) memcpy((uint8_t *)rec_out + i * area * bpp, pred, area * bpp);
+  }
+  return bad ? -1 : 0;
+}
+
+/* get_tx_set (src/context/transform_unit.rs:123-148) with TxSize::sqr / sqr_up
+ * (src/transform/mod.rs:220-239) on the sides, then the row of av1_tx_used
+ * (transform_unit.rs:37-44) as a bit mask over TxType; rav1e_only keeps the
+ * entries of RAV1E_TX_TYPES (src/transform/mod.rs:28-44).  This is the filter
+ * of rdo_tx_type_decision's loop (src/rdo.rs:1732-1736). */
+uint32_t r1o_tx_type_mask(int tx_size, int is_inter, int use_reduced_set, int rav1e_only) {
+  static const uint8_t used[6][16] = {
+      {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},   /* TX_SET_DCTONLY */
+      {1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0},   /* TX_SET_INTER_3 */
+      {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0},   /* TX_SET_INTRA_2 */
+      {1, 1, 1, 1, 0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0},   /* TX_SET_INTRA_1 */
+      {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0},   /* TX_SET_INTER_2 */
+      {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}};  /* TX_SET_INTER_1 */
+  static const uint8_t rav1e_types[7] = {0, 1, 2, 3, 9, 10, 11};
+  if (tx_size < 0 || tx_size >= 19) return 0;
+  const int w = r1o_tx_width(tx_size), h = r1o_tx_height(tx_size);
+  const int sqr_up = w > h ? w : h, sqr = w < h ? w : h;
+  int set;
+  if (sqr_up > 32) set = 0;
+  else if (is_inter) set = (use_reduced_set || sqr_up == 32) ? 1 : (sqr == 16 ? 4 : 5);
+  else if (sqr_up == 32) set = 0;
+  else set = (use_reduced_set || sqr == 16) ? 2 : 3;
+  uint32_t m = 0;
+  if (rav1e_only) {
+    for (int k = 0; k < 7; k++)
+      if (used[set][rav1e_types[k]]) m |= 1u << rav1e_types[k];
+  } else {
+    for (int t = 0; t < 16; t++)
+      if (used[set][t]) m |= 1u << t;
+  }
+  return m;
+}
+
+/* rdo_tx_type_decision's loop body (src/rdo.rs:1731-1810) for one prediction per
+ * candidate: for every TxType t of the mask in ascending order the evaluation of
+ * r1o_rdo_pixel_cand_batch (kind 2 / 3) or r1o_rdo_full_cand_batch (kind 0) with
+ * tx_type = t on the SAME prediction (the reference re-runs motion_compensate per
+ * type; the prediction does not depend on t).  Slot (i, j) = i * nt + j. */
+int r1o_rdo_txsearch_batch(const r1o_plane *org, const r1o_plane *ref, const void *pred_in,
+                           int w, int h, int tx_size, const r1o_rdo_cand *c, int n,
+                           uint32_t tx_type_mask, int qindex, int is_intra, int dc_delta_q,
+                           int ac_delta_q, int kind, const uint32_t *scales, int scale_stride,
+                           int xdec, int ydec, uint32_t *sad_out, uint32_t *satd_out,
+                           uint16_t *eob_out, uint64_t *dist_out, uint64_t *est_rate_out,
+                           void *qcoeffs_out, void *rec_out) {
+  const int hbd = org->bytes_per_px == 2, bpp = org->bytes_per_px;
+  const int cb = hbd ? 4 : 2;
+  const int cw = w < 32 ? w : 32, ch = h < 32 ? h : 32;
+  const size_t carea = (size_t)cw * ch, area = (size_t)w * h;
+  int nt = 0, types[16];
+  for (int t = 0; t < 16; t++)
+    if ((tx_type_mask >> t) & 1) types[nt++] = t;
+  if (!nt || (tx_type_mask >> 16)) return -1;
+  int bad = 0;
+  for (int j = 0; j < nt; j++) {
+    r1o_rdo_cand *cj = (r1o_rdo_cand *)malloc(sizeof(*cj) * (size_t)(n > 0 ? n : 1));
+    uint16_t *eob = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(n > 0 ? n : 1));
+    uint64_t *dist = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+    uint8_t *qc = qcoeffs_out ? (uint8_t *)malloc(carea * cb * (size_t)(n > 0 ? n : 1)) : NULL;
+    uint8_t *rec = rec_out ? (uint8_t *)malloc(area * bpp * (size_t)(n > 0 ? n : 1)) : NULL;
+    for (int i = 0; i < n; i++) {
+      cj[i] = c[i];
+      cj[i].tx_type = (uint8_t)types[j];
+    }
+    if (r1o_rdo_pixel_cand_batch(org, ref, w, h, tx_size, cj, n, qindex, is_intra, dc_delta_q,
+                                 ac_delta_q, kind, scales, scale_stride, xdec, ydec,
+                                 j == 0 ? sad_out : NULL, j == 0 ? satd_out : NULL, eob, dist, qc, rec,
+                                 pred_in))
+      bad = 1;
+    for (int i = 0; i < n; i++) {
+      const size_t s = (size_t)i * nt + j;
+      eob_out[s] = eob[i];
+      dist_out[s] = dist[i];
+      if (est_rate_out && kind == 0) est_rate_out[s] = r1o_estimate_rate(qindex, tx_size, dist[i]);
+      if (qc) memcpy((uint8_t *)qcoeffs_out + s * carea * cb, qc + (size_t)i * carea * cb, carea * cb);
+      if (rec) memcpy((uint8_t *)rec_out + s * area * bpp, rec + (size_t)i * area * bpp, area * bpp);
+    }
+    free(cj); free(eob); free(dist); free(qc); free(rec);
   }
   return bad ? -1 : 0;
 }

@@ -296,6 +296,14 @@ int r1o_rdo_pixel_cand_batch(const r1o_plane *org, const r1o_plane *ref, int w, 
                              uint32_t *sad_out, uint32_t *satd_out, uint16_t *eob_out,
                              uint64_t *dist_out, void *qcoeffs_out, void *rec_out,
                              const void *pred_in);
+uint32_t r1o_tx_type_mask(int tx_size, int is_inter, int use_reduced_set, int rav1e_only);
+int r1o_rdo_txsearch_batch(const r1o_plane *org, const r1o_plane *ref, const void *pred_in,
+                           int w, int h, int tx_size, const r1o_rdo_cand *c, int n,
+                           uint32_t tx_type_mask, int qindex, int is_intra, int dc_delta_q,
+                           int ac_delta_q, int kind, const uint32_t *scales, int scale_stride,
+                           int xdec, int ydec, uint32_t *sad_out, uint32_t *satd_out,
+                           uint16_t *eob_out, uint64_t *dist_out, uint64_t *est_rate_out,
+                           void *qcoeffs_out, void *rec_out);
 
 #ifdef __cplusplus
 }

@@ -126,6 +126,9 @@ SYMBOLS = {
                                      _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "r1_rdo_pred_cand_batch": (_i, [_vp, _PP, _vp, _i, _i, _i, _vp, _i, C.POINTER(R1QuantParams), _i,
                                     _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "r1_rdo_txsearch_batch": (_i, [_vp, _PP, _PP, _vp, _i, _i, _i, _vp, _i, C.c_uint32, C.POINTER(R1QuantParams),
+                                   _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "r1_tx_type_mask": (C.c_uint32, [_i, _i, _i, _i]),
     "r1_lrf_sgrproj_plane": (_i, [_vp, _PP, _PP, _PP, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "r1_sgrproj_solve_batch": (_i, [_vp, _PP, _PP, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "r1_lrf_search_batch": (_i, [_vp, _PP, _PP, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, C.c_uint32, _vp, _vp, _vp, _vp]),

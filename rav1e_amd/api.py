@@ -580,7 +580,7 @@ class Context:
 
     def rdo_full_cand_batch(self, org, ref, w, h, cands, qindex, is_intra=0, dc_delta_q=0,
                             ac_delta_q=0, n=None, want_sad=True, want_satd=True, want_rate=True,
-                            want_qcoeffs=False, want_coeffs=False):
+                            want_qcoeffs=False, want_coeffs=False, outs=None):
         """mc -> sad/satd -> diff -> forward_transform -> quantize -> dequantize ->
         tx-domain distortion -> estimate_rate for every candidate, one launch."""
         from .types import TxSize
@@ -588,18 +588,19 @@ class Context:
         dc = _dev_cands(cands, RDO_CAND)
         n = dc.numel() // RDO_CAND.itemsize if n is None else n
         ct = torch.int16 if org.bpp == 1 else torch.int32
-        o = {"eob": torch.empty(n, dtype=torch.int16, device="cuda"),
-             "tx_dist": torch.empty(n, dtype=torch.int64, device="cuda")}
+        o = outs if outs is not None else {}
+        o.setdefault("eob", torch.empty(n, dtype=torch.int16, device="cuda"))
+        o.setdefault("tx_dist", torch.empty(n, dtype=torch.int64, device="cuda"))
         if want_sad:
-            o["sad"] = torch.empty(n, dtype=torch.int32, device="cuda")
+            o.setdefault("sad", torch.empty(n, dtype=torch.int32, device="cuda"))
         if want_satd:
-            o["satd"] = torch.empty(n, dtype=torch.int32, device="cuda")
+            o.setdefault("satd", torch.empty(n, dtype=torch.int32, device="cuda"))
         if want_rate:
-            o["est_rate"] = torch.empty(n, dtype=torch.int64, device="cuda")
+            o.setdefault("est_rate", torch.empty(n, dtype=torch.int64, device="cuda"))
         if want_qcoeffs:
-            o["qcoeffs"] = torch.empty((n, min(w, 32) * min(h, 32)), dtype=ct, device="cuda")
+            o.setdefault("qcoeffs", torch.empty((n, min(w, 32) * min(h, 32)), dtype=ct, device="cuda"))
         if want_coeffs:
-            o["coeffs"] = torch.empty((n, w * h), dtype=ct, device="cuda")
+            o.setdefault("coeffs", torch.empty((n, w * h), dtype=ct, device="cuda"))
         po, pr = org.cstruct(), ref.cstruct()
         qp = self._qparams(qindex, org.bit_depth, is_intra, dc_delta_q, ac_delta_q)
 
@@ -786,6 +787,54 @@ class Context:
             scales.data_ptr() if scales is not None else None,
             scales.stride(0) if scales is not None else 0, xdec, ydec, p("sad"), p("satd"), p("eob"),
             p("dist"), p("qcoeffs"), p("rec"), _stream_ptr()), "r1_rdo_pixel_cand_batch")
+        return o
+
+    def tx_type_mask(self, tx_size, is_inter, use_reduced_set=False, rav1e_types_only=True):
+        """av1_tx_used[get_tx_set(..)] (src/context/transform_unit.rs:37-44, 123-148) as a TxType bit
+        mask, by default cut down to RAV1E_TX_TYPES (src/transform/mod.rs:28-44)"""
+        return int(self.lib.r1_tx_type_mask(int(tx_size), int(bool(is_inter)), int(bool(use_reduced_set)),
+                                            int(bool(rav1e_types_only))))
+
+    def rdo_txsearch_batch(self, org, ref, w, h, cands, tx_type_mask, qindex, dist_kind, scales=None, xdec=0,
+                           ydec=0, is_intra=0, dc_delta_q=0, ac_delta_q=0, n=None, want_sad=False,
+                           want_satd=False, want_est_rate=False, want_qcoeffs=False, want_rec=False,
+                           outs=None, pred=None):
+        """r1_rdo_txsearch_batch: rdo_tx_type_decision's per-type loop (src/rdo.rs:1701-1817) on one
+        prediction per candidate -- put_8tap(ref), or the dense `pred` (n, h, w) tensor when ref is None.
+        eob / dist (/ est_rate): (n, nt); qcoeffs: (n, nt, coded area); rec: (n, nt, h, w); slot j = the
+        j-th set bit of tx_type_mask."""
+        from .types import TxSize
+        tx_size = int(TxSize.by_dims(w, h))
+        dc = _dev_cands(cands, RDO_CAND)
+        n = dc.numel() // RDO_CAND.itemsize if n is None else n
+        nt = bin(int(tx_type_mask)).count("1")
+        ct = torch.int16 if org.bpp == 1 else torch.int32
+        o = outs if outs is not None else {}
+        o.setdefault("eob", torch.empty((n, nt), dtype=torch.int16, device="cuda"))
+        o.setdefault("dist", torch.empty((n, nt), dtype=torch.int64, device="cuda"))
+        if want_sad:
+            o.setdefault("sad", torch.empty(n, dtype=torch.int32, device="cuda"))
+        if want_satd:
+            o.setdefault("satd", torch.empty(n, dtype=torch.int32, device="cuda"))
+        if want_est_rate:
+            o.setdefault("est_rate", torch.empty((n, nt), dtype=torch.int64, device="cuda"))
+        if want_qcoeffs:
+            o.setdefault("qcoeffs", torch.empty((n, nt, min(w, 32) * min(h, 32)), dtype=ct, device="cuda"))
+        if want_rec:
+            o.setdefault("rec", torch.empty((n, nt, h, w), dtype=torch.uint8 if org.bpp == 1 else torch.int16,
+                                            device="cuda"))
+        po = org.cstruct()
+        pr = ref.cstruct() if ref is not None else None
+        qp = self._qparams(qindex, org.bit_depth, is_intra, dc_delta_q, ac_delta_q)
+
+        def p(k):
+            return o[k].data_ptr() if k in o else None
+        self._check(self.lib.r1_rdo_txsearch_batch(
+            self.h, C.byref(po), C.byref(pr) if pr is not None else None,
+            pred.data_ptr() if pred is not None else None, w, h, tx_size, dc.data_ptr(), n, int(tx_type_mask),
+            C.byref(qp), dist_kind, scales.data_ptr() if scales is not None else None,
+            scales.stride(0) if scales is not None else 0, xdec, ydec, p("sad"), p("satd"), p("eob"), p("dist"),
+            p("est_rate"), p("qcoeffs"), p("rec"), _stream_ptr()), "r1_rdo_txsearch_batch")
         return o
 
     # ---- lrf:: ----

@@ -90,10 +90,15 @@ template <int BPP>
 __device__ __forceinline__ void load_row(const uint8_t *p, int kw, int32_t *out) {
   if (kw == 8) {
     load_px_row<BPP, 8>(p, out);
-  } else {
+  } else if (kw == 4) {
     load_px_row<BPP, 4>(p, out);
 #pragma unroll
     for (int i = 4; i < 8; i++) out[i] = 0;
+  } else {
+    // a block cut by the edge of a frame whose size is not a multiple of 4 (cdef_dist_wxh hands
+    // cdef_dist_kernel any kernel_w x kernel_h, rdo.rs:152-165): pixel by pixel, nothing past kw is read
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = i < kw ? (int32_t)ld_px<BPP>(p + i * BPP) : 0;
   }
 }
 

@@ -152,9 +152,9 @@ extern "C" int r1_dist_scaled_batch(r1_ctx *ctx, int kind, const R1Plane *org,
       }
       return R1_OK;
     }
-  } else {
-    R1_REQUIRE(w >= 4 && h >= 4 && w % 4 == 0 && h % 4 == 0);
   }
+  // R1_DIST_CDEF: any w, h >= 1 -- cdef_dist_wxh tiles the visible block in 8x8 kernels and hands
+  // cdef_dist_kernel whatever is left at the right / bottom (rdo.rs:152-165, AREA_DIVISORS[w * h - 1])
   R1_REQUIRE(xdec >= 0 && xdec <= 1 && ydec >= 0 && ydec <= 1);
   // cdef_dist is only defined on non-subsampled planes (rdo.rs:146-149)
   R1_REQUIRE(kind != R1_DIST_CDEF || (xdec == 0 && ydec == 0));

@@ -11,6 +11,9 @@ the kernels by executing the reference's own text (tests/golden/gen_rdo_glue_ref
   scale_distortion           src/rdo.rs:613-615,674-695   (RawDistortion * DistortionScale -> mul_u64)
   compute_tx_distortion      src/rdo.rs:349-434       (composition; the SSE comes from a callable:
                                                        Context.dist_scaled_batch on the GPU)
+  compute_distortion         src/rdo.rs:254-347       (composition: luma by tune, chroma sse_wxh per plane)
+  rav1e_tx_types / tx_type_slots   src/transform/mod.rs:28-44, src/rdo.rs:1731-1736
+                                                      (which slot of r1_rdo_txsearch_batch holds which TxType)
 """
 from .types import BlockSize, TxSize
 
@@ -91,3 +94,33 @@ def compute_tx_distortion(sse_wxh, frame_w, frame_h, bsize, is_chroma_block, bo_
         for p in (1, 2):
             dist += scale_distortion(sse_wxh(p, cx, cy, cw, ch), dist_scale[p])
     return dist
+
+
+def compute_distortion(dist_wxh, frame_w, frame_h, bsize, is_chroma_block, bo_x, bo_y, luma_only, dist_scale,
+                       tune_psychovisual, xdec=1, ydec=1, monochrome=False):
+    """compute_distortion for one block.  dist_wxh(kind, plane_index, x, y, w, h) -> the RawDistortion of
+    sse_wxh (kind 2) / cdef_dist_wxh (kind 3) on that plane at plane position (x, y) over the VISIBLE w x h
+    (r1_dist_scaled_batch; the per-importance-block bias of temporal RDO is inside it).  Luma: cdef_dist_wxh
+    under Tune::Psychovisual, sse_wxh under Tune::Psnr, times fi.dist_scale[0]; chroma (is_chroma_block and
+    not luma_only): sse_wxh per plane on the decimated planes, times fi.dist_scale[p]."""
+    bw, bh = BlockSize(bsize).dims
+    x, y = bo_x << MI_SIZE_LOG2, bo_y << MI_SIZE_LOG2
+    vw, vh = clip_visible_bsize(frame_w, frame_h, bw, bh, x, y)
+    if vw == 0 or vh == 0:
+        return 0
+    dist = scale_distortion(dist_wxh(3 if tune_psychovisual else 2, 0, x, y, vw, vh), dist_scale[0])
+    if is_chroma_block and not luma_only and not monochrome:
+        cw, ch = chroma_dist_dims(bsize, vw, vh, xdec, ydec)
+        cx, cy = (bo_x >> xdec) << MI_SIZE_LOG2, (bo_y >> ydec) << MI_SIZE_LOG2
+        for p in (1, 2):
+            dist += scale_distortion(dist_wxh(2, p, cx, cy, cw, ch), dist_scale[p])
+    return dist
+
+
+RAV1E_TX_TYPES = (0, 1, 2, 3, 9, 10, 11)   # DCT_DCT, ADST_DCT, DCT_ADST, ADST_ADST, IDTX, V_DCT, H_DCT
+
+
+def tx_type_slots(tx_type_mask):
+    """slot j of r1_rdo_txsearch_batch's outputs -> TxType: the set bits of the mask in ascending order,
+    which is also the order of RAV1E_TX_TYPES (the loop order of rdo_tx_type_decision)"""
+    return [t for t in range(16) if (int(tx_type_mask) >> t) & 1]

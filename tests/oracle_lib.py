@@ -111,6 +111,9 @@ def lib():
         "r1o_estimate_tile_motion": (i, [vp, vp, vp, vp, vp]),
         "r1o_rdo_pixel_cand_batch": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i, vp, i, i, i,
                                          vp, vp, vp, vp, vp, vp, vp]),
+        "r1o_tx_type_mask": (C.c_uint32, [i, i, i, i]),
+        "r1o_rdo_txsearch_batch": (i, [vp, vp, vp, i, i, i, vp, i, C.c_uint32, i, i, i, i, i, vp, i, i, i,
+                                       vp, vp, vp, vp, vp, vp, vp]),
         "r1o_deblock_plane": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i]),
         "r1o_deblock_sse_plane": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, i, vp, vp]),
         "r1o_deblock_pick_levels": (None, [vp, vp, i, vp]),

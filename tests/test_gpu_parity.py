@@ -1360,6 +1360,124 @@ def test_rdo_pred_cand_vs_oracle(ctx, oracle, bd):
                 assert np.array_equal(o["rec"].cpu().numpy().view(dt), wrec), key
 
 
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_rdo_txsearch_vs_oracle(ctx, oracle, bd):
+    """r1_rdo_txsearch_batch (the transform-type fan-out of rdo_tx_type_decision, src/rdo.rs:1701-1817):
+    ONE launch evaluates every type of the mask on one prediction per candidate.  Every tx size up to
+    32x32, inter and intra masks (RAV1E_TX_TYPES cut by the tx set) and the full 16-type set, fractional
+    motion vectors, candidate counts that leave the last wave ragged, the three distortion kinds, from
+    the reference plane and from a dense prediction buffer; 64-point sides go to the plain kernel."""
+    import ctypes as C
+    a, b = planes(bd, seed=180 + bd, pads=(88, 120))
+    near = planes(bd, seed=180 + bd, pads=(88, 120))[0]
+    nz = np.random.default_rng(8).integers(-5, 6, near.data.shape)
+    near.data[...] = np.clip(near.data.astype(np.int64) + nz, 0, (1 << bd) - 1).astype(near.data.dtype)
+    da, db, dn = dev_plane(a), dev_plane(b), dev_plane(near)
+    rng = np.random.default_rng(1950 + bd)
+    ct = np.int16 if bd == 8 else np.int32
+    dt = np.uint8 if bd == 8 else np.uint16
+    scales = rng.integers(1 << 12, 1 << 16, ((a.height + 7) // 8, (a.width + 7) // 8)).astype(np.uint32)
+    dscales = _t(scales.view(np.int32))
+    for ts, (w, h) in enumerate(TX_SIZES):
+        carea = min(w, 32) * min(h, 32)
+        side64 = max(w, h) == 64
+        m_intra, m_inter = ctx.tx_type_mask(ts, False), ctx.tx_type_mask(ts, True)
+        m_all = ctx.tx_type_mask(ts, True, rav1e_types_only=False)
+        assert m_intra == oracle.r1o_tx_type_mask(ts, 0, 0, 1) and m_all == oracle.r1o_tx_type_mask(ts, 1, 0, 0)
+        for hp, dp, qi, kind, use_sc, mask, intra in ((near, dn, 25, 3, True, m_inter, 0), (b, db, 70, 2, True, m_intra, 1),
+                                                      (near, dn, 140, 0, False, m_all, 0), (b, db, 200, 3, False, m_intra, 1),
+                                                      (near, dn, 60, 2, False, 1 << 9 if not side64 else 1, 0)):
+            nt = bin(mask).count("1")
+            n = (29 if w * h <= 256 else 11) if not side64 else 5
+            c = rand_rdo_cands(rng, n, a.width, a.height, w, h, 50, ts)
+            c["tx_type"] = 0 if side64 else rng.integers(0, 16, n)      # ignored below 64-point sides
+            if hp is near:
+                c["rx"], c["ry"] = c["ox"], c["oy"]
+            pa, pb = a.cstruct(), hp.cstruct()
+            wsad, wsatd = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+            weob, wdist, wrate = np.zeros((n, nt), np.uint16), np.zeros((n, nt), np.uint64), np.zeros((n, nt), np.uint64)
+            wq, wrec = np.zeros((n, nt, carea), ct), np.zeros((n, nt, h, w), dt)
+            assert oracle.r1o_rdo_txsearch_batch(
+                C.byref(pa), C.byref(pb), None, w, h, ts, O.ptr(c), n, mask, qi, intra, 0, 0, kind,
+                O.ptr(scales) if use_sc else None, scales.shape[1], 0, 0, O.ptr(wsad), O.ptr(wsatd), O.ptr(weob),
+                O.ptr(wdist), O.ptr(wrate) if kind == 0 else None, O.ptr(wq), O.ptr(wrec) if kind else None) == 0
+            o = ctx.rdo_txsearch_batch(da, dp, w, h, c, mask, qi, kind, scales=dscales if use_sc else None,
+                                       is_intra=intra, want_sad=True, want_satd=True, want_est_rate=kind == 0,
+                                       want_qcoeffs=True, want_rec=bool(kind))
+            key = (bd, w, h, qi, kind, hex(mask))
+            assert np.array_equal(o["sad"].cpu().numpy().view(np.uint32), wsad), key
+            assert np.array_equal(o["satd"].cpu().numpy().view(np.uint32), wsatd), key
+            assert np.array_equal(o["eob"].cpu().numpy().view(np.uint16), weob), key
+            assert np.array_equal(o["qcoeffs"].cpu().numpy(), wq), key
+            assert np.array_equal(o["dist"].cpu().numpy().view(np.uint64), wdist), key
+            if kind:
+                assert np.array_equal(o["rec"].cpu().numpy().view(dt), wrec), key
+            else:
+                assert np.array_equal(o["est_rate"].cpu().numpy().view(np.uint64), wrate), key
+            # scalars only, as the search consumes them
+            o2 = ctx.rdo_txsearch_batch(da, dp, w, h, c, mask, qi, kind, scales=dscales if use_sc else None,
+                                        is_intra=intra)
+            assert np.array_equal(o2["dist"].cpu().numpy().view(np.uint64), wdist), key
+            assert np.array_equal(o2["eob"].cpu().numpy().view(np.uint16), weob), key
+        if side64:
+            continue
+        # the prediction from a dense buffer (the intra case of the reference: do_rdo_tx_type needs !is_inter)
+        n = 19
+        c = rand_rdo_cands(rng, n, a.width, a.height, w, h, 0, ts)
+        pred = np.zeros((n, h, w), dt)
+        for i in range(n):
+            blk = a.view()[c["oy"][i]:c["oy"][i] + h, c["ox"][i]:c["ox"][i] + w].astype(np.int64)
+            pred[i] = np.clip(blk + rng.integers(-12, 13, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1)
+        dpred = _t(pred.view(np.int16) if bd > 8 else pred)
+        nt = bin(m_intra).count("1")
+        pa = a.cstruct()
+        for kind, qi in ((3, 90), (0, 50)):
+            weob, wdist = np.zeros((n, nt), np.uint16), np.zeros((n, nt), np.uint64)
+            wq = np.zeros((n, nt, carea), ct)
+            assert oracle.r1o_rdo_txsearch_batch(
+                C.byref(pa), None, O.ptr(pred), w, h, ts, O.ptr(c), n, m_intra, qi, 1, 0, 0, kind, O.ptr(scales),
+                scales.shape[1], 0, 0, None, None, O.ptr(weob), O.ptr(wdist), None, O.ptr(wq), None) == 0
+            o = ctx.rdo_txsearch_batch(da, None, w, h, c, m_intra, qi, kind, scales=dscales, is_intra=1,
+                                       want_qcoeffs=True, pred=dpred)
+            key = (bd, w, h, kind, "pred")
+            assert np.array_equal(o["eob"].cpu().numpy().view(np.uint16), weob), key
+            assert np.array_equal(o["qcoeffs"].cpu().numpy(), wq), key
+            assert np.array_equal(o["dist"].cpu().numpy().view(np.uint64), wdist), key
+
+
+def test_rdo_txsearch_equals_single_type_launches(ctx):
+    """Size-independent property at frame scale: slot j of the fan-out equals r1_rdo_pixel_cand_batch /
+    r1_rdo_full_cand_batch run with tx_type = the j-th type, on thousands of candidates (many waves)."""
+    import torch
+    from rav1e_amd import rdo_glue as RG
+    for bd in (8, 10):
+        a, b = planes(bd, w=640, h=384, seed=277)
+        b.data[...] = np.clip(a.data.astype(np.int64) + np.random.default_rng(3).integers(-9, 10, a.data.shape), 0,
+                              (1 << bd) - 1).astype(a.data.dtype)
+        da, db = dev_plane(a), dev_plane(b)
+        rng = np.random.default_rng(278)
+        for ts in (0, 1, 2, 3, 7, 16):
+            w, h = TX_SIZES[ts]
+            n = 3001
+            c = rand_rdo_cands(rng, n, a.width, a.height, w, h, 8, ts)
+            c["rx"] = np.clip(c["rx"], c["ox"] - 2, c["ox"] + 2)
+            c["ry"] = np.clip(c["ry"], c["oy"] - 2, c["oy"] + 2)
+            mask = ctx.tx_type_mask(ts, True)
+            types = RG.tx_type_slots(mask)
+            px = ctx.rdo_txsearch_batch(da, db, w, h, c, mask, 80, 3, want_qcoeffs=True)
+            tx = ctx.rdo_txsearch_batch(da, db, w, h, c, mask, 80, 0, want_est_rate=True)
+            for j, t in enumerate(types):
+                c["tx_type"] = t
+                one = ctx.rdo_pixel_cand_batch(da, db, w, h, c, 80, 3, want_sad=False, want_satd=False,
+                                               want_qcoeffs=True)
+                assert torch.equal(px["eob"][:, j], one["eob"]), (bd, ts, t)
+                assert torch.equal(px["dist"][:, j], one["dist"]), (bd, ts, t)
+                assert torch.equal(px["qcoeffs"][:, j], one["qcoeffs"]), (bd, ts, t)
+                full = ctx.rdo_full_cand_batch(da, db, w, h, c, 80, want_sad=False, want_satd=False)
+                assert torch.equal(tx["dist"][:, j], full["tx_dist"]), (bd, ts, t)
+                assert torch.equal(tx["est_rate"][:, j], full["est_rate"]), (bd, ts, t)
+
+
 # ------------------------ N3: loop restoration (self-guided filter)
 def _lrf_run(ctx, cdef, debl, ydec, fh, us, sh, units, bd):
     import torch

@@ -277,6 +277,66 @@ def test_rdo_pixel_ref_encode_tx_block_pixel_leg(ctx):
     assert RC.check_pixel_blocks(G, pixel_cand) == 482 * 4
 
 
+def _gpu_dist_scaled(ctx):
+    import torch
+    from rav1e_amd.api import DIST_CAND
+
+    def dist_scaled(kind, bd, src, rec, x, y, vw, vh, grid, xdec=0, ydec=0):
+        c = np.zeros(1, DIST_CAND)
+        c["ox"], c["oy"], c["rx"], c["ry"] = x, y, x, y
+        sc = None if grid is None else torch.from_numpy(grid.view(np.int32)).cuda()
+        return int(ctx.dist_scaled_batch(kind, dev_plane(src), dev_plane(rec), vw, vh, c, sc, xdec, ydec)
+                   .cpu().numpy().view(np.uint64)[0])
+    return dist_scaled
+
+
+def test_rdo_txsearch_ref_every_visited_type_on_one_prediction(ctx):
+    """rdo_tx_type_decision's loop body as executed from the reference's text (gen_rdo_txsearch_ref.py):
+    r1_rdo_txsearch_batch in ONE launch reproduces eob, quantized coefficients, reconstruction and the
+    four distortions (sse_wxh / cdef_dist_wxh, with and without the temporal-RDO grid) of EVERY TxType the
+    loop visits (RAV1E_TX_TYPES cut by av1_tx_used[get_tx_set]), bit depths 8 / 10 / 12, intra and inter
+    quantizer offsets, moving grid phases; for blocks cut by the frame edge (frame 102 x 78) the visible-
+    part distortion of compute_distortion comes from the reconstruction through r1_dist_scaled_batch."""
+    import torch
+    import rdo_glue_cases as RC
+    from rav1e_amd.api import RDO_CAND
+    G = np.load(RC.GOLD_TXSEARCH)
+    cache = {}
+
+    def txsearch(bd, ts, mask, qidx, is_intra, src, pred, ox, oy, kind, grid):
+        w, h = RC.TX_W[ts], RC.TX_H[ts]
+        if bd not in cache:
+            cache[bd] = (dev_plane(src), dev_plane(pred), torch.from_numpy(grid_of[bd].view(np.int32)).cuda())
+        ds, dp, dg = cache[bd]
+        c = np.zeros(1, RDO_CAND)
+        c["ox"], c["oy"], c["rx"], c["ry"], c["tx_type"] = ox, oy, ox, oy, 14     # the field is ignored
+        o = ctx.rdo_txsearch_batch(ds, dp, w, h, c, mask, qidx, kind, scales=None if grid is None else dg,
+                                   is_intra=is_intra, want_qcoeffs=True, want_rec=True)
+        pt = np.uint8 if bd == 8 else np.uint16
+        return (o["eob"].cpu().numpy().view(np.uint16)[0], o["dist"].cpu().numpy().view(np.uint64)[0],
+                o["qcoeffs"].cpu().numpy()[0], o["rec"].cpu().numpy().view(pt)[0])
+    grid_of = {bd: np.ascontiguousarray(G["tsr_scales_%d" % bd]) for bd in (8, 10, 12)}
+    n = RC.check_txsearch(G, txsearch, _gpu_dist_scaled(ctx))
+    assert n == sum(len(G["tsr_types_" + str(k)]) for k in G["tsr_keys"]) * 4 and n > 5000
+
+
+def test_rdo_txsearch_ref_compute_distortion_with_chroma(ctx):
+    """compute_distortion (src/rdo.rs:254-347) with is_chroma_block and !luma_only as executed from the
+    reference's text on 4:2:0 / 4:2:2 / 4:4:4 planes, bit depths 8 / 10 / 12: rav1e_amd.rdo_glue's
+    composition over r1_dist_scaled_batch (cdef_dist_wxh / sse_wxh on luma, sse_wxh on the decimated
+    chroma planes, blocks cut by the frame edge down to kernels that are not multiples of 4)."""
+    import rdo_glue_cases as RC
+    G = np.load(RC.GOLD_TXSEARCH)
+    ds = _gpu_dist_scaled(ctx)
+
+    def make_dist(bd, srcs, recs, grid, xdec, ydec):
+        def dist_wxh(kind, p, x, y, w, h):
+            xd, yd = (xdec, ydec) if p else (0, 0)
+            return ds(kind, bd, srcs[p], recs[p], x, y, w, h, grid, xd, yd)
+        return dist_wxh
+    assert RC.check_compute_distortion(G, make_dist) == 5 * 104
+
+
 def test_rdo_glue_ref_compute_tx_distortion(ctx):
     """compute_tx_distortion (src/rdo.rs:349-434): rav1e_amd.rdo_glue's composition over
     r1_dist_scaled_batch (sse_wxh)"""

@@ -1,0 +1,88 @@
+"""The transform-type search (rdo_tx_type_decision, src/rdo.rs:1701-1817) and compute_distortion's
+chroma leg: the CPU oracle and the host glue against rdo_txsearch_ref.npz -- vectors produced by
+executing the reference's own text (tests/golden/gen_rdo_txsearch_ref.py)."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib as O
+import rdo_glue_cases as RC
+
+
+def test_tx_type_mask_is_the_loop_filter_of_the_executed_reference(oracle):
+    """av1_tx_used[get_tx_set(..)] & RAV1E_TX_TYPES for every TxSize x is_inter x use_reduced_set: the
+    oracle's restatement, the product's host function (no device work) and the glue's slot order"""
+    from rav1e_amd import _lib
+    from rav1e_amd import rdo_glue as RG
+    G = np.load(RC.GOLD_TXSEARCH)
+    L = _lib.load()
+    assert tuple(int(t) for t in G["rav1e_tx_types"]) == RG.RAV1E_TX_TYPES
+    for ts in range(19):
+        for inter in (0, 1):
+            for red in (0, 1):
+                for allt in (0, 1):
+                    want = int(G["ts_mask"][ts, inter, red, allt])
+                    assert int(oracle.r1o_tx_type_mask(ts, inter, red, 1 - allt)) == want, (ts, inter, red, allt)
+                    assert int(L.r1_tx_type_mask(ts, inter, red, 1 - allt)) == want, (ts, inter, red, allt)
+                # the slot order of the fan-out = the loop order of rdo_tx_type_decision over RAV1E_TX_TYPES
+                m = int(G["ts_mask"][ts, inter, red, 0])
+                assert RG.tx_type_slots(m) == [t for t in RG.RAV1E_TX_TYPES if (m >> t) & 1]
+    assert int(L.r1_tx_type_mask(19, 0, 0, 1)) == 0 and int(L.r1_tx_type_mask(-1, 0, 0, 1)) == 0
+
+
+def oracle_dist_scaled(oracle):
+    def dist_scaled(kind, bd, src, rec, x, y, vw, vh, grid):
+        pa, pb = src.cstruct(), rec.cstruct()
+        c = np.zeros(1, O.DIST_CAND)
+        c["ox"], c["oy"], c["rx"], c["ry"] = x, y, x, y
+        out = np.zeros(1, np.uint64)
+        sc = None if grid is None else O.ptr(grid)
+        assert oracle.r1o_dist_scaled_batch(kind, C.byref(pa), C.byref(pb), vw, vh, O.ptr(c), 1, sc,
+                                            0 if grid is None else grid.shape[1], 0, 0, O.ptr(out)) == 0
+        return int(out[0])
+    return dist_scaled
+
+
+def test_type_search_every_visited_type_on_one_prediction(oracle):
+    """r1o_rdo_txsearch_batch: eob, quantized coefficients, reconstruction and the four distortions
+    of every TxType the loop visits, bit depths 8 / 10 / 12, inter and intra quantizer offsets, grid
+    phases, blocks cut by the frame edge (distortion over the visible part through the reconstruction)"""
+    G = np.load(RC.GOLD_TXSEARCH)
+
+    def txsearch(bd, ts, mask, qidx, is_intra, src, pred, ox, oy, kind, grid):
+        w, h = RC.TX_W[ts], RC.TX_H[ts]
+        hbd = int(bd > 8)
+        nt = bin(mask).count("1")
+        c = np.zeros(1, O.RDO_CAND)
+        c["ox"], c["oy"], c["rx"], c["ry"], c["tx_type"] = ox, oy, ox, oy, 15   # the field is ignored
+        pa, pb = src.cstruct(), pred.cstruct()
+        eob, dist = np.zeros(nt, np.uint16), np.zeros(nt, np.uint64)
+        qc = np.zeros((nt, min(w, 32) * min(h, 32)), np.int32 if hbd else np.int16)
+        rec = np.zeros((nt, h, w), np.uint16 if hbd else np.uint8)
+        sc = None if grid is None else O.ptr(grid)
+        assert oracle.r1o_rdo_txsearch_batch(C.byref(pa), C.byref(pb), None, w, h, ts, O.ptr(c), 1, mask, qidx,
+                                             is_intra, 0, 0, kind, sc, 0 if grid is None else grid.shape[1], 0, 0,
+                                             None, None, O.ptr(eob), O.ptr(dist), None, O.ptr(qc), O.ptr(rec)) == 0
+        return eob, dist, qc, rec
+    n = RC.check_txsearch(G, txsearch, oracle_dist_scaled(oracle))
+    assert n == sum(len(G["tsr_types_" + str(k)]) for k in G["tsr_keys"]) * 4 and n > 5000
+
+
+def test_compute_distortion_with_chroma(oracle):
+    """compute_distortion (src/rdo.rs:254-347) with is_chroma_block and !luma_only on 4:2:0 / 4:2:2 /
+    4:4:4 planes: rav1e_amd.rdo_glue.compute_distortion over the oracle's sse_wxh / cdef_dist_wxh"""
+    G = np.load(RC.GOLD_TXSEARCH)
+
+    def make_dist(bd, srcs, recs, grid, xdec, ydec):
+        def dist_wxh(kind, p, x, y, w, h):
+            pa, pb = srcs[p].cstruct(), recs[p].cstruct()
+            c = np.zeros(1, O.DIST_CAND)
+            c["ox"], c["oy"], c["rx"], c["ry"] = x, y, x, y
+            out = np.zeros(1, np.uint64)
+            xd, yd = (xdec, ydec) if p else (0, 0)
+            sc = None if grid is None else O.ptr(grid)
+            assert oracle.r1o_dist_scaled_batch(kind, C.byref(pa), C.byref(pb), w, h, O.ptr(c), 1, sc,
+                                                0 if grid is None else grid.shape[1], xd, yd, O.ptr(out)) == 0
+            return int(out[0])
+        return dist_wxh
+    assert RC.check_compute_distortion(G, make_dist) == 5 * 104

@@ -1,0 +1,108 @@
+#!/bin/bash
+# Round 5: ONE parameterised lease script (the one-off tools/gpu_r3_* / gpu_r4_* scripts are gone).
+#   gpurun -- bash tools/gpu_r5.sh TAG STEP [STEP ...]        -> gpurun_out/TAG/
+# steps:
+#   tests         pytest -m gpu (whole suite)
+#   tests:EXPR    pytest -m gpu -k EXPR
+#   smoke         __graft_entry__.smoke()
+#   bench         bench.py, default flags          -> bench.json
+#   chains        bench.py --chain full|pixel, 8- and 10-bit
+#   txs           tools/bench_txsearch.py, 8- and 10-bit, cdef_dist and transform-domain distortion
+#   txs_ab:LIBS   the same with each library of the comma-separated list copied in (same-box A/B)
+#   px_ab:LIBS    bench.py --chain pixel, 8- and 10-bit, per library
+#   kernels       tools/bench_kernels.py, 8- and 10-bit
+#   frame         tools/frame_pipeline.py, 8- and 10-bit
+#   me            tools/bench_me.py
+#   prof          rocprofv3 --kernel-trace --stats of bench.py (100 steps) and of tools/bench_txsearch.py
+#   pmc_txs       SQ counters of the fan-out launches (separate --pmc passes, no trace domains)
+#   pmc_px        SQ / LDS counters of the pixel chain
+#   pmc_lrf       SQ counters of r1_lrf_search_batch
+#   pmc_me        SQ counters of the persistent tile ME
+TAG=$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT || exit 1
+cp rav1e_amd/librav1e_hip.so /tmp/lib_orig.so
+
+pmc_pass() {   # pmc_pass NAME "COUNTERS" -- cmd...   (one rocprofv3 run per counter group; csv kept small)
+  local name=$1 ctrs=$2; shift 2; shift
+  (cd /tmp && timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- "$@" > /tmp/pmc_$name.log 2>&1)
+  local f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 tools/pmc_rows.py "$f" > $OUT/pmc_$name.json || echo "no counters for $name (see /tmp/pmc_$name.log)"; tail -2 /tmp/pmc_$name.log > $OUT/pmc_$name.log
+}
+
+for STEP in "$@"; do
+  ARG=${STEP#*:}; [ "$ARG" = "$STEP" ] && ARG=""
+  case ${STEP%%:*} in
+    tests)
+      echo "== pytest -m gpu ${ARG:+-k $ARG}"
+      if [ -n "$ARG" ]; then timeout 1800 python -m pytest tests -m gpu -x -q -k "$ARG" 2>&1 | tail -15 | tee $OUT/pytest_gpu_k.log
+      else timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $OUT/pytest_gpu.log; fi ;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log ;;
+    bench) timeout 1200 python bench.py 2>$OUT/bench.err | grep "^{" | tee $OUT/bench.json | cut -c1-400 ;;
+    chains)
+      for bd in 8 10; do
+        [ $bd = 10 ] && timeout 600 python bench.py --cpu-seconds 0 --no-extra --bit-depth 10 2>/dev/null | grep "^{" > $OUT/bench_10bit.json
+        for chain in full pixel; do
+          timeout 600 python bench.py --cpu-seconds 0 --chain $chain --bit-depth $bd 2>/dev/null | grep "^{" > $OUT/${chain}_chain_${bd}bit.json
+          python3 -c "
+import json; d=json.loads(open('$OUT/${chain}_chain_${bd}bit.json').read()); print('$chain $bd', d.get('value'), d.get('kernel_ms'), d.get('rdo_only',{}).get('value'))"
+        done
+      done ;;
+    txs)
+      for bd in 8 10; do for kind in 3 0; do
+        timeout 600 python tools/bench_txsearch.py --bit-depth $bd --kind $kind 2>&1 | grep "^{" | tee -a $OUT/txsearch.jsonl | cut -c1-330
+      done; done ;;
+    txs_ab)
+      for pass in 1 2; do for lib in ${ARG//,/ }; do
+        cp $lib rav1e_amd/librav1e_hip.so
+        for bd in 8 10; do
+          timeout 600 python tools/bench_txsearch.py --bit-depth $bd --kind 3 2>&1 | grep "^{" | python3 -c "
+import json,sys
+for l in sys.stdin:
+    d=json.loads(l); print('%-22s bd %2d %2dx%-2d fan %.4f ind %.4f ratio %.3f ok %s' % ('$lib'.split('/')[-1], d['bd'], d['size'], d['size'], d['fanout_ms'], d['independent_ms'], d['ratio'], d['slots_equal_independent']))"
+        done
+      done; done 2>&1 | tee $OUT/txs_ab.txt
+      cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
+    px_ab)
+      for pass in 1 2; do for lib in ${ARG//,/ }; do
+        cp $lib rav1e_amd/librav1e_hip.so
+        for bd in 8 10; do
+          timeout 600 python bench.py --no-extra --cpu-seconds 0 --bit-depth $bd --chain pixel 2>/dev/null | grep '^{' | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('%-22s bd %2d %9.0f Mpx/s rdo_only %s kernel_ms %s ok %s' % ('$lib'.split('/')[-1], $bd, d['value'], d.get('rdo_only',{}).get('value'), d['kernel_ms'], d.get('parity_ok')))"
+        done
+      done; done 2>&1 | tee $OUT/px_ab.txt
+      cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
+    kernels) for bd in 8 10; do timeout 900 python tools/bench_kernels.py --bit-depth $bd 2>/dev/null | grep "^{" > $OUT/kernels_${bd}bit.jsonl; wc -l $OUT/kernels_${bd}bit.jsonl; done ;;
+    frame) for bd in 8 10; do timeout 600 python tools/frame_pipeline.py --bit-depth $bd 2>/dev/null | grep "^{" | tee $OUT/frame_pipeline_${bd}bit.json | cut -c1-600; done ;;
+    me) timeout 900 python tools/bench_me.py --cpu 2>/dev/null | grep "^{" | tee $OUT/me_4k.jsonl | cut -c1-200 ;;
+    prof)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 5 --cpu-seconds 0 --no-extra > /tmp/prof_$TAG.log 2>&1; tail -1 /tmp/prof_$TAG.log | cut -c1-200)
+      find /tmp/prof_$TAG -name "*kernel_stats*" -exec cp {} $OUT/kernel_stats.csv \; 2>/dev/null
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proft_$TAG -o prof -- python $GRAFT_REPO_ROOT/tools/bench_txsearch.py --bit-depth 10 --kind 3 > /tmp/proft_$TAG.log 2>&1; tail -3 /tmp/proft_$TAG.log | cut -c1-200)
+      find /tmp/proft_$TAG -name "*kernel_stats*" -exec cp {} $OUT/txsearch_kernel_stats.csv \; 2>/dev/null ;;
+    pmc_txs)
+      for bd in 8 10; do
+        pmc_pass txs${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- python $GRAFT_REPO_ROOT/tools/bench_txsearch.py --bit-depth $bd --kind 3 --fanout-only --reps 3 --sustain-ms 0
+        pmc_pass txs${bd}_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- python $GRAFT_REPO_ROOT/tools/bench_txsearch.py --bit-depth $bd --kind 3 --fanout-only --reps 3 --sustain-ms 0
+        pmc_pass txs${bd}_c "FETCH_SIZE WRITE_SIZE" -- python $GRAFT_REPO_ROOT/tools/bench_txsearch.py --bit-depth $bd --kind 3 --fanout-only --reps 3 --sustain-ms 0
+      done ;;
+    pmc_px)
+      for bd in 8 10; do
+        pmc_pass px${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --prewarm-ms 0 --cpu-seconds 0 --no-extra --chain pixel --bit-depth $bd
+        pmc_pass px${bd}_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --prewarm-ms 0 --cpu-seconds 0 --no-extra --chain pixel --bit-depth $bd
+      done ;;
+    pmc_lrf)
+      pmc_pass lrf_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --only lrf_search --reps 3 --sustain-ms 0
+      pmc_pass lrf_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --only lrf_search --reps 3 --sustain-ms 0
+      pmc_pass lrf_c "FETCH_SIZE WRITE_SIZE" -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --only lrf_search --reps 3 --sustain-ms 0 ;;
+    pmc_me)
+      pmc_pass me_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- python $GRAFT_REPO_ROOT/tools/bench_me.py --reps 2
+      pmc_pass me_b "SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" -- python $GRAFT_REPO_ROOT/tools/bench_me.py --reps 2 ;;
+    *) echo "unknown step $STEP" ;;
+  esac
+done
+cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so
+ls $OUT
