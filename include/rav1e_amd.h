@@ -794,8 +794,10 @@ int r1_rdo_pred_cand_batch(r1_ctx *ctx, const R1Plane *org, const void *pred, in
  * rec_out (optional): n * nt dense w*h reconstructions.  The host adds the rate of each slot's qcoeffs
  * and keeps the cheapest (compute_rd_cost, rdo.rs:718-723), applying the reference's early exit after the
  * first type itself (rdo.rs:1793-1802: a pure saving there, it changes no result).
- * Sizes with a 64-point side code DCT_DCT only (TX_SET_DCTONLY): tx_type_mask must be 1 and the call is
- * r1_rdo_pixel_cand_batch / r1_rdo_full_cand_batch (the candidates' tx_type must then be 0). */
+ * Sizes up to 16x16 (up to 7 types here, 16 in AV1) run the fan-out kernel.  Sizes with a 32-point side
+ * (DCT_DCT, + IDTX for inter blocks) and with a 64-point side (TX_SET_DCTONLY: tx_type_mask must be 1) run one
+ * plain launch per type with the type forced -- two waves per SIMD of the fan-out kernel lose against two
+ * launches at four (measured) -- same results, same slots. */
 int r1_rdo_txsearch_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, const void *pred, int w,
                           int h, int tx_size, const R1RdoCand *cands, int n, uint32_t tx_type_mask,
                           const R1QuantParams *params, int dist_kind, const uint32_t *scales,

@@ -149,6 +149,9 @@ struct RdoQuantArgs {
   // prediction / residual; result slot of (candidate i, j-th set bit) = i * nt + j, nt = popcount
   uint32_t tx_mask;
   int nt;
+  // plain (non-MT) kernels: tx_mask != 0 forces the type of every candidate to its lowest set bit and the
+  // results go to slot `slot` of nt (sizes with a 32-point side: one launch per type, see r1_rdo_txsearch_batch)
+  int slot;
 };
 namespace {
 using r1tx::T;
@@ -164,9 +167,17 @@ constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm, bool mt = false) {
 #ifdef R1_HINT_MT
     if (R1_HINT_MT_COND) return R1_HINT_MT;
 #endif
-    if (wl <= 3 && hl <= 3) return qm == 2 ? (bd == 8 ? 7 : 8) : 1;
-    if (wl <= 4 && hl <= 4) return qm == 2 ? (bd == 8 ? 6 : 5) : 1;
-    return qm == 2 ? 3 : 1;
+    // what the straight-line kernels are asked for leaves the loop with 50-350 B of scratch per lane, and at
+    // thousands of waves in flight that is traffic to the Infinity Cache: same-box A/B (r05_ab_notes.md, ab1)
+    // 16x16 fan-out 0.754 -> 0.610 ms (8-bit), 0.855 -> 0.602 (10-bit), 10-bit 8x8 0.655 -> 0.553 at the steps below
+#ifndef R1_MT_H8
+#define R1_MT_H8 (qm == 2 ? (bd == 8 ? 7 : 6) : 1)
+#endif
+#ifndef R1_MT_H16
+#define R1_MT_H16 (qm == 2 ? 4 : 1)
+#endif
+    if (wl <= 3 && hl <= 3) return R1_MT_H8;
+    return R1_MT_H16;
   }
 #ifdef R1_HINT_8X8
   if (wl == 3 && hl == 3 && qm == 0) return R1_HINT_8X8;   // A/B: the pipelined 8x8 kernel sits at 69 (8-bit)
@@ -228,7 +239,25 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
   constexpr int TXB_ROWS = SPLIT_T ? 32 : H;
   constexpr int TXB_BYTES = TXB_ROWS * LSTRIDE * (int)sizeof(TB);
   constexpr int IRB_BYTES = QM == 2 ? (H < 32 ? H : 32) * ISTRIDE * 4 : 0;
-  constexpr int QT_BYTES = QM != 0 ? NC * (W < 32 ? W : 32) * (H < 32 ? H : 32) * 4 : 0;
+  // The quantizer's coded-area tile, one per candidate, P dwords of padding between candidates: at the bare
+  // stride (64 / 128 / 256 dwords for 8x8 .. 16x16) the NC candidates of a lane group wrote, gathered and read
+  // back the same banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.36 / 0.26 of the pixel chain's 8x8 / 16x16
+  // launches, profiles/r04_v5_pmc_pixel_summary.json); the forward kernel's TPAD, carried over (R1_QT_PAD: A/B)
+#ifndef R1_QT_PAD
+#define R1_QT_PAD 1
+#endif
+  constexpr int QT_PAD = (R1_QT_PAD && NC > 1) ? P : 0;
+  constexpr int QT_STRIDE = (W < 32 ? W : 32) * (H < 32 ? H : 32) + QT_PAD;
+  constexpr int QT_BYTES = QM != 0 ? NC * QT_STRIDE * 4 : 0;
+  // QM == 2 (pixel-domain leg): only the coded area (32 x 32 of a 64-point side) is quantized, and there is no
+  // `tail` energy to sum (encoder.rs:1617-1640 computes it only when rdo_type.needs_tx_dist()), so vertical
+  // frequencies >= 32 are never read: the column pass does not store them -- the compiler then prunes the
+  // fdct64 network down to the outputs that are (its upper-half outputs are dead) -- and the row pass runs
+  // on rows 0 .. 31 only; horizontal frequencies >= 32 die the same way inside the row lanes (R1_PRUNE64: A/B)
+#ifndef R1_PRUNE64
+#define R1_PRUNE64 1
+#endif
+  constexpr int HU = (R1_PRUNE64 && QM == 2 && H > 32) ? 32 : H;   // vertical frequencies that are used
   constexpr int REC_BYTES = QM == 2 ? NC * W * H * BPP : 0;
   // The source block is staged in LDS next to the window (16-byte row chunks: H*W*BPP/1024
   // load instructions per wave instead of H one-pixel-per-lane loads) and read back column by
@@ -511,8 +540,11 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
   }
   // ---- C: column transform on the residual registers ----
   __syncthreads();  // every lane is done reading the window (MT: the previous type's last phase); LDS becomes buf
-  const int tx_type = MT ? (int)__builtin_ctz(tmask) : (int)cd.tx_type;
-  const long long oslot = MT ? cand * (long long)qa.nt + slot : cand;   // result slot of (candidate, type)
+  const int tx_type = MT ? (int)__builtin_ctz(tmask)
+                         : (QM != 0 && qa.tx_mask != 0 ? (int)__builtin_ctz(qa.tx_mask) : (int)cd.tx_type);
+  // result slot of (candidate, type)
+  const long long oslot = MT ? cand * (long long)qa.nt + slot
+                             : (QM != 0 && qa.nt != 0 ? cand * (long long)qa.nt + qa.slot : cand);
   const bool any_ud = __any(live && r1tx::ud_flip(tx_type));
   if (col_live) {
     if (any_ud) {   // wave-uniform: skipped when no candidate of the wave flips
@@ -530,7 +562,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
     if constexpr (!SPLIT_T) {
       const int cc = cl * W + (r1tx::lr_flip(tx_type) ? W - 1 - c : c);
 #pragma unroll
-      for (int r = 0; r < H; r++)
+      for (int r = 0; r < HU; r++)
         tbuf[r * LSTRIDE + cc] = (TB)r1tx::shift_fwd_ct<SH1>(v[r]);
     }
   }
@@ -541,7 +573,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
   // of the same candidate -- its descriptor is still in registers
   const int cl2 = cl, r = c;
   const bool live2 = live;
-  const bool row_live = live2 && r < H;
+  const bool row_live = live2 && r < HU;
   const int tt = tx_type;
   constexpr int OS = H < 32 ? H : 32, WC = W < 32 ? W : 32;
   T u[W];
@@ -550,7 +582,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
     // the same bytes for lanes 32..63 (one candidate per wave here: cl = cl2 = 0)
     const int cc = r1tx::lr_flip(tx_type) ? W - 1 - c : c;
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
+    for (int half = 0; half < HU / 32; half++) {
       if (col_live) {
 #pragma unroll
         for (int rr = 0; rr < 32; rr++)
@@ -674,7 +706,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
     constexpr int NPLQ = CODED / P;
     static_assert(CODED % P == 0 && NPLQ >= 1, "P lanes share the coded area");
     __syncthreads();
-    int32_t *tile = (int32_t *)smem + cl2 * CODED;
+    int32_t *tile = (int32_t *)smem + cl2 * QT_STRIDE;
     unsigned long long tail = 0;
     if (row_live) {
 #pragma unroll
@@ -991,10 +1023,11 @@ int slice(int tx_size, const R1Plane &org, const R1Plane &ref, const R1RdoCand *
 #ifndef R1_RDO_TU_TSMASK
 #define R1_RDO_TU_TSMASK 0x7ffff
 #endif
-  // the type-search slices: sizes up to 32 x 32 (a 64-point side has TX_SET_DCTONLY, get_tx_set
-  // src/context/transform_unit.rs:123-131: one type, the plain kernel)
-  constexpr unsigned TSM = MT ? ((R1_RDO_TU_TSMASK) & ~((1u << 4) | (1u << 11) | (1u << 12) | (1u << 17) | (1u << 18)))
-                              : (unsigned)(R1_RDO_TU_TSMASK);
+  // the type-search slices: sizes up to 16 x 16 (ids 0-2, 5-8, 13, 14).  A 64-point side has TX_SET_DCTONLY
+  // (get_tx_set, src/context/transform_unit.rs:123-131) and a 32-point side DCT_DCT (+ IDTX for inter blocks):
+  // one or two types, which the plain kernel evaluates at twice the occupancy (same-box A/B,
+  // profiles/r05_ab_notes.md: the 32x32 fan-out kernel held 2 waves per SIMD and LOST 13-22 % against two launches)
+  constexpr unsigned TSM = MT ? ((R1_RDO_TU_TSMASK) & 0x61E7u) : (unsigned)(R1_RDO_TU_TSMASK);
 #define R1_RC_CASE(ID, WL, HL)                                                                   \
   case ID:                                                                                       \
     if constexpr ((TSM >> ID) & 1)                                                               \
@@ -1087,7 +1120,7 @@ int r1_mc_fast_launch(bool prep, const R1Plane *ref, int w, int h, const R1McCan
 namespace {
 int rdo_dispatch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w, int h, int tx_size,
                  const R1RdoCand *cands, int n, uint32_t *sad_out, uint32_t *satd_out,
-                 void *coeffs, void *pred_out, const RdoQuantArgs *qa, void *stream) {
+                 void *coeffs, void *pred_out, const RdoQuantArgs *qa, void *stream, bool mt = false) {
   const bool from_pred = qa && qa->pred_in;
   R1_REQUIRE(ctx && org && (ref || from_pred));
   const R1Plane no_ref = {};
@@ -1118,8 +1151,7 @@ int rdo_dispatch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, int w, int
       {r1_rdo_slice_b8_q0, r1_rdo_slice_b8_q1, r1_rdo_slice_b8_q2, r1_rdo_slice_b8_q3, r1_rdo_slice_b8_q4},
       {r1_rdo_slice_b10_q0, r1_rdo_slice_b10_q1, r1_rdo_slice_b10_q2, r1_rdo_slice_b10_q3, r1_rdo_slice_b10_q4},
       {r1_rdo_slice_b12_q0, r1_rdo_slice_b12_q1, r1_rdo_slice_b12_q2, r1_rdo_slice_b12_q3, r1_rdo_slice_b12_q4}};
-  const bool mt = qa && qa->tx_mask != 0;
-  R1_REQUIRE(!mt || (qm != 0 && !coeffs));
+  R1_REQUIRE(!mt || (qa && qa->tx_mask != 0 && qm != 0 && !coeffs));
   return kSlices[(bd - 8) / 2][mt ? qm + 2 : qm](tx_size, *org, *ref, cands, n, sad_out, satd_out, coeffs, pred_out,
                                                  qa, st);
 #endif
@@ -1264,8 +1296,9 @@ extern "C" int r1_rdo_txsearch_batch(r1_ctx *ctx, const R1Plane *org, const R1Pl
   R1_REQUIRE(dist_kind == 0 || !est_rate_out);
   // WHT (16) has no scan order; the mask is over the 16 TxTypes of the tx sets
   R1_REQUIRE(tx_type_mask != 0 && tx_type_mask <= 0xFFFFu);
-  const bool side64 = r1tx::kTxWLog2[tx_size] > 5 || r1tx::kTxHLog2[tx_size] > 5;
-  // a 64-point side codes DCT_DCT only (TX_SET_DCTONLY): the plain kernel, which reads the candidates' tx_type
+  const int up = r1tx::kTxWLog2[tx_size] > r1tx::kTxHLog2[tx_size] ? r1tx::kTxWLog2[tx_size] : r1tx::kTxHLog2[tx_size];
+  const bool side64 = up > 5, side32 = up == 5;
+  // a 64-point side codes DCT_DCT only (TX_SET_DCTONLY)
   R1_REQUIRE(!side64 || tx_type_mask == 1u);
   RdoQuantArgs qa = {};
   qa.qp = r1q::make_qparams(*params, tx_size, org->bytes_per_px == 1 ? 2 : 4);
@@ -1275,10 +1308,8 @@ extern "C" int r1_rdo_txsearch_batch(r1_ctx *ctx, const R1Plane *org, const R1Pl
   qa.eob = eob_out;
   qa.qcoeffs = qcoeffs_out;
   qa.pred_in = pred;
-  if (!side64) {
-    qa.tx_mask = tx_type_mask;
-    qa.nt = __builtin_popcount(tx_type_mask);
-  }
+  qa.tx_mask = tx_type_mask;
+  qa.nt = __builtin_popcount(tx_type_mask);
   if (dist_kind == 0) {
     qa.tx_dist = (unsigned long long *)dist_out;
     qa.est_rate = (unsigned long long *)est_rate_out;
@@ -1292,6 +1323,17 @@ extern "C" int r1_rdo_txsearch_batch(r1_ctx *ctx, const R1Plane *org, const R1Pl
     qa.pix_dist = (unsigned long long *)dist_out;
     qa.rec = rec_out;
   }
-  return rdo_dispatch(ctx, org, ref, w, h, tx_size, cands, n, sad_out, satd_out, nullptr, nullptr, &qa, stream);
+  if (!side64 && !side32)
+    return rdo_dispatch(ctx, org, ref, w, h, tx_size, cands, n, sad_out, satd_out, nullptr, nullptr, &qa, stream, true);
+  // 32- and 64-point sides: one plain launch per type (at most two), the type forced, results into its slot
+  int slot = 0;
+  for (uint32_t m = tx_type_mask; m != 0; m &= m - 1, slot++) {
+    qa.tx_mask = m & (0u - m);
+    qa.slot = slot;
+    const int rc = rdo_dispatch(ctx, org, ref, w, h, tx_size, cands, n, slot == 0 ? sad_out : nullptr,
+                                slot == 0 ? satd_out : nullptr, nullptr, nullptr, &qa, stream, false);
+    if (rc != R1_OK) return rc;
+  }
+  return R1_OK;
 }
 #endif   // R1_RDO_DISPATCH_TU
