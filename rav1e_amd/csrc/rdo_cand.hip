@@ -198,7 +198,7 @@ constexpr int rdo_waves_hint(int bd, int wl, int hl, int qm, bool mt = false) {
   // the pixel-domain chain sat a few registers above an allocation step at three sizes; asked for the
   // step, the allocator gets there without a spill worth mentioning (same-box, r04_ab_notes.md ab8:
   // 8-bit 290.3 -> 295.0 k, 10-bit 274.2 -> 283.5 k)
-  if (wl == 3 && hl == 3 && qm == 2) return bd == 8 ? 7 : 8;   // 73 / 74 VGPRs -> 58 / 62: 6 -> 8 waves, launch -2.2 / -3.7 % (10-bit at 7: 72 VGPRs, -1.6 %; ab13)
+  if (wl == 3 && hl == 3 && qm == 2) return 8;   // 73 / 74 VGPRs -> 58 / 62: 6 -> 8 waves, launch -2.2 / -3.7 % (10-bit at 7: 72 VGPRs, -1.6 %; ab13)
   if (wl == 4 && hl == 4 && qm == 2) return bd == 8 ? 6 : 5;   // 105 / 107 -> 80 + 44 B scratch / 94: 4 -> 6 / 5 waves, -6 / -5.1 % (10-bit at 6: 68 B of scratch, +1 %; ab13)
   if (wl == 5 && hl == 5 && qm == 2) return 4;              // 8-bit 132 -> 128; 10-bit 131 -> 128 (8 B of scratch): 3 -> 4 waves, -5.4 %
   if (wl == 5 && hl == 5 && qm == 1) return 5;              // 8-bit 97 -> 96; 10-bit 120 -> 96 (20 B of scratch): 4 -> 5 waves, launch -4 % (ab10)
@@ -246,7 +246,9 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
 #ifndef R1_QT_PAD
 #define R1_QT_PAD 1
 #endif
-  constexpr int QT_PAD = (R1_QT_PAD && NC > 1) ? P : 0;
+  // (two candidates per wave sit in different 32-lane groups and never meet in a bank: no padding there --
+  // with it the 10-bit 32x32 launch was 2.8 % slower, r05_ab_notes.md ab2)
+  constexpr int QT_PAD = (R1_QT_PAD && NC > 2) ? P : 0;
   constexpr int QT_STRIDE = (W < 32 ? W : 32) * (H < 32 ? H : 32) + QT_PAD;
   constexpr int QT_BYTES = QM != 0 ? NC * QT_STRIDE * 4 : 0;
   // QM == 2 (pixel-domain leg): only the coded area (32 x 32 of a 64-point side) is quantized, and there is no
