@@ -287,7 +287,8 @@ def _latest(pattern):
 def _kernel_key(d, bd, size):
     lg = {64: 6, 32: 5, 16: 4, 8: 3, 4: 2}[size]
     base = "k_rdo_cand<%d,%d,%d,%s" % (bd, lg, lg, "short" if bd == 8 else "int")
-    return next((k for k in (base + ",0>", base + ">") if k in d), None)   # QM = 0: the headline variant
+    # QM = 0: the headline variant (round 5 added a trailing template flag to the kernel's name)
+    return next((k for k in (base + ",0,false>", base + ",0>", base + ">") if k in d), None)
 
 
 def pmc_counters(bd, size, fw, fh, k):
@@ -346,7 +347,7 @@ def rdo_launch_key(bd, size, qm, n):
     lg = {64: 6, 32: 5, 16: 4, 8: 3, 4: 2}[size]
     nc = 64 // size
     # the grid is rounded up to a multiple of 8 workgroups (XCD-aware mapping, csrc/rdo_cand.hip)
-    return ("k_rdo_cand<%d,%d,%d,%s,%d>" % (bd, lg, lg, "short" if bd == 8 else "int", qm),
+    return ("k_rdo_cand<%d,%d,%d,%s,%d" % (bd, lg, lg, "short" if bd == 8 else "int", qm),
             ((((n + nc - 1) // nc) + 7) & ~7) * 64)
 
 
@@ -934,7 +935,58 @@ def config_lines(ctx, args):
                                                "pass_ratio": round(step / step_ind, 4)}},
          working_set=ho.nbytes + hr.nbytes,
          wbytes={"txsearch %dx%d x%d" % (s_, s_, len(t_[2])): 10 * len(t_[2]) * len(t_[0]) for s_, t_ in tcands.items()})
+    del touts, fns, fns_ind
+    torch.cuda.empty_cache()
+    lines.append(frame_line(ctx, args, timed, launch_how))
     return lines
+
+
+def frame_line(ctx, args, timed, launch_how):
+    """BASELINE.json configs[3] as ONE measured workload: every stage of a coded 3840x2160 10-bit 4:2:0 frame
+    (tools/frame_stages.py: tile ME 8 tiles x 3 references, sub-pel search, 13-mode intra pre-screen, pixel-domain
+    chain on luma AND both chroma planes, the 7-type transform search, deblock level search + filter, CDEF search +
+    filter, restoration search + filter), HIP events per stage, a strided parity sample per stage against the CPU
+    oracle (outside the timed region), the dominant stage against its roofline."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import frame_stages
+    F = frame_stages.build(ctx, 10, k=args.k, qindex=args.qindex)
+    fw, fh, bd = F["frame"]
+    parity = F["verify"]()
+    per, step = timed(F["stages"], graph_ok=False)     # the ME and the composite CDEF call synchronise: not capturable
+    ok_me = bool(ctx.me_status(wait=True)[0])
+    bad = [n for n, (c, ok) in parity.items() if not ok] + ([] if ok_me else ["tile ME flagged a timed-out wait"])
+    n_chk = sum(c for c, _ in parity.values())
+    dom = max(per, key=lambda t: per[t])
+    kkeys = {"rdo_pixel_luma_%dx%d_K%d" % (s, s, args.k): rdo_launch_key(10, s, 2, n) for s, n in F["luma_launch_n"].items()}
+    lc, lsrc = launch_pmc(kkeys.get(dom))
+    roof = build_roofline("config4_frame: %s" % dom, F["algorithmic_bytes"][dom], per[dom], None, None, None,
+                          working_set=F["working_set_bytes"], line_counters=lc, line_src=lsrc)
+    if dom.startswith("estimate_tile_motion"):
+        roof["binding_roof"] = "latency"
+        roof["binding_note"] = ("the hierarchical ME is a dependent chain (block rows x pyramid levels per tile, ~128 steps of ~10 us): "
+                                "neither HBM nor VALU issue limits it; counters: profiles/r05_pmc_me.json")
+    cand_px = sum(F["candidate_pixels"].values())
+    cand_ms = sum(per[n] for n in F["candidate_pixels"])
+    return {"name": "config4_frame_4k_10bit", "metric": "frames/s", "value": round(1e3 / sum(per.values()), 2), "unit": "frames/s",
+            "steps": 20, "ms_per_step": round(sum(per.values()), 4), "ms_per_pass_wall": round(step, 4), "dtype": "u16",
+            "config": {"workload": "%dx%d 10-bit 4:2:0, every device-resident stage of one coded frame (BASELINE configs[3]: speed-4 "
+                                   "full RDO + CDEF, all kernels): tile ME 8 tiles x 3 refs, sub-pel search, 13-mode intra pre-screen, "
+                                   "pixel-domain chain K=%d on luma and both chroma planes, 7-type transform search, deblock level "
+                                   "search + filter, CDEF strength search + filter, restoration search (8 sets) + filter" % (fw, fh, args.k),
+                       "launch": "one call per stage, serialized; stage_ms by HIP events on the launch stream"},
+            "stage_ms": {n: round(v, 4) for n, v in per.items()},
+            "rdo_candidate_Mpixels_s": round(cand_px / (cand_ms * 1e-3) / 1e6, 1),
+            "rdo_candidate_note": "luma + chroma candidates and (block, type) evaluations of the type search over their stages' time",
+            "roofline": roof, "dominant_stage": dom,
+            "algorithmic_bytes_by_stage": {n: int(v) for n, v in F["algorithmic_bytes"].items()},
+            "parity_by_stage": {n: {"checked": c, "ok": ok} for n, (c, ok) in parity.items()},
+            "parity_not_sampled_here": {"lookahead_intra_costs": "tests/test_gpu_ref_vectors.py (lookahead_ref.npz)",
+                                        "update_block_importances_3refs": "tests/test_gpu_ref_vectors.py (lookahead_chain_ref.npz)",
+                                        "intra_prescreen_16x16_13modes": "tests/test_gpu_parity.py (predict_ref.npz, 4 992 dispatches)",
+                                        "cdef_strength_search_8_presets_420": "tests/test_gpu_fullsize.py at 3840x2160 10-bit, whole frame",
+                                        "cdef_luma": "tests/test_gpu_fullsize.py at 3840x2160 10-bit, whole plane",
+                                        "lrf_sgrproj_luma": "tests/test_gpu_parity.py (lrf_ref.npz)"},
+            "parity_checked": n_chk, "parity_ok": not bad, "parity_bad": bad}
 
 
 # N = 1: one stream per block size, the 64x64 launch (the longest workgroups) at high queue priority;

@@ -76,7 +76,7 @@ d=json.loads(sys.stdin.read()); print('%-22s bd %2d %9.0f Mpx/s rdo_only %s kern
       done; done 2>&1 | tee $OUT/px_ab.txt
       cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
     kernels) for bd in 8 10; do timeout 900 python tools/bench_kernels.py --bit-depth $bd 2>/dev/null | grep "^{" > $OUT/kernels_${bd}bit.jsonl; wc -l $OUT/kernels_${bd}bit.jsonl; done ;;
-    frame) for bd in 8 10; do timeout 600 python tools/frame_pipeline.py --bit-depth $bd 2>/dev/null | grep "^{" | tee $OUT/frame_pipeline_${bd}bit.json | cut -c1-600; done ;;
+    frame) for bd in 8 10; do timeout 900 python tools/frame_pipeline.py --verify --bit-depth $bd 2>$OUT/frame_${bd}.err | grep "^{" | tee $OUT/frame_pipeline_${bd}bit.json | cut -c1-600; done ;;
     me) timeout 900 python tools/bench_me.py --cpu 2>/dev/null | grep "^{" | tee $OUT/me_4k.jsonl | cut -c1-200 ;;
     prof)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 5 --cpu-seconds 0 --no-extra > /tmp/prof_$TAG.log 2>&1; tail -1 /tmp/prof_$TAG.log | cut -c1-200)
