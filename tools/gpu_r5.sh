@@ -16,8 +16,7 @@
 #   prof          rocprofv3 --kernel-trace --stats of bench.py (100 steps) and of tools/bench_txsearch.py
 #   pmc_txs       SQ counters of the fan-out launches (separate --pmc passes, no trace domains)
 #   pmc_px        SQ / LDS counters of the pixel chain
-#   pmc_lrf       SQ counters of r1_lrf_search_batch
-#   pmc_me        SQ counters of the persistent tile ME
+#   pmc_frame     SQ / LDS / HBM counters of every kernel of the config-4 frame (tools/frame_pipeline.py)
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -94,13 +93,14 @@ d=json.loads(sys.stdin.read()); print('%-22s bd %2d %9.0f Mpx/s rdo_only %s kern
         pmc_pass px${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --prewarm-ms 0 --cpu-seconds 0 --no-extra --chain pixel --bit-depth $bd
         pmc_pass px${bd}_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --prewarm-ms 0 --cpu-seconds 0 --no-extra --chain pixel --bit-depth $bd
       done ;;
-    pmc_lrf)
-      pmc_pass lrf_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --only lrf_search --reps 3 --sustain-ms 0
-      pmc_pass lrf_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --only lrf_search --reps 3 --sustain-ms 0
-      pmc_pass lrf_c "FETCH_SIZE WRITE_SIZE" -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --only lrf_search --reps 3 --sustain-ms 0 ;;
-    pmc_me)
-      pmc_pass me_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- python $GRAFT_REPO_ROOT/tools/bench_me.py --reps 2
-      pmc_pass me_b "SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" -- python $GRAFT_REPO_ROOT/tools/bench_me.py --reps 2 ;;
+    pmc_frame)   # every kernel of the config-4 frame (ME, pre-screen, chains, type search, deblock, CDEF, LRF search / filter)
+      for bd in 10 8; do
+        FP="python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --bit-depth $bd --reps 2 --sustain-ms 0"
+        pmc_pass frame${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- $FP
+        pmc_pass frame${bd}_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- $FP
+        pmc_pass frame${bd}_c "FETCH_SIZE WRITE_SIZE" -- $FP
+        [ $bd = 10 ] && pmc_pass frame${bd}_d "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_INST_LEVEL_VMEM" -- $FP
+      done ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
