@@ -1071,11 +1071,13 @@ def main():
         rects = W.tile_rects(world, fw, fh)
         x0, y0, x1, y1 = rects[rank]
         my_tile = ref.data[ref.yorigin + y0:ref.yorigin + y1, ref.xorigin + x0:ref.xorigin + x1]
+        orig_vis = tiles.visible(ref).clone()      # what the after-run check recomputes the tiles from
         try:
             comm = tiles.Comm(ctx, rank, world)
             exch_note = "r1_comm_exchange_halos (64 px) + r1_comm_allgather_tiles per step, in stream order"
         except Exception as e:   # keep the scaling run alive; the JSON says which path ran
-            exch_note = "torch.distributed all_gather_into_tensor (C-ABI comm failed: %s)" % (str(e)[:80],)
+            exch_note = ("torch.distributed all_gather_into_tensor of row slabs, NO halo leg -- exchange_ms is not comparable with "
+                         "the peer-store / RCCL p2p paths (C-ABI comm failed: %s)" % (str(e)[:80],))
             send, gathered = tiles.make_exchange_buffers(ref.data, rank, world)
     push_why = None   # why the peer-store exchange is not the one in use (None: it is, or N = 1)
 
@@ -1112,6 +1114,7 @@ def main():
     # a two-plane ring (a new buffer per frame, as in the reference), so nobody stores into a plane
     # a peer may still be reading; ring[cur[0]] is the plane the step's launches read
     ring, ring_launches, ring_peers, cur = [ref], [launches], [], [0]
+    tile_ring, xsteps = [None], [0]     # tiles.TileRing when the peer stores are in use; exchange steps done
 
     def abytes_per_cand(s):
         if pixel:  # window + source (read twice: residual, distortion) + sad/satd/eob/dist
@@ -1210,19 +1213,17 @@ def main():
             # step, so the exchange never moves bytes the peers already hold
             if ring_peers:
                 # peer stores: the new tile goes into the other plane of the ring, its borders and
-                # then the whole tile straight into the peers' copies of that plane
-                nxt = cur[0] ^ 1
-                torch.bitwise_xor(ring_tiles[cur[0]], 1, out=ring_tiles[nxt])
-                ring_peers[nxt].push_halos(rects)
-                ring_peers[nxt].push_tile(rects)
-                cur[0] = nxt
+                # then the whole tile straight into the peers' copies of that plane (tiles.TileRing)
+                tile_ring[0].advance()
+                cur[0] = tile_ring[0].cur
             elif comm is not None:
-                my_tile.bitwise_xor_(1)
+                my_tile.bitwise_xor_(tiles.ring_delta(xsteps[0]))
                 comm.exchange_tile_halos(ref, rects)
                 comm.allgather_tiles(ref, rects)
             else:
-                my_tile.bitwise_xor_(1)
+                my_tile.bitwise_xor_(tiles.ring_delta(xsteps[0]))
                 tiles.exchange_rows(send, gathered)
+            xsteps[0] += 1
             if split:
                 xe[2].record()
                 xev.append(xe)
@@ -1300,8 +1301,7 @@ def main():
                 mine_ok = push_ok
                 through = "peer stores (r1_comm_push_*), both planes of the ring"
                 ring_launches.append(build_launches(ring[1]))
-                ring_tiles = [pl.data[pl.yorigin + vrects[rank][1]:pl.yorigin + vrects[rank][3],
-                                      pl.xorigin + vrects[rank][0]:pl.xorigin + vrects[rank][2]] for pl in ring]
+                tile_ring[0] = tiles.TileRing(ring, ring_peers, vrects, rank, tiles.visible(ring[0]).clone())
                 exch_note = None if world == 1 else (
                              "r1_comm_push_halos (64 px) + r1_comm_push_tile per step: peer stores into "
                              "IPC-mapped planes (two-plane ring) + %s" %
@@ -1367,6 +1367,23 @@ def main():
         step(True)
     fence()
     dt = time.perf_counter() - t0
+    # ---- N > 1: is the exchange still right AFTER the timed loop?  Every rank recomputes what every tile of
+    # the plane the last step left must hold -- ORIGINAL ^ ring_tag(exchange steps done), the peers' tiles
+    # included -- on its own copy; MIN over ranks.  A store that raced the hand-shake, or arrived a ring cycle
+    # late, leaves a stale tag that the single pre-run check cannot see.
+    if world > 1 and exchange_ok is not None:
+        if tile_ring[0] is not None:
+            after = tile_ring[0].check() and tile_ring[0].t == xsteps[0]
+        elif comm is not None:
+            after = bool(torch.equal(tiles.visible(ref), torch.bitwise_xor(orig_vis, tiles.ring_tag(xsteps[0]))))
+        else:
+            after = None    # torch.distributed row slabs: no per-tile content to recompute (and no halo leg)
+        flag = torch.tensor([1.0 if after in (True, None) else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        exchange_ok["after_run"] = None if after is None else bool(flag.item() == 1.0)
+        exchange_ok["after_run_note"] = ("every rank's copy of every tile == original ^ ring_tag(%d exchange steps), checked "
+                                         "after the timed loop, MIN over ranks" % xsteps[0]) if after is not None else \
+            "torch.distributed row-slab fallback: no halo leg, exchange_ms not comparable with the other two paths"
 
     # ---- aggregate: max time over ranks, total pixels over ranks ----
     if world > 1:

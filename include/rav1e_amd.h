@@ -848,8 +848,15 @@ int r1_comm_exchange_halos(r1_comm *comm, const R1Plane *plane, const R1HaloXfer
 /* ---- the same exchange as direct peer stores (an addition: the ABI version stays 4).  xGMI is a load / store fabric: once a
  * peer's plane is mapped into this process, a kernel stores this rank's rectangles straight into
  * it -- N - 1 links at once, no staging copy, nothing to unpack.  Planes have the same geometry on
- * every rank.  The destination must not be a plane a peer may still be reading: the
- * reconstruction of a frame is a new buffer (src/encoder.rs:3322), so rotate two. */
+ * every rank.  INVARIANT: the destination plane is in no peer's live reference set -- nobody may still
+ * read it (motion search / compensation of a later frame included) when the stores start; the
+ * hand-shake (r1_comm_barrier) only orders the stores of THIS step before the kernels behind it.
+ * The reconstruction of a frame is a new buffer (src/encoder.rs:3322) that then sits in up to 8
+ * reference slots (encoder.rs rec -> ref_frames): a host keeps a pool of (live reference slots + 1)
+ * planes per rank, maps every plane of the pool ONCE at start-up (r1_comm_open_peer_planes is a blocking
+ * collective per plane: not a per-frame call) and stores a new reconstruction only into the plane that
+ * left every rank's reference set.  bench.py / rav1e_amd.tiles.TileRing model the two-plane case (the
+ * previous frame as the only reference): one reader, so rotating two is enough THERE and only there. */
 typedef struct R1IpcMem {
   uint8_t handle[64];      /* hipIpcMemHandle_t of the allocation */
   uint64_t offset;         /* of the exported range inside it */

@@ -58,11 +58,19 @@ int find_loaded_rccl(struct dl_phdr_info *info, size_t, void *out) {
 // the one attempt (dlerror() is per thread and is cleared by the read: a later call would see nothing)
 std::string g_rccl_why;
 
-RcclApi *rccl_api() {
+// One attempt per process (positive and negative results are both cached); `why` receives the reason of a
+// failure under the same lock that guards the attempt.
+RcclApi *rccl_api_locked();
+RcclApi *rccl_api(std::string *why = nullptr) {
   static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  RcclApi *a = rccl_api_locked();
+  if (!a && why) *why = g_rccl_why;
+  return a;
+}
+RcclApi *rccl_api_locked() {
   static RcclApi api;
   static bool tried = false;
-  std::lock_guard<std::mutex> lk(mu);
   if (tried) return api.ok ? &api : nullptr;
   tried = true;
   std::vector<std::string> cands;
@@ -138,10 +146,11 @@ struct r1_comm {
   } while (0)
 
 #define R1_NEED_RCCL(api)                                                          \
-  RcclApi *api = rccl_api();                                                       \
+  std::string why_;                                                                \
+  RcclApi *api = rccl_api(&why_);                                                  \
   if (!api) {                                                                      \
     r1_set_error("no RCCL library could be loaded (R1_RCCL_LIBRARY, a loaded librccl.so, librccl.so.1, " \
-                 "/opt/rocm/lib/librccl.so.1): %s", g_rccl_why.c_str());                                   \
+                 "/opt/rocm/lib/librccl.so.1): %s", why_.c_str());                                         \
     return R1_ECOMM;                                                               \
   }
 
@@ -183,10 +192,20 @@ extern "C" int r1_comm_create(r1_ctx *ctx, int rank, int world, const uint8_t *i
     delete c;
     return R1_EHIP;
   }
+  // r1_comm_barrier's two words: here, not on the barrier's first call (a hipMalloc + synchronous hipMemset in
+  // the per-frame path, and a rank failing between them would have left its peers inside the all-reduce)
+  if (hipMalloc((void **)&c->flag, 8) != hipSuccess || hipMemset(c->flag, 0, 8) != hipSuccess) {
+    r1_set_error("r1_comm_create: the barrier's flag words could not be allocated");
+    if (c->flag) (void)hipFree(c->flag);
+    (void)hipEventDestroy(c->pack_done);
+    delete c;
+    return R1_EHIP;
+  }
   ncclResult_t r = api->CommInitRank(&c->nccl, world, id, rank);
   if (r != ncclSuccess) {
     r1_set_error("ncclCommInitRank(rank %d of %d) -> %s", rank, world, api->GetErrorString(r));
     (void)hipEventDestroy(c->pack_done);
+    (void)hipFree(c->flag);
     delete c;
     return R1_ECOMM;
   }
@@ -244,11 +263,20 @@ int comm_staging_done(r1_comm *c, hipStream_t st) {
 // From the first copy into the staging buffer to the end of the call: whatever way the call is
 // left (an R1_HIP_CHECK return included), pack_done is recorded on the stream, so that a later call
 // on another stream waits for the staging traffic already enqueued.
+// finish(): the same on the success path, with the record's own error handed to the caller (the destructor
+// cannot return it).
 struct StagingScope {
   r1_comm *c;
   hipStream_t st;
+  bool done = false;
   StagingScope(r1_comm *c_, hipStream_t st_) : c(c_), st(st_) {}
-  ~StagingScope() { (void)comm_staging_done(c, st); }
+  int finish() {
+    done = true;
+    return comm_staging_done(c, st);
+  }
+  ~StagingScope() {
+    if (!done) (void)comm_staging_done(c, st);
+  }
 };
 // a rectangle in visible-area coordinates must lie inside the plane's visible area and the rows it
 // touches inside the allocation
@@ -328,7 +356,7 @@ extern "C" int r1_comm_exchange_halos(r1_comm *c, const R1Plane *plane, const R1
     R1_HIP_CHECK(hipMemcpy2DAsync(rect_ptr(x), pitch, c->pack + off[i], rb, rb, x.y1 - x.y0,
                                   hipMemcpyDeviceToDevice, st));
   }
-  return R1_OK;
+  return staged.finish();   // pack_done recorded: its own failure is the call's
 }
 
 // The reference-frame all-gather on TILES: rank r owns rects[r] (x0, y0, x1, y1 in plane pixels)
@@ -338,7 +366,7 @@ extern "C" int r1_comm_exchange_halos(r1_comm *c, const R1Plane *plane, const R1
 //   p2p  (default)  one group of ncclSend (my tile to every peer) + ncclRecv (every peer's tile):
 //        xGMI is point to point -- every GPU has its own link to each of the 7 others -- so the
 //        N - 1 transfers of a rank run on N - 1 links at once, each carrying one tile's exact bytes;
-//   ring ($R1_COMM_GATHER=ring)  one ncclAllGather of equal slots (the size of the largest tile):
+//   ring (-DR1_COMM_GATHER_RING=1)  one ncclAllGather of equal slots (the size of the largest tile):
 //        RCCL's ring puts the N - 1 hops behind each other on one link per direction.
 // Both orders of operations are the same on every rank (a collective).
 extern "C" int r1_comm_allgather_tiles(r1_comm *c, const R1Plane *plane, const int32_t *rects4, void *stream) {
@@ -354,10 +382,10 @@ extern "C" int r1_comm_allgather_tiles(r1_comm *c, const R1Plane *plane, const i
     if (b > slot) slot = b;
   }
   slot = (slot + 255) & ~(size_t)255;
-  static const bool ring = [] {
-    const char *e = getenv("R1_COMM_GATHER");
-    return e && !strcmp(e, "ring");
-  }();
+#ifndef R1_COMM_GATHER_RING
+#define R1_COMM_GATHER_RING 0   // A/B builds: -DR1_COMM_GATHER_RING=1
+#endif
+  constexpr bool ring = R1_COMM_GATHER_RING != 0;
   CommDeviceGuard guard(c);
   { const int rc = comm_staging(c, slot * (c->world + 1), st); if (rc != R1_OK) return rc; }
   StagingScope staged(c, st);
@@ -401,7 +429,7 @@ extern "C" int r1_comm_allgather_tiles(r1_comm *c, const R1Plane *plane, const i
     R1_HIP_CHECK(hipMemcpy2DAsync(rect_ptr(q), pitch, recv + slot * rk, rb, rb, q[3] - q[1],
                                   hipMemcpyDeviceToDevice, st));
   }
-  return R1_OK;
+  return staged.finish();
 }
 
 // ---- direct peer stores: a rank writes its rectangles straight into the peers' planes --------
@@ -466,7 +494,11 @@ struct IpcMap {
 };
 std::mutex g_ipc_mu;
 std::vector<IpcMap> g_ipc_maps;
-std::vector<std::pair<void *, void *>> g_ipc_ptrs;   // (pointer handed out, base of its mapping)
+struct IpcPtr {
+  void *ptr, *base;   // pointer handed out, base of its mapping
+  int device;         // the device of the context it was opened on
+};
+std::vector<IpcPtr> g_ipc_ptrs;
 }  // namespace
 
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "R1IpcMem carries the handle as 64 bytes");
@@ -529,7 +561,7 @@ extern "C" int r1_ipc_open(r1_ctx *ctx, const R1IpcMem *mem, void **ptr) {
   }
   m->uses++;
   *ptr = (uint8_t *)m->base + mem->offset;
-  g_ipc_ptrs.emplace_back(*ptr, m->base);
+  g_ipc_ptrs.push_back(IpcPtr{*ptr, m->base, ctx->device});
   return R1_OK;
 }
 
@@ -540,20 +572,20 @@ extern "C" int r1_ipc_close(r1_ctx *ctx, void *ptr) {
   {
     std::lock_guard<std::mutex> lk(g_ipc_mu);
     for (size_t i = 0; i < g_ipc_ptrs.size(); i++)
-      if (g_ipc_ptrs[i].first == ptr) {
-        base = g_ipc_ptrs[i].second;
+      if (g_ipc_ptrs[i].ptr == ptr && g_ipc_ptrs[i].device == ctx->device) {
+        base = g_ipc_ptrs[i].base;
         g_ipc_ptrs.erase(g_ipc_ptrs.begin() + i);
         break;
       }
     for (size_t i = 0; base && i < g_ipc_maps.size(); i++)
-      if (g_ipc_maps[i].base == base) {
+      if (g_ipc_maps[i].base == base && g_ipc_maps[i].device == ctx->device) {
         unmap = --g_ipc_maps[i].uses == 0;
         if (unmap) g_ipc_maps.erase(g_ipc_maps.begin() + i);
         break;
       }
   }
   if (!base) {
-    r1_set_error("r1_ipc_close: %p was not returned by r1_ipc_open", ptr);
+    r1_set_error("r1_ipc_close: %p was not returned by r1_ipc_open on device %d", ptr, ctx->device);
     return R1_EINVAL;
   }
   if (!unmap) return R1_OK;
@@ -620,18 +652,38 @@ extern "C" int r1_comm_open_peer_planes(r1_comm *c, r1_ctx *ctx, const R1Plane *
   int rc = r1_ipc_export(ctx, plane->data, bytes, &mine);
   if (rc != R1_OK) memset(&mine, 0, sizeof(mine));
   CommDeviceGuard guard(c);
-  R1IpcMem *dev = nullptr;
   std::vector<R1IpcMem> all(c->world);
-  R1_HIP_CHECK(hipMalloc((void **)&dev, sizeof(R1IpcMem) * (c->world + 1)));
-  hipError_t he = hipMemcpy(dev + c->world, &mine, sizeof(mine), hipMemcpyHostToDevice);
-  ncclResult_t nr = ncclSuccess;
-  if (he == hipSuccess) {
-    nr = c->api->AllGather(dev + c->world, dev, sizeof(R1IpcMem), ncclUint8, c->nccl, (hipStream_t) nullptr);
-    if (nr == ncclSuccess) he = hipStreamSynchronize(nullptr);
-    if (nr == ncclSuccess && he == hipSuccess)
-      he = hipMemcpy(all.data(), dev, sizeof(R1IpcMem) * c->world, hipMemcpyDeviceToHost);
+  // the exports travel through the communicator's staging buffer (grown here if need be).  NOTHING returns
+  // before the all-gather: if the buffer cannot be had or the upload fails, this rank still enters the
+  // collective -- with whatever the buffer holds when there is one, its slot zeroed where possible (bytes == 0 =
+  // "no export") -- and reports its error afterwards; only a rank with no device buffer at all cannot enter,
+  // and that is an out-of-memory the peers see as an RCCL error / timeout rather than a silent hang here.
+  const size_t need = sizeof(R1IpcMem) * (size_t)(c->world + 1);
+  hipError_t he = hipSuccess;
+  if (c->pack_bytes < need) {
+    if (c->pack_used) (void)hipEventSynchronize(c->pack_done);
+    if (c->pack) (void)hipFree(c->pack);
+    c->pack = nullptr;
+    c->pack_bytes = 0;
+    he = hipMalloc((void **)&c->pack, need);
+    if (he == hipSuccess) c->pack_bytes = need;
+  } else if (c->pack_used) {
+    (void)hipEventSynchronize(c->pack_done);
   }
-  (void)hipFree(dev);
+  ncclResult_t nr = ncclSuccess;
+  if (c->pack) {
+    R1IpcMem *dev = (R1IpcMem *)c->pack;
+    hipError_t up = hipMemcpy(dev + c->world, &mine, sizeof(mine), hipMemcpyHostToDevice);
+    if (up != hipSuccess) {
+      (void)hipMemset(dev + c->world, 0, sizeof(mine));   // best effort: travel as "no export"
+      he = up;
+    }
+    nr = c->api->AllGather(dev + c->world, dev, sizeof(R1IpcMem), ncclUint8, c->nccl, (hipStream_t) nullptr);
+    hipError_t sy = nr == ncclSuccess ? hipStreamSynchronize(nullptr) : hipSuccess;
+    if (nr == ncclSuccess && sy == hipSuccess)
+      sy = hipMemcpy(all.data(), dev, sizeof(R1IpcMem) * c->world, hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = sy;
+  }
   if (nr != ncclSuccess) {
     r1_set_error("r1_comm_open_peer_planes: %s", c->api->GetErrorString(nr));
     return R1_ECOMM;
@@ -677,10 +729,6 @@ extern "C" int r1_comm_barrier(r1_comm *c, void *stream) {
     return R1_ECOMM;
   }
   CommDeviceGuard guard(c);
-  if (!c->flag) {
-    R1_HIP_CHECK(hipMalloc((void **)&c->flag, 8));
-    R1_HIP_CHECK(hipMemset(c->flag, 0, 8));
-  }
   R1_NCCL_CHECK(c->api, c->api->AllReduce(c->flag, c->flag + 1, 1, ncclInt32, ncclSum, c->nccl, (hipStream_t)stream));
   return R1_OK;
 }

@@ -705,12 +705,15 @@ extern "C" int r1_intra_edges_batch(r1_ctx *ctx, const R1Plane *rec, int tile_x,
   // logic, the clipping, the block's address) is the same for every lane of a block and dominates; with 8
   // lanes a wave prepares 8 blocks and walks the 17 .. 129 entries in strides of 8.  Measured against one
   // lane per entry (gpurun_out/r04_g, 4K luma): 4x4 0.097 -> 0.037 ms, 8x8 0.048 -> 0.015, 16x16 0.0165 ->
-  // 0.0124, 32x32 0.0121 -> 0.0119.  ($R1_EDGES_LPC_SHIFT: 0 restores one lane per entry, for A/B runs.)
-  static const int lpc_shift = [] {
-    const char *e = getenv("R1_EDGES_LPC_SHIFT");
-    return e ? atoi(e) : 3;
-  }();
-  lpc_log2 = lpc_log2 - lpc_shift < 3 ? 3 : lpc_log2 - lpc_shift;
+  // 0.0124, 32x32 0.0121 -> 0.0119.  (-DR1_EDGES_LPC_SHIFT=0 restores one lane per entry, for A/B builds.)
+  // (the A/B switch is a build-time macro like the others -- -DR1_EDGES_LPC_SHIFT=0 -- not an environment variable:
+  // the shipped library's behaviour does not depend on the process environment)
+#ifndef R1_EDGES_LPC_SHIFT
+#define R1_EDGES_LPC_SHIFT 3
+#endif
+  static_assert(R1_EDGES_LPC_SHIFT >= 0 && R1_EDGES_LPC_SHIFT <= 3, "lanes per candidate stay within 8 .. 64");
+  lpc_log2 = lpc_log2 - R1_EDGES_LPC_SHIFT < 3 ? 3 : lpc_log2 - R1_EDGES_LPC_SHIFT;
+  if (lpc_log2 > 6) lpc_log2 = 6;
   const int cpw = 64 >> lpc_log2;
   const unsigned grid = (unsigned)((n + cpw - 1) / cpw);
   if (rec->bytes_per_px == 1)

@@ -281,6 +281,54 @@ def verify_exchange(plane, rects, rank, world, do_halos, do_gather, halo=None, p
     return res
 
 
+# ---- the stand-in reconstruction of the multi-GPU runs, and the check that survives the timed loop ----
+# Step t turns a rank's own tile into ORIGINAL ^ ring_tag(t): four tags (a period longer than the
+# two-plane ring), so a store that arrives a whole ring cycle late is as visible as one that is missing.
+def ring_tag(t):
+    return t & 3
+
+
+def ring_delta(t):
+    """what step t -> t + 1 xors into the tile: ring_tag(t) ^ ring_tag(t + 1)"""
+    return (t & 3) ^ ((t + 1) & 3)
+
+
+def visible(plane):
+    return plane.data[plane.yorigin:plane.yorigin + plane.height, plane.xorigin:plane.xorigin + plane.width]
+
+
+class TileRing:
+    """The reconstruction as the tile-sharded runs model it (bench.py --gpus N, tests/test_distributed.py):
+    a ring of two planes mapped on every rank (PeerPlanes); advance() writes this rank's tile of the
+    NEXT plane (the stand-in reconstruction: the current tile ^ ring_delta(t)), stores its borders and
+    then the tile into every peer's copy of that plane and hand-shakes; the next step's launches read
+    that plane.  Nobody stores into a plane a peer may still be reading: the previous frame is the only
+    reader of the other plane (the invariant a real encoder needs is "the destination is in no peer's
+    live reference set": rav1e keeps up to 8 reference slots, so a pool of live slots + 1 planes, mapped
+    once at start-up -- include/rav1e_amd.h, r1_comm_open_peer_planes).
+    check(): every tile of the current plane, the peers' included, must be ORIGINAL ^ ring_tag(steps
+    done) on this rank -- run it after the hand-shake of a step (bench.py runs it once more AFTER the
+    timed loop: an ordering race that a pre-run exchange cannot see shows as a stale tag)."""
+
+    def __init__(self, planes, peers, rects, rank, original_visible):
+        assert len(planes) == 2 and len(peers) == 2
+        self.planes, self.peers, self.rects, self.rank = planes, peers, rects, rank
+        self.orig = original_visible           # device tensor: the visible area both planes started from
+        x0, y0, x1, y1 = rects[rank]
+        self.tiles = [visible(p)[y0:y1, x0:x1] for p in planes]
+        self.cur, self.t = 0, 0
+
+    def advance(self):
+        nxt = self.cur ^ 1
+        torch.bitwise_xor(self.tiles[self.cur], ring_delta(self.t), out=self.tiles[nxt])
+        self.peers[nxt].push_halos(self.rects)
+        self.peers[nxt].push_tile(self.rects)
+        self.cur, self.t = nxt, self.t + 1
+
+    def check(self):
+        return bool(torch.equal(visible(self.planes[self.cur]), torch.bitwise_xor(self.orig, ring_tag(self.t))))
+
+
 def owned_rows(alloc_height, rank, world):
     """Contiguous slab of plane rows rank `rank` contributes: ceil split of the
     padded allocation (every rank sends the same count; the tail is zero-padded)."""

@@ -485,6 +485,113 @@ def test_peer_stores_two_processes_one_gpu(bd):
         assert n == 1 and ok_halo and ok_all, (rank, n, ok_halo, ok_all)
 
 
+def _worker_ring(rank, world, port, q, bd, steps, devices):
+    """tiles.TileRing -- the code bench.py --gpus N steps -- for `steps` ring steps with the check after
+    EVERY step; devices: one GPU index per rank (the same one twice: two processes on one GPU)."""
+    try:
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(devices[rank])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from rav1e_amd import tiles
+        from rav1e_amd import workload as W
+        from rav1e_amd.api import Context, Plane
+        fw, fh = 1290, 714
+        rects = W.tile_rects(world, fw, fh)
+        host = W.random_plane_array(fw, fh, bd, 91)
+        ctx = Context(devices[rank])
+        ring = [Plane.from_numpy(host, fw, fh, bd, 88, 88) for _ in range(2)]
+        peers = [tiles.PeerPlanes(ctx, pl, rank, world, comm=None) for pl in ring]
+        dist.barrier()
+        tr = tiles.TileRing(ring, peers, rects, rank, tiles.visible(ring[0]).clone())
+        ok0 = tr.check()                                   # t = 0: both planes are the original
+        bad_at = -1
+        for i in range(steps):
+            tr.advance()
+            if not tr.check() and bad_at < 0:
+                bad_at = i
+        # the check is not vacuous: a step whose tile store is skipped on ONE rank leaves a stale tag in
+        # the OTHER rank's copy (and a late store -- the previous ring cycle's bytes -- does too)
+        nxt = tr.cur ^ 1
+        torch.bitwise_xor(tr.tiles[tr.cur], tiles.ring_delta(tr.t), out=tr.tiles[nxt])
+        if rank != 0:
+            tr.peers[nxt].push_halos(rects)
+            tr.peers[nxt].push_tile(rects)                 # rank 0 "forgets" its stores
+        else:
+            torch.cuda.synchronize()
+            dist.barrier()
+            dist.barrier()                                 # the two hand-shakes the peers run
+        tr.cur, tr.t = nxt, tr.t + 1
+        stale_seen = not tr.check()
+        flags = torch.tensor([1.0 if stale_seen else 0.0])
+        dist.all_reduce(flags, op=dist.ReduceOp.SUM)       # every rank but the forgetful one must see it
+        dist.barrier()
+        for pp in peers:
+            pp.close()
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok0, bad_at, int(flags.item()), None))
+    except Exception:   # noqa: BLE001
+        import traceback
+        q.put((rank, False, 0, 0, traceback.format_exc()[-1500:]))
+
+
+def _run_ring(devices, bd, steps):
+    import torch.multiprocessing as mp
+    world = len(devices)
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_worker_ring, args=(r, world, port, q, bd, steps, devices)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=600) for _ in ps]
+    for p in ps:
+        p.join(60)
+    for rank, ok0, bad_at, stale, err in res:
+        assert err is None, "rank %d: %s" % (rank, err)
+        assert ok0 and bad_at == -1, (rank, ok0, "first bad step", bad_at)
+        assert stale == world - 1, (rank, stale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bd", [8, 10])
+def test_tile_ring_240_steps_two_processes_one_gpu(bd):
+    """The timed loop's exchange as a stress test, not one exchange: tiles.TileRing (stand-in
+    reconstruction into the other plane of the ring, halo stores, tile stores, hand-shake) for 240 steps
+    between two processes sharing one GPU, every rank's copy of EVERY tile checked against
+    original ^ ring_tag(t) after every step; then a step in which one rank skips its stores must be seen
+    by the other."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _run_ring([0, 0], bd, 240)
+
+
+@pytest.mark.gpu
+def test_tile_ring_240_steps_two_gpus():
+    """the same loop across two physical GPUs (separate L2s / Infinity Caches: the cross-device visibility
+    of peer stores after the hand-shake).  Needs two GPUs; the 1-GPU boxes of the round skip it."""
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_ring([0, 1], 8, 240)
+
+
+def test_ring_tags_have_a_period_longer_than_the_ring():
+    """ring_tag / ring_delta: composing the deltas reproduces the tags, four distinct values, so neither a
+    missing store (tag t - 1 ... wait: the other plane holds tag t - 1) nor one that is a whole two-plane
+    cycle late (tag t - 2) can pass for tag t"""
+    from rav1e_amd import tiles
+    v = 0
+    for t in range(64):
+        assert v == tiles.ring_tag(t)
+        assert tiles.ring_tag(t) != tiles.ring_tag(t + 1) and tiles.ring_tag(t) != tiles.ring_tag(t + 2)
+        v ^= tiles.ring_delta(t)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("bd", [8, 10])
 def test_push_rects_into_a_second_plane(bd):

@@ -10,6 +10,7 @@
 #   txs           tools/bench_txsearch.py, 8- and 10-bit, cdef_dist and transform-domain distortion
 #   txs_ab:LIBS   the same with each library of the comma-separated list copied in (same-box A/B)
 #   px_ab:LIBS    bench.py --chain pixel, 8- and 10-bit, per library
+#   dry           bench.py --gpus 2 / 4 --single-device (control flow of the N > 1 path on one GPU)
 #   kernels       tools/bench_kernels.py, 8- and 10-bit
 #   frame         tools/frame_pipeline.py, 8- and 10-bit
 #   me            tools/bench_me.py
@@ -74,6 +75,12 @@ d=json.loads(sys.stdin.read()); print('%-22s bd %2d %9.0f Mpx/s rdo_only %s kern
         done
       done; done 2>&1 | tee $OUT/px_ab.txt
       cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
+    dry)   # N = 2 and 4 control flow on ONE GPU (numbers mean nothing): the exchange, its pre-run and after-run self-checks
+      for n in 2 4; do
+        timeout 600 python bench.py --gpus $n --single-device --backend gloo --steps 30 --warmup 3 --cpu-seconds 0 --no-extra 2>$OUT/dry$n.err | grep "^{" > $OUT/dry$n.json
+        python3 -c "
+import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['value'], d['config']['exchange'][:60], d['config']['exchange_ok'])" || tail -5 $OUT/dry$n.err
+      done ;;
     kernels) for bd in 8 10; do timeout 900 python tools/bench_kernels.py --bit-depth $bd 2>/dev/null | grep "^{" > $OUT/kernels_${bd}bit.jsonl; wc -l $OUT/kernels_${bd}bit.jsonl; done ;;
     frame) for bd in 8 10; do timeout 900 python tools/frame_pipeline.py --verify --bit-depth $bd 2>$OUT/frame_${bd}.err | grep "^{" | tee $OUT/frame_pipeline_${bd}bit.json | cut -c1-600; done ;;
     me) timeout 900 python tools/bench_me.py --cpu 2>/dev/null | grep "^{" | tee $OUT/me_4k.jsonl | cut -c1-200 ;;
