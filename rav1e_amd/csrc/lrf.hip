@@ -570,6 +570,87 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
   const int bw = CHROMA ? 8 >> xdec : 8, bh = CHROMA ? 8 >> ydec : 8;
   const int nbx = u.w / bw, nby = u.h / bh;
   unsigned long long mine = 0;
+#ifndef R1_LRF_COOP_ERR
+#define R1_LRF_COOP_ERR 1   // A/B switch: 0 = one thread per block (round 4)
+#endif
+  // rdo_loop_plane_error (rdo.rs:2027-2093), the whole workgroup on it.  Round 4 gave a block to a thread: 64 of
+  // the 256 threads looped over 64 pixels each -- one-pixel global loads of the source at a stride of a plane
+  // row -- while the other waves waited at the barrier.  Now a thread owns a ROW SEGMENT of a block (the 8 lanes
+  // of a unit row read 64 contiguous source pixels), the rows of a block meet by xor-shuffles inside their wave
+  // (a wave covers exactly one row of blocks), the five sums of every block are parked in LDS and ONE wave runs
+  // the 64 fixed-point tails (ssim boost, 64-bit arithmetic) side by side instead of one after the other.
+  if constexpr (R1_LRF_COOP_ERR && !CHROMA) {
+    uint32_t(*bs)[5] = (uint32_t(*)[5]) & F1[0][0];   // 64 x 5 sums over the filter outputs, which are dead by now
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int y = half * 32 + wave * 8 + (lane >> 3), xs = lane & 7;    // unit row, 8-pixel segment of it
+      uint32_t sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
+      if (xs < nbx && y < nby * 8) {
+        const uint8_t *po = px_addr<BPP>(src, u.x + xs * 8, u.y + y);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const uint32_t sv = (uint32_t)ld_px<BPP>(po + (size_t)i * BPP), dv = P[y][xs * 8 + i];
+          sum_s += sv; sum_d += dv;
+          sum_s2 += sv * sv; sum_d2 += dv * dv; sum_sd += sv * dv;
+        }
+      }
+#pragma unroll
+      for (int m = 8; m < 64; m <<= 1) {     // the 8 rows of a block: lanes 8 apart
+        sum_s += __shfl_xor(sum_s, m, 64); sum_d += __shfl_xor(sum_d, m, 64);
+        sum_s2 += __shfl_xor(sum_s2, m, 64); sum_d2 += __shfl_xor(sum_d2, m, 64);
+        sum_sd += __shfl_xor(sum_sd, m, 64);
+      }
+      if (lane < 8) {
+        uint32_t *b = bs[(half * 4 + wave) * 8 + lane];
+        b[0] = sum_s; b[1] = sum_d; b[2] = sum_s2; b[3] = sum_d2; b[4] = sum_sd;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int by = threadIdx.x >> 3, bx = threadIdx.x & 7;
+      if (bx < nbx && by < nby) {
+        const uint32_t *b = bs[threadIdx.x];
+        // RawDistortion(cdef_dist_kernel) * bias: the tail multiplies by the block's DistortionScale
+        mine = r1dist::cdef_tile_tail<0>(b[0], b[1], b[2], b[3], b[4], 64, u.x + bx * 8, u.y + by * 8, scales,
+                                         scale_stride, bd);
+      }
+    }
+  } else if constexpr (R1_LRF_COOP_ERR && CHROMA) {
+    if (bw == 4 && bh == 4) {
+      // 4:2:0: a block is one 4x4 cell of get_weighted_sse (dist.rs:234-283) with the block's bias.  A thread owns
+      // a 4-pixel row segment; a wave pass covers four unit rows = one row of cells; rows meet by xor-shuffles.
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+      for (int pass = 0; pass < 4; pass++) {
+        const int y = (pass * 4 + wave) * 4 + (lane >> 4), xs = lane & 15;
+        uint32_t cell = 0;
+        const bool in = xs < nbx && y < nby * 4;
+        if (in) {
+          const uint8_t *po = px_addr<BPP>(src, u.x + xs * 4, u.y + y);
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int32_t d = (int32_t)ld_px<BPP>(po + (size_t)i * BPP) - (int32_t)P[y][xs * 4 + i];
+            cell += (uint32_t)(d * d);
+          }
+        }
+        cell += __shfl_xor(cell, 16, 64);
+        cell += __shfl_xor(cell, 32, 64);
+        if (in && lane < 16) {
+          const int px = u.x + xs * 4, py = u.y + y;
+          const uint32_t sc = scales ? scales[(size_t)((py << ydec) >> 3) * scale_stride + ((px << xdec) >> 3)] : (1u << 14);
+          mine += ((((unsigned long long)cell * sc + 128) >> 8) + 32) >> 6;
+        }
+      }
+    } else {
+      for (int b = threadIdx.x; b < 16 * nby; b += 256) {
+        const int by = b >> 4, bx = b & 15;
+        if (bx >= nbx) continue;
+        mine += lrf_block_err<BPP, CHROMA, 64>(src, &P[by * bh][bx * bw], u.x + bx * bw, u.y + by * bh, bw, bh, xdec, ydec,
+                                               scales, scale_stride, bd);
+      }
+    }
+  } else
   for (int b = threadIdx.x; b < 16 * nby; b += 256) {   // rows of 16 block slots (a unit is at most 16 blocks wide)
     const int by = b >> 4, bx = b & 15;
     if (bx >= nbx) continue;

@@ -567,13 +567,17 @@ __device__ void get_subset_predictors(const TileView &t, int bx, int by, int pix
   for (int i = 0; i < 2 * s.nc; i++) s.all[2 * n + i] = (s.c[i] >>= ssdec);
 }
 
+// Inlined, the running best by value.  As an out-of-line function (round 4) every call received the Block BY
+// REFERENCE: the 112-byte block state (source rows, masks, MV range, cost model) was written to scratch memory per
+// block and read back through flat loads by each of the up to four calls of a step, and the running best (20 bytes)
+// was stored and reloaded around every call -- all on the dependent chain of the persistent kernel.
 template <class B>
-__device__ void try_cands(const B &b, const int16_t *list, int n, Msr &best) {
+__device__ __forceinline__ Msr try_cands(const B &b, const int16_t *list, int n, const Msr best) {
   Msr r = msr_empty();
   b.scan(n, [&](int i, int &row, int &col) { row = list[2 * i]; col = list[2 * i + 1]; }, true, r,
          nullptr);
   fullpel_diamond_search(b, r);
-  if (r.cost < best.cost) best = r;
+  return r.cost < best.cost ? r : best;
 }
 
 template <class B, bool AGENT = false>
@@ -588,19 +592,18 @@ __device__ Msr full_pixel_me(const B &b, const TileView &t, const R1MeParams &p,
   get_subset_predictors<AGENT>(t, bx, by, b.w, b.h, rng, corner, ssdec, s);
   Msr best = msr_empty();
   if (!extensive) {
-    try_cands(b, s.all, s.has_median + s.nb + s.nc, best);
-    return best;
+    return try_cands(b, s.all, s.has_median + s.nb + s.nc, best);
   }
   // (min_sad as f32 * 1.2) as u32 + ((w * h) << (bit_depth - 8)), me.rs:773-774
   const uint32_t thresh = (uint32_t)__fmul_rn((float)s.min_sad, 1.2f) +
                           ((uint32_t)(b.w * b.h) << (p.bit_depth - 8));
   if (s.has_median) {
-    try_cands(b, s.median, 1, best);
+    best = try_cands(b, s.median, 1, best);
     if (best.sad < thresh) return best;
   }
-  try_cands(b, s.b, s.nb, best);
+  best = try_cands(b, s.b, s.nb, best);
   if (best.sad < thresh) return best;
-  try_cands(b, s.c, s.nc, best);
+  best = try_cands(b, s.c, s.nc, best);
   if (best.sad < thresh) return best;
   uneven_multi_hex_search(b, best, 24);
   if (!p.allow_full_search || best.sad < thresh) return best;
@@ -633,7 +636,9 @@ __device__ __forceinline__ void setup_block(B &b, const R1Plane &org, const R1Pl
   b.po_x = (fbx * MI) >> ssdec;
   b.po_y = (fby * MI) >> ssdec;
   b.mvx_min = rng[0]; b.mvx_max = rng[1]; b.mvy_min = rng[2]; b.mvy_max = rng[3];
-  b.mc.lambda = p.lambda[ssdec];
+  // (a select, not p.lambda[ssdec]: a run-time index into the by-value parameter block sends the whole block to
+  // scratch memory -- 112 bytes re-read on every step of the persistent kernel's dependent chain)
+  b.mc.lambda = ssdec == 0 ? p.lambda[0] : (ssdec == 1 ? p.lambda[1] : p.lambda[2]);
   b.mc.allow_hp = p.allow_hp;
   // estimate_motion with pmv = None / refine_subsampled_motion_estimate: pmv = [0, 0]
   b.mc.pmv_row[0] = b.mc.pmv_row[1] = b.mc.pmv_col[0] = b.mc.pmv_col[1] = 0;
@@ -879,14 +884,8 @@ __device__ __forceinline__ bool me_wait(const unsigned int *f, unsigned int epoc
 }
 
 // up to four progress counters polled by four lanes in ONE load per round (a wait is a memory
-// round trip even when the counter is already there): lane k < n polls f[k] for need[k]
-__device__ __forceinline__ bool me_wait4(const unsigned int *const *f, const unsigned int *need, int n,
-                                         unsigned int epoch, int spin, int lane) {
-  const unsigned int *mf = nullptr;
-  unsigned int mn = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (lane == k && k < n) { mf = f[k]; mn = need[k]; }
+// round trip even when the counter is already there): a lane with mf != nullptr polls *mf for mn
+__device__ __forceinline__ bool me_wait_lanes(const unsigned int *mf, unsigned int mn, unsigned int epoch, int spin) {
   for (int it = 0; it < spin; it++) {
     bool done = true;
     if (mf) {
@@ -916,12 +915,18 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
   // every wave of a job sits on ONE XCD (the job's rows are handed out only to waves that find
   // themselves there), so a hand-over never leaves that XCD's L2
   const int xcd = PIN ? (__builtin_amdgcn_s_getreg(6164) & 7) : 0;   // hwreg(HW_REG_XCC_ID, 0, 4)
+  // this XCD's slice of the row list, by selects: a.xoff[xcd] -- a run-time index into the kernel's by-value
+  // argument block -- made the compiler keep a copy of the whole block in scratch memory
+  int x_lo = a.xoff[0], x_hi = a.xoff[1];
+#pragma unroll
+  for (int k = 1; k < 8; k++)
+    if (xcd == k) { x_lo = a.xoff[k]; x_hi = a.xoff[k + 1]; }
   for (;;) {
     if (lane == 0) sh_item = atomicAdd(a.counter + xcd, 1u);
     __syncthreads();
-    const unsigned int ii = __builtin_amdgcn_readfirstlane(sh_item) + (unsigned int)a.xoff[xcd];
+    const unsigned int ii = __builtin_amdgcn_readfirstlane(sh_item) + (unsigned int)x_lo;
     __syncthreads();
-    if (ii >= (unsigned int)a.xoff[xcd + 1]) return;
+    if (ii >= (unsigned int)x_hi) return;
     const MeRow row = a.rows[ii];
     // the row's view of its job BY VALUE (scalar registers): nothing of it is re-read per block
     // behind the stores and atomics of the loop
@@ -981,28 +986,30 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
         int rng[4];
         setup_block(b, org, ref, p, t, bx, by, w, h, ssdec, lane, rng);
         {
-          const unsigned int *wf[4];
-          unsigned int wn[4];
-          int nw = 0;
-          if (row.gy > 0) { wf[nw] = a.prog + fo[pass] + row.gy - 1; wn[nw++] = gx + 1; }
+          // up to four progress words, lane k polling the k-th: each lane's own (pointer, count) pair is set
+          // directly -- lists indexed by a run-time count lived in scratch memory, a store and a load round trip
+          // on every step of the chain
+          const unsigned int *mf = nullptr;
+          unsigned int mn = 0;
+          if (row.gy > 0 && lane == 0) { mf = a.prog + fo[pass] + row.gy - 1; mn = gx + 1; }
           if (!init) {
             const int psz = sz * 2;                            // the parents' size, px
-            wf[nw] = a.prog + fo[2 + pass] + y / psz; wn[nw++] = x / psz + 1;   // own parent refined
+            if (lane == 1) { mf = a.prog + fo[2 + pass] + y / psz; mn = x / psz + 1; }   // own parent refined
             // get_subset_predictors' right / bottom sample positions (me.rs:420-452), tile px
             const int wu = ((w << ssdec) + MI - 1) >> 2, hu = ((h << ssdec) + MI - 1) >> 2;   // 4x4 units
             const int half_w = imin(wu >> 1, t.tcols - 1 - bx), half_h = imin(hu >> 1, t.trows - 1 - by);
-            if (bx + wu < t.tcols) {
+            if (bx + wu < t.tcols && lane == 2) {
               const int px = (bx + wu) * MI, py = (by + half_h) * MI;
               const bool same = px / SB == sbx && py / SB == sby;
-              wf[nw] = a.prog + fo[same ? 2 + pass : pass - 1] + py / psz; wn[nw++] = px / psz + 1;
+              mf = a.prog + fo[same ? 2 + pass : pass - 1] + py / psz; mn = px / psz + 1;
             }
-            if (by + hu < t.trows) {
+            if (by + hu < t.trows && lane == 3) {
               const int px = (bx + half_w) * MI, py = (by + hu) * MI;
               const bool same = px / SB == sbx && py / SB == sby;
-              wf[nw] = a.prog + fo[same ? 2 + pass : pass - 1] + py / psz; wn[nw++] = px / psz + 1;
+              mf = a.prog + fo[same ? 2 + pass : pass - 1] + py / psz; mn = px / psz + 1;
             }
           }
-          if (nw) ok = me_wait4(wf, wn, nw, a.epoch, a.spin, lane) && ok;
+          if (row.gy > 0 || !init) ok = me_wait_lanes(mf, mn, a.epoch, a.spin) && ok;
         }
         const int corner = init ? 0 : (1 | ((xin & sz) ? 2 : 0) | ((yin & sz) ? 4 : 0));
         const Msr r = full_pixel_me<Block<BPP, 16, 3>, true>(b, t, p, bx, by, rng, corner, init, ssdec, sh_subsets);
