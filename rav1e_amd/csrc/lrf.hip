@@ -58,16 +58,19 @@ struct SgrATable {
 };
 __device__ const SgrATable kSgrA = SgrATable();
 
+#ifndef R1_LRF_ATAB_LDS
+#define R1_LRF_ATAB_LDS 1   // A/B switch: the a(z) table read from LDS (a copy per workgroup) instead of global memory
+#endif
 // sgrproj_sum_finish -> a | b << 9
 __device__ __forceinline__ uint32_t sum_finish(uint32_t ssq, uint32_t sum, uint32_t n,
-                                               uint32_t one_over_n, uint32_t s, int bd) {
+                                               uint32_t one_over_n, uint32_t s, int bd, const uint16_t *atab) {
   const int sh = bd - 8;
   const uint32_t scaled_ssq = (ssq + ((1u << (2 * sh)) >> 1)) >> (2 * sh);
   const uint32_t scaled_sum = (sum + ((1u << sh) >> 1)) >> sh;
   const uint32_t t = scaled_ssq * n, u = scaled_sum * scaled_sum;
   const uint32_t p = t > u ? t - u : 0;
   const uint32_t z = (p * s + (1u << 19)) >> 20;
-  const uint32_t a = kSgrA.v[z < 255u ? z : 255u];
+  const uint32_t a = atab[z < 255u ? z : 255u];
   const uint32_t b = (((1u << 8) - a) * sum * one_over_n + (1u << 11)) >> 12;
   return a | (b << 9);
 }
@@ -89,6 +92,15 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
   __shared__ uint32_t ab1[A1H][AW];
   __shared__ uint32_t ab2[A2H][AW];
   const int tid = threadIdx.x;
+  // a(z): one table lookup per (a, b) pair -- 26 per thread and tile, each a global-memory round trip in the sliding
+  // loops when the table sits in device memory; a 512-byte copy per workgroup makes it an LDS read
+#if R1_LRF_ATAB_LDS
+  __shared__ uint16_t atab_s[256];
+  if (tid < 128) ((uint32_t *)atab_s)[tid] = ((const uint32_t *)kSgrA.v)[tid];   // visible after the barrier below
+  const uint16_t *atab = atab_s;
+#else
+  const uint16_t *atab = kSgrA.v;
+#endif
   const uint32_t s2 = kSgrS[set & 15][0], s1 = kSgrS[set & 15][1];
   // ---- 1: padded tile -> LDS (VertPaddedIter / HorzPaddedIter, lrf.rs:402-524) ----
   const int h2 = t.uh + (t.uh & 1), th2 = t.th + (t.th & 1);
@@ -128,7 +140,7 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
           row3(r0 + 3, sb, qb);
           for (int r = r0; r < r1; r++) {   // centre (c - 1, r - 1): S rows r + 2 .. r + 4
             row3(r + 4, sc, qc);
-            ab1[r][c] = sum_finish(qa + qb + qc, sa + sb + sc, 9, 455, s1, bd);
+            ab1[r][c] = sum_finish(qa + qb + qc, sa + sb + sc, 9, 455, s1, bd, atab);
             sa = sb; qa = qb; sb = sc; qb = qc;
           }
         }
@@ -153,7 +165,7 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
           for (int r = r0; r < r1; r++) {   // centre (c - 1, 2 r - 1): S rows 2 r + 1 .. 2 r + 5
             row5(2 * r + 4, m4, q4);
             row5(2 * r + 5, m5, q5);
-            ab2[r][c] = sum_finish(q1 + q2 + q3 + q4 + q5, m1 + m2 + m3 + m4 + m5, 25, 164, s2, bd);
+            ab2[r][c] = sum_finish(q1 + q2 + q3 + q4 + q5, m1 + m2 + m3 + m4 + m5, 25, 164, s2, bd, atab);
             m1 = m3; q1 = q3; m2 = m4; q2 = q4; m3 = m5; q3 = q5;
           }
         }
@@ -487,7 +499,7 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
   typedef typename std::conditional<BPP == 1, uint8_t, uint16_t>::type PT;
   __shared__ uint32_t F1[64][64];
   __shared__ uint32_t F2[PACK ? 1 : 64][64];         // PACK: f1 | f2 << 16 in F1
-  __shared__ PT P[64][64];                           // the unit's pixels, then the filtered unit
+  __shared__ __attribute__((aligned(16))) PT P[64][64];   // the unit's pixels, then the filtered unit
   __shared__ long long mpart[4][5];
   __shared__ unsigned long long epart[4];
   __shared__ int8_t xq[2];
@@ -588,9 +600,22 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
       uint32_t sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
       if (xs < nbx && y < nby * 8) {
         const uint8_t *po = px_addr<BPP>(src, u.x + xs * 8, u.y + y);
+        // eight source pixels in one load where the segment is aligned (units start at multiples of 8 pixels in
+        // every configuration the encoder ships; anything else takes the pixel-by-pixel path), eight filtered
+        // pixels in one LDS read
+        PT sv8[8], dv8[8];
+        if (((uintptr_t)po & (8 * BPP - 1)) == 0) {
+          if constexpr (BPP == 1) *(uint2 *)sv8 = *(const uint2 *)po;
+          else *(uint4 *)sv8 = *(const uint4 *)po;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) sv8[i] = (PT)ld_px<BPP>(po + (size_t)i * BPP);
+        }
+        if constexpr (BPP == 1) *(uint2 *)dv8 = *(const uint2 *)&P[y][xs * 8];
+        else *(uint4 *)dv8 = *(const uint4 *)&P[y][xs * 8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-          const uint32_t sv = (uint32_t)ld_px<BPP>(po + (size_t)i * BPP), dv = P[y][xs * 8 + i];
+          const uint32_t sv = sv8[i], dv = dv8[i];
           sum_s += sv; sum_d += dv;
           sum_s2 += sv * sv; sum_d2 += dv * dv; sum_sd += sv * dv;
         }
