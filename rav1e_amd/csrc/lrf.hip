@@ -641,7 +641,10 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
                                          scale_stride, bd);
       }
     }
-  } else if constexpr (R1_LRF_COOP_ERR && CHROMA) {
+#ifndef R1_LRF_COOP_ERR_CHROMA
+#define R1_LRF_COOP_ERR_CHROMA 0   // measured (profiles/r05_ab_notes.md, ab4): the chroma form LOSES 5-6 % -- off
+#endif
+  } else if constexpr (R1_LRF_COOP_ERR_CHROMA && CHROMA) {
     if (bw == 4 && bh == 4) {
       // 4:2:0: a block is one 4x4 cell of get_weighted_sse (dist.rs:234-283) with the block's bias.  A thread owns
       // a 4-pixel row segment; a wave pass covers four unit rows = one row of cells; rows meet by xor-shuffles.
