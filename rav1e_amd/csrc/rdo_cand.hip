@@ -519,6 +519,15 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
 #pragma unroll
     for (int r = 0; r < H; r++) vkeep[r] = v[r];
   }
+  // TAIL_DEFER (type search of an 8x8 block under cdef_dist: one 8x8 kernel per candidate, eight lanes per
+  // candidate, at most seven types): see the end of the kernel
+#ifndef R1_MT_TAIL_DEFER
+#define R1_MT_TAIL_DEFER 1
+#endif
+  constexpr bool TAIL_DEFER = R1_MT_TAIL_DEFER && MT && QM == 2 && W == 8 && H == 8;
+  // (a mask of more than eight types -- the full AV1 inter set has sixteen -- keeps its tails inside the loop)
+  const bool tail_defer = TAIL_DEFER && qa.dist_kind == R1_DIST_CDEF && qa.nt <= 8;   // wave-uniform
+  uint32_t tail_keep[5] = {0, 0, 0, 0, 0};
   uint32_t tmask = MT ? qa.tx_mask : 1u;
   int slot = 0;
   do {
@@ -866,7 +875,14 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
 #pragma unroll
             for (int t = 1; t < NR; t++) P5[q5] = j == t ? S[t][q5] : P5[q5];
           }
-          if (col_live && j < NR)
+          if (TAIL_DEFER && tail_defer) {
+            // type search, 8x8: lane `slot` of the candidate's eight keeps this type's five sums; the tails run
+            // once, behind the loop
+            if (j == slot) {
+#pragma unroll
+              for (int q5 = 0; q5 < 5; q5++) tail_keep[q5] = P5[q5];
+            }
+          } else if (col_live && j < NR)
             acc += r1dist::cdef_tile_tail<BD>(P5[0], P5[1], P5[2], P5[3], P5[4], KW * KH, cd.ox + c - j,
                                               cd.oy + j * KH, qa.scales, qa.scale_stride, BD);
         } else {
@@ -924,19 +940,31 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
       }
       }
 #endif
+      if (!(TAIL_DEFER && tail_defer)) {   // wave-uniform
 #pragma unroll
-      for (int m = 1; m < P; m <<= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)acc, m, 64);
-        const uint32_t hi = __shfl_xor((uint32_t)(acc >> 32), m, 64);
-        acc += ((unsigned long long)hi << 32) | lo;
+        for (int m = 1; m < P; m <<= 1) {
+          const uint32_t lo = __shfl_xor((uint32_t)acc, m, 64);
+          const uint32_t hi = __shfl_xor((uint32_t)(acc >> 32), m, 64);
+          acc += ((unsigned long long)hi << 32) | lo;
+        }
+        if (live_st && c == 0) qa.pix_dist[oslot] = qa.dist_kind == R1_DIST_WSSE ? (acc + 32) / 64 : acc;
       }
-      if (live_st && c == 0) qa.pix_dist[oslot] = qa.dist_kind == R1_DIST_WSSE ? (acc + 32) / 64 : acc;
     }
   }
   if constexpr (!MT) break;
   tmask &= tmask - 1;
   slot++;
   } while (tmask != 0);
+  if constexpr (TAIL_DEFER) {
+    // the fixed-point tails of cdef_dist_kernel (ssim boost, 64-bit arithmetic, ~120 instructions): inside the loop
+    // they ran once per type with ONE lane of a candidate's eight alive; here lane j runs the tail of type j --
+    // one pass for all (up to seven) types of the candidate
+    if (tail_defer && col_live && c < qa.nt) {
+      const unsigned long long d = r1dist::cdef_tile_tail<BD>(tail_keep[0], tail_keep[1], tail_keep[2], tail_keep[3],
+                                                              tail_keep[4], 64, cd.ox, cd.oy, qa.scales, qa.scale_stride, BD);
+      if (live_st) qa.pix_dist[cand * (long long)qa.nt + c] = d;
+    }
+  }
 }
 
 #ifdef R1_RDO_DISPATCH_TU

@@ -55,11 +55,11 @@ import json; d=json.loads(open('$OUT/${chain}_chain_${bd}bit.json').read()); pri
       for bd in 8 10; do for kind in 3 0; do
         timeout 600 python tools/bench_txsearch.py --bit-depth $bd --kind $kind 2>&1 | grep "^{" | tee -a $OUT/txsearch.jsonl | cut -c1-330
       done; done ;;
-    txs_ab)
-      for pass in 1 2; do for lib in ${ARG//,/ }; do
+    txs_ab)   # TXS_SIZES=8 TXS_PASSES=1 narrow the run
+      for pass in $(seq 1 ${TXS_PASSES:-2}); do for lib in ${ARG//,/ }; do
         cp $lib rav1e_amd/librav1e_hip.so
         for bd in 8 10; do
-          timeout 600 python tools/bench_txsearch.py --bit-depth $bd --kind 3 2>&1 | grep "^{" | python3 -c "
+          timeout 600 python tools/bench_txsearch.py --bit-depth $bd --kind 3 --sizes ${TXS_SIZES:-8,16,32} 2>&1 | grep "^{" | python3 -c "
 import json,sys
 for l in sys.stdin:
     d=json.loads(l); print('%-22s bd %2d %2dx%-2d fan %.4f ind %.4f ratio %.3f ok %s' % ('$lib'.split('/')[-1], d['bd'], d['size'], d['size'], d['fanout_ms'], d['independent_ms'], d['ratio'], d['slots_equal_independent']))"
