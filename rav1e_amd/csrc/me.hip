@@ -299,7 +299,7 @@ __constant__ int8_t kUmh[16][2] = {{4, -2}, {4, -1}, {4, 0}, {4, 1}, {4, 2}, {2,
                                    {-4, 2}, {-4, 1}, {-4, 0}, {-4, -1}, {-4, -2}, {-2, 3}, {0, -4}, {2, -3}};
 
 template <class B>
-__device__ void fullpel_diamond_search(const B &b, Msr &cur) {
+__device__ __forceinline__ void fullpel_diamond_search(const B &b, Msr &cur) {
   // me.rs:955-1000: radius 2 until no candidate improves, then radius 1 until none does.  While at
   // radius 2 the four radius-1 candidates of the same centre are fetched in the same round trip:
   // they are what the next step evaluates whenever radius 2 brings no improvement (the common
@@ -337,7 +337,7 @@ __device__ void fullpel_diamond_search(const B &b, Msr &cur) {
 }
 
 template <class B>
-__device__ void hexagon_search(const B &b, Msr &cur) {
+__device__ __forceinline__ void hexagon_search(const B &b, Msr &cur) {
   int best_idx = 0;
   Msr best = msr_empty();
   {
@@ -372,7 +372,7 @@ __device__ void hexagon_search(const B &b, Msr &cur) {
 }
 
 template <class B>
-__device__ void uneven_multi_hex_search(const B &b, Msr &cur, int me_range) {
+__device__ __forceinline__ void uneven_multi_hex_search(const B &b, Msr &cur, int me_range) {
   {
     const int cr = cur.row, cc = cur.col;
     const int nh = (me_range + 1) / 2;   // i = 1, 3, .. <= me_range
@@ -409,7 +409,7 @@ __device__ void uneven_multi_hex_search(const B &b, Msr &cur, int me_range) {
 
 // full_search (me.rs:1464-1510): rows outer, every `step`-th window
 template <class B>
-__device__ Msr full_search(const B &b, int x_lo, int x_hi, int y_lo, int y_hi, int step) {
+__device__ __forceinline__ Msr full_search(const B &b, int x_lo, int x_hi, int y_lo, int y_hi, int step) {
   Msr best = msr_empty();
   if (x_hi < x_lo || y_hi < y_lo) return best;
   const int nx = (x_hi - x_lo) / step + 1, ny = (y_hi - y_lo) / step + 1;
@@ -483,7 +483,7 @@ __device__ __forceinline__ void process_cand(unsigned long long v, const int *rn
 // 64-job launches 3.6x slower) or by another workgroup in an earlier launch (kernel boundaries
 // make that visible).
 template <bool AGENT = false>
-__device__ void get_subset_predictors(const TileView &t, int bx, int by, int pix_w, int pix_h,
+__device__ __forceinline__ void get_subset_predictors(const TileView &t, int bx, int by, int pix_w, int pix_h,
                                       const int *rng, int corner, int ssdec, Subsets &s) {
   uint32_t min_sad = 0xFFFFFFFFu;
   s.nb = s.nc = s.has_median = 0;
@@ -581,7 +581,7 @@ __device__ __forceinline__ Msr try_cands(const B &b, const int16_t *list, int n,
 }
 
 template <class B, bool AGENT = false>
-__device__ Msr full_pixel_me(const B &b, const TileView &t, const R1MeParams &p, int bx, int by,
+__device__ __forceinline__ Msr full_pixel_me(const B &b, const TileView &t, const R1MeParams &p, int bx, int by,
                              const int *rng, int corner, bool extensive, int ssdec,
                              int16_t *lds) {
   Subsets s;
@@ -1314,7 +1314,10 @@ __global__ __launch_bounds__(256) void k_me_blocks(R1MeJob job, R1MeParams p,
 // candidate: window staging, put_8tap (lane = column), SATD / SAD with one lane
 // per Hadamard tile, all inside the group; the four costs meet by shuffles.
 template <int BPP>
-__global__ __launch_bounds__(256, 3) void k_me_blocks_small(R1MeJob job, R1MeParams p,
+#ifndef R1_ME_SMALL_WAVES
+#define R1_ME_SMALL_WAVES(BPP) 3   // A/B: workgroups the register allocator makes room for (x 4 waves)
+#endif
+__global__ __launch_bounds__(256, R1_ME_SMALL_WAVES(BPP)) void k_me_blocks_small(R1MeJob job, R1MeParams p,
                                                          const R1MeBlockCand *__restrict__ cands,
                                                          int n, int max_w, int max_h, int use_satd,
                                                          int filter_mode,

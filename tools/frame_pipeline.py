@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--sustain-ms", type=float, default=300.0,
                     help="untimed passes for this long before the timed ones (sustained clocks); 0 = off")
     ap.add_argument("--verify", action="store_true", help="the per-stage parity samples against the CPU oracle first")
+    ap.add_argument("--stages", default="", help="A/B runs: time only the stages whose name contains one of these comma-separated "
+                                                  "substrings (the ME still runs once first: later stages read its MEStats)")
     args = ap.parse_args()
     import torch
     import frame_stages
@@ -37,10 +39,16 @@ def main():
     else:
         for _, fn in F["stages"][:3]:      # the ME fills the MEStats the later stages read
             fn()
-    per, wall = frame_stages.time_stages(F["stages"], args.reps, 5, args.sustain_ms)
+    sel = [s for s in args.stages.split(",") if s]
+    timed_stages = [(n, f) for n, f in F["stages"] if not sel or any(s in n for s in sel)]
+    per, wall = frame_stages.time_stages(timed_stages, args.reps, 5, args.sustain_ms)
     stages = {n: round(v, 4) for n, v in per.items()}
     assert ctx.me_status(wait=True)[0], "a persistent tile-ME launch flagged a timed-out wait"
     total = round(sum(stages.values()), 3)
+    if sel:
+        print(json.dumps({"frame": "%dx%d %d-bit 4:2:0" % (fw, fh, bd), "stage_ms": stages}))
+        ctx.close()
+        return
     ov_fn = F["overlapped"]
     ov_fn()
     torch.cuda.synchronize()

@@ -10,6 +10,7 @@
 #   txs           tools/bench_txsearch.py, 8- and 10-bit, cdef_dist and transform-domain distortion
 #   txs_ab:LIBS   the same with each library of the comma-separated list copied in (same-box A/B)
 #   lrf_ab:LIBS   tools/bench_lrf_search.py per library
+#   stage_ab:LIBS STAGES=... tools/frame_pipeline.py --stages per library
 #   px_ab:LIBS    bench.py --chain pixel, 8- and 10-bit, per library
 #   dry           bench.py --gpus 2 / 4 --single-device (control flow of the N > 1 path on one GPU)
 #   kernels       tools/bench_kernels.py, 8- and 10-bit
@@ -71,6 +72,12 @@ for l in sys.stdin:
         cp $lib rav1e_amd/librav1e_hip.so
         for bd in 8 10; do echo "$(basename $lib) $(timeout 300 python tools/bench_lrf_search.py --bit-depth $bd 2>/dev/null | grep '^{')"; done
       done; done 2>&1 | tee $OUT/lrf_ab.txt
+      cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
+    stage_ab)   # STAGES=substr,substr: tools/frame_pipeline.py --stages per library, 8- and 10-bit
+      for pass in 1 2; do for lib in ${ARG//,/ }; do
+        cp $lib rav1e_amd/librav1e_hip.so
+        for bd in 8 10; do echo "$(basename $lib) $(timeout 300 python tools/frame_pipeline.py --bit-depth $bd --stages "$STAGES" 2>/dev/null | grep '^{')"; done
+      done; done 2>&1 | tee $OUT/stage_ab.txt
       cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
     px_ab)
       for pass in 1 2; do for lib in ${ARG//,/ }; do
