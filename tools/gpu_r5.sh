@@ -18,6 +18,7 @@
 #   me            tools/bench_me.py
 #   prof          rocprofv3 --kernel-trace --stats of bench.py (100 steps) and of tools/bench_txsearch.py
 #   pmc_txs       SQ counters of the fan-out launches (separate --pmc passes, no trace domains)
+#   pmc_hbm       FETCH_SIZE / WRITE_SIZE (separate passes) of the 10-bit frame and of the type search
 #   pmc_px        SQ / LDS counters of the pixel chain
 #   pmc_frame     SQ / LDS / HBM counters of every kernel of the config-4 frame (tools/frame_pipeline.py)
 TAG=$1; shift
@@ -29,7 +30,7 @@ cp rav1e_amd/librav1e_hip.so /tmp/lib_orig.so
 
 pmc_pass() {   # pmc_pass NAME "COUNTERS" -- cmd...   (one rocprofv3 run per counter group; csv kept small)
   local name=$1 ctrs=$2; shift 2; shift
-  (cd /tmp && timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- "$@" > /tmp/pmc_$name.log 2>&1)
+  (cd /tmp && timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- "$@" > /tmp/pmc_$name.log 2>&1)
   local f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 tools/pmc_rows.py "$f" > $OUT/pmc_$name.json || echo "no counters for $name (see /tmp/pmc_$name.log)"; tail -2 /tmp/pmc_$name.log > $OUT/pmc_$name.log
 }
@@ -107,8 +108,14 @@ import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['va
       for bd in 8 10; do
         pmc_pass txs${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- python $GRAFT_REPO_ROOT/tools/bench_txsearch.py --bit-depth $bd --kind 3 --fanout-only --reps 3 --sustain-ms 0
         pmc_pass txs${bd}_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- python $GRAFT_REPO_ROOT/tools/bench_txsearch.py --bit-depth $bd --kind 3 --fanout-only --reps 3 --sustain-ms 0
-        pmc_pass txs${bd}_c "FETCH_SIZE WRITE_SIZE" -- python $GRAFT_REPO_ROOT/tools/bench_txsearch.py --bit-depth $bd --kind 3 --fanout-only --reps 3 --sustain-ms 0
       done ;;
+    pmc_hbm)   # FETCH_SIZE and WRITE_SIZE in SEPARATE passes (together they do not fit one pass and the run hangs until its timeout)
+      FP="python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --bit-depth 10 --reps 2 --sustain-ms 0"
+      TX="python $GRAFT_REPO_ROOT/tools/bench_txsearch.py --bit-depth 10 --kind 3 --fanout-only --reps 3 --sustain-ms 0"
+      PMC_TIMEOUT=150 pmc_pass frame10_fetch "FETCH_SIZE" -- $FP
+      PMC_TIMEOUT=150 pmc_pass frame10_write "WRITE_SIZE" -- $FP
+      PMC_TIMEOUT=120 pmc_pass txs10_fetch "FETCH_SIZE" -- $TX
+      PMC_TIMEOUT=120 pmc_pass txs10_write "WRITE_SIZE" -- $TX ;;
     pmc_px)
       for bd in 8 10; do
         pmc_pass px${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --prewarm-ms 0 --cpu-seconds 0 --no-extra --chain pixel --bit-depth $bd
@@ -119,7 +126,6 @@ import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['va
         FP="python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --bit-depth $bd --reps 2 --sustain-ms 0"
         pmc_pass frame${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- $FP
         pmc_pass frame${bd}_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- $FP
-        pmc_pass frame${bd}_c "FETCH_SIZE WRITE_SIZE" -- $FP
         [ $bd = 10 ] && pmc_pass frame${bd}_d "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_INST_LEVEL_VMEM" -- $FP
       done ;;
     *) echo "unknown step $STEP" ;;
