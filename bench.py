@@ -953,6 +953,7 @@ def frame_line(ctx, args, timed, launch_how):
     fw, fh, bd = F["frame"]
     parity = F["verify"]()
     per, step = timed(F["stages"], graph_ok=False)     # the ME and the composite CDEF call synchronise: not capturable
+    per = {n: v for n, v in per.items() if not n.endswith("_untimed")}   # the restore of the in-place filtered planes
     ok_me = bool(ctx.me_status(wait=True)[0])
     bad = [n for n, (c, ok) in parity.items() if not ok] + ([] if ok_me else ["tile ME flagged a timed-out wait"])
     n_chk = sum(c for c, _ in parity.values())

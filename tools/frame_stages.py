@@ -55,6 +55,11 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
     stages, optional, checks = [], [], {}
     TS = {64: 4, 32: 3, 16: 2, 8: 1, 4: 0}
 
+    # 0 (untimed) the deblocking stage filters the reconstruction IN PLACE and its run time depends on what it finds
+    # (an already filtered plane takes fewer taps): every pass starts from the pristine reconstruction.  Consumers drop
+    # stages whose name ends in "_untimed" from their sums.
+    restore = []
+    stages.append(("restore_reconstruction_untimed", lambda: [p.data.copy_(b) for p, b in restore]))
     # 1 lookahead cost maps
     stages.append(("lookahead_intra_costs", lambda: ctx.estimate_intra_costs(org[0])))
     # 2 hierarchical ME: 8 tiles x 3 references
@@ -263,6 +268,7 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
     h_rec3, h_src3 = [h_refs[0][0], h_chroma[0], h_chroma[2]], [h_org[0], h_chroma[1], h_chroma[3]]
     tall = torch.zeros((3, 2, 65), dtype=torch.int64, device="cuda")
     rec3, src3 = [a for (a, b, p, xd, yd) in planes3], [b for (a, b, p, xd, yd) in planes3]
+    restore.extend((p, p.data.clone()) for p in rec3)
     stages.append(("deblock_level_search_420", lambda: ctx.deblock_sse_frame(rec3, src3, 1, 1, dblocks, fw, fh, tallies=tall)))
 
     def chk_deblock_search():
@@ -357,13 +363,14 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
     s_me, s_rdo = torch.cuda.Stream(), torch.cuda.Stream()
     by_name = dict(stages)
     main_order = [n for n, _ in stages if n not in ("lookahead_intra_costs", "estimate_tile_motion_8tiles_x_3refs",
-                                                    "update_block_importances_3refs")]
+                                                    "update_block_importances_3refs", "restore_reconstruction_untimed")]
 
     def overlapped():
         with torch.cuda.stream(s_me):
             tile_me()
             importances()
         with torch.cuda.stream(s_rdo):
+            by_name["restore_reconstruction_untimed"]()
             for n in main_order:
                 by_name[n]()
     px = {"rdo_pixel_candidates_chroma_2planes_K%d" % k: 2 * sum(len(v) * kk * kk for kk, v in ccands.items()),
