@@ -124,3 +124,71 @@ def tx_type_slots(tx_type_mask):
     """slot j of r1_rdo_txsearch_batch's outputs -> TxType: the set bits of the mask in ascending order,
     which is also the order of RAV1E_TX_TYPES (the loop order of rdo_tx_type_decision)"""
     return [t for t in range(16) if (int(tx_type_mask) >> t) & 1]
+
+
+RESTORATION_TILESIZE_MAX_LOG2 = 8
+
+
+def restoration_plane_configs(width, height, xdec, ydec, base_q_idx, enable_large_lru=True, enable_restoration=True,
+                              use_128x128_superblock=False, tiling=(1, 1, 0, 0)):
+    """RestorationState::new (src/lrf.rs:1321-1480): the restoration-unit geometry of the three planes of a frame --
+    per plane dict(unit_size, sb_h_shift, sb_v_shift, stripe_height, cols, rows).  tiling = (cols, rows,
+    tile_width_sb, tile_height_sb).  cols / rows follow the specification's last-unit rule (a remainder of less than
+    half a unit stretches the last unit instead of starting a new one)."""
+    stripe_uv_decimate = 1 if (xdec > 0 and ydec > 0) else 0
+    y_sb_log2 = 7 if use_128x128_superblock else 6
+    uv_sb_h_log2, uv_sb_v_log2 = y_sb_log2 - xdec, y_sb_log2 - ydec
+    if enable_large_lru and enable_restoration:
+        assert width > 1 and height > 1
+        lrf_base_shift = 0 if base_q_idx > 200 else (1 if base_q_idx > 160 else 2)
+        if stripe_uv_decimate:
+            if lrf_base_shift == 2:
+                lrf_chroma_shift = 1
+            else:
+                us = 1 << (RESTORATION_TILESIZE_MAX_LOG2 - lrf_base_shift)
+                unshifted = ((width >> xdec) - 1) % us <= us // 2 or ((height >> ydec) - 1) % us <= us // 2
+                shifted = ((width >> xdec) - 1) % (us >> 1) <= us // 4 or ((height >> ydec) - 1) % (us >> 1) <= us // 4
+                lrf_chroma_shift = 1 if (unshifted and not shifted) else 0
+        else:
+            lrf_chroma_shift = 0
+        lrf_y_shift, lrf_uv_shift = lrf_base_shift, lrf_base_shift + lrf_chroma_shift
+    else:
+        lrf_y_shift = 1 if use_128x128_superblock else 2
+        lrf_uv_shift = lrf_y_shift + stripe_uv_decimate
+    y_unit = 1 << (RESTORATION_TILESIZE_MAX_LOG2 - lrf_y_shift)
+    uv_unit = 1 << (RESTORATION_TILESIZE_MAX_LOG2 - lrf_uv_shift)
+    t_cols, t_rows, tw_sb, th_sb = tiling
+    if t_cols > 1 or t_rows > 1:
+        tz = lambda v: (v & -v).bit_length() - 1 if v else 64     # usize::trailing_zeros (0 -> the type's width)
+        hz, vz = tz(tw_sb), tz(th_sb)
+        y_unit = min(y_unit, 1 << (y_sb_log2 + min(hz, vz)))
+        uv_unit = min(uv_unit, min(1 << (uv_sb_h_log2 + hz), 1 << (uv_sb_v_log2 + vz)))
+    if ydec == 0 and y_unit != uv_unit:
+        y_unit = min(uv_unit, y_unit)
+        uv_unit = y_unit
+    y_log2, uv_log2 = y_unit.bit_length() - 1, uv_unit.bit_length() - 1
+    y_cols = max((width + (y_unit >> 1)) // y_unit, 1)
+    y_rows = max((height + (y_unit >> 1)) // y_unit, 1)
+    uv_cols = max((((width + (1 << xdec >> 1)) >> xdec) + (uv_unit >> 1)) // uv_unit, 1)
+    uv_rows = max((((height + (1 << ydec >> 1)) >> ydec) + (uv_unit >> 1)) // uv_unit, 1)
+    y = dict(unit_size=y_unit, sb_h_shift=y_log2 - y_sb_log2, sb_v_shift=y_log2 - y_sb_log2, stripe_height=64, cols=y_cols,
+             rows=y_rows)
+    uv = dict(unit_size=uv_unit, sb_h_shift=uv_log2 - uv_sb_h_log2, sb_v_shift=uv_log2 - uv_sb_v_log2,
+              stripe_height=64 >> stripe_uv_decimate, cols=uv_cols, rows=uv_rows)
+    return [y, dict(uv), dict(uv)]
+
+
+def restoration_search_units(cfg, crop_w, crop_h, dec_x=0, dec_y=0):
+    """The (x, y, vis_w, vis_h) rectangles the restoration leg of rdo_loop_decision solves and filters, for a WHOLE
+    plane: one per restoration unit (x, y) < (cfg.cols, cfg.rows) -- has_restoration_unit(.., stretch = false) -- at
+    loop_sbo.plane_offset = unit index x unit_size, clipped to the visible plane: vis = min(unit_size, (crop >> dec) -
+    offset) (src/rdo.rs:2645-2654; the stretched remainder of a last unit is filtered at frame time, not searched).
+    This is the `units` list of r1_lrf_search_batch (one entry per parameter set each)."""
+    us, out = cfg["unit_size"], []
+    pw, ph = crop_w >> dec_x, crop_h >> dec_y
+    for uy in range(cfg["rows"]):
+        for ux in range(cfg["cols"]):
+            x, y = ux * us, uy * us
+            if x < pw and y < ph:
+                out.append((x, y, min(us, pw - x), min(us, ph - y)))
+    return out

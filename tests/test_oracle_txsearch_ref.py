@@ -86,3 +86,42 @@ def test_compute_distortion_with_chroma(oracle):
             return int(out[0])
         return dist_wxh
     assert RC.check_compute_distortion(G, make_dist) == 5 * 104
+
+
+def test_restoration_geometry_is_the_executed_restoration_state():
+    """RestorationState::new (src/lrf.rs:1321-1480) executed for 260-odd frame configurations (sizes, chroma
+    samplings, quantizers on both sides of its thresholds, large / small units, 128x128 superblocks, tilings, random
+    sizes): rav1e_amd.rdo_glue.restoration_plane_configs reproduces unit size, sb shifts, stripe height and the
+    last-unit rule of cols / rows of all three planes, and restoration_search_units the visible size of the last
+    unit column / row (rdo.rs:2645-2654) -- the geometry the restoration search's unit lists are built from
+    (tools/frame_stages.py, tools/bench_lrf_search.py) and that gen_lrf_search_ref.py used to state by hand."""
+    import os
+    from rav1e_amd import rdo_glue as RG
+    G = np.load(os.path.join(os.path.dirname(RC.GOLD), "lrf_geometry_ref.npz"))
+    n = 0
+    for inp, cfg, vis in zip(G["geo_in"], G["geo_cfg"], G["geo_vis"]):
+        w, h, xd, yd, q, large, rest, sb128, tc, tr, tw, th = [int(v) for v in inp]
+        if (cfg[:, 1:3] < 0).any():
+            continue      # a unit smaller than the superblock: the reference's own usize subtraction underflows there
+        got = RG.restoration_plane_configs(w, h, xd, yd, q, bool(large), bool(rest), bool(sb128), (tc, tr, tw, th))
+        for pli in range(3):
+            g = got[pli]
+            assert [g["unit_size"], g["sb_h_shift"], g["sb_v_shift"], g["stripe_height"], g["cols"], g["rows"]] == \
+                [int(v) for v in cfg[pli]], (tuple(inp), pli, g, cfg[pli])
+            dx, dy = (xd, yd) if pli else (0, 0)
+            units = RG.restoration_search_units(g, w, h, dx, dy)
+            if units:
+                assert max(u[0] for u in units) // g["unit_size"] <= g["cols"] - 1
+                last_col = max(u[0] for u in units)
+                last_row = max(u[1] for u in units)
+                vw = [u[2] for u in units if u[0] == last_col][0]
+                vh = [u[3] for u in units if u[1] == last_row][0]
+                assert (vw, vh) == (int(vis[pli][0]), int(vis[pli][1])), (tuple(inp), pli, vw, vh, vis[pli])
+                # the list is a partition of what it covers: no unit wider than the nominal size, none empty
+                assert all(0 < u[2] <= g["unit_size"] and 0 < u[3] <= g["unit_size"] for u in units)
+        n += 1
+    assert n > 200
+    # the 4K frame of BASELINE config 4 at qindex 100: 64-pixel luma units, 32-pixel chroma units (what the benches use)
+    c4 = RG.restoration_plane_configs(3840, 2160, 1, 1, 100)
+    assert (c4[0]["unit_size"], c4[1]["unit_size"], c4[0]["cols"], c4[0]["rows"]) == (64, 32, 60, 34)
+    assert len(RG.restoration_search_units(c4[0], 3840, 2160)) == 60 * 34

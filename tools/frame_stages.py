@@ -316,20 +316,25 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
     stages.append(("cdef_luma", lambda: ctx.cdef_filter_frame_plane(refs[0][0], refs[0][0], dst, 0, 0, 0, fw, fh, skip, ci,
                                                                     [36] * 8, [36] * 8, 5, bd)))
 
-    def unit_list(pw, ph, us_):
-        u = [(x, y, min(us_, pw - x), min(us_, ph - y), s_, (0, 0, 0))
-             for y in range(0, ph, us_) for x in range(0, pw, us_) for s_ in LRF_SETS]
+    # the restoration units of the frame as RestorationState::new lays them out for this quantizer (rdo_glue, pinned by
+    # lrf_geometry_ref.npz: 64-pixel luma / 32-pixel chroma units at qindex <= 160 on 4:2:0), every set per unit
+    rcfg = RG.restoration_plane_configs(fw, fh, 1, 1, qindex)
+
+    def unit_list(cfg, dec):
+        u = [(x, y, w_, h_, s_, (0, 0, 0)) for (x, y, w_, h_) in RG.restoration_search_units(cfg, fw, fh, dec, dec)
+             for s_ in LRF_SETS]
         return np.array(u, api.SGR_SOLVE_UNIT)
-    h_ul, h_uc = unit_list(fw, fh, 64), unit_list(cw, ch, 32)
+    h_ul, h_uc = unit_list(rcfg[0], 0), unit_list(rcfg[1], 1)
+    us_l, us_c = rcfg[0]["unit_size"], rcfg[1]["unit_size"]
     ul = torch.from_numpy(h_ul.view(np.uint8).reshape(-1).copy()).cuda()
     uc = torch.from_numpy(h_uc.view(np.uint8).reshape(-1).copy()).cuda()
     lrf_res = {}
 
     def lrf_search():
-        lrf_res[0] = ctx.lrf_search_batch(rec3[0], src3[0], ul, scales=scales, max_w=64, max_h=64)
+        lrf_res[0] = ctx.lrf_search_batch(rec3[0], src3[0], ul, scales=scales, max_w=us_l, max_h=us_l)
         for pl in (1, 2):
             lrf_res[pl] = ctx.lrf_search_batch(rec3[pl], src3[pl], uc, is_chroma=True, xdec=1, ydec=1, scales=scales,
-                                               max_w=32, max_h=32)
+                                               max_w=us_c, max_h=us_c)
     stages.append(("lrf_search_8_sets_420", lrf_search))
 
     def chk_lrf_search():
