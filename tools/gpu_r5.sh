@@ -80,6 +80,10 @@ for l in sys.stdin:
         for bd in 8 10; do echo "$(basename $lib) $(timeout 300 python tools/frame_pipeline.py --bit-depth $bd --stages "$STAGES" 2>/dev/null | grep '^{')"; done
       done; done 2>&1 | tee $OUT/stage_ab.txt
       cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
+    me_grid)   # the persistent tile ME at different grid sizes / spin settings (environment knobs of csrc/me.hip)
+      for pass in 1 2; do for g in 2048 1024 1536 3072 4096; do for bd in 8 10; do
+        echo "grid $g $(R1_ME_PERSISTENT_GRID=$g timeout 300 python tools/frame_pipeline.py --bit-depth $bd --stages estimate_tile 2>/dev/null | grep '^{')"
+      done; done; done 2>&1 | tee $OUT/me_grid.txt ;;
     px_ab)
       for pass in 1 2; do for lib in ${ARG//,/ }; do
         cp $lib rav1e_amd/librav1e_hip.so
