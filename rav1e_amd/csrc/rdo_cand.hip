@@ -227,7 +227,12 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
   // 6240 B, 4 -> 5 waves per SIMD, launch 0.252 -> 0.237 ms (profiles/r04_ab_notes.md).  At 8-bit
   // 32x32 the same change (5 -> 6 waves) made the launch 1.5 % SLOWER -- that kernel is not short of
   // waves -- and is off.  Row stride 66 int16 = 33 dwords: a candidate's row lanes read 32 banks.
-  constexpr bool TB16 = R1_TX_TILE_I16 && R1_TB16_POLICY(BD, WL, HL);
+  // The type search's shared tile (COLSHARE, below) is int16 at every bit depth: with both sides <= 16 the column
+  // pass's output after shift[1] is bounded by 8193 / 16433 / 16445 at 8 / 10 / 12 bits (tests/test_tx_range.py).
+#ifndef R1_MT_COLSHARE
+#define R1_MT_COLSHARE 1
+#endif
+  constexpr bool TB16 = R1_TX_TILE_I16 && (R1_TB16_POLICY(BD, WL, HL) || (R1_MT_COLSHARE && MT && W <= 16 && H <= 16));
   typedef typename std::conditional<TB16, int16_t, T>::type TB;
   constexpr int LSTRIDE = NC * W + (TB16 ? 2 : 1);
   constexpr int ISTRIDE = NC * W + 1;       // the inverse transform's row buffer (QM == 2): int32
@@ -292,10 +297,16 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
   constexpr int LDS_B = QT_BYTES > REC_BYTES ? QT_BYTES : REC_BYTES;
   constexpr int LDS_WORK = ((LDS_A > LDS_B ? LDS_A : LDS_B) + 15) & ~15;
   constexpr int SRC_OFF = SRC_KEEP ? LDS_WORK : (SRC_LATE ? 0 : WIN_PAD);
-  constexpr int LDS_BYTES = LDS_WORK + (SRC_KEEP ? SRC_BYTES : 0);
+  // MT, COLSHARE: the transposed output of the column pass in a tile of its own behind everything else -- the later
+  // phases of a type alias the work area, and the types that share a column kernel (the seven RAV1E types use three:
+  // DCT x3, ADST x2, identity x2) all read their rows from this one tile (see the type loop)
+  constexpr bool COLSHARE = R1_MT_COLSHARE && MT && !SPLIT_T;
+  constexpr int TKEEP_OFF = (LDS_WORK + (SRC_KEEP ? SRC_BYTES : 0) + 15) & ~15;
+  constexpr int LDS_BYTES = COLSHARE ? TKEEP_OFF + H * LSTRIDE * (int)sizeof(TB) : LDS_WORK + (SRC_KEEP ? SRC_BYTES : 0);
   __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
   T *buf = (T *)smem;
   TB *tbuf = (TB *)smem;
+  TB *tkeep = COLSHARE ? (TB *)(smem + TKEEP_OFF) : tbuf;
 
   R1_PROF_INIT;
   // Workgroup -> candidate group, XCD-aware.  The dispatcher deals workgroups round-robin over the 8 XCDs
@@ -528,11 +539,27 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
   // (a mask of more than eight types -- the full AV1 inter set has sixteen -- keeps its tails inside the loop)
   const bool tail_defer = TAIL_DEFER && qa.dist_kind == R1_DIST_CDEF && qa.nt <= 8;   // wave-uniform
   uint32_t tail_keep[5] = {0, 0, 0, 0, 0};
-  uint32_t tmask = MT ? qa.tx_mask : 1u;
-  int slot = 0;
+  // The loop: groups of types that share the column pass (same vertical 1-D kernel and the same flips; without
+  // COLSHARE every type is a group of its own), and inside a group the types in ascending order.  The result slot of
+  // a type is its rank in the launch's mask, whatever order the groups come in.
+  uint32_t rem = MT ? qa.tx_mask : 1u;
+  bool fresh = true;   // v still holds the residual as phase B left it
   do {
+  int t0 = 0;
+  uint32_t gmask = 1u;
   if constexpr (MT) {
-    if (slot != 0) {   // wave-uniform
+    t0 = (int)__builtin_ctz(rem);
+    gmask = 1u << t0;
+    if constexpr (COLSHARE) {
+      auto colkey = [](int t) { return r1tx::vtx_1d(t) | ((int)r1tx::ud_flip(t) << 4) | ((int)r1tx::lr_flip(t) << 5); };
+      const int k0 = colkey(t0);
+      for (uint32_t m = rem & (rem - 1); m != 0; m &= m - 1) {   // scalar: the mask is a kernel argument
+        const int t = (int)__builtin_ctz(m);
+        if (colkey(t) == k0) gmask |= 1u << t;
+      }
+    }
+    rem &= ~gmask;
+    if (!fresh) {   // wave-uniform
       if constexpr (MT_RECOMP) {
         if (col_live) {
 #pragma unroll
@@ -548,18 +575,15 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
         for (int r = 0; r < H; r++) v[r] = vkeep[r];
       }
     }
+    fresh = false;
   }
   // ---- C: column transform on the residual registers ----
   __syncthreads();  // every lane is done reading the window (MT: the previous type's last phase); LDS becomes buf
-  const int tx_type = MT ? (int)__builtin_ctz(tmask)
-                         : (QM != 0 && qa.tx_mask != 0 ? (int)__builtin_ctz(qa.tx_mask) : (int)cd.tx_type);
-  // result slot of (candidate, type)
-  const long long oslot = MT ? cand * (long long)qa.nt + slot
-                             : (QM != 0 && qa.nt != 0 ? cand * (long long)qa.nt + qa.slot : cand);
-  const bool any_ud = __any(live && r1tx::ud_flip(tx_type));
+  const int tx_col = MT ? t0 : (QM != 0 && qa.tx_mask != 0 ? (int)__builtin_ctz(qa.tx_mask) : (int)cd.tx_type);
+  const bool any_ud = __any(live && r1tx::ud_flip(tx_col));
   if (col_live) {
     if (any_ud) {   // wave-uniform: skipped when no candidate of the wave flips
-      const bool ud = r1tx::ud_flip(tx_type);
+      const bool ud = r1tx::ud_flip(tx_col);
 #pragma unroll
       for (int r = 0; r < H / 2; r++) {
         const T t0 = v[r], t1 = v[H - 1 - r];
@@ -569,16 +593,22 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
     }
 #pragma unroll
     for (int r = 0; r < H; r++) v[r] = r1tx::shift_fwd_ct<SH0>(v[r]);
-    r1tx::fwd_1d_m24<H>(v, r1tx::vtx_1d(tx_type));
+    r1tx::fwd_1d_m24<H>(v, r1tx::vtx_1d(tx_col));
     if constexpr (!SPLIT_T) {
-      const int cc = cl * W + (r1tx::lr_flip(tx_type) ? W - 1 - c : c);
+      const int cc = cl * W + (r1tx::lr_flip(tx_col) ? W - 1 - c : c);
 #pragma unroll
       for (int r = 0; r < HU; r++)
-        tbuf[r * LSTRIDE + cc] = (TB)r1tx::shift_fwd_ct<SH1>(v[r]);
+        tkeep[r * LSTRIDE + cc] = (TB)r1tx::shift_fwd_ct<SH1>(v[r]);
     }
   }
   if constexpr (!SPLIT_T) __syncthreads();
   R1_PROF(3);   // C: column transform, transpose written
+  do {   // the types of the group: rows from the shared tile, then everything that depends on the type
+  const int tx_type = MT ? (int)__builtin_ctz(gmask) : tx_col;
+  const int slot = MT ? (int)__builtin_popcount(qa.tx_mask & ((1u << tx_type) - 1u)) : 0;
+  // result slot of (candidate, type)
+  const long long oslot = MT ? cand * (long long)qa.nt + slot
+                             : (QM != 0 && qa.nt != 0 ? cand * (long long)qa.nt + qa.slot : cand);
   // ---- D: row transform, transposed store ----
   // P lanes per candidate again: the lane that filtered column c of candidate cl now owns row c
   // of the same candidate -- its descriptor is still in registers
@@ -610,7 +640,7 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
   if (row_live) {
     if constexpr (!SPLIT_T) {
 #pragma unroll
-      for (int k = 0; k < W; k++) u[k] = tbuf[r * LSTRIDE + cl2 * W + k];
+      for (int k = 0; k < W; k++) u[k] = tkeep[r * LSTRIDE + cl2 * W + k];
     }
     r1tx::fwd_1d_m24<W>(u, r1tx::htx_1d(tt));
 #pragma unroll
@@ -952,9 +982,10 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
     }
   }
   if constexpr (!MT) break;
-  tmask &= tmask - 1;
-  slot++;
-  } while (tmask != 0);
+  gmask &= gmask - 1;
+  } while (gmask != 0);
+  if constexpr (!MT) break;
+  } while (rem != 0);
   if constexpr (TAIL_DEFER) {
     // the fixed-point tails of cdef_dist_kernel (ssim boost, 64-bit arithmetic, ~120 instructions): inside the loop
     // they ran once per type with ONE lane of a candidate's eight alive; here lane j runs the tail of type j --

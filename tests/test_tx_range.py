@@ -22,3 +22,25 @@ def test_multiplier_inputs_fit_24_bits_for_pixel_residuals():
     src = open(os.path.join(ROOT, "rav1e_amd", "csrc", "fwd_tx_1d.inc")).read()
     consts = [int(m) for m in re.findall(r"TX_MUL\(\w+, (-?\d+), \d+\)", src)]
     assert consts and 0 < min(consts) and max(consts) < 2 ** 23
+
+
+def test_transposed_tile_of_blocks_up_to_16x16_fits_int16():
+    """The type search keeps the column pass's output (after shift[1]) in an int16 LDS tile shared by the types of a
+    column kernel (csrc/rdo_cand.hip, COLSHARE): exact because, for residuals that come from pixels and both sides
+    <= 16, that value is bounded by 8193 / 16433 / 16445 at 8 / 10 / 12 bits, every valid type."""
+    import tx_range as R
+    F = R.F
+    worst = {8: 0.0, 10: 0.0, 12: 0.0}
+    for bd in worst:
+        for ts, (w, h) in enumerate(F.TX_DIMS):
+            if max(w, h) > 16:
+                continue
+            for tt in range(16):
+                if not F.valid_av1_transform(ts, tt):
+                    continue
+                sh = F.FWD_SHIFT[ts][(bd - 8) // 2]
+                tcol = F.TXFM_TYPE_LS[h.bit_length() - 3][F.VTX_TAB[tt]]
+                b0 = ((1 << bd) - 1) * (1 << sh[0])
+                _, go = R.l1_gain(tcol)
+                worst[bd] = max(worst[bd], (b0 * go + 64) * 2.0 ** sh[1] + 1)
+    assert worst[8] <= 8193 and worst[10] <= 16433 and worst[12] <= 16445 and max(worst.values()) < 32767, worst
