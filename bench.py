@@ -934,7 +934,10 @@ def config_lines(ctx, args):
                                                "fanout_over_independent": ratio,
                                                "pass_ratio": round(step / step_ind, 4)}},
          working_set=ho.nbytes + hr.nbytes,
-         wbytes={"txsearch %dx%d x%d" % (s_, s_, len(t_[2])): 10 * len(t_[2]) * len(t_[0]) for s_, t_ in tcands.items()})
+         wbytes={"txsearch %dx%d x%d" % (s_, s_, len(t_[2])): 10 * len(t_[2]) * len(t_[0]) for s_, t_ in tcands.items()},
+         # the fan-out launches of 8x8 / 16x16 are the MT instantiations (",2,true"); 32x32 runs plain launches per type
+         kkeys={"txsearch %dx%d x%d" % (s_, s_, len(t_[2])): (rdo_launch_key(10, s_, 2, len(t_[0]))[0] + (",true" if s_ <= 16 else ",false"),
+                                                              rdo_launch_key(10, s_, 2, len(t_[0]))[1]) for s_, t_ in tcands.items()})
     del touts, fns, fns_ind
     torch.cuda.empty_cache()
     lines.append(frame_line(ctx, args, timed, launch_how))
@@ -959,6 +962,7 @@ def frame_line(ctx, args, timed, launch_how):
     n_chk = sum(c for c, _ in parity.values())
     dom = max(per, key=lambda t: per[t])
     kkeys = {"rdo_pixel_luma_%dx%d_K%d" % (s, s, args.k): rdo_launch_key(10, s, 2, n) for s, n in F["luma_launch_n"].items()}
+    kkeys["estimate_tile_motion_8tiles_x_3refs"] = ("k_me_persist<2,true>", 2048 * 64)     # one persistent launch, 2048 waves
     lc, lsrc = launch_pmc(kkeys.get(dom))
     roof = build_roofline("config4_frame: %s" % dom, F["algorithmic_bytes"][dom], per[dom], None, None, None,
                           working_set=F["working_set_bytes"], line_counters=lc, line_src=lsrc)
