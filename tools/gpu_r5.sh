@@ -11,6 +11,7 @@
 #   txs_ab:LIBS   the same with each library of the comma-separated list copied in (same-box A/B)
 #   lrf_ab:LIBS   tools/bench_lrf_search.py per library
 #   stage_ab:LIBS STAGES=... tools/frame_pipeline.py --stages per library
+#   soak          tools/gpu_soak.py (type search x 12 rounds, everything x 3), tools/me_persist_soak.py (90 s)
 #   px_ab:LIBS    bench.py --chain pixel, 8- and 10-bit, per library
 #   dry           bench.py --gpus 2 / 4 --single-device (control flow of the N > 1 path on one GPU)
 #   kernels       tools/bench_kernels.py, 8- and 10-bit
@@ -84,6 +85,10 @@ for l in sys.stdin:
       for pass in 1 2; do for g in 2048 1024 1536 3072 4096; do for bd in 8 10; do
         echo "grid $g $(R1_ME_PERSISTENT_GRID=$g timeout 300 python tools/frame_pipeline.py --bit-depth $bd --stages estimate_tile 2>/dev/null | grep '^{')"
       done; done; done 2>&1 | tee $OUT/me_grid.txt ;;
+    soak)   # seeded GPU parity tests re-run with shifted seeds (type search, chains, ME), then the persistent ME against the diagonal launches
+      timeout 400 python tools/gpu_soak.py --rounds ${SOAK_ROUNDS:-12} -k txsearch 2>&1 | tail -3 | tee $OUT/soak_txsearch.log
+      timeout 400 python tools/gpu_soak.py --rounds 3 2>&1 | tail -3 | tee $OUT/soak_all.log
+      timeout 200 python tools/me_persist_soak.py --seconds 90 2>&1 | tail -3 | tee $OUT/soak_me_persist.log ;;
     px_ab)
       for pass in 1 2; do for lib in ${ARG//,/ }; do
         cp $lib rav1e_amd/librav1e_hip.so
