@@ -12,6 +12,7 @@
 #   lrf_ab:LIBS   tools/bench_lrf_search.py per library
 #   stage_ab:LIBS STAGES=... tools/frame_pipeline.py --stages per library
 #   soak          tools/gpu_soak.py (type search x 12 rounds, everything x 3), tools/me_persist_soak.py (90 s)
+#   bench_ab:LIBS the headline bench (bench.py --no-extra $BENCH_ARGS) per library
 #   px_ab:LIBS    bench.py --chain pixel, 8- and 10-bit, per library
 #   dry           bench.py --gpus 2 / 4 --single-device (control flow of the N > 1 path on one GPU)
 #   kernels       tools/bench_kernels.py, 8- and 10-bit
@@ -89,6 +90,14 @@ for l in sys.stdin:
       timeout 400 python tools/gpu_soak.py --rounds ${SOAK_ROUNDS:-12} -k txsearch 2>&1 | tail -3 | tee $OUT/soak_txsearch.log
       timeout 400 python tools/gpu_soak.py --rounds 3 2>&1 | tail -3 | tee $OUT/soak_all.log
       timeout 200 python tools/me_persist_soak.py --seconds 90 2>&1 | tail -3 | tee $OUT/soak_me_persist.log ;;
+    bench_ab)   # the headline bench per library (BENCH_ARGS, e.g. "--bit-depth 10"), two passes
+      for pass in 1 2; do for lib in ${ARG//,/ }; do
+        cp $lib rav1e_amd/librav1e_hip.so
+        timeout 600 python bench.py --no-extra --cpu-seconds 0 $BENCH_ARGS 2>/dev/null | grep '^{' | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('%-22s %9.0f Mpx/s kernel_ms %s ok %s' % ('$lib'.split('/')[-1], d['value'], d['kernel_ms'], d.get('parity_ok')))"
+      done; done 2>&1 | tee $OUT/bench_ab.txt
+      cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
     px_ab)
       for pass in 1 2; do for lib in ${ARG//,/ }; do
         cp $lib rav1e_amd/librav1e_hip.so
