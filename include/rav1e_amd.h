@@ -797,7 +797,9 @@ int r1_rdo_pred_cand_batch(r1_ctx *ctx, const R1Plane *org, const void *pred, in
  * Sizes up to 16x16 (up to 7 types here, 16 in AV1) run the fan-out kernel.  Sizes with a 32-point side
  * (DCT_DCT, + IDTX for inter blocks) and with a 64-point side (TX_SET_DCTONLY: tx_type_mask must be 1) run one
  * plain launch per type with the type forced -- two waves per SIMD of the fan-out kernel lose against two
- * launches at four (measured) -- same results, same slots. */
+ * launches at four (measured) -- same results, same slots.
+ * R1_EINVAL: an empty mask, bits beyond the 16 TxTypes, a type the size has no kernel for (tx_type_mask must be a
+ * subset of r1_tx_type_mask(tx_size, 1, 0, 0): the inter sets are the largest), both or neither of ref / pred. */
 int r1_rdo_txsearch_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, const void *pred, int w,
                           int h, int tx_size, const R1RdoCand *cands, int n, uint32_t tx_type_mask,
                           const R1QuantParams *params, int dist_kind, const uint32_t *scales,

@@ -1338,6 +1338,7 @@ extern "C" uint32_t r1_tx_type_mask(int tx_size, int is_inter, int use_reduced_s
   return rav1e_types_only ? (m & 0x0E0Fu) : m;
 }
 
+extern "C" uint32_t r1_tx_type_mask(int tx_size, int is_inter, int use_reduced_set, int rav1e_types_only);
 extern "C" int r1_rdo_txsearch_batch(r1_ctx *ctx, const R1Plane *org, const R1Plane *ref, const void *pred,
                                      int w, int h, int tx_size, const R1RdoCand *cands, int n,
                                      uint32_t tx_type_mask, const R1QuantParams *params, int dist_kind,
@@ -1361,6 +1362,9 @@ extern "C" int r1_rdo_txsearch_batch(r1_ctx *ctx, const R1Plane *org, const R1Pl
   const bool side64 = up > 5, side32 = up == 5;
   // a 64-point side codes DCT_DCT only (TX_SET_DCTONLY)
   R1_REQUIRE(!side64 || tx_type_mask == 1u);
+  // every type of the mask must exist for the size: the inter sets are the largest (av1_tx_used; a 32-point side has
+  // DCT_DCT and IDTX only -- the reference's 1-D tables have no other kernel there and would panic)
+  R1_REQUIRE((tx_type_mask & ~r1_tx_type_mask(tx_size, 1, 0, 0)) == 0);
   RdoQuantArgs qa = {};
   qa.qp = r1q::make_qparams(*params, tx_size, org->bytes_per_px == 1 ? 2 : 4);
   for (int k = 0; k < 3; k++) qa.scan[k] = ctx->scan_dev + ctx->scan_off[tx_size][k];

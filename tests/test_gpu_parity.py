@@ -1445,6 +1445,27 @@ def test_rdo_txsearch_vs_oracle(ctx, oracle, bd):
             assert np.array_equal(o["dist"].cpu().numpy().view(np.uint64), wdist), key
 
 
+def test_rdo_txsearch_rejects_what_the_reference_cannot_code(ctx):
+    """argument checks of r1_rdo_txsearch_batch: a type the size has no kernel for (ADST at 32x32), anything but DCT_DCT
+    on a 64-point side, an empty mask, bits beyond the 16 TxTypes, both / neither prediction source"""
+    import torch
+    a, b = planes(8, seed=5)
+    da, db = dev_plane(a), dev_plane(b)
+    c = rand_rdo_cands(np.random.default_rng(1), 4, a.width, a.height, 32, 32, 0, 3)
+    for (w, h, mask) in ((32, 32, 0x2), (32, 32, 0x203), (64, 64, 0x201), (16, 16, 0), (16, 16, 0x10001), (32, 8, 0x4)):
+        cc = rand_rdo_cands(np.random.default_rng(2), 4, a.width, a.height, w, h, 0, 0)
+        with pytest.raises(RuntimeError):
+            ctx.rdo_txsearch_batch(da, db, w, h, cc, mask, 60, 3)
+    pred = torch.zeros((4, 32, 32), dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError):
+        ctx.rdo_txsearch_batch(da, db, 32, 32, c, 0x201, 60, 3, pred=pred)       # both sources
+    with pytest.raises(RuntimeError):
+        ctx.rdo_txsearch_batch(da, None, 32, 32, c, 0x201, 60, 3)                 # neither
+    o = ctx.rdo_txsearch_batch(da, db, 32, 32, c, 0x201, 60, 3)                   # DCT_DCT + IDTX: fine
+    torch.cuda.synchronize()
+    assert o["eob"].shape == (4, 2)
+
+
 def test_rdo_txsearch_equals_single_type_launches(ctx):
     """Size-independent property at frame scale: slot j of the fan-out equals r1_rdo_pixel_cand_batch /
     r1_rdo_full_cand_batch run with tx_type = the j-th type, on thousands of candidates (many waves)."""
