@@ -1308,8 +1308,8 @@ def main():
                 ring_launches.append(build_launches(ring[1]))
                 tile_ring[0] = tiles.TileRing(ring, ring_peers, vrects, rank, tiles.visible(ring[0]).clone())
                 exch_note = None if world == 1 else (
-                             "r1_comm_push_halos (64 px) + r1_comm_push_tile per step: peer stores into "
-                             "IPC-mapped planes (two-plane ring) + %s" %
+                             "r1_comm_push_frame per step: halo stores (64 px) + tile stores into IPC-mapped planes "
+                             "(two-plane ring) behind ONE hand-shake: %s" %
                              ("r1_comm_barrier, in stream order" if vcomm is not None else
                               "a host hand-shake (stream synchronize + torch.distributed barrier: no C-ABI communicator)"))
             else:

@@ -892,6 +892,9 @@ int r1_comm_barrier(r1_comm *comm, void *stream);
  * xfers list only the dir == 0 entries are used: a rank's receives are its peers' stores) */
 int r1_comm_push_tile(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
                       const int32_t *rects4, void *stream);
+/* both legs of a frame behind ONE hand-shake: the halo stores, the tile stores, r1_comm_barrier (ABI 5 addition) */
+int r1_comm_push_frame(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
+                       const R1HaloXfer *xfers, int n, const int32_t *rects4, void *stream);
 int r1_comm_push_halos(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
                        const R1HaloXfer *xfers, int n, void *stream);
 

@@ -106,6 +106,7 @@ SYMBOLS = {
     "r1_comm_barrier": (_i, [_vp, _vp]),
     "r1_comm_push_tile": (_i, [_vp, _vp, _PP, _vp, _vp, _vp]),
     "r1_comm_push_halos": (_i, [_vp, _vp, _PP, _vp, _vp, _i, _vp]),
+    "r1_comm_push_frame": (_i, [_vp, _vp, _PP, _vp, _vp, _i, _vp, _vp]),
     "r1_rdo_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "r1_rdo_full_cand_batch": (_i, [_vp, _PP, _PP, _i, _i, _i, _vp, _i, C.POINTER(R1QuantParams),
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -746,6 +746,28 @@ extern "C" int r1_comm_push_tile(r1_comm *c, r1_ctx *ctx, const R1Plane *plane, 
   return rc != R1_OK ? rc : r1_comm_barrier(c, stream);
 }
 
+// Both legs of a frame's exchange behind ONE hand-shake: the border rectangles first (the neighbours' post filters
+// wait for nothing else), then the tile into every peer, then one r1_comm_barrier -- the all-reduce is the expensive
+// part of a leg (a launch and a round trip over the fabric for 4 bytes), and nothing between the two legs needs it.
+extern "C" int r1_comm_push_frame(r1_comm *c, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
+                                  const R1HaloXfer *xfers, int n, const int32_t *rects4, void *stream) {
+  R1_REQUIRE(c && ctx && plane && peer_data && rects4 && (n == 0 || xfers));
+  std::vector<R1PushRect> rects;
+  for (int i = 0; i < n; i++) {
+    R1_REQUIRE(xfers[i].dir == 0 || xfers[i].dir == 1);
+    R1_REQUIRE(xfers[i].peer >= 0 && xfers[i].peer < c->world && xfers[i].peer != c->rank);
+    if (xfers[i].dir == 0) rects.push_back(R1PushRect{xfers[i].peer, xfers[i].x0, xfers[i].y0, xfers[i].x1, xfers[i].y1});
+  }
+  int rc = r1_push_rects(ctx, plane, peer_data, c->world, rects.data(), (int)rects.size(), stream);
+  if (rc != R1_OK) return rc;
+  const int32_t *q = rects4 + 4 * c->rank;
+  rects.clear();
+  for (int r = 0; r < c->world; r++)
+    if (r != c->rank) rects.push_back(R1PushRect{r, q[0], q[1], q[2], q[3]});
+  rc = r1_push_rects(ctx, plane, peer_data, c->world, rects.data(), (int)rects.size(), stream);
+  return rc != R1_OK ? rc : r1_comm_barrier(c, stream);
+}
+
 // The halo exchange by peer stores: the dir == 0 (send) entries of the same list
 // r1_comm_exchange_halos takes are stored into the peers' planes (the receives are the peers'
 // sends), then the hand-shake.

@@ -221,6 +221,34 @@ class PeerPlanes:
         return len(x)
 
 
+def _push_frame(self, rects, halo=None):
+    """both legs of a frame's exchange -- the border rectangles, then the tile into every peer -- behind ONE hand-shake
+    (r1_comm_push_frame; without a communicator: two store launches, one stream synchronize + barrier)"""
+    halo = POSTFILTER_HALO if halo is None else halo
+    st = torch.cuda.current_stream().cuda_stream
+    p = self.plane.cstruct()
+    sends, _ = tile_halo_plan(rects, self.rank, halo, self.plane.width, self.plane.height)
+    if self.comm is not None:
+        x = np.zeros(len(sends), HALO_XFER)
+        for i, (peer, r) in enumerate(sends):
+            x[i] = (peer, 0, r[0], r[1], r[2], r[3])
+        r4 = np.ascontiguousarray(np.array(rects, np.int32).reshape(-1))
+        self._check(self.lib.r1_comm_push_frame(self.comm.h, self.ctx.h, C.byref(p), self.ptrs, x.ctypes.data, len(x),
+                                                r4.ctypes.data, st), "r1_comm_push_frame")
+        return
+    x = np.zeros(len(sends) + self.world - 1, PUSH_RECT)
+    for i, (peer, r) in enumerate(sends):
+        x[i] = (peer, r[0], r[1], r[2], r[3])
+    for i, r in enumerate(q for q in range(self.world) if q != self.rank):
+        x[len(sends) + i] = (r,) + tuple(int(v) for v in rects[self.rank])
+    self._check(self.lib.r1_push_rects(self.ctx.h, C.byref(p), self.ptrs, self.world, x.ctypes.data, len(x), st),
+                "r1_push_rects")
+    self._handshake()
+
+
+PeerPlanes.push_frame = _push_frame
+
+
 def verify_exchange(plane, rects, rank, world, do_halos, do_gather, halo=None, pre=None):
     """Self-check of the exchange before a multi-GPU run is timed: did the bytes land where the
     tile grid says?  Every rank paints its own tile of `plane` with its tag (rank + 1; the rest of
@@ -321,8 +349,7 @@ class TileRing:
     def advance(self):
         nxt = self.cur ^ 1
         torch.bitwise_xor(self.tiles[self.cur], ring_delta(self.t), out=self.tiles[nxt])
-        self.peers[nxt].push_halos(self.rects)
-        self.peers[nxt].push_tile(self.rects)
+        self.peers[nxt].push_frame(self.rects)      # halo stores, tile stores, ONE hand-shake
         self.cur, self.t = nxt, self.t + 1
 
     def check(self):
