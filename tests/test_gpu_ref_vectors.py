@@ -156,6 +156,18 @@ def test_comm_c_abi_single_rank(ctx):
     comm.allgather(send, recv)
     torch.cuda.synchronize()
     assert torch.equal(before, dp.data) and torch.equal(send, recv)
+    # the peer-store entry points through the communicator (world 1: no peers, the stores and the hand-shake are
+    # no-ops, the argument checks and the plumbing are not): r1_comm_open_peer_planes, r1_comm_push_frame, the ring
+    pp = [tiles.PeerPlanes(ctx, dp, 0, 1, comm=comm), tiles.PeerPlanes(ctx, dev_plane(hp), 0, 1, comm=comm)]
+    pp[0].push_frame(rects)
+    ring = tiles.TileRing([pp[0].plane, pp[1].plane], pp, rects, 0, tiles.visible(dp).clone())
+    assert ring.check()
+    for _ in range(5):
+        ring.advance()
+        assert ring.check()
+    torch.cuda.synchronize()
+    for p in pp:
+        p.close()
     comm.close()
 
 
