@@ -758,13 +758,11 @@ extern "C" int r1_comm_push_frame(r1_comm *c, r1_ctx *ctx, const R1Plane *plane,
     R1_REQUIRE(xfers[i].peer >= 0 && xfers[i].peer < c->world && xfers[i].peer != c->rank);
     if (xfers[i].dir == 0) rects.push_back(R1PushRect{xfers[i].peer, xfers[i].x0, xfers[i].y0, xfers[i].x1, xfers[i].y1});
   }
-  int rc = r1_push_rects(ctx, plane, peer_data, c->world, rects.data(), (int)rects.size(), stream);
-  if (rc != R1_OK) return rc;
+  // one list, the border rectangles in front: up to 8 neighbours + 7 peers fit ONE store launch (R1_PUSH_MAX = 16)
   const int32_t *q = rects4 + 4 * c->rank;
-  rects.clear();
   for (int r = 0; r < c->world; r++)
     if (r != c->rank) rects.push_back(R1PushRect{r, q[0], q[1], q[2], q[3]});
-  rc = r1_push_rects(ctx, plane, peer_data, c->world, rects.data(), (int)rects.size(), stream);
+  const int rc = r1_push_rects(ctx, plane, peer_data, c->world, rects.data(), (int)rects.size(), stream);
   return rc != R1_OK ? rc : r1_comm_barrier(c, stream);
 }
 
