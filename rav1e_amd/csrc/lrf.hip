@@ -36,10 +36,7 @@ __constant__ uint16_t kSgrS[16][2] = {{140, 3236}, {112, 2158}, {93, 1618}, {80,
 
 constexpr int TW = 32;                 // chunk width
 constexpr int SW = TW + 7;             // padded chunk width
-constexpr int SH_MAX = 64 + 6;         // padded stripe height
 constexpr int AW = TW + 2;             // (a, b) columns: centres -1 .. TW
-constexpr int A1H = 64 + 2;            // r = 1 rows: centres -1 .. 64
-constexpr int A2H = 64 / 2 + 1;        // r = 2 rows: centres -1, 1, .., 63
 
 struct LrfGeom {
   int ydec, crop_w, crop_h, stripe_n, unit_size, unit_cols, unit_rows, stripe_height, bd;
@@ -85,12 +82,15 @@ struct SgrTile {
 
 // Stage the padded tile, compute the (a, b) pairs of both passes, then hand
 // every pixel of the tile to `emit(x, y, p, f1, f2)` (x, y tile-relative).
-template <int BPP, class Emit>
+// TROWS: the most rows a tile of this instantiation has (t.th <= TROWS): sizes the three LDS arrays -- the restoration
+// search runs 32-row tiles (9 KB less LDS per workgroup: one more workgroup per CU), the frame filter 64-row stripes
+template <int BPP, int TROWS = 64, class Emit>
 __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane &outside_p,
                                          const SgrTile &t, int set, int bd, Emit emit) {
-  __shared__ uint16_t S[SH_MAX][SW + 1];
-  __shared__ uint32_t ab1[A1H][AW];
-  __shared__ uint32_t ab2[A2H][AW];
+  static_assert(TROWS % 2 == 0 && TROWS <= 64, "row tiles start on even rows");
+  __shared__ uint16_t S[TROWS + 6][SW + 1];
+  __shared__ uint32_t ab1[TROWS + 2][AW];
+  __shared__ uint32_t ab2[TROWS / 2 + 1][AW];
   const int tid = threadIdx.x;
   // a(z): one table lookup per (a, b) pair -- 26 per thread and tile, each a global-memory round trip in the sliding
   // loops when the table sits in device memory; a 512-byte copy per workgroup makes it an LDS read
@@ -520,17 +520,22 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
     if (threadIdx.x == 0) xqd_out[2 * blockIdx.x] = xqd_out[2 * blockIdx.x + 1] = 0;
   } else {
     long long m[5] = {0, 0, 0, 0, 0};
+#ifndef R1_LRF_SEARCH_TROWS
+#define R1_LRF_SEARCH_TROWS 32   // A/B: 64 = one tile per 32 columns as in round 4
+#endif
+    constexpr int TR = R1_LRF_SEARCH_TROWS;
     const int ntx = (u.w + TW - 1) / TW;
+    for (int ty = 0; ty < u.h; ty += TR)
     for (int tx = 0; tx < ntx; tx++) {
       SgrTile t;
       t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
       t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the unit (rdo.rs:2651-2666)
       t.cx0 = u.x + tx * TW;
-      t.ty0 = 0;
+      t.ty0 = ty;
       t.tw = (u.w - tx * TW) < TW ? (u.w - tx * TW) : TW;
-      t.th = u.h;
-      sgr_tile<BPP>(lrf_in, lrf_in, t, u.set, bd, [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2) {
-        const int X = tx * TW + x;
+      t.th = (u.h - ty) < TR ? (u.h - ty) : TR;
+      sgr_tile<BPP, TR>(lrf_in, lrf_in, t, u.set, bd, [&](int x, int yt, uint32_t p, uint32_t f1, uint32_t f2) {
+        const int X = tx * TW + x, y = ty + yt;
         if constexpr (!PACK) { F1[y][X] = f1; F2[y][X] = f2; }
         else F1[y][X] = f1 | (f2 << 16);
         P[y][X] = (PT)p;
