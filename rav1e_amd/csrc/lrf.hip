@@ -490,8 +490,14 @@ __global__ __launch_bounds__(256) void k_sgr_unit_err(R1Plane lrf_in, R1Plane sr
 // pixel stay in LDS between the moments and the projection, so the box filters run once.
 // PACK: both filter outputs of a pixel in one dword (f <= 16 * 1023 + rounding: up to 10 bits; at 12 bits an
 // all-white unit reaches 65588)
+// workgroups per CU the register allocator makes room for: an 8-bit chroma workgroup (32-row tile, 31 KB of LDS) fits
+// five times once its registers do (106 -> 89, no scratch): -13 % on the chroma planes (ab9); the 8-bit luma kernel keeps
+// its 64-row tile (four by LDS) and the 16-bit kernels are LDS-bound at four
+#ifndef R1_LRF_SEARCH_WGS
+#define R1_LRF_SEARCH_WGS(BPP, CHROMA) (((BPP) == 1 && (CHROMA)) ? 5 : 1)
+#endif
 template <int BPP, bool CHROMA, bool PACK>
-__global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane src,
+__global__ __launch_bounds__(256, R1_LRF_SEARCH_WGS(BPP, CHROMA)) void k_lrf_search_unit(R1Plane lrf_in, R1Plane src,
                                                          const R1SgrSolveUnit *__restrict__ units, int xdec, int ydec,
                                                          const uint32_t *__restrict__ scales, int scale_stride,
                                                          uint32_t dist_scale, int8_t *__restrict__ xqd_out,
@@ -520,10 +526,13 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
     if (threadIdx.x == 0) xqd_out[2 * blockIdx.x] = xqd_out[2 * blockIdx.x + 1] = 0;
   } else {
     long long m[5] = {0, 0, 0, 0, 0};
+    // rows per tile.  32: the tile arrays shrink by 9 KB and a 16-bit workgroup fits four times on a CU instead of three
+    // (same-box A/B, r05_ab_notes.md ab9: 10-bit luma -6 %, chroma -19 %); an 8-bit workgroup already fits four times
+    // (its registers allow no fifth) and only pays for the two extra tiles of a 64-row luma unit (+15 %): 64 there
 #ifndef R1_LRF_SEARCH_TROWS
-#define R1_LRF_SEARCH_TROWS 32   // A/B: 64 = one tile per 32 columns as in round 4
+#define R1_LRF_SEARCH_TROWS(BPP, CHROMA) (((BPP) == 1 && !(CHROMA)) ? 64 : 32)
 #endif
-    constexpr int TR = R1_LRF_SEARCH_TROWS;
+    constexpr int TR = R1_LRF_SEARCH_TROWS(BPP, CHROMA);
     const int ntx = (u.w + TW - 1) / TW;
     for (int ty = 0; ty < u.h; ty += TR)
     for (int tx = 0; tx < ntx; tx++) {
