@@ -651,7 +651,10 @@ int r1_deblock_sse_frame(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src, in
  * sets the stripe count), ydec: the plane's vertical decimation, unit_size /
  * unit_cols / unit_rows / stripe_height: RestorationPlaneConfig, units:
  * unit_rows x unit_cols entries (DEVICE), filter = RESTORE_NONE 0 or
- * RESTORE_SGRPROJ 3, set = index into SGRPROJ_PARAMS_S, xqd as coded. */
+ * RESTORE_SGRPROJ 3, set = index into SGRPROJ_PARAMS_S, xqd as coded.
+ * All three restoration entry points address pixels with 32-bit byte offsets:
+ * R1_EINVAL for an input plane whose allocation (stride * alloc_height *
+ * bytes_per_px) reaches 4 GiB or whose stride / alloc_height reach 2^24. */
 typedef struct R1LrfUnit {
   uint8_t filter, set;
   int8_t xqd[2];

@@ -55,20 +55,60 @@ struct SgrATable {
 };
 __device__ const SgrATable kSgrA = SgrATable();
 
-#ifndef R1_LRF_ATAB_LDS
-#define R1_LRF_ATAB_LDS 1   // A/B switch: the a(z) table read from LDS (a copy per workgroup) instead of global memory
-#endif
-// sgrproj_sum_finish -> a | b << 9
+// Full-rate 24-bit multiplies, spelled out: where an operand is carried around a loop the instruction selector's
+// known-bits walk loses the range and __umul24 comes out as the quarter-rate v_mul_lo_u32 (same finding as
+// tx_common.hpp's m24).  Callers state the operand ranges.
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ int32_t mad_i24(int32_t a, int32_t b, int32_t c) {
+  int32_t r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// Byte offset of pixel (x, y) from the start of a plane's allocation, in 32 bits with the full-rate multiplier: the
+// entry points require stride, alloc_height < 2^24 and an allocation below 4 GiB (lrf_plane_ok).  A load at
+// `data + offset` then takes the uniform base from SGPRs and needs no 64-bit vector arithmetic (px_addr is a
+// quarter-rate 64-bit multiply-add per address: 20 of them per thread and tile here).
+template <int BPP>
+__device__ __forceinline__ uint32_t px_off(const R1Plane &p, int x, int y) {
+  return mad_u24((uint32_t)(p.yorigin + y), (uint32_t)p.stride, (uint32_t)(p.xorigin + x)) * BPP;
+}
+template <int BPP>
+__device__ __forceinline__ uint32_t ld_px_at(const R1Plane &p, uint32_t off) {
+  return ld_px<BPP>((const uint8_t *)p.data + off);
+}
+inline bool lrf_plane_ok(const R1Plane *p) {
+  return p->stride > 0 && p->stride < (1 << 24) && p->alloc_height > 0 && p->alloc_height < (1 << 24) &&
+         (unsigned long long)p->stride * (unsigned long long)p->alloc_height * (unsigned long long)p->bytes_per_px < (1ull << 32);
+}
+
+// sgrproj_sum_finish -> a | b << 9.  Every product but (for bit depth 12) the last has operands below 2^24 whatever
+// the bit depth -- the sums are scaled to the 8-bit range first: scaled_ssq <= 25 * 2^16, scaled_sum <= 25 * 2^8,
+// p = n * ssq - sum^2 <= n^2 * (255 / 2)^2 + rounding < 2^24 (the min below keeps the full-rate multiplier exact
+// even if that bound were wrong: z saturates at 255 from p * s >= 255 << 20 on, and (2^24 - 1) * 22 is past it),
+// (256 - a) * sum <= 255 * 25 * 4095 < 2^25 and, for bit depths up to 10 (NARROW), < 2^23
+template <bool NARROW>
 __device__ __forceinline__ uint32_t sum_finish(uint32_t ssq, uint32_t sum, uint32_t n,
                                                uint32_t one_over_n, uint32_t s, int bd, const uint16_t *atab) {
   const int sh = bd - 8;
   const uint32_t scaled_ssq = (ssq + ((1u << (2 * sh)) >> 1)) >> (2 * sh);
   const uint32_t scaled_sum = (sum + ((1u << sh) >> 1)) >> sh;
-  const uint32_t t = scaled_ssq * n, u = scaled_sum * scaled_sum;
-  const uint32_t p = t > u ? t - u : 0;
-  const uint32_t z = (p * s + (1u << 19)) >> 20;
+  const int32_t d = (int32_t)__umul24(scaled_ssq, n) - (int32_t)mul_u24(scaled_sum, scaled_sum);
+  uint32_t p = (uint32_t)(d > 0 ? d : 0);
+  p = p < 0xFFFFFFu ? p : 0xFFFFFFu;
+  const uint32_t z = (__umul24(p, s) + (1u << 19)) >> 20;
   const uint32_t a = atab[z < 255u ? z : 255u];
-  const uint32_t b = (((1u << 8) - a) * sum * one_over_n + (1u << 11)) >> 12;
+  const uint32_t x = mul_u24((1u << 8) - a, sum);
+  const uint32_t b = ((NARROW ? __umul24(x, one_over_n) : x * one_over_n) + (1u << 11)) >> 12;
   return a | (b << 9);
 }
 
@@ -80,42 +120,80 @@ struct SgrTile {
   int cx0, ty0, tw, th;
 };
 
-// Stage the padded tile, compute the (a, b) pairs of both passes, then hand
-// every pixel of the tile to `emit(x, y, p, f1, f2)` (x, y tile-relative).
-// TROWS: the most rows a tile of this instantiation has (t.th <= TROWS): sizes the three LDS arrays -- the restoration
-// search runs 32-row tiles (9 KB less LDS per workgroup: one more workgroup per CU), the frame filter 64-row stripes
-template <int BPP, int TROWS = 64, class Emit>
+// Stage the padded tile, compute the (a, b) pairs of both passes, then hand every pixel of the tile to
+// `emit(x, y, p, f1, f2, extra)` (x, y tile-relative).
+//   TROWS   the most rows a tile of this instantiation has (t.th <= TROWS): sizes the three LDS arrays -- the restoration
+//           search runs 32-row tiles where that buys a workgroup per CU, the frame filter 64-row stripes
+//   NARROW  the caller guarantees bit depth <= 10: sum_finish's last product fits the full-rate 24-bit multiplier
+//   extra_p the pixel of this plane under every pixel of the tile (tile pixel (x, y) <-> plane pixel (ex0 + x, ey0 + y))
+//           is loaded for the thread's own pixels BEFORE the tile is staged and handed to emit: the load the caller
+//           needs per pixel (the source plane of the moments) is in flight behind the whole tile; null: extra = 0
+//   flush() called after every four rows of a thread's column and at its end (a caller accumulating products of
+//           14-bit differences in 32 bits moves them to its wide sums there)
+// Round 5 (ab10): the tile went on an instruction diet -- the kernel sits at ~80 % of the VALU issue rate, so what
+// counts is the count: staging walks rows with a fixed column per thread (47 -> ~15 instructions per element, no
+// division in the loop), every multiply whose operands are proven below 2^24 is the full-rate v_mul_u32_u24 /
+// v_mad_u32_u24 (v_mul_lo_u32 is quarter rate: 5 per (a, b) pair, 2 per pixel), and the stencil loop is unrolled
+// over the thread's rows (even / odd rows of the radius-2 pass resolved at compile time, no register rotation).
+template <int BPP, int TROWS, bool NARROW, class Emit, class Flush>
 __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane &outside_p,
-                                         const SgrTile &t, int set, int bd, Emit emit) {
+                                         const SgrTile &t, int set, int bd, const R1Plane *extra_p, int ex0, int ey0,
+                                         Emit emit, Flush flush) {
   static_assert(TROWS % 2 == 0 && TROWS <= 64, "row tiles start on even rows");
   __shared__ uint16_t S[TROWS + 6][SW + 1];
   __shared__ uint32_t ab1[TROWS + 2][AW];
   __shared__ uint32_t ab2[TROWS / 2 + 1][AW];
   const int tid = threadIdx.x;
-  // a(z): one table lookup per (a, b) pair -- 26 per thread and tile, each a global-memory round trip in the sliding
-  // loops when the table sits in device memory; a 512-byte copy per workgroup makes it an LDS read
-#if R1_LRF_ATAB_LDS
+  // a(z): one table lookup per (a, b) pair; a 512-byte copy per workgroup makes it an LDS read
   __shared__ uint16_t atab_s[256];
   if (tid < 128) ((uint32_t *)atab_s)[tid] = ((const uint32_t *)kSgrA.v)[tid];   // visible after the barrier below
   const uint16_t *atab = atab_s;
-#else
-  const uint16_t *atab = kSgrA.v;
-#endif
   const uint32_t s2 = kSgrS[set & 15][0], s1 = kSgrS[set & 15][1];
+  // ---- 0: the thread's pixels of the stencil phase (a column x over `per` rows from y0) and the caller's loads ----
+  static_assert(TW == 32, "column = tid & 31");
+  constexpr int PER_MAX = (((TROWS + 7) >> 3) + 1) & ~1;
+  const int x = tid & (TW - 1);
+  const int per = (((t.th + 7) >> 3) + 1) & ~1;
+  const int y0 = (tid >> 5) * per;                       // 8 segments
+  const int ny = x < t.tw ? (t.th - y0 < per ? t.th - y0 : per) : 0;   // <= 0: nothing to do in phase 3
+  uint32_t extra[PER_MAX];
+  if (extra_p) {
+    const uint32_t o0 = px_off<BPP>(*extra_p, ex0 + x, ey0 + y0);
+#pragma unroll
+    for (int k = 0; k < PER_MAX; k++) extra[k] = k < ny ? ld_px_at<BPP>(*extra_p, o0 + (uint32_t)(k * extra_p->stride * BPP)) : 0u;
+  } else {
+#pragma unroll
+    for (int k = 0; k < PER_MAX; k++) extra[k] = 0u;
+  }
   // ---- 1: padded tile -> LDS (VertPaddedIter / HorzPaddedIter, lrf.rs:402-524) ----
   const int h2 = t.uh + (t.uh & 1), th2 = t.th + (t.th & 1);
-  const int lu = t.x0 == 0 ? 0 : 4;
-  int ru = (t.crop_w - t.x0) - t.uw;
-  ru = ru < 3 ? ru : 3;
-  const int rows = th2 + 6;
-  for (int e = tid; e < rows * SW; e += 256) {
-    const int j = e / SW, i = e - j * SW;   // S[j][i] <-> unit pixel (cx0 - x0 + i - 4, ty0 + j - 4)
-    const int cy = clampi(t.y0 + t.ty0 + j - 4, 0, t.crop_h - 1);
-    const int ly = clampi(cy, t.y0 - 2, t.y0 + h2 + 1);
-    const bool inside = ly >= t.y0 && ly < t.y0 + h2;
-    const int xi = clampi(t.cx0 - t.x0 + i - 4, -lu, t.uw + ru - 1);
-    const R1Plane &src = inside ? inside_p : outside_p;
-    S[j][i] = (uint16_t)ld_px<BPP>(px_addr<BPP>(src, t.x0 + xi, ly));
+  {
+    constexpr int SROWS = 256 / SW;          // rows per pass: a thread keeps its column
+    const int jj = tid / SW, i = tid - jj * SW;   // S[j][i] <-> unit pixel (cx0 - x0 + i - 4, ty0 + j - 4)
+    if (jj < SROWS) {
+      const int lu = t.x0 == 0 ? 0 : 4;
+      int ru = (t.crop_w - t.x0) - t.uw;
+      ru = ru < 3 ? ru : 3;
+      const int xa = t.x0 + clampi(t.cx0 - t.x0 + i - 4, -lu, t.uw + ru - 1);
+      const bool one_plane = inside_p.data == outside_p.data;   // workgroup-uniform (the search filters a unit in isolation)
+      const int rows = th2 + 6;
+      constexpr int NPASS = (TROWS + 6 + SROWS - 1) / SROWS;
+      uint32_t v[NPASS];                     // every load of the column in flight before the first LDS store
+#pragma unroll
+      for (int q = 0; q < NPASS; q++) {
+        const int j = jj + q * SROWS;
+        const int cy = clampi(t.y0 + t.ty0 + j - 4, 0, t.crop_h - 1);   // (rows past the tile clamp to a valid address)
+        const int ly = clampi(cy, t.y0 - 2, t.y0 + h2 + 1);
+        const bool inside = ly >= t.y0 && ly < t.y0 + h2;
+        if (one_plane) v[q] = ld_px_at<BPP>(inside_p, px_off<BPP>(inside_p, xa, ly));
+        else v[q] = inside ? ld_px_at<BPP>(inside_p, px_off<BPP>(inside_p, xa, ly)) : ld_px_at<BPP>(outside_p, px_off<BPP>(outside_p, xa, ly));
+      }
+#pragma unroll
+      for (int q = 0; q < NPASS; q++) {
+        const int j = jj + q * SROWS;
+        if (j < rows) S[j][i] = (uint16_t)v[q];
+      }
+    }
   }
   __syncthreads();
   // ---- 2: (a, b) of both passes ----
@@ -124,15 +202,15 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
   // every other row) instead of the whole 3x3 (5x5) box -- 9 -> 3 and 25 -> 10 LDS reads per centre.
   {
     constexpr int NSEG = 256 / AW;          // row segments per column
-    const int c = tid % AW, seg = tid / AW;
+    const int seg = tid / AW, c = tid - seg * AW;
     if (seg < NSEG && c <= t.tw + 1) {
       if (s1 > 0) {
-        const int rows1 = t.th + 2, per = (rows1 + NSEG - 1) / NSEG;
-        const int r0 = seg * per, r1 = r0 + per < rows1 ? r0 + per : rows1;
+        const int rows1 = t.th + 2, per1 = (rows1 + NSEG - 1) / NSEG;
+        const int r0 = seg * per1, r1 = r0 + per1 < rows1 ? r0 + per1 : rows1;
         auto row3 = [&](int j, uint32_t &sm, uint32_t &sq) {   // S[j][c + 2 .. c + 4]
           const uint32_t v0 = S[j][c + 2], v1 = S[j][c + 3], v2 = S[j][c + 4];
           sm = v0 + v1 + v2;
-          sq = v0 * v0 + v1 * v1 + v2 * v2;
+          sq = __umul24(v0, v0) + __umul24(v1, v1) + __umul24(v2, v2);
         };
         if (r0 < r1) {
           uint32_t sa, qa, sb, qb, sc, qc;
@@ -140,21 +218,21 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
           row3(r0 + 3, sb, qb);
           for (int r = r0; r < r1; r++) {   // centre (c - 1, r - 1): S rows r + 2 .. r + 4
             row3(r + 4, sc, qc);
-            ab1[r][c] = sum_finish(qa + qb + qc, sa + sb + sc, 9, 455, s1, bd, atab);
+            ab1[r][c] = sum_finish<NARROW>(qa + qb + qc, sa + sb + sc, 9, 455, s1, bd, atab);
             sa = sb; qa = qb; sb = sc; qb = qc;
           }
         }
       }
       if (s2 > 0) {
-        const int nr = th2 / 2 + 1, per = (nr + NSEG - 1) / NSEG;
-        const int r0 = seg * per, r1 = r0 + per < nr ? r0 + per : nr;
+        const int nr = th2 / 2 + 1, per2 = (nr + NSEG - 1) / NSEG;
+        const int r0 = seg * per2, r1 = r0 + per2 < nr ? r0 + per2 : nr;
         auto row5 = [&](int j, uint32_t &sm, uint32_t &sq) {   // S[j][c + 1 .. c + 5]
           sm = 0; sq = 0;
 #pragma unroll
           for (int dx = 0; dx < 5; dx++) {
             const uint32_t v = S[j][c + 1 + dx];
             sm += v;
-            sq += v * v;
+            sq += __umul24(v, v);
           }
         };
         if (r0 < r1) {
@@ -165,7 +243,7 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
           for (int r = r0; r < r1; r++) {   // centre (c - 1, 2 r - 1): S rows 2 r + 1 .. 2 r + 5
             row5(2 * r + 4, m4, q4);
             row5(2 * r + 5, m5, q5);
-            ab2[r][c] = sum_finish(q1 + q2 + q3 + q4 + q5, m1 + m2 + m3 + m4 + m5, 25, 164, s2, bd, atab);
+            ab2[r][c] = sum_finish<NARROW>(q1 + q2 + q3 + q4 + q5, m1 + m2 + m3 + m4 + m5, 25, 164, s2, bd, atab);
             m1 = m3; q1 = q3; m2 = m4; q2 = q4; m3 = m5; q3 = q5;
           }
         }
@@ -175,63 +253,79 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
   __syncthreads();
   // ---- 3: the weighted stencils ----
   // A thread owns a pixel COLUMN over a segment of rows (an even number of them: the radius-2 pass pairs
-  // rows) and slides down: the 3x3 stencil of the radius-1 pass is (3 4 3) on its outer rows and (4 4 4)
+  // rows) and walks down: the 3x3 stencil of the radius-1 pass is (3 4 3) on its outer rows and (4 4 4)
   // on the middle one, so a row of (a, b) pairs is read once and its two horizontal forms kept; the
-  // radius-2 pass reads one row of pairs per TWO pixel rows.
-  {
-    static_assert(TW == 32, "column = tid & 31");
-    const int x = tid & (TW - 1), seg = tid >> 5;               // 8 segments
-    const int per = (((t.th + 7) >> 3) + 1) & ~1;
-    const int y0 = seg * per, y1 = y0 + per < t.th ? y0 + per : t.th;
-    if (x < t.tw && y0 < y1) {
-      auto row1 = [&](int j, uint32_t &oa, uint32_t &ob, uint32_t &ma, uint32_t &mb) {   // ab1 row j at x .. x + 2
-        const uint32_t v0 = ab1[j][x], v1 = ab1[j][x + 1], v2 = ab1[j][x + 2];
-        const uint32_t a0 = v0 & 511u, a1 = v1 & 511u, a2 = v2 & 511u;
-        const uint32_t b0 = v0 >> 9, b1 = v1 >> 9, b2 = v2 >> 9;
-        oa = 3u * (a0 + a2) + 4u * a1;
-        ob = 3u * (b0 + b2) + 4u * b1;
-        ma = 4u * (a0 + a1 + a2);
-        mb = 4u * (b0 + b1 + b2);
-      };
-      auto row2 = [&](int r, uint32_t &ha, uint32_t &hb) {   // ab2 row r at x .. x + 2: (5 6 5)
-        const uint32_t v0 = ab2[r][x], v1 = ab2[r][x + 1], v2 = ab2[r][x + 2];
-        ha = 5u * ((v0 & 511u) + (v2 & 511u)) + 6u * (v1 & 511u);
-        hb = 5u * ((v0 >> 9) + (v2 >> 9)) + 6u * (v1 >> 9);
-      };
-      uint32_t oa0 = 0, ob0 = 0, oa1 = 0, ob1 = 0, ma1 = 0, mb1 = 0, oa2, ob2, ma2, mb2, dump_a, dump_b;
-      if (s1 > 0) {
+  // radius-2 pass reads one row of pairs per TWO pixel rows.  Weight sums: A <= 32 * 256, p < 2^12: 24-bit products.
+  if (ny > 0) {
+    auto row1 = [&](int j, uint32_t &oa, uint32_t &ob, uint32_t &ma, uint32_t &mb) {   // ab1 row j at x .. x + 2
+      const uint32_t v0 = ab1[j][x], v1 = ab1[j][x + 1], v2 = ab1[j][x + 2];
+      const uint32_t a0 = v0 & 511u, a1 = v1 & 511u, a2 = v2 & 511u;
+      const uint32_t b0 = v0 >> 9, b1 = v1 >> 9, b2 = v2 >> 9;
+      const uint32_t as = a0 + a2, bs = b0 + b2;
+      oa = 3u * as + 4u * a1;
+      ob = 3u * bs + 4u * b1;
+      ma = 4u * (as + a1);
+      mb = 4u * (bs + b1);
+    };
+    auto row2 = [&](int r, uint32_t &ha, uint32_t &hb) {   // ab2 row r at x .. x + 2: (5 6 5)
+      const uint32_t v0 = ab2[r][x], v1 = ab2[r][x + 1], v2 = ab2[r][x + 2];
+      ha = 5u * ((v0 & 511u) + (v2 & 511u)) + 6u * (v1 & 511u);
+      hb = 5u * ((v0 >> 9) + (v2 >> 9)) + 6u * (v1 >> 9);
+    };
+    // one straight-line body per (radius-1 pass on, radius-2 pass on): the parameter set is workgroup-uniform
+    auto stencil = [&](auto has1, auto has2) {
+      constexpr bool H1 = decltype(has1)::value, H2 = decltype(has2)::value;
+      uint32_t oa0 = 0, ob0 = 0, oa1 = 0, ob1 = 0, ma1 = 0, mb1 = 0, dump_a, dump_b;
+      if constexpr (H1) {
         row1(y0, oa0, ob0, dump_a, dump_b);
         row1(y0 + 1, oa1, ob1, ma1, mb1);
       }
-      uint32_t ha0 = 0, hb0 = 0, ha1 = 0, hb1 = 0;
-      if (s2 > 0) row2(y0 / 2, ha0, hb0);
-      for (int y = y0; y < y1; y++) {
-        const uint32_t p = S[y + 4][x + 4];
-        uint32_t f1, f2;
-        if (s1 > 0) {
-          row1(y + 2, oa2, ob2, ma2, mb2);
-          const uint32_t A = oa0 + ma1 + oa2, B = ob0 + mb1 + ob2;
-          f1 = (A * p + B + (1u << 8)) >> 9;
-          oa0 = oa1; ob0 = ob1;
-          oa1 = oa2; ob1 = ob2; ma1 = ma2; mb1 = mb2;
-        } else {
-          f1 = p << 4;
-        }
-        if (s2 > 0) {
-          if ((y & 1) == 0) {
-            row2(y / 2 + 1, ha1, hb1);
-            f2 = ((ha0 + ha1) * p + hb0 + hb1 + (1u << 8)) >> 9;
-          } else {
-            f2 = (ha1 * p + hb1 + (1u << 7)) >> 8;
-            ha0 = ha1; hb0 = hb1;
+      uint32_t ha0 = 0, hb0 = 0;
+      if constexpr (H2) row2(y0 / 2, ha0, hb0);
+#pragma unroll
+      for (int k = 0; k < PER_MAX; k += 2) {
+        if (k < ny) {
+          const int y = y0 + k;                                   // an even row and, below, the odd row after it
+          const uint32_t pe = S[y + 4][x + 4];
+          uint32_t f1 = pe << 4, f2 = pe << 4, ha1 = 0, hb1 = 0;   // sgrproj_box_f_r0 once per row pair: the odd row
+          if constexpr (H1) {                                     // reuses the even row's value
+            uint32_t oa2, ob2, ma2, mb2;
+            row1(y + 2, oa2, ob2, ma2, mb2);
+            f1 = mad_u24(oa0 + ma1 + oa2, pe, ob0 + mb1 + ob2 + (1u << 8)) >> 9;
+            oa0 = oa1; ob0 = ob1;
+            oa1 = oa2; ob1 = ob2; ma1 = ma2; mb1 = mb2;
           }
-        } else {
-          // sgrproj_box_f_r0 once per row pair: the odd row reuses the even row's value
-          f2 = (uint32_t)S[(y & ~1) + 4][x + 4] << 4;
+          if constexpr (H2) {
+            row2(y / 2 + 1, ha1, hb1);
+            f2 = mad_u24(ha0 + ha1, pe, hb0 + hb1 + (1u << 8)) >> 9;
+          }
+          emit(x, y, pe, f1, f2, extra[k]);
+          if (k + 1 < ny) {
+            const uint32_t po = S[y + 5][x + 4];
+            if constexpr (H1) {
+              uint32_t oa2, ob2, ma2, mb2;
+              row1(y + 3, oa2, ob2, ma2, mb2);
+              f1 = mad_u24(oa0 + ma1 + oa2, po, ob0 + mb1 + ob2 + (1u << 8)) >> 9;
+              oa0 = oa1; ob0 = ob1;
+              oa1 = oa2; ob1 = ob2; ma1 = ma2; mb1 = mb2;
+            } else {
+              f1 = po << 4;
+            }
+            if constexpr (H2) {
+              f2 = mad_u24(ha1, po, hb1 + (1u << 7)) >> 8;
+              ha0 = ha1; hb0 = hb1;
+            }
+            emit(x, y + 1, po, f1, f2, extra[k + 1]);
+          }
+          if ((k & 2) != 0) flush();
         }
-        emit(x, y, p, f1, f2);
       }
-    }
+      flush();
+    };
+    if (s1 > 0 && s2 > 0) stencil(std::true_type(), std::true_type());
+    else if (s1 > 0) stencil(std::true_type(), std::false_type());
+    else if (s2 > 0) stencil(std::false_type(), std::true_type());
+    else stencil(std::false_type(), std::false_type());
   }
 }
 
@@ -269,7 +363,8 @@ __global__ __launch_bounds__(256) void k_lrf_sgr(R1Plane cdeffed, R1Plane debloc
   t.th = sh_;
   const int w0 = u.xqd[0], w1 = u.xqd[1], w2 = 128 - w0 - w1;
   const int32_t pmax = (1 << g.bd) - 1;
-  sgr_tile<BPP>(cdeffed, deblocked, t, u.set, g.bd, [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2) {
+  sgr_tile<BPP, 64, BPP == 1>(cdeffed, deblocked, t, u.set, BPP == 1 ? 8 : g.bd, nullptr, 0, 0,
+                              [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2, uint32_t) {
     // apply_filter (lrf.rs:796-815)
     const int32_t v = w0 * (int32_t)f2 + w1 * (int32_t)(p << 4) + w2 * (int32_t)f1;
     const int32_t s = (v + (1 << 10)) >> 11;
@@ -277,7 +372,7 @@ __global__ __launch_bounds__(256) void k_lrf_sgr(R1Plane cdeffed, R1Plane debloc
     uint8_t *d = (uint8_t *)px_addr<BPP>(out, cx0 + x, y0 + y);
     if constexpr (BPP == 1) *d = (uint8_t)o;
     else *(uint16_t *)d = (uint16_t)o;
-  });
+  }, [] {});
 }
 
 // sgrproj_solve's moments (lrf.rs:1010-1054): grid.x = tiles of the largest
@@ -301,13 +396,13 @@ __global__ __launch_bounds__(256) void k_sgr_moments(R1Plane cdeffed, R1Plane in
   t.tw = (u.w - tx * TW) < TW ? (u.w - tx * TW) : TW;
   t.th = (u.h - ty * 64) < 64 ? (u.h - ty * 64) : 64;
   long long m[5] = {0, 0, 0, 0, 0};
-  sgr_tile<BPP>(cdeffed, cdeffed, t, u.set, cdeffed.bit_depth,
-                [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2) {
+  sgr_tile<BPP, 64, BPP == 1>(cdeffed, cdeffed, t, u.set, BPP == 1 ? 8 : cdeffed.bit_depth, &input, t.cx0, u.y + t.ty0,
+                [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2, uint32_t in_px) {
     const int32_t uu = (int32_t)(p << 4);
-    const long long sv = ((int32_t)ld_px<BPP>(px_addr<BPP>(input, t.cx0 + x, u.y + t.ty0 + y)) << 4) - uu;
+    const long long sv = ((int32_t)in_px << 4) - uu;
     const long long g2 = (int32_t)f2 - uu, g1 = (int32_t)f1 - uu;
     m[0] += g2 * g2; m[1] += g1 * g1; m[2] += g1 * g2; m[3] += g2 * sv; m[4] += g1 * sv;
-  });
+  }, [] {});
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 5; k++) {
@@ -465,12 +560,13 @@ __global__ __launch_bounds__(256) void k_sgr_unit_err(R1Plane lrf_in, R1Plane sr
   } else {
     const int w0 = xqd[2 * blockIdx.y], w1 = xqd[2 * blockIdx.y + 1], w2 = 128 - w0 - w1;
     const int32_t pmax = (1 << bd) - 1;
-    sgr_tile<BPP>(lrf_in, lrf_in, t, u.set, bd, [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2) {
+    sgr_tile<BPP, 64, BPP == 1>(lrf_in, lrf_in, t, u.set, bd, nullptr, 0, 0,
+                                [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2, uint32_t) {
       // apply_filter (lrf.rs:796-815)
       const int32_t v = w0 * (int32_t)f2 + w1 * (int32_t)(p << 4) + w2 * (int32_t)f1;
       const int32_t sft = (v + (1 << 10)) >> 11;
       F[y][x] = (uint16_t)(sft < 0 ? 0 : (sft > pmax ? pmax : sft));
-    });
+    }, [] {});
   }
   __syncthreads();
   const int bw = CHROMA ? 8 >> xdec : 8, bh = CHROMA ? 8 >> ydec : 8;
@@ -490,14 +586,10 @@ __global__ __launch_bounds__(256) void k_sgr_unit_err(R1Plane lrf_in, R1Plane sr
 // pixel stay in LDS between the moments and the projection, so the box filters run once.
 // PACK: both filter outputs of a pixel in one dword (f <= 16 * 1023 + rounding: up to 10 bits; at 12 bits an
 // all-white unit reaches 65588)
-// workgroups per CU the register allocator makes room for: an 8-bit chroma workgroup (32-row tile, 31 KB of LDS) fits
-// five times once its registers do (106 -> 89, no scratch): -13 % on the chroma planes (ab9); the 8-bit luma kernel keeps
-// its 64-row tile (four by LDS) and the 16-bit kernels are LDS-bound at four
-#ifndef R1_LRF_SEARCH_WGS
-#define R1_LRF_SEARCH_WGS(BPP, CHROMA) (((BPP) == 1 && (CHROMA)) ? 5 : 1)
-#endif
+// Occupancy (ab9, ab10): with 32-row tiles an 8-bit workgroup holds 31 KB of LDS and 96 VGPRs -- five per CU -- and a
+// 16-bit one 35 KB -- four (three with the 64-row tile of round 4); no register hint is needed since the tile was rewritten
 template <int BPP, bool CHROMA, bool PACK>
-__global__ __launch_bounds__(256, R1_LRF_SEARCH_WGS(BPP, CHROMA)) void k_lrf_search_unit(R1Plane lrf_in, R1Plane src,
+__global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane src,
                                                          const R1SgrSolveUnit *__restrict__ units, int xdec, int ydec,
                                                          const uint32_t *__restrict__ scales, int scale_stride,
                                                          uint32_t dist_scale, int8_t *__restrict__ xqd_out,
@@ -510,7 +602,7 @@ __global__ __launch_bounds__(256, R1_LRF_SEARCH_WGS(BPP, CHROMA)) void k_lrf_sea
   __shared__ unsigned long long epart[4];
   __shared__ int8_t xq[2];
   const R1SgrSolveUnit u = units[blockIdx.x];
-  const int bd = lrf_in.bit_depth;
+  const int bd = BPP == 1 ? 8 : lrf_in.bit_depth;
   if (u.w > 64 || u.h > 64 || u.w <= 0 || u.h <= 0) {   // not what max_w / max_h promised: no result
     if (threadIdx.x == 0) {
       err_out[blockIdx.x] = ~0ull;
@@ -526,13 +618,13 @@ __global__ __launch_bounds__(256, R1_LRF_SEARCH_WGS(BPP, CHROMA)) void k_lrf_sea
     if (threadIdx.x == 0) xqd_out[2 * blockIdx.x] = xqd_out[2 * blockIdx.x + 1] = 0;
   } else {
     long long m[5] = {0, 0, 0, 0, 0};
-    // rows per tile.  32: the tile arrays shrink by 9 KB and a 16-bit workgroup fits four times on a CU instead of three
-    // (same-box A/B, r05_ab_notes.md ab9: 10-bit luma -6 %, chroma -19 %); an 8-bit workgroup already fits four times
-    // (its registers allow no fifth) and only pays for the two extra tiles of a 64-row luma unit (+15 %): 64 there
+    // rows per tile: 32 -- the tile arrays are 9 KB smaller than with 64 and one more workgroup fits a CU at either
+    // pixel width; the two extra tiles of a 64-row luma unit cost less than that buys since the tile's fixed part shrank
+    // (r05_ab_notes.md ab9 / ab10)
 #ifndef R1_LRF_SEARCH_TROWS
-#define R1_LRF_SEARCH_TROWS(BPP, CHROMA) (((BPP) == 1 && !(CHROMA)) ? 64 : 32)
+#define R1_LRF_SEARCH_TROWS 32
 #endif
-    constexpr int TR = R1_LRF_SEARCH_TROWS(BPP, CHROMA);
+    constexpr int TR = R1_LRF_SEARCH_TROWS;
     const int ntx = (u.w + TW - 1) / TW;
     for (int ty = 0; ty < u.h; ty += TR)
     for (int tx = 0; tx < ntx; tx++) {
@@ -543,15 +635,32 @@ __global__ __launch_bounds__(256, R1_LRF_SEARCH_WGS(BPP, CHROMA)) void k_lrf_sea
       t.ty0 = ty;
       t.tw = (u.w - tx * TW) < TW ? (u.w - tx * TW) : TW;
       t.th = (u.h - ty) < TR ? (u.h - ty) : TR;
-      sgr_tile<BPP, TR>(lrf_in, lrf_in, t, u.set, bd, [&](int x, int yt, uint32_t p, uint32_t f1, uint32_t f2) {
+      // PACK (bit depth <= 10): f - u and s - u are 14-bit-and-a-sign differences of Q4 pixels (|f - u| <= 16 * 1023 +
+      // rounding), their products < 2^28.1: four of them fit an int32, so the moments of a thread's four rows are
+      // gathered with the full-rate 24-bit multiply-add and widened once per four rows instead of five quarter-rate
+      // 64-bit multiply-adds per pixel
+      int32_t a32[5] = {0, 0, 0, 0, 0};
+      sgr_tile<BPP, TR, PACK>(lrf_in, lrf_in, t, u.set, bd, &src, u.x + tx * TW, u.y + ty,
+                              [&](int x, int yt, uint32_t p, uint32_t f1, uint32_t f2, uint32_t src_px) {
         const int X = tx * TW + x, y = ty + yt;
         if constexpr (!PACK) { F1[y][X] = f1; F2[y][X] = f2; }
         else F1[y][X] = f1 | (f2 << 16);
         P[y][X] = (PT)p;
         const int32_t uu = (int32_t)(p << 4);
-        const long long sv = ((int32_t)ld_px<BPP>(px_addr<BPP>(src, u.x + X, u.y + y)) << 4) - uu;
-        const long long g2 = (int32_t)f2 - uu, g1 = (int32_t)f1 - uu;
-        m[0] += g2 * g2; m[1] += g1 * g1; m[2] += g1 * g2; m[3] += g2 * sv; m[4] += g1 * sv;
+        if constexpr (PACK) {
+          const int32_t sv = ((int32_t)src_px << 4) - uu, g2 = (int32_t)f2 - uu, g1 = (int32_t)f1 - uu;
+          a32[0] = mad_i24(g2, g2, a32[0]); a32[1] = mad_i24(g1, g1, a32[1]); a32[2] = mad_i24(g1, g2, a32[2]);
+          a32[3] = mad_i24(g2, sv, a32[3]); a32[4] = mad_i24(g1, sv, a32[4]);
+        } else {
+          const long long sv = ((int32_t)src_px << 4) - uu;
+          const long long g2 = (int32_t)f2 - uu, g1 = (int32_t)f1 - uu;
+          m[0] += g2 * g2; m[1] += g1 * g1; m[2] += g1 * g2; m[3] += g2 * sv; m[4] += g1 * sv;
+        }
+      }, [&] {
+        if constexpr (PACK) {
+#pragma unroll
+          for (int k = 0; k < 5; k++) { m[k] += a32[k]; a32[k] = 0; }
+        }
       });
       __syncthreads();   // the tile's LDS is staged again by the next one
     }
@@ -718,6 +827,7 @@ extern "C" int r1_lrf_sgrproj_plane(r1_ctx *ctx, const R1Plane *cdeffed, const R
                                     int frame_height, int unit_size, int unit_cols, int unit_rows,
                                     int stripe_height, const R1LrfUnit *units, void *stream) {
   R1_REQUIRE(ctx && cdeffed && deblocked && out && units);
+  R1_REQUIRE(lrf_plane_ok(cdeffed) && lrf_plane_ok(deblocked));   // 32-bit byte offsets in the tile loads
   R1_REQUIRE(cdeffed->bytes_per_px == deblocked->bytes_per_px &&
              cdeffed->bytes_per_px == out->bytes_per_px);
   R1_REQUIRE(cdeffed->bytes_per_px == 1 || cdeffed->bytes_per_px == 2);
@@ -752,6 +862,7 @@ extern "C" int r1_sgrproj_solve_batch(r1_ctx *ctx, const R1Plane *cdeffed, const
                                       const R1SgrSolveUnit *units, int n, int max_w, int max_h,
                                       int64_t *moments_scratch, int8_t *xqd_out, void *stream) {
   R1_REQUIRE(ctx && cdeffed && input);
+  R1_REQUIRE(lrf_plane_ok(cdeffed) && lrf_plane_ok(input));
   R1_REQUIRE(cdeffed->bytes_per_px == input->bytes_per_px && cdeffed->bit_depth == input->bit_depth);
   R1_REQUIRE(cdeffed->bytes_per_px == 1 || cdeffed->bytes_per_px == 2);
   R1_REQUIRE((cdeffed->bytes_per_px == 1) == (cdeffed->bit_depth == 8));
@@ -781,6 +892,7 @@ extern "C" int r1_lrf_search_batch(r1_ctx *ctx, const R1Plane *lrf_in, const R1P
                                    uint32_t dist_scale, int64_t *scratch, int8_t *xqd_out,
                                    uint64_t *err_out, void *stream) {
   R1_REQUIRE(ctx && lrf_in && src);
+  R1_REQUIRE(lrf_plane_ok(lrf_in) && lrf_plane_ok(src));
   R1_REQUIRE(lrf_in->bytes_per_px == src->bytes_per_px && lrf_in->bit_depth == src->bit_depth);
   R1_REQUIRE(lrf_in->bytes_per_px == 1 || lrf_in->bytes_per_px == 2);
   R1_REQUIRE((lrf_in->bytes_per_px == 1) == (lrf_in->bit_depth == 8));

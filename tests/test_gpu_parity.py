@@ -1632,6 +1632,33 @@ def test_lrf_search_ref(ctx, case):
                                                     want[sel][:4])
 
 
+def test_lrf_entry_points_reject_planes_their_32_bit_offsets_cannot_address(ctx):
+    """the restoration kernels address pixels with 32-bit byte offsets and 24-bit row / stride factors
+    (csrc/lrf.hip, px_off): a descriptor beyond that is R1_EINVAL before anything is launched"""
+    from rav1e_amd.api import SGR_SOLVE_UNIT
+    a, b = planes(8, seed=3)
+    da, db = dev_plane(a), dev_plane(b)
+    u = np.array([(0, 0, 64, 64, 3, (0, 0, 0))], SGR_SOLVE_UNIT)
+    ctx.lrf_search_batch(da, db, u, max_w=64, max_h=64)                 # as it is: fine
+    for field, value in (("stride", 1 << 24), ("alloc_height", 1 << 24)):
+        keep = getattr(da, field)
+        setattr(da, field, value)
+        try:
+            with pytest.raises(RuntimeError):
+                ctx.lrf_search_batch(da, db, u, max_w=64, max_h=64)
+            with pytest.raises(RuntimeError):
+                ctx.sgrproj_solve_batch(da, db, u)
+        finally:
+            setattr(da, field, keep)
+    keep = (da.stride, da.alloc_height)
+    da.stride, da.alloc_height = 1 << 16, 1 << 16                       # 4 GiB of bytes
+    try:
+        with pytest.raises(RuntimeError):
+            ctx.lrf_search_batch(db, da, u, max_w=64, max_h=64)
+    finally:
+        da.stride, da.alloc_height = keep
+
+
 @pytest.mark.parametrize("bd", [8, 10])
 def test_lrf_search_vs_oracle_frame_units(ctx, oracle, bd):
     """every 64x64 luma unit (and the 32x32 units of a 4:2:0 chroma plane) of a 520x264 frame -- the last

@@ -23,6 +23,7 @@
 #   pmc_hbm       FETCH_SIZE / WRITE_SIZE (separate passes) of the 10-bit frame and of the type search
 #   pmc_px        SQ / LDS counters of the pixel chain
 #   pmc_frame     SQ / LDS / HBM counters of every kernel of the config-4 frame (tools/frame_pipeline.py)
+#   pmc_lrf[:BD]  SQ / LDS counters of the restoration search alone (tools/bench_lrf_search.py)
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -145,6 +146,12 @@ import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['va
         pmc_pass frame${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" -- $FP
         pmc_pass frame${bd}_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- $FP
         [ $bd = 10 ] && pmc_pass frame${bd}_d "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_INST_LEVEL_VMEM" -- $FP
+      done ;;
+    pmc_lrf)     # the restoration search alone (tools/bench_lrf_search.py), 8-bit then 10-bit
+      for bd in ${ARG:-8}; do
+        LB="python $GRAFT_REPO_ROOT/tools/bench_lrf_search.py --bit-depth $bd --reps 3 --sustain-ms 0"
+        PMC_TIMEOUT=120 pmc_pass lrf${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" -- $LB
+        PMC_TIMEOUT=120 pmc_pass lrf${bd}_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- $LB
       done ;;
     *) echo "unknown step $STEP" ;;
   esac
