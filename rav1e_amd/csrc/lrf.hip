@@ -601,12 +601,24 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
   __shared__ long long mpart[4][5];
   __shared__ unsigned long long epart[4];
   __shared__ int8_t xq[2];
-  const R1SgrSolveUnit u = units[blockIdx.x];
+  // Consecutive workgroup ids go to the eight XCDs in turn, each with its own L2.  Callers list the parameter sets of
+  // a unit next to each other (rdo_loop_decision's loop order): handing an XCD a CONTIGUOUS run of pairs keeps the nine
+  // launches that read the same unit -- its pixels and the source's -- on one L2 (before: every set of a unit fetched
+  // it again, 135 MB a luma launch for 17 MB of planes; the tile loads are a quarter of a wave's life)
+#ifndef R1_LRF_XCD_RUNS
+#define R1_LRF_XCD_RUNS 1   // A/B switch
+#endif
+  int pair = blockIdx.x;
+  if (R1_LRF_XCD_RUNS) {
+    const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = pair & 7, i = pair >> 3;
+    pair = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const R1SgrSolveUnit u = units[pair];
   const int bd = BPP == 1 ? 8 : lrf_in.bit_depth;
   if (u.w > 64 || u.h > 64 || u.w <= 0 || u.h <= 0) {   // not what max_w / max_h promised: no result
     if (threadIdx.x == 0) {
-      err_out[blockIdx.x] = ~0ull;
-      xqd_out[2 * blockIdx.x] = xqd_out[2 * blockIdx.x + 1] = 0;
+      err_out[pair] = ~0ull;
+      xqd_out[2 * pair] = xqd_out[2 * pair + 1] = 0;
     }
     return;
   }
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
       const int y = e >> 6, x = e & 63;   // rows of 64: no runtime division
       if (x < u.w) P[y][x] = (PT)ld_px<BPP>(px_addr<BPP>(lrf_in, u.x + x, u.y + y));
     }
-    if (threadIdx.x == 0) xqd_out[2 * blockIdx.x] = xqd_out[2 * blockIdx.x + 1] = 0;
+    if (threadIdx.x == 0) xqd_out[2 * pair] = xqd_out[2 * pair + 1] = 0;
   } else {
     long long m[5] = {0, 0, 0, 0, 0};
     // rows per tile: 32 -- the tile arrays are 9 KB smaller than with 64 and one more workgroup fits a CU at either
@@ -683,8 +695,8 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
       long long tot[5];
       for (int k = 0; k < 5; k++) tot[k] = mpart[0][k] + mpart[1][k] + mpart[2][k] + mpart[3][k];
       sgr_solve_xqd(tot, u.w, u.h, u.set, xq);
-      xqd_out[2 * blockIdx.x] = xq[0];
-      xqd_out[2 * blockIdx.x + 1] = xq[1];
+      xqd_out[2 * pair] = xq[0];
+      xqd_out[2 * pair + 1] = xq[1];
     }
     __syncthreads();
     const int w0 = xq[0], w1 = xq[1], w2 = 128 - w0 - w1;
@@ -810,7 +822,7 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
   }
   const unsigned long long v = wg_sum_u64(mine, epart);
   // Distortion * fi.dist_scale[pli] (rdo.rs:2092; DistortionScale::mul_u64, rdo.rs:613-615)
-  if (threadIdx.x == 0) err_out[blockIdx.x] = ((unsigned long long)dist_scale * v + 8192) >> 14;
+  if (threadIdx.x == 0) err_out[pair] = ((unsigned long long)dist_scale * v + 8192) >> 14;
 }
 
 // Distortion * fi.dist_scale[pli] (rdo.rs:2092; DistortionScale::mul_u64, rdo.rs:613-615)

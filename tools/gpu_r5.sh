@@ -23,7 +23,7 @@
 #   pmc_hbm       FETCH_SIZE / WRITE_SIZE (separate passes) of the 10-bit frame and of the type search
 #   pmc_px        SQ / LDS counters of the pixel chain
 #   pmc_frame     SQ / LDS / HBM counters of every kernel of the config-4 frame (tools/frame_pipeline.py)
-#   pmc_lrf[:BD]  SQ / LDS counters of the restoration search alone (tools/bench_lrf_search.py)
+#   pmc_lrf[:BD]  SQ / LDS counters of the restoration search alone (tools/bench_lrf_search.py); pmc_lrf_hbm[:BD]: its FETCH_SIZE
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -152,6 +152,11 @@ import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['va
         LB="python $GRAFT_REPO_ROOT/tools/bench_lrf_search.py --bit-depth $bd --reps 3 --sustain-ms 0"
         PMC_TIMEOUT=120 pmc_pass lrf${bd}_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" -- $LB
         PMC_TIMEOUT=120 pmc_pass lrf${bd}_b "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES" -- $LB
+      done ;;
+    pmc_lrf_hbm)   # FETCH_SIZE of the restoration search alone (its own pass, as the guide prescribes)
+      for bd in ${ARG:-10}; do
+        LB="python $GRAFT_REPO_ROOT/tools/bench_lrf_search.py --bit-depth $bd --reps 3 --sustain-ms 0"
+        PMC_TIMEOUT=120 pmc_pass lrf${bd}_fetch "FETCH_SIZE" -- $LB
       done ;;
     *) echo "unknown step $STEP" ;;
   esac
