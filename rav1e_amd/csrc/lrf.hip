@@ -608,11 +608,7 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
 #ifndef R1_LRF_XCD_RUNS
 #define R1_LRF_XCD_RUNS 1   // A/B switch
 #endif
-  int pair = blockIdx.x;
-  if (R1_LRF_XCD_RUNS) {
-    const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = pair & 7, i = pair >> 3;
-    pair = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-  }
+  const int pair = R1_LRF_XCD_RUNS ? xcd_run_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // common.hpp
   const R1SgrSolveUnit u = units[pair];
   const int bd = BPP == 1 ? 8 : lrf_in.bit_depth;
   if (u.w > 64 || u.h > 64 || u.w <= 0 || u.h <= 0) {   // not what max_w / max_h promised: no result

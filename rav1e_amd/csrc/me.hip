@@ -1328,7 +1328,12 @@ __global__ __launch_bounds__(256, R1_ME_SMALL_WAVES(BPP)) void k_me_blocks_small
   __shared__ int16_t sh_subsets[4][kSubsetWords];
   __shared__ __attribute__((aligned(16))) uint8_t sh_src[4][16 * 16 * BPP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long bi = (long long)blockIdx.x * 4 + wave;
+  // an XCD takes a contiguous run of the block list (common.hpp): callers list blocks in raster order, and the search
+  // windows of neighbouring blocks overlap -- dealt round-robin, every XCD's L2 fetched the whole reference
+#ifndef R1_ME_SMALL_XCD_RUNS
+#define R1_ME_SMALL_XCD_RUNS 1   // A/B switch
+#endif
+  const long long bi = (long long)(R1_ME_SMALL_XCD_RUNS ? xcd_run_item(blockIdx.x, gridDim.x) : (int)blockIdx.x) * 4 + wave;
   if (bi >= n) return;                         // wave-uniform; no barriers below
   const R1MeBlockCand cd = cands[bi];
   const int w = cd.w, h = cd.h;

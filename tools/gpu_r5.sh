@@ -77,8 +77,8 @@ for l in sys.stdin:
         for bd in 8 10; do echo "$(basename $lib) $(timeout 300 python tools/bench_lrf_search.py --bit-depth $bd 2>/dev/null | grep '^{')"; done
       done; done 2>&1 | tee $OUT/lrf_ab.txt
       cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
-    stage_ab)   # STAGES=substr,substr: tools/frame_pipeline.py --stages per library, 8- and 10-bit
-      for pass in 1 2; do for lib in ${ARG//,/ }; do
+    stage_ab)   # STAGES=substr,substr [PASSES="1 2"]: tools/frame_pipeline.py --stages per library, 8- and 10-bit
+      for pass in ${PASSES:-1 2}; do for lib in ${ARG//,/ }; do
         cp $lib rav1e_amd/librav1e_hip.so
         for bd in 8 10; do echo "$(basename $lib) $(timeout 300 python tools/frame_pipeline.py --bit-depth $bd --stages "$STAGES" 2>/dev/null | grep '^{')"; done
       done; done 2>&1 | tee $OUT/stage_ab.txt
