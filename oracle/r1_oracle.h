@@ -11,7 +11,7 @@
  * reproduces either known answers the reference itself holds (get_sad / get_satd: src/dist.rs:418-500;
  * 4x4 intra prediction: src/predict.rs:1523-1693; estimate_rate: src/rdo.rs:2749) or vectors made by
  * EXECUTING the reference's source text in the build container (tools/rustlite,
- * tests/golden/gen_*_ref.py -> tests/golden/*_ref.npz; tests/test_oracle_*_ref.py).  Exception:
+ * tests/golden/gen_NAME_ref.py -> tests/golden/NAME_ref.npz; tests/test_oracle_NAME_ref.py).  Exception:
  * Plane::pad / Plane::downsampled restate the un-vendored v_frame 0.3.9 crate (oracle/plane.c).
  *
  * Conventions: strides are in ELEMENTS (not bytes); `hbd` != 0 means the
