@@ -23,6 +23,7 @@
 #   pmc_hbm       FETCH_SIZE / WRITE_SIZE (separate passes) of the 10-bit frame and of the type search
 #   pmc_px        SQ / LDS counters of the pixel chain
 #   pmc_frame     SQ / LDS / HBM counters of every kernel of the config-4 frame (tools/frame_pipeline.py)
+#   pmc_stage_hbm[:BD]  STAGES=substr: FETCH_SIZE of the kernels of those stages of tools/frame_pipeline.py
 #   pmc_lrf[:BD]  SQ / LDS counters of the restoration search alone (tools/bench_lrf_search.py); pmc_lrf_hbm[:BD]: its FETCH_SIZE
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -158,6 +159,9 @@ import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['va
         LB="python $GRAFT_REPO_ROOT/tools/bench_lrf_search.py --bit-depth $bd --reps 3 --sustain-ms 0"
         PMC_TIMEOUT=120 pmc_pass lrf${bd}_fetch "FETCH_SIZE" -- $LB
       done ;;
+    pmc_stage_hbm)   # STAGES=substr: FETCH_SIZE of the kernels of those frame stages, 10-bit (its own pass)
+      FP="python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --bit-depth ${ARG:-10} --reps 2 --sustain-ms 0 --stages $STAGES"
+      PMC_TIMEOUT=60 pmc_pass stage_fetch "FETCH_SIZE" -- $FP ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
