@@ -105,7 +105,11 @@ const char *r1_last_error(void);
  *    has not been acknowledged through r1_me_status; r1_cdef_filter_frame_plane checks luma->bit_depth
  *    against params->bit_depth and the _dirs variant wants 8-aligned tile_w / tile_h; skip_mi bytes are
  *    bools (any non-zero value) in the CDEF filter and the strength search alike.
- * 5 (round 5): + r1_rdo_txsearch_batch, r1_tx_type_mask (additions only; nothing of 4 changed). */
+ * 5 (round 5): + r1_rdo_txsearch_batch, r1_tx_type_mask (additions only; nothing of 4 changed).
+ * 6 (round 5): R1SgrSolveUnit.reserved[0] became `edges` (R1_SGR_EDGE_*): what r1_sgrproj_solve_batch /
+ *    r1_lrf_search_batch see left of / above a unit is the caller's statement of the unit's place in its
+ *    rdo_loop_decision area, no longer the unit's place in the frame (0 = nothing, the case of one unit per
+ *    plane and area); the restoration entry points refuse planes of 4 GiB and more. */
 int r1_abi_version(void);
 
 /* ---- dist:: (reference: src/dist.rs get_sad 31, get_satd 156; dispatch
@@ -675,8 +679,24 @@ int r1_lrf_sgrproj_plane(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *deb
  * so the weights are bit-identical. */
 typedef struct R1SgrSolveUnit {
   int16_t x, y, w, h;
-  uint8_t set, reserved[3];
+  uint8_t set;
+  uint8_t edges;      /* R1_SGR_EDGE_* (ABI 6; was reserved = 0) */
+  uint8_t reserved[2];
 } R1SgrSolveUnit;
+/* What setup_integral_image (src/lrf.rs:530-630) sees outside the unit.  rdo_loop_decision filters
+ * a unit on its scratch copy of the AREA it is deciding -- the largest restoration unit of the three
+ * planes, in superblocks (src/rdo.rs:2119-2141, 2277-2296) -- and that copy has no pixels outside the
+ * area.  The right and bottom edges are always clipped to the unit (crop = the unit).  On the left
+ * the filter reads 4 real columns, above 2 real rows, IF the unit's slice does not start in column 0
+ * / row 0 of the area copy, i.e. if the plane has more than one unit per area (a 64-pixel luma unit
+ * beside 128-pixel chroma units) and this is not the first:
+ *   edges = (unit x in plane pixels) % (area width in plane pixels) != 0 ? R1_SGR_EDGE_LEFT : 0
+ *         | (unit y ...) % (area height ...) != 0 ? R1_SGR_EDGE_ABOVE : 0
+ * 0 (every unit of the 64 / 32-pixel configuration: one unit per plane and area) = the unit alone.
+ * A flag is ignored at the plane's own left / top edge.  Found by executing rdo_loop_decision itself
+ * (tests/golden/gen_loop_decision_ref.py); up to ABI 5 the kernels decided from the unit's position
+ * in the FRAME, which matches the reference only for areas at the frame's left / top edge. */
+enum { R1_SGR_EDGE_LEFT = 1, R1_SGR_EDGE_ABOVE = 2 };
 int r1_sgrproj_solve_batch(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *input,
                            const R1SgrSolveUnit *units, int n, int max_w, int max_h,
                            int64_t *moments_scratch, int8_t *xqd_out, void *stream);

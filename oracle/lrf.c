@@ -44,12 +44,18 @@ static uint32_t px(const r1o_plane *p, int x, int y) {
 }
 
 /* setup_integral_image: (x0, y0) = the unit's origin in the plane; crop_w /
- * crop_h are ABSOLUTE here (the reference passes them relative to the slice) */
+ * crop_h are ABSOLUTE here (the reference passes them relative to the slice).
+ * The reference decides what lies left of / above the unit from the slice's position IN ITS PLANE
+ * (lrf.rs: `cdeffed.x == 0`, `clamp(y, 0, crop - 1)`).  For the frame filter that plane is the
+ * frame: left_real = x0 != 0, top_min = 0.  For the restoration search it is rdo_loop_decision's
+ * scratch copy of the AREA being decided (rdo.rs:2277-2296: no padding, origin = the area's): a
+ * unit in the area's first column / row sees nothing left of / above itself wherever the area
+ * lies in the frame -- left_real / top_min come from the caller's edge flags there. */
 static void setup_integral_image(uint32_t *ii, uint32_t *sq, int crop_w, int crop_h, int stripe_w,
                                  int stripe_h, const r1o_plane *cdeffed, const r1o_plane *deblocked,
-                                 int x0, int y0) {
+                                 int x0, int y0, int left_real, int top_min) {
   const int left_w = 4, right_w = 3;
-  const int left_uniques = x0 == 0 ? 0 : left_w;
+  const int left_uniques = left_real ? left_w : 0;
   const int right_uniques = imin(right_w, (crop_w - x0) - stripe_w);
   const int h2 = stripe_h + (stripe_h & 1);
   const int rows_above = 4, rows_below = 2;
@@ -57,13 +63,13 @@ static void setup_integral_image(uint32_t *ii, uint32_t *sq, int crop_w, int cro
   const int nrows = rows_above + h2 + rows_below, ncols = left_w + stripe_w + right_w;
   for (int j = 0; j < nrows; j++) {
     const int y = y0 - rows_above + j;
-    const int cy = clampi(y, 0, crop_h - 1);
+    const int cy = clampi(y, top_min, crop_h - 1);
     const int ly = clampi(cy, stripe_begin - 2, stripe_end + 1);
     const r1o_plane *src = (ly >= stripe_begin && ly < stripe_end) ? cdeffed : deblocked;
     uint32_t sum = 0, sqs = 0;
     for (int i = 0; i < ncols; i++) {
       /* HorzPaddedIter over row[x0 - left_uniques ..][..row_uniques] from start_index */
-      const int idx = clampi((x0 == 0 ? -left_w : 0) + i, 0, left_uniques + stripe_w + right_uniques - 1);
+      const int idx = clampi((left_real ? 0 : -left_w) + i, 0, left_uniques + stripe_w + right_uniques - 1);
       const uint32_t cur = px(src, x0 - left_uniques + idx, ly);
       sum += cur;
       sqs += cur * cur;
@@ -194,7 +200,7 @@ int r1o_lrf_filter_plane(const r1o_plane *cdeffed, const r1o_plane *deblocked, c
       const r1o_lrf_unit *u = &units[ruy * unit_cols + imin(rux, unit_cols - 1)];
       if (u->filter != 3 || size <= 0) continue; /* RESTORE_SGRPROJ */
       if (size > IMG_MAX) { free(ii); return -1; }
-      setup_integral_image(ii, sq, crop_w, crop_h, size, sz, cdeffed, deblocked, x0, y0);
+      setup_integral_image(ii, sq, crop_w, crop_h, size, sz, cdeffed, deblocked, x0, y0, x0 != 0, 0);
       stripe_filter(u->set, u->xqd, bd, ii, sq, cdeffed, out, x0, y0, size, sz);
     }
   }
@@ -207,11 +213,12 @@ int r1o_lrf_filter_plane(const r1o_plane *cdeffed, const r1o_plane *deblocked, c
  * cdeffed == deblocked (monolithic), then the least-squares projection
  * weights.  input: the source plane (same coordinates). */
 void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0, int y0, int w, int h,
-                       int set, int bd, int8_t *xqd_out) {
+                       int set, int edges, int bd, int8_t *xqd_out) {
   const int rows = h + (h & 1) + 6;
   uint32_t *ii = (uint32_t *)calloc((size_t)IMG_STRIDE * rows * 2, sizeof(uint32_t));
   uint32_t *sq = ii + (size_t)IMG_STRIDE * rows;
-  setup_integral_image(ii, sq, x0 + w, y0 + h, w, h, cdeffed, cdeffed, x0, y0);
+  setup_integral_image(ii, sq, x0 + w, y0 + h, w, h, cdeffed, cdeffed, x0, y0, (edges & R1O_SGR_EDGE_LEFT) && x0 > 0,
+                       (edges & R1O_SGR_EDGE_ABOVE) ? 0 : y0);
   static uint32_t a_r2[2][IMG_MAX + 2], b_r2[2][IMG_MAX + 2], f_r2_0[IMG_MAX], f_r2_1[IMG_MAX];
   static uint32_t a_r1[3][IMG_MAX + 2], b_r1[3][IMG_MAX + 2], f_r1[IMG_MAX];
 #pragma omp threadprivate(a_r2, b_r2, f_r2_0, f_r2_1, a_r1, b_r1, f_r1)
@@ -311,12 +318,16 @@ void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0,
  *         8x8-luma blocks of the unit  cdef_dist_kernel * bias (luma)  /  sse_wxh with |_, _| bias
  *         on (8 >> xdec) x (8 >> ydec) pixels (chroma), bias = the DistortionScale of the block's
  *         8x8 luma position, summed, * fi.dist_scale[pli].
+ * edges: R1O_SGR_EDGE_LEFT / R1O_SGR_EDGE_ABOVE -- whether the 4 columns left of / the 2 rows above
+ * the unit are pixels the filter sees: they are when the unit is not in the first unit column /
+ * row of the AREA rdo_loop_decision is deciding (its scratch copy has no pixels outside the area;
+ * found by executing rdo_loop_decision itself, tests/golden/gen_loop_decision_ref.py).
  * (x0, y0, w, h): the unit in pixels of THIS plane, w % (8 >> xdec) == 0 and h % (8 >> ydec) == 0
  * (the visible frame a multiple of 8 luma pixels: otherwise the reference's last blocks read the
  * working copy beyond what the filter wrote).  scales: one per 8x8 luma block of the frame (NULL:
  * the default scale).  Returns -1 on geometry it does not take. */
 int r1o_lrf_search_unit(const r1o_plane *lrf_in, const r1o_plane *src, int x0, int y0, int w, int h,
-                        int set, int is_chroma, int xdec, int ydec, const uint32_t *scales,
+                        int set, int edges, int is_chroma, int xdec, int ydec, const uint32_t *scales,
                         int scale_stride, uint32_t dist_scale, int bd, int8_t *xqd_out,
                         uint64_t *err_out) {
   const int bw = 8 >> xdec, bh = 8 >> ydec, hbd = lrf_in->bytes_per_px == 2;
@@ -332,11 +343,12 @@ int r1o_lrf_search_unit(const r1o_plane *lrf_in, const r1o_plane *src, int x0, i
                  ((size_t)(lrf_in->yorigin + y0 + y) * lrf_in->stride + lrf_in->xorigin + x0) * bpp,
              (size_t)w * bpp);
   } else {
-    r1o_sgrproj_solve(lrf_in, src, x0, y0, w, h, set, bd, xqd_out);
+    r1o_sgrproj_solve(lrf_in, src, x0, y0, w, h, set, edges, bd, xqd_out);
     const int rows = h + (h & 1) + 6;
     uint32_t *ii = (uint32_t *)calloc((size_t)IMG_STRIDE * rows * 2, sizeof(uint32_t));
     uint32_t *sq = ii + (size_t)IMG_STRIDE * rows;
-    setup_integral_image(ii, sq, x0 + w, y0 + h, w, h, lrf_in, lrf_in, x0, y0);
+    setup_integral_image(ii, sq, x0 + w, y0 + h, w, h, lrf_in, lrf_in, x0, y0, (edges & R1O_SGR_EDGE_LEFT) && x0 > 0,
+                         (edges & R1O_SGR_EDGE_ABOVE) ? 0 : y0);
     /* a plane whose pixel (x0, y0) is tmp[0] */
     r1o_plane out = *lrf_in;
     out.data = tmp;

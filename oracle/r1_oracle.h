@@ -247,12 +247,16 @@ typedef struct {
 int r1o_lrf_filter_plane(const r1o_plane *cdeffed, const r1o_plane *deblocked, const r1o_plane *out,
                          int ydec, int crop_w, int crop_h, int frame_h, int unit_size, int unit_cols,
                          int unit_rows, int stripe_height, const r1o_lrf_unit *units, int bd);
+/* edges of a unit of the restoration search: which of its left / upper neighbourhood exists in the
+ * area rdo_loop_decision is working on (oracle/lrf.c, setup_integral_image) */
+#define R1O_SGR_EDGE_LEFT 1
+#define R1O_SGR_EDGE_ABOVE 2
 int r1o_lrf_search_unit(const r1o_plane *lrf_in, const r1o_plane *src, int x0, int y0, int w, int h,
-                        int set, int is_chroma, int xdec, int ydec, const uint32_t *scales,
+                        int set, int edges, int is_chroma, int xdec, int ydec, const uint32_t *scales,
                         int scale_stride, uint32_t dist_scale, int bd, int8_t *xqd_out,
                         uint64_t *err_out);
 void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0, int y0, int w, int h,
-                       int set, int bd, int8_t *xqd_out);
+                       int set, int edges, int bd, int8_t *xqd_out);
 void r1o_activity_scales(const r1o_plane *luma, uint32_t *variances, uint32_t *scales);
 /* plane.c: v_frame 0.3.9 Plane::pad / Plane::downsampled (see the header of plane.c) */
 void r1o_plane_pad(const r1o_plane *p, int w, int h, int xdec, int ydec);

@@ -79,8 +79,9 @@ assert ME_BLOCK_CAND.itemsize == 16 and ME_RESULT.itemsize == 16
 
 CFL_ALPHA_CAND = np.dtype([("x", "<i2"), ("y", "<i2"), ("variant", "u1"), ("vis_w", "u1"), ("vis_h", "u1"),
                            ("reserved", "u1")])
-SGR_SOLVE_UNIT = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("set", "u1"),
-                           ("reserved", "u1", (3,))])
+SGR_SOLVE_UNIT = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("set", "u1"), ("edges", "u1"),
+                           ("reserved", "u1", (2,))])
+SGR_EDGE_LEFT, SGR_EDGE_ABOVE = 1, 2   # R1_SGR_EDGE_*: see include/rav1e_amd.h, R1SgrSolveUnit
 assert SGR_SOLVE_UNIT.itemsize == 12
 
 

@@ -118,7 +118,18 @@ struct SgrTile {
   int x0, y0, uw, uh;      // the unit (restoration unit x stripe, or an RDO unit)
   int crop_w, crop_h;      // absolute crop of the plane / of the unit
   int cx0, ty0, tw, th;
+  // What setup_integral_image sees left of / above the unit (lrf.rs: `cdeffed.x == 0`, `clamp(y, 0, crop - 1)`): it
+  // asks where the unit's slice starts IN ITS PLANE.  The frame filter's plane is the frame: lu = 4 unless x0 == 0,
+  // top = 2 (rows above exist down to the plane's row 0).  The restoration search's plane is rdo_loop_decision's
+  // scratch copy of the AREA it is deciding (rdo.rs:2277-2296: no padding): a unit in the area's first unit column /
+  // row sees nothing left of / above itself, wherever the area lies in the frame -- the caller's edge flags.
+  int lu, top;             // real columns left of the unit (0 or 4) / real rows above it (0 or 2)
 };
+// R1SgrSolveUnit::edges -> (lu, top); a flag is void at the plane's own edge
+__device__ __forceinline__ void sgr_unit_edges(SgrTile &t, int edges) {
+  t.lu = (edges & R1_SGR_EDGE_LEFT) && t.x0 > 0 ? 4 : 0;
+  t.top = (edges & R1_SGR_EDGE_ABOVE) && t.y0 > 0 ? 2 : 0;
+}
 
 // Stage the padded tile, compute the (a, b) pairs of both passes, then hand every pixel of the tile to
 // `emit(x, y, p, f1, f2, extra)` (x, y tile-relative).
@@ -171,7 +182,7 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
     constexpr int SROWS = 256 / SW;          // rows per pass: a thread keeps its column
     const int jj = tid / SW, i = tid - jj * SW;   // S[j][i] <-> unit pixel (cx0 - x0 + i - 4, ty0 + j - 4)
     if (jj < SROWS) {
-      const int lu = t.x0 == 0 ? 0 : 4;
+      const int lu = t.lu;
       int ru = (t.crop_w - t.x0) - t.uw;
       ru = ru < 3 ? ru : 3;
       const int xa = t.x0 + clampi(t.cx0 - t.x0 + i - 4, -lu, t.uw + ru - 1);
@@ -183,7 +194,7 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
       for (int q = 0; q < NPASS; q++) {
         const int j = jj + q * SROWS;
         const int cy = clampi(t.y0 + t.ty0 + j - 4, 0, t.crop_h - 1);   // (rows past the tile clamp to a valid address)
-        const int ly = clampi(cy, t.y0 - 2, t.y0 + h2 + 1);
+        const int ly = clampi(cy, t.y0 - t.top, t.y0 + h2 + 1);
         const bool inside = ly >= t.y0 && ly < t.y0 + h2;
         if (one_plane) v[q] = ld_px_at<BPP>(inside_p, px_off<BPP>(inside_p, xa, ly));
         else v[q] = inside ? ld_px_at<BPP>(inside_p, px_off<BPP>(inside_p, xa, ly)) : ld_px_at<BPP>(outside_p, px_off<BPP>(outside_p, xa, ly));
@@ -357,6 +368,7 @@ __global__ __launch_bounds__(256) void k_lrf_sgr(R1Plane cdeffed, R1Plane debloc
   if (u.filter != 3) return;   // RESTORE_NONE: `out` already holds the CDEF output
   SgrTile t;
   t.x0 = x0; t.y0 = y0; t.uw = uw; t.uh = sh_;
+  t.lu = x0 == 0 ? 0 : 4; t.top = 2;
   t.crop_w = g.crop_w; t.crop_h = g.crop_h;
   t.cx0 = cx0; t.ty0 = 0;
   t.tw = (x0 + uw - cx0) < TW ? (x0 + uw - cx0) : TW;
@@ -389,6 +401,7 @@ __global__ __launch_bounds__(256) void k_sgr_moments(R1Plane cdeffed, R1Plane in
   if ((int)blockIdx.x >= ntx * nty || u.set > 15) return;   // workgroup-uniform (set 255: r1_lrf_search_batch's "no filter")
   SgrTile t;
   t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
+  sgr_unit_edges(t, u.edges);
   t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the unit (rdo.rs:2651-2666)
   const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
   t.cx0 = u.x + tx * TW;
@@ -545,6 +558,7 @@ __global__ __launch_bounds__(256) void k_sgr_unit_err(R1Plane lrf_in, R1Plane sr
   if ((int)blockIdx.x >= ntx * nty) return;   // workgroup-uniform
   SgrTile t;
   t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
+  sgr_unit_edges(t, u.edges);
   t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the unit (rdo.rs:2651-2666)
   const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
   t.cx0 = u.x + tx * TW;
@@ -589,7 +603,7 @@ __global__ __launch_bounds__(256) void k_sgr_unit_err(R1Plane lrf_in, R1Plane sr
 // Occupancy (ab9, ab10): with 32-row tiles an 8-bit workgroup holds 31 KB of LDS and 96 VGPRs -- five per CU -- and a
 // 16-bit one 35 KB -- four (three with the 64-row tile of round 4); no register hint is needed since the tile was rewritten
 template <int BPP, bool CHROMA, bool PACK>
-__global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane src,
+__global__ __launch_bounds__(256, BPP == 1 ? 5 : 1) void k_lrf_search_unit(R1Plane lrf_in, R1Plane src,
                                                          const R1SgrSolveUnit *__restrict__ units, int xdec, int ydec,
                                                          const uint32_t *__restrict__ scales, int scale_stride,
                                                          uint32_t dist_scale, int8_t *__restrict__ xqd_out,
@@ -638,7 +652,8 @@ __global__ __launch_bounds__(256) void k_lrf_search_unit(R1Plane lrf_in, R1Plane
     for (int tx = 0; tx < ntx; tx++) {
       SgrTile t;
       t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
-      t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the unit (rdo.rs:2651-2666)
+      sgr_unit_edges(t, u.edges);
+      t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // clipped to the unit on the right and below (rdo.rs:2651-2666)
       t.cx0 = u.x + tx * TW;
       t.ty0 = ty;
       t.tw = (u.w - tx * TW) < TW ? (u.w - tx * TW) : TW;

@@ -119,8 +119,8 @@ def lib():
         "r1o_deblock_pick_levels": (None, [vp, vp, i, vp]),
         "r1o_activity_scales": (None, [vp, vp, vp]),
         "r1o_lrf_filter_plane": (i, [vp, vp, vp, i, i, i, i, i, i, i, i, vp, i]),
-        "r1o_sgrproj_solve": (None, [vp, vp, i, i, i, i, i, i, vp]),
-        "r1o_lrf_search_unit": (i, [vp, vp, i, i, i, i, i, i, i, i, vp, i, C.c_uint32, i, vp, vp]),
+        "r1o_sgrproj_solve": (None, [vp, vp, i, i, i, i, i, i, i, vp]),
+        "r1o_lrf_search_unit": (i, [vp, vp, i, i, i, i, i, i, i, i, i, vp, i, C.c_uint32, i, vp, vp]),
         "r1o_estimate_motion_batch": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
         "r1o_rdo_full_cand_batch": (i, [vp, vp, i, i, i, vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp]),
         "r1o_cdef_strength_search": (i, [vp, vp, vp, i, i, i, vp, i, vp, vp, vp]),

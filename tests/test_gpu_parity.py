@@ -1575,13 +1575,13 @@ def test_sgrproj_solve_vs_oracle(ctx, oracle, bd):
     u = np.zeros(len(rects) * 16, SGR_SOLVE_UNIT)
     for i, (x, y, ww, hh) in enumerate(rects):
         for s in range(16):
-            u[i * 16 + s] = (x, y, ww, hh, s, (0, 0, 0))
+            u[i * 16 + s] = (x, y, ww, hh, s, (i + s) & 3, (0, 0))      # every R1_SGR_EDGE_* combination
     got = ctx.sgrproj_solve_batch(dev_plane(hc), dev_plane(hs), u).cpu().numpy()
     cc, cs = hc.cstruct(), hs.cstruct()
     for i in range(len(u)):
         want = np.zeros(2, np.int8)
         oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), int(u["x"][i]), int(u["y"][i]), int(u["w"][i]),
-                                 int(u["h"][i]), int(u["set"][i]), bd, want.ctypes.data)
+                                 int(u["h"][i]), int(u["set"][i]), int(u["edges"][i]), bd, want.ctypes.data)
         assert np.array_equal(got[i], want), (bd, u[i], got[i], want)
     assert len(np.unique(got, axis=0)) > 12      # the weights actually vary (not all clamped)
 
@@ -1596,22 +1596,31 @@ def test_sgrproj_solve_ref(ctx, bd):
     cases = REF["solve%d_cases" % bd]
     u = np.zeros(len(cases), SGR_SOLVE_UNIT)
     for i, (x0, y0, uw, uh, set_, q0, q1) in enumerate(cases.tolist()):
-        u[i] = (x0, y0, uw, uh, set_, (0, 0, 0))
+        u[i] = (x0, y0, uw, uh, set_, 3, (0, 0))     # the vectors were made on slices of the whole frame: LEFT | ABOVE
     got = ctx.sgrproj_solve_batch(dev_plane(hc), dev_plane(hs), u).cpu().numpy()
     assert np.array_equal(got.astype(np.int64), cases[:, 5:7].astype(np.int64)), (bd, got[:4], cases[:4])
 
 
-@pytest.mark.parametrize("case", ["s0", "s1", "s2", "s3"])
+def _lrf_search_cases():
+    L = np.load(os.path.join(GOLD, "loop_decision_ref.npz"))
+    return ["s0", "s1", "s2", "s3"] + sorted(k[:-5] for k in L.files if k.startswith("ldl") and k.endswith("_meta"))
+
+
+@pytest.mark.parametrize("case", _lrf_search_cases())
 def test_lrf_search_ref(ctx, case):
     """r1_lrf_search_batch (the restoration leg of rdo_loop_decision but the rate) on what
     setup_integral_image + sgrproj_solve + sgrproj_stripe_filter + rdo_loop_plane_error of the
     reference's own text returned: (xqd, err) per (unit, set) and the no-filter error, three planes
-    (lrf_search_ref.npz)"""
+    (lrf_search_ref.npz: the callees executed on slices of whole-frame planes -- everything around a unit exists,
+    R1_SGR_EDGE_LEFT | ABOVE) and on what rdo_loop_decision ITSELF, executed whole, made of its restoration leg
+    (loop_decision_ref.npz, cases ldl*: the units, their order, their visible sizes and which of them see pixels
+    left of / above themselves are that function's)"""
     import torch
     from rav1e_amd.api import SGR_SOLVE_UNIT
-    REF = np.load(os.path.join(GOLD, "lrf_search_ref.npz"))
+    REF = np.load(os.path.join(GOLD, "loop_decision_ref.npz" if case.startswith("ld") else "lrf_search_ref.npz"))
     W, H, xdec, ydec, bd, lru_sb = [int(v) for v in REF[case + "_meta"]]
     rows, want = REF[case + "_rows"], REF[case + "_err"]
+    edges = REF[case + "_edges"] if case + "_edges" in REF.files else np.full(len(rows), 3, np.uint8)
     scales = torch.from_numpy(REF[case + "_scales"].astype(np.int64).astype(np.int32)).cuda()
     for pli in range(3):
         hi = O.plane_from_image(REF[case + "_in%d" % pli].astype(np.int64), bd, 16, 16)
@@ -1619,8 +1628,8 @@ def test_lrf_search_ref(ctx, case):
         sel = rows[:, 0] == pli
         r = rows[sel]
         u = np.zeros(len(r), SGR_SOLVE_UNIT)
-        for i, (_, x, y, w, h, set_, q0, q1) in enumerate(r.tolist()):
-            u[i] = (x, y, w, h, set_, (0, 0, 0))
+        for i, ((_, x, y, w, h, set_, q0, q1), e) in enumerate(zip(r.tolist(), edges[sel].tolist())):
+            u[i] = (x, y, w, h, set_, e, (0, 0))
         xd, yd = (0, 0) if pli == 0 else (xdec, ydec)
         # units up to 64 x 64: the one-launch kernel; max 256: moments / solve / filter-and-error launches
         for mx in ([64, 256] if r[:, 3:5].max() <= 64 else [256]):
@@ -1638,7 +1647,7 @@ def test_lrf_entry_points_reject_planes_their_32_bit_offsets_cannot_address(ctx)
     from rav1e_amd.api import SGR_SOLVE_UNIT
     a, b = planes(8, seed=3)
     da, db = dev_plane(a), dev_plane(b)
-    u = np.array([(0, 0, 64, 64, 3, (0, 0, 0))], SGR_SOLVE_UNIT)
+    u = np.array([(0, 0, 64, 64, 3, 0, (0, 0))], SGR_SOLVE_UNIT)
     ctx.lrf_search_batch(da, db, u, max_w=64, max_h=64)                 # as it is: fine
     for field, value in (("stride", 1 << 24), ("alloc_height", 1 << 24)):
         keep = getattr(da, field)
@@ -1683,7 +1692,8 @@ def test_lrf_search_vs_oracle_frame_units(ctx, oracle, bd):
         for y in range(0, s_.shape[0], us):
             for x in range(0, s_.shape[1], us):
                 for set_ in (255, 2, 11, 14, 9):
-                    u.append((x, y, min(us, s_.shape[1] - x), min(us, s_.shape[0] - y), set_, (0, 0, 0)))
+                    u.append((x, y, min(us, s_.shape[1] - x), min(us, s_.shape[0] - y), set_, (x // us + 2 * (y // us) + set_) & 3,
+                              (0, 0)))                                # every R1_SGR_EDGE_* combination
         u = np.array(u, SGR_SOLVE_UNIT)
         xqd, err = ctx.lrf_search_batch(dev_plane(hi), dev_plane(hs), u, is_chroma=chroma, xdec=xd, ydec=yd,
                                         scales=dscales, dist_scale=21000, max_w=64, max_h=64)
@@ -1695,7 +1705,7 @@ def test_lrf_search_vs_oracle_frame_units(ctx, oracle, bd):
         wx, we = np.zeros((len(u), 2), np.int8), np.zeros(len(u), np.uint64)
         for i in range(len(u)):
             assert oracle.r1o_lrf_search_unit(C.byref(ci), C.byref(cs), int(u["x"][i]), int(u["y"][i]), int(u["w"][i]),
-                                              int(u["h"][i]), int(u["set"][i]), int(chroma), xd, yd, grid.ctypes.data,
+                                              int(u["h"][i]), int(u["set"][i]), int(u["edges"][i]), int(chroma), xd, yd, grid.ctypes.data,
                                               grid.shape[1], 21000, bd, wx[i].ctypes.data, we[i:].ctypes.data) == 0
         assert np.array_equal(xqd, wx), (bd, chroma)
         assert np.array_equal(err, we), (bd, chroma, np.argwhere(err != we)[:4].ravel())

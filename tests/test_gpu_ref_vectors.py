@@ -526,9 +526,15 @@ def test_me_ref_tile_motion_and_block_searches(ctx, name, launch_mode):
 
 
 # ---- a14: the CDEF strength search against the executed reference (gen_cdef_search_ref.py) ----
+def _cdef_search_file(name):
+    # ldc* / ldb*: the CDEF leg as rdo_loop_decision ITSELF, executed whole, ran it (gen_loop_decision_ref.py)
+    return os.path.join(GOLD, "loop_decision_ref.npz" if name.startswith("ld") else "cdef_search_ref.npz")
+
+
 def _cdef_search_cases():
-    S = np.load(os.path.join(GOLD, "cdef_search_ref.npz"))
-    return sorted(k[:-5] for k in S.files if k.endswith("_meta"))
+    S, L = np.load(os.path.join(GOLD, "cdef_search_ref.npz")), np.load(os.path.join(GOLD, "loop_decision_ref.npz"))
+    return sorted(k[:-5] for k in S.files if k.endswith("_meta")) + \
+        sorted(k[:-5] for k in L.files if k.startswith(("ldc", "ldb")) and k.endswith("_meta"))
 
 
 def run_cdef_search_gpu(ctx, rec, src, skip, scales, prm):
@@ -548,7 +554,7 @@ def run_cdef_search_gpu(ctx, rec, src, skip, scales, prm):
 def test_cdef_search_ref(ctx, name):
     """r1_cdef_strength_search on what cdef_filter_superblock + rdo_loop_plane_error of the
     reference's own text produced: every (superblock, index) error and every pick."""
-    S = np.load(os.path.join(GOLD, "cdef_search_ref.npz"))
+    S = np.load(_cdef_search_file(name))
     rec, src, skip, scales, prm, want_err, want_best = O.cdef_search_case(S, name)
     got_err, got_best = run_cdef_search_gpu(ctx, rec, src, skip, scales, prm)
     assert np.array_equal(got_best, want_best), (name, got_best, want_best)

@@ -9,8 +9,13 @@ import pytest
 
 import oracle_lib as O
 
-REF = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cdef_search_ref.npz"))
-CASES = sorted(k[:-5] for k in REF.files if k.endswith("_meta"))
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REF = dict(np.load(os.path.join(GOLDEN, "cdef_search_ref.npz")))
+# + the CDEF-only cases of loop_decision_ref.npz (ldc*) and the CDEF leg's first pass of its both-filters case (ldb*):
+# the same arrays, made by EXECUTING rdo_loop_decision itself (gen_loop_decision_ref.py)
+LOOP = np.load(os.path.join(GOLDEN, "loop_decision_ref.npz"))
+REF.update({k: LOOP[k] for k in LOOP.files if k.startswith(("ldc", "ldb"))})
+CASES = sorted(k[:-5] for k in REF if k.endswith("_meta"))
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -13,6 +13,7 @@ CASES = sorted(k[:-5] for k in G if k.endswith("_meta"))
 # the same frames filtered by the reference's own lrf_filter_frame text (tests/golden/gen_lrf_ref.py)
 # + sgrproj_solve results of the reference's text
 REF = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "lrf_ref.npz")))
+IN_FRAME = 3          # R1O_SGR_EDGE_LEFT | R1O_SGR_EDGE_ABOVE
 REF_CASES = sorted(k[:-5] for k in REF if k.endswith("_meta"))
 
 
@@ -66,7 +67,7 @@ def test_sgrproj_solve_matches_the_independent_model(oracle, bd):
     for (x0, y0, uw, uh) in ((0, 0, 24, 20), (32, 16, 28, 17), (64, 40, 24, 32)):
         for set_ in range(16):
             got = np.zeros(2, np.int8)
-            oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), x0, y0, uw, uh, set_, bd, got.ctypes.data)
+            oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), x0, y0, uw, uh, set_, IN_FRAME, bd, got.ctypes.data)
             want = L.solve_unit(cdef, src, x0, y0, uw, uh, set_, bd)
             assert tuple(int(v) for v in got) == want, (bd, x0, y0, set_, got, want)
 
@@ -89,16 +90,25 @@ def test_sgrproj_solve_equals_the_executed_reference(oracle, bd):
     cc, cs = pc.cstruct(), ps.cstruct()
     for (x0, y0, uw, uh, set_, q0, q1) in REF["solve%d_cases" % bd].tolist():
         got = np.zeros(2, np.int8)
-        oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), x0, y0, uw, uh, set_, bd, got.ctypes.data)
+        oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), x0, y0, uw, uh, set_, IN_FRAME, bd, got.ctypes.data)
         assert (int(got[0]), int(got[1])) == (q0, q1), (bd, x0, y0, uw, uh, set_, got, (q0, q1))
 
 
 # ---- the restoration leg of rdo_loop_decision (everything but the rate) -------------------------
-SEARCH = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lrf_search_ref.npz"))
+# Which pixels left of / above a unit the filter sees (oracle/lrf.c, setup_integral_image): the vectors made by calling
+# the reference's functions on slices of whole-frame planes (lrf_ref.npz's solve cases, lrf_search_ref.npz) are the
+# "everything around the unit exists" case -- LEFT | ABOVE, the left flag void at x = 0.  The vectors made by
+# executing rdo_loop_decision (loop_decision_ref.npz) carry the flags of each unit as that function set things up.
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SEARCH = dict(np.load(os.path.join(GOLDEN, "lrf_search_ref.npz")))
+# + the restoration-only cases of loop_decision_ref.npz: the same rows, but made by EXECUTING rdo_loop_decision itself
+# (gen_loop_decision_ref.py) instead of a hand-stated loop around its callees
+LOOP = np.load(os.path.join(GOLDEN, "loop_decision_ref.npz"))
+SEARCH.update({k: LOOP[k] for k in LOOP.files if k.startswith("ldl")})
 
 
 def search_cases():
-    return sorted({k.split("_")[0] for k in SEARCH.files})
+    return sorted(k[:-5] for k in SEARCH if k.endswith("_meta"))
 
 
 @pytest.mark.parametrize("case", search_cases())
@@ -107,16 +117,18 @@ def test_lrf_search_units_equal_the_executed_reference(oracle, case):
     sgrproj_stripe_filter + rdo_loop_plane_error of the reference's own text, unit by unit and set by
     set (and the "no filter option"), luma and both chroma planes (lrf_search_ref.npz)"""
     W, H, xdec, ydec, bd, lru_sb = [int(v) for v in SEARCH[case + "_meta"]]
+    assert len(SEARCH[case + "_rows"]) == len(SEARCH[case + "_err"]) > 20
     pin = [O.plane_from_image(SEARCH[case + "_in%d" % p].astype(np.int64), bd, 16, 16) for p in range(3)]
     psrc = [O.plane_from_image(SEARCH[case + "_src%d" % p].astype(np.int64), bd, 16, 16) for p in range(3)]
     scales = np.ascontiguousarray(SEARCH[case + "_scales"])
     dscale = SEARCH[case + "_dscale"]
     rows, errs = SEARCH[case + "_rows"], SEARCH[case + "_err"]
-    for (pli, x, y, w, h, set_, q0, q1), want in zip(rows, errs):
+    edges = SEARCH[case + "_edges"] if case + "_edges" in SEARCH else np.full(len(rows), IN_FRAME)
+    for (pli, x, y, w, h, set_, q0, q1), want, edge in zip(rows, errs, edges):
         xd, yd = (0, 0) if pli == 0 else (xdec, ydec)
         ci, cs = pin[pli].cstruct(), psrc[pli].cstruct()
         xqd, err = np.zeros(2, np.int8), np.zeros(1, np.uint64)
-        rc = oracle.r1o_lrf_search_unit(C.byref(ci), C.byref(cs), int(x), int(y), int(w), int(h), int(set_),
+        rc = oracle.r1o_lrf_search_unit(C.byref(ci), C.byref(cs), int(x), int(y), int(w), int(h), int(set_), int(edge),
                                         int(pli != 0), xd, yd, scales.ctypes.data, scales.shape[1],
                                         int(dscale[pli]), bd, xqd.ctypes.data, err.ctypes.data)
         assert rc == 0
@@ -129,7 +141,7 @@ def test_lrf_search_rejects_partial_blocks(oracle):
     p = O.plane_from_image(a, 8, 16, 16)
     c = p.cstruct()
     xqd, err = np.zeros(2, np.int8), np.zeros(1, np.uint64)
-    args = lambda w, h, s: (C.byref(c), C.byref(c), 0, 0, w, h, s, 0, 0, 0, None, 0, 1 << 14, 8, xqd.ctypes.data,
+    args = lambda w, h, s: (C.byref(c), C.byref(c), 0, 0, w, h, s, 0, 0, 0, 0, None, 0, 1 << 14, 8, xqd.ctypes.data,
                             err.ctypes.data)
     assert oracle.r1o_lrf_search_unit(*args(60, 64, 3)) == -1      # a width that cuts an 8x8 block
     assert oracle.r1o_lrf_search_unit(*args(64, 64, 16)) == -1     # no such parameter set

@@ -339,7 +339,7 @@ def main():
     cin = [Plane.from_numpy(W.random_plane_array(cw, ch, bd, 40 + i, 44, 44), cw, ch, bd, 44, 44) for i in range(4)]
 
     def unit_list(pw, ph, us_):
-        u = [(x, y, min(us_, pw - x), min(us_, ph - y), s_, (0, 0, 0))
+        u = [(x, y, min(us_, pw - x), min(us_, ph - y), s_, 0, (0, 0))
              for y in range(0, ph, us_) for x in range(0, pw, us_) for s_ in sets]
         return torch.from_numpy(np.array(u, api.SGR_SOLVE_UNIT).view(np.uint8).reshape(-1).copy()).cuda()
     ul, uc = unit_list(fw, fh, 64), unit_list(cw, ch, 32)

@@ -32,7 +32,7 @@ def main():
     scales = torch.from_numpy(np.random.default_rng(9).integers(1 << 12, 1 << 16, ((fh + 7) // 8, (fw + 7) // 8)).astype(np.int32)).cuda()
 
     def unit_list(pw, ph, us):
-        u = [(x, y, min(us, pw - x), min(us, ph - y), s_, (0, 0, 0)) for y in range(0, ph, us) for x in range(0, pw, us) for s_ in sets]
+        u = [(x, y, min(us, pw - x), min(us, ph - y), s_, 0, (0, 0)) for y in range(0, ph, us) for x in range(0, pw, us) for s_ in sets]
         return torch.from_numpy(np.array(u, api.SGR_SOLVE_UNIT).view(np.uint8).reshape(-1).copy()).cuda()
     ul, uc = unit_list(fw, fh, 64), unit_list(fw // 2, fh // 2, 32)
     luma = lambda: ctx.lrf_search_batch(planes[0][0], planes[0][1], ul, scales=scales, max_w=64, max_h=64)

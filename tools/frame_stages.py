@@ -321,7 +321,7 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
     rcfg = RG.restoration_plane_configs(fw, fh, 1, 1, qindex)
 
     def unit_list(cfg, dec):
-        u = [(x, y, w_, h_, s_, (0, 0, 0)) for (x, y, w_, h_) in RG.restoration_search_units(cfg, fw, fh, dec, dec)
+        u = [(x, y, w_, h_, s_, 0, (0, 0)) for (x, y, w_, h_) in RG.restoration_search_units(cfg, fw, fh, dec, dec)
              for s_ in LRF_SETS]
         return np.array(u, api.SGR_SOLVE_UNIT)
     h_ul, h_uc = unit_list(rcfg[0], 0), unit_list(rcfg[1], 1)
@@ -347,7 +347,7 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
             for i in sample(len(hu), 27):      # strided over (unit, set): every set appears
                 wx, we = np.zeros(2, np.int8), np.zeros(1, np.uint64)
                 assert L.r1o_lrf_search_unit(C.byref(pc), C.byref(sc), int(hu["x"][i]), int(hu["y"][i]), int(hu["w"][i]),
-                                             int(hu["h"][i]), int(hu["set"][i]), int(pl != 0), xd, xd, h_scales.ctypes.data,
+                                             int(hu["h"][i]), int(hu["set"][i]), int(hu["edges"][i]), int(pl != 0), xd, xd, h_scales.ctypes.data,
                                              h_scales.shape[1], 1 << 14, bd, wx.ctypes.data, we.ctypes.data) == 0
                 ok = ok and np.array_equal(xqd[i], wx) and int(err[i]) == int(we[0])
                 n_chk += 1

@@ -1530,5 +1530,20 @@ class PlaneRegion(RStruct):
         zero._0 = G["S_BlockOffset"](x=0, y=0)
         return self.to_frame_block_offset(zero)
 
+    def is_null(self):
+        return self.data is None
+
+    def home(self):
+        # plane_region.rs:325-338: the same pixels, the rectangle's origin moved to (0, 0)
+        return PlaneRegion(self.data, self.base, self.plane_cfg, 0, 0, self.rw, self.rh)
+
     def scratch_copy(self):
-        raise Panic("scratch_copy unsupported")
+        # plane_region.rs:390-401: a new plane without padding holding the rectangle's pixels
+        c = self.plane_cfg
+        ret = Plane.new(self.rw, self.rh, c.xdec, c.ydec, 0, 0)
+        ret.data = PlaneData(ret.data)
+        s = c.stride
+        for r in range(self.rh):
+            b = (ret.cfg.yorigin + r) * ret.cfg.stride + ret.cfg.xorigin
+            ret.data[b:b + self.rw] = list(self.data[self.base + r * s:self.base + r * s + self.rw])
+        return ret
