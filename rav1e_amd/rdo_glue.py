@@ -192,3 +192,41 @@ def restoration_search_units(cfg, crop_w, crop_h, dec_x=0, dec_y=0):
             if x < pw and y < ph:
                 out.append((x, y, min(us, pw - x), min(us, ph - y)))
     return out
+
+
+def restoration_area_sb(cfgs):
+    """The area one rdo_loop_decision call decides, in superblocks: the largest restoration unit of the planes
+    (src/rdo.rs:2119-2141).  cfgs: restoration_plane_configs(..)."""
+    return (max(1 << c["sb_h_shift"] for c in cfgs), max(1 << c["sb_v_shift"] for c in cfgs))
+
+
+SGR_EDGE_LEFT, SGR_EDGE_ABOVE = 1, 2
+
+
+def restoration_unit_edges(x, y, dec_x, dec_y, area_sb, sb_log2=6):
+    """R1SgrSolveUnit.edges of the unit at plane pixel (x, y): rdo_loop_decision filters on a scratch copy of the
+    area (src/rdo.rs:2277-2296), so setup_integral_image (src/lrf.rs: `cdeffed.x == 0`, `clamp(y, 0, ..)`) finds
+    pixels left of / above the unit exactly when the unit does not start the area's first unit column / row."""
+    aw, ah = (area_sb[0] << sb_log2) >> dec_x, (area_sb[1] << sb_log2) >> dec_y
+    return (SGR_EDGE_LEFT if x % aw else 0) | (SGR_EDGE_ABOVE if y % ah else 0)
+
+
+def compute_rd_cost(lam, rate, distortion):
+    """compute_rd_cost (src/rdo.rs:718-723): fi.lambda.mul_add(rate / 8, distortion) -- ONE rounding (f64 fused
+    multiply-add), reproduced here through exact rationals"""
+    from fractions import Fraction
+    return float(Fraction(float(lam)) * Fraction(int(rate), 8) + Fraction(int(distortion)))
+
+
+def pick_restoration_filter(options, lam, best_cost=-1.0):
+    """The choice of one restoration unit (src/rdo.rs:2617-2745).  options: [(rate, err)] in the order the leg tries
+    them -- the no-filter option first, then one per parameter set, err = what r1_lrf_search_batch returned, rate =
+    cw.fc.count_lrf_switchable for that option.  Returns (index into options or None when nothing beat best_cost,
+    the cost kept).  First smallest cost wins; the no-filter option also wins when no cost was kept before."""
+    pick = None
+    for i, (rate, err) in enumerate(options):
+        cost = compute_rd_cost(lam, rate, err)
+        if (i == 0 and best_cost < 0.0) or cost < best_cost:
+            best_cost, pick = cost, i
+    return pick, best_cost
+

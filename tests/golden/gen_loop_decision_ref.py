@@ -335,8 +335,7 @@ def main():
             ax = ay = 0
             cur = None
             first_pass = True
-            tried = set()
-            ntrial = {}
+            trials, done = {}, set()              # per superblock: trial indices seen so far / its final pass seen
             for i, (k, a, b, c_, d, e, f) in enumerate(tr.tolist()):
                 if k == 3:
                     ax, ay = a, b
@@ -344,17 +343,23 @@ def main():
                 elif k == 1:
                     first_pass = False
                 elif k == 2 and first_pass:
-                    cur = (ay + b, ax + a, c_)
-                    ntrial[cur[:2]] = ntrial.get(cur[:2], 0) + 1
-                    if ntrial[cur[:2]] > n_idx:      # the call after the n_idx trials: the final pass with the chosen index
+                    sb = (ay + b, ax + a)
+                    if sb in done:
+                        cur = None                # a later pass over the area
+                    elif c_ < trials.get(sb, 0):  # an index again: the final pass with the chosen index, not a trial
+                        done.add(sb)
                         cur = None
+                    else:
+                        trials[sb] = trials.get(sb, 0) + 1
+                        cur = sb + (c_,)
                 elif k == 0 and cur is not None and first_pass:
                     err[cur[0], cur[1], cur[2]] += te[i]
-                    tried.add(cur[:2])
+            tried = set(trials)
             best1 = np.full((sbh, sbw), -1, np.int8)
             for (sy, sx) in tried:
-                best1[sy, sx] = int(np.argmin(err[sy, sx, :n_idx]))     # "first smallest cost wins"; the rate is the same
-            if kind == "c":                                              # for every index (rdo.rs:2444-2456)
+                # "first smallest cost wins" over the indices the loop visited; the rate is the same for every index
+                best1[sy, sx] = int(np.argmin(err[sy, sx, :trials[(sy, sx)]]))
+            if kind == "c":
                 for sy in range(sbh):
                     for sx in range(sbw):
                         if (sy, sx) not in tried:

@@ -220,3 +220,37 @@ def test_lrf_search_fixture_follows_the_reference_text(tmp_path):
             "      SGRPROJ_XQD_MAX[1] as i32 - 60,\n    );\n    (xqd0 as i8, xqd1 as i8)", "b")
     assert not np.array_equal(m["s2_rows"], base["s2_rows"])                 # weights moved
 
+
+
+def test_loop_decision_fixture_follows_the_reference_text(tmp_path):
+    """loop_decision_ref.npz is what rdo_loop_decision's OWN text does, loop and all: the generator run on a scratch
+    copy of src/ with (a) the visible width of a restoration unit (rdo.rs:2645-2649) shortened by 8 changes the units'
+    rows and every error behind them; (b) the CDEF leg's trial loop cut to index 0 (rdo.rs:2394) leaves no error
+    for any other index and moves the picks.  One small case each."""
+    import shutil
+    import subprocess
+    src = tmp_path / "src"
+    shutil.copytree(REF, src)
+    gen = os.path.join(ROOT, "tests", "golden", "gen_loop_decision_ref.py")
+    base = np.load(os.path.join(ROOT, "tests", "golden", "loop_decision_ref.npz"))
+
+    def run(old, new, tag, case):
+        text = open(os.path.join(REF, "rdo.rs")).read()
+        assert text.count(old) == 1, old
+        (src / "rdo.rs").write_text(text.replace(old, new))
+        out = tmp_path / tag
+        out.mkdir()
+        env = dict(os.environ, R1_REF_SRC=str(src), R1_GOLDEN_OUT=str(out), R1_LOOP_DECISION_CASES=case)
+        subprocess.run([sys.executable, gen], check=True, env=env, cwd=os.path.dirname(gen), stdout=subprocess.DEVNULL,
+                       timeout=900)
+        (src / "rdo.rs").write_text(text)
+        return np.load(out / "loop_decision_ref.npz")
+    m = run("              let vis_width = unit_size.min(\n                (crop_w >> xdec)\n",
+            "              let vis_width = unit_size.min(\n                (crop_w >> xdec) - 8\n", "a", "ldl2")
+    assert m["ldl2_rows"].shape == base["ldl2_rows"].shape
+    assert (m["ldl2_rows"][:, 3] != base["ldl2_rows"][:, 3]).any()          # widths of the last unit column moved
+    assert (m["ldl2_err"] != base["ldl2_err"]).mean() > 0.3
+    m = run("          for cdef_index in 0..(1 << fi.cdef_bits) {", "          for cdef_index in 0..1 {", "b", "ldc2")
+    assert np.array_equal(m["ldc2_err"][:, :, 0], base["ldc2_err"][:, :, 0])
+    assert not m["ldc2_err"][:, :, 1:].any() and base["ldc2_err"][:, :, 1].any()
+    assert not np.array_equal(m["ldc2_best"], base["ldc2_best"])
