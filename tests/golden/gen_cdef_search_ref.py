@@ -14,6 +14,8 @@ test rdo.rs:2196-2211, cdef_index 0 .. (1 << cdef_bits) - 1, filter into the wor
 error of the three planes, rate 0, "first smallest cost wins"), the scratch copy of the area
 (rdo.rs:2277-2284: planes without padding), and the encoder-state containers (FrameInvariants
 fields, TileBlocks, the Tile / Frame wrappers), which are plain data here.
+(Round 5: gen_loop_decision_ref.py executes rdo_loop_decision itself; its CDEF-only cases go through the same tests and
+confirm this hand-stated loop.)
 
 Keys per case <c>: <c>_meta = [W, H, xdec, ydec, bd, damping, n_idx, area_sb_w, area_sb_h, planes],
 <c>_rec{0,1,2} / <c>_src{0,1,2} (whole-frame planes), <c>_skip (per 4x4), <c>_ystr / <c>_uvstr,

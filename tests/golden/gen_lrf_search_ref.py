@@ -15,6 +15,13 @@ copy itself (lrf_ref = a clone of the CDEF output) and the encoder-state contain
 choice (cw.fc.count_lrf_switchable: the entropy coder's CDFs) and the comparison of costs are NOT
 here: the device returns (xqd, error) per (unit, set) and the host adds its rate.
 
+Round 5: gen_loop_decision_ref.py executes rdo_loop_decision itself and showed what this hand-stated loop has
+DIFFERENT from it: the function filters every unit on a scratch copy of the AREA it is deciding, so the pixels left
+of / above a unit exist only inside that area; here setup_integral_image is handed slices of WHOLE-FRAME planes, so
+every unit with x > 0 / y > 0 sees its real neighbours.  These vectors therefore stand for "everything around the
+unit exists" (R1SgrSolveUnit.edges = LEFT | ABOVE, what a unit in the middle of a multi-unit area sees); the
+function's own behaviour is in loop_decision_ref.npz.
+
 Keys per case <c>: <c>_meta = [W, H, xdec, ydec, bd, lru_sb], <c>_in{0,1,2} (the CDEF output) /
 <c>_src{0,1,2}, <c>_scales (per 8x8 luma block, Q14), <c>_dscale (fi.dist_scale),
 <c>_rows = [pli, x, y, w, h, set (255 = no filter), xqd0, xqd1], <c>_err (u64, one per row).
