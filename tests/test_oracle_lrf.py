@@ -72,6 +72,35 @@ def test_sgrproj_solve_matches_the_independent_model(oracle, bd):
             assert tuple(int(v) for v in got) == want, (bd, x0, y0, set_, got, want)
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_edge_flags_equal_cropping_the_picture(oracle, bd):
+    """R1O_SGR_EDGE_*: a unit solved with a flag CLEAR must not depend on anything beyond that side -- it equals the
+    unit solved in a picture cropped there.  The independent model (tests/lrf_util.py: a unit inside a whole picture,
+    i.e. every neighbour it has is visible) run on the four crops gives the four flag combinations."""
+    import lrf_util as L
+    rng = np.random.default_rng(71 + bd)
+    h, w = 80, 96
+    yy, xx = np.mgrid[0:h, 0:w]
+    src = np.clip((np.sin(xx / 5.0) + np.cos(yy / 4.0) + 2) / 4 * ((1 << bd) - 1), 0, (1 << bd) - 1).astype(np.int64)
+    cdef = np.clip(src + rng.integers(-7, 8, (h, w)) * (1 << (bd - 8)), 0, (1 << bd) - 1)
+    x0, y0, uw, uh = 40, 24, 32, 24
+    cdef[:, x0 - 4:x0] = (1 << bd) - 1          # what lies just outside the unit is nothing like its inside:
+    cdef[y0 - 2:y0, :] = 0                      # seeing it or not must show in the weights
+    pc, ps = O.plane_from_image(cdef, bd, 16, 16), O.plane_from_image(src, bd, 16, 16)
+    cc, cs = pc.cstruct(), ps.cstruct()
+    seen = set()
+    for set_ in (0, 3, 7, 9, 10, 12, 14, 15):
+        for edges in range(4):
+            got = np.zeros(2, np.int8)
+            oracle.r1o_sgrproj_solve(C.byref(cc), C.byref(cs), x0, y0, uw, uh, set_, edges, bd, got.ctypes.data)
+            cx, cy = (x0 - 4 if edges & 1 else x0), (y0 - 2 if edges & 2 else y0)     # what is left of the crop
+            want = L.solve_unit(cdef[cy:, cx:], src[cy:, cx:], x0 - cx, y0 - cy, uw, uh, set_, bd)
+            assert tuple(int(v) for v in got) == want, (bd, set_, edges, got, want)
+            seen.add((set_, edges, want))
+    # the flags matter: for some set the four neighbourhoods give different weights
+    assert any(len({w_ for (s_, e_, w_) in seen if s_ == set_}) > 1 for set_ in (0, 3, 7, 9, 10, 12, 14, 15))
+
+
 @pytest.mark.parametrize("name", REF_CASES)
 def test_sgrproj_frames_equal_the_executed_reference(oracle, name):
     """oracle/lrf.c against RestorationState::lrf_filter_frame of the reference's own text"""
