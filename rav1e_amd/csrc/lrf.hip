@@ -601,7 +601,8 @@ __global__ __launch_bounds__(256) void k_sgr_unit_err(R1Plane lrf_in, R1Plane sr
 // PACK: both filter outputs of a pixel in one dword (f <= 16 * 1023 + rounding: up to 10 bits; at 12 bits an
 // all-white unit reaches 65588)
 // Occupancy (ab9, ab10): with 32-row tiles an 8-bit workgroup holds 31 KB of LDS and 96 VGPRs -- five per CU -- and a
-// 16-bit one 35 KB -- four (three with the 64-row tile of round 4); no register hint is needed since the tile was rewritten
+// 16-bit one 35 KB -- four (three with the 64-row tile of round 4).  The 8-bit kernels are asked for five: with the unit's
+// edge flags (t.lu / t.top) they would settle at 106 VGPRs otherwise; the request costs 12 B of scratch
 template <int BPP, bool CHROMA, bool PACK>
 __global__ __launch_bounds__(256, BPP == 1 ? 5 : 1) void k_lrf_search_unit(R1Plane lrf_in, R1Plane src,
                                                          const R1SgrSolveUnit *__restrict__ units, int xdec, int ydec,
