@@ -38,7 +38,7 @@ Cases, in the formats the existing tests read:
   restoration working copy; value in _trace_err), 1 = solve (set, px, py, vis_w, vis_h, xqd0 * 256 + (xqd1 & 255)),
   2 = cdef_filter_superblock (loop_sbx, loop_sby, index), 3 = area start (sbx0, sby0)
 
-Run in the build container:  python tests/golden/gen_loop_decision_ref.py      (about 10 minutes)
+Run in the build container:  python tests/golden/gen_loop_decision_ref.py      (about 3 minutes)
 """
 import os
 import time
