@@ -50,3 +50,31 @@ def test_enum_values_match_reference_order():
     assert TxSize.TX_64X64 == 4 and TxSize.TX_64X16 == 18 and TxSize.TX_4X16 == 13
     assert TxType.IDTX == 9 and TxType.WHT_WHT == 16
     assert TxSize.TX_16X64.dims == (16, 64)
+
+
+def test_numpy_candidate_layouts_equal_the_header_compiled_as_c(tmp_path):
+    """include/rav1e_amd.h compiled by gcc AS C (the boundary is a C ABI): sizeof and the offset of every field of the
+    candidate / unit structs the Python host mirrors as numpy dtypes -- a renamed or re-ordered field on either side
+    fails here, without a GPU"""
+    import subprocess
+    from rav1e_amd import api
+    pairs = {"R1DistCand": api.DIST_CAND, "R1McCand": api.MC_CAND, "R1RdoCand": api.RDO_CAND,
+             "R1IntraEdgeCand": api.INTRA_EDGE_CAND, "R1IntraCand": api.INTRA_CAND, "R1CflAcCand": api.CFL_AC_CAND,
+             "R1CflAlphaCand": api.CFL_ALPHA_CAND, "R1CdefBlockCand": api.CDEF_BLOCK_CAND,
+             "R1MeBlockCand": api.ME_BLOCK_CAND, "R1MeResult": api.ME_RESULT, "R1SgrSolveUnit": api.SGR_SOLVE_UNIT}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rav1e_amd.h"', 'int main(void) {']
+    for cname, dt in pairs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in dt.names:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l}
+    for cname, dt in pairs.items():
+        assert got[(cname, "size")] == dt.itemsize, (cname, got[(cname, "size")], dt.itemsize)
+        for f in dt.names:
+            assert got[(cname, f)] == dt.fields[f][1], (cname, f, got[(cname, f)], dt.fields[f][1])
