@@ -62,11 +62,19 @@ def test_numpy_candidate_layouts_equal_the_header_compiled_as_c(tmp_path):
              "R1IntraEdgeCand": api.INTRA_EDGE_CAND, "R1IntraCand": api.INTRA_CAND, "R1CflAcCand": api.CFL_AC_CAND,
              "R1CflAlphaCand": api.CFL_ALPHA_CAND, "R1CdefBlockCand": api.CDEF_BLOCK_CAND,
              "R1MeBlockCand": api.ME_BLOCK_CAND, "R1MeResult": api.ME_RESULT, "R1SgrSolveUnit": api.SGR_SOLVE_UNIT}
+    from rav1e_amd import _lib
+    structs = {n: getattr(_lib, n) for n in dir(_lib)          # the ctypes mirrors of the parameter structs
+               if n.startswith("R1") and isinstance(getattr(_lib, n), type) and issubclass(getattr(_lib, n), C.Structure)}
+    assert len(structs) >= 7
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rav1e_amd.h"', 'int main(void) {']
     for cname, dt in pairs.items():
         lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
         for f in dt.names:
             lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    for cname, st in structs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, *_ in st._fields_:       # (a trailing underscore on the Python side: `lambda` is a keyword there)
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f.rstrip("_")))
     lines += ['  return 0;', '}']
     src = tmp_path / "layout.c"
     src.write_text("\n".join(lines))
@@ -78,3 +86,7 @@ def test_numpy_candidate_layouts_equal_the_header_compiled_as_c(tmp_path):
         assert got[(cname, "size")] == dt.itemsize, (cname, got[(cname, "size")], dt.itemsize)
         for f in dt.names:
             assert got[(cname, f)] == dt.fields[f][1], (cname, f, got[(cname, f)], dt.fields[f][1])
+    for cname, st in structs.items():
+        assert got[(cname, "size")] == C.sizeof(st), (cname, got[(cname, "size")], C.sizeof(st))
+        for f, *_ in st._fields_:
+            assert got[(cname, f)] == getattr(st, f).offset, (cname, f, got[(cname, f)], getattr(st, f).offset)
