@@ -671,7 +671,8 @@ int r1_lrf_sgrproj_plane(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *deb
  * (rdo_loop_decision, src/rdo.rs:2651-2676): for each (restoration unit,
  * parameter set) pair the least-squares projection weights xqd of the
  * self-guided filter of `cdeffed` towards `input` (the source frame), the
- * unit hard-clipped at its right / bottom edge, no stripes.  units (DEVICE):
+ * unit hard-clipped at its right / bottom edge, its left / upper neighbourhood
+ * as the unit's `edges` say (below), no stripes.  units (DEVICE):
  * (x, y, w, h) in plane pixels, w <= max_w, h <= max_h (<= 384); xqd_out:
  * 2 int8 per pair; moments_scratch: 5 int64 per pair (device; zeroed here).
  * The moments are exact integers, the 2x2 solve is done in IEEE doubles with
