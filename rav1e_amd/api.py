@@ -852,8 +852,8 @@ class Context:
                     "r1_lrf_sgrproj_plane")
 
     def sgrproj_solve_batch(self, cdeffed, inp, units, max_w=256, max_h=256):
-        """sgrproj_solve (src/lrf.rs:847-1096) for (unit, set) pairs; units: SGR_SOLVE_UNIT array
-        -> (n, 2) int8 xqd"""
+        """sgrproj_solve (src/lrf.rs:847-1096) for (unit, set) pairs; units: SGR_SOLVE_UNIT array (`edges`: SGR_EDGE_* --
+        the unit's place in its rdo_loop_decision area, rdo_glue.restoration_unit_edges) -> (n, 2) int8 xqd"""
         dc = _dev_cands(units, SGR_SOLVE_UNIT)
         n = dc.numel() // SGR_SOLVE_UNIT.itemsize
         scratch = torch.empty(n * 5, dtype=torch.int64, device="cuda")
@@ -867,7 +867,8 @@ class Context:
     def lrf_search_batch(self, lrf_in, src, units, is_chroma=False, xdec=0, ydec=0, scales=None, dist_scale=1 << 14,
                          max_w=256, max_h=256):
         """the restoration leg of rdo_loop_decision for one plane (src/rdo.rs:2575-2763) but the rate:
-        units: SGR_SOLVE_UNIT array (set 255 = the no-filter option); scales: 2-D int32/uint32 device
+        units: SGR_SOLVE_UNIT array (set 255 = the no-filter option; `edges` from rdo_glue.restoration_unit_edges, 0 for
+        one unit per plane and area; list the sets of a unit next to each other); scales: 2-D int32/uint32 device
         tensor (one DistortionScale per 8x8 luma block) or None -> ((n, 2) int8 xqd, (n,) int64 err)"""
         dc = _dev_cands(units, SGR_SOLVE_UNIT)
         n = dc.numel() // SGR_SOLVE_UNIT.itemsize
