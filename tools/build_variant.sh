@@ -2,7 +2,7 @@
 # Experiment builds of the headline kernel: tools/build_variant.sh NAME [-DFLAG ...]
 #   -> build/lib_NAME.so = the current objects with rdo_cand.hip recompiled (headline
 #      instantiations only, so that a variant builds in well under a minute) with the flags.
-# A/B on one GPU box: gpurun -- bash tools/gpu_r5.sh TAG bench_ab:build/lib_A.so,build/lib_B.so
+# A/B on one GPU box: gpurun -- bash tools/gpu_lease.sh TAG bench_ab:build/lib_A.so,build/lib_B.so
 set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../rav1e_amd/csrc"

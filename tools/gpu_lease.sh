@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 5: ONE parameterised lease script (the one-off tools/gpu_r3_* / gpu_r4_* scripts are gone).
-#   gpurun -- bash tools/gpu_r5.sh TAG STEP [STEP ...]        -> gpurun_out/TAG/
+# ONE parameterised lease script (the one-off tools/gpu_r3_* / gpu_r4_* scripts are gone).
+#   gpurun -- bash tools/gpu_lease.sh TAG STEP [STEP ...]        -> gpurun_out/TAG/
 # steps:
 #   tests         pytest -m gpu (whole suite)
 #   tests:EXPR    pytest -m gpu -k EXPR
@@ -47,12 +47,17 @@ for STEP in "$@"; do
       if [ -n "$ARG" ]; then timeout 1800 python -m pytest tests -m gpu -x -q -k "$ARG" 2>&1 | tail -15 | tee $OUT/pytest_gpu_k.log
       else timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $OUT/pytest_gpu.log; fi ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.log ;;
-    bench) timeout 1200 python bench.py 2>$OUT/bench.err | grep "^{" | tee $OUT/bench.json | cut -c1-400 ;;
+    bench) timeout 1200 python bench.py --detail-out gpurun_out/$TAG/bench_detail.json 2>$OUT/bench.err | grep "^{" | tee $OUT/bench.json | cut -c1-400
+           python3 -c "
+import json; s=open('$OUT/bench.json').read(); d=json.loads(s); print('compact bytes', len(s), 'lines', len(s.strip().splitlines()), 'roofline' in d, 'cpu_baseline' in d)
+for e in d['extra_lines']: print(' ', e['name'], e['value'], e.get('unit','Mpx/s'), e['ms_per_step'], e['parity_ok'], e.get('cpu'))" ;;
+    bench_driver)   # exactly the driver's command
+           timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail-out gpurun_out/$TAG/bench_driver_detail.json 2>$OUT/bench_driver.err | tee $OUT/bench_driver.json | wc -c ;;
     chains)
       for bd in 8 10; do
-        [ $bd = 10 ] && timeout 600 python bench.py --cpu-seconds 0 --no-extra --bit-depth 10 2>/dev/null | grep "^{" > $OUT/bench_10bit.json
+        [ $bd = 10 ] && timeout 600 python bench.py --cpu-seconds 0 --no-extra --bit-depth 10 --detail-out gpurun_out/$TAG/bench_10bit_detail.json 2>/dev/null | grep "^{" > $OUT/bench_10bit.json
         for chain in full pixel; do
-          timeout 600 python bench.py --cpu-seconds 0 --chain $chain --bit-depth $bd 2>/dev/null | grep "^{" > $OUT/${chain}_chain_${bd}bit.json
+          timeout 600 python bench.py --cpu-seconds 0 --chain $chain --bit-depth $bd --detail-out gpurun_out/$TAG/${chain}_chain_${bd}bit_detail.json 2>/dev/null | grep "^{" > $OUT/${chain}_chain_${bd}bit.json
           python3 -c "
 import json; d=json.loads(open('$OUT/${chain}_chain_${bd}bit.json').read()); print('$chain $bd', d.get('value'), d.get('kernel_ms'), d.get('rdo_only',{}).get('value'))"
         done

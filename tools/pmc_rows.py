@@ -2,7 +2,7 @@
 """One rocprofv3 counter_collection.csv -> JSON on stdout: per kernel (template arguments kept), the average
 of every counter per dispatch, the dispatch count, the average dispatch duration of that pass and, where the
 pass has them, the derived figures (VALU instructions per wave, LDS bank-conflict share, HBM bytes with the
-gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md "HBM").  Used by tools/gpu_r5.sh (pmc_* steps)."""
+gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md "HBM").  Used by tools/gpu_lease.sh (pmc_* steps)."""
 import collections
 import csv
 import json
