@@ -387,6 +387,62 @@ int r1_cdef_strength_search(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src,
                             const R1CdefSearchParams *params, uint64_t *err_out,
                             int8_t *best_out, void *scratch, void *stream);
 
+/* ---- rdo_loop_decision with BOTH filters on: the later passes of its CDEF leg, and the working copy
+ * (src/rdo.rs:2366-2574; BASELINE configs[3]: speed 4 enables cdef and lrf,
+ * src/api/config/speedsettings.rs:78-79,168-171).  The reference alternates the two legs until no
+ * choice changes.  From the second pass on a restoration unit may hold a self-guided choice, and every
+ * CDEF trial of a superblock under it then goes (rdo.rs:2407-2530)
+ *   cdef_filter_superblock(index)  ->  per plane: setup_integral_image on THAT SUPERBLOCK of the working
+ *   copy (crop = the superblock: hard-clipped right and below; 4 columns left / 2 rows above from the
+ *   working copy when the superblock is not first in its area) -> sgrproj_stripe_filter(set, xqd of the
+ *   unit's current choice) -> rdo_loop_plane_error of the RESTORED superblock,
+ * planes without such a choice as in the first pass (error of the CDEF output itself).
+ *
+ * r1_cdef_lrf_trial_batch: ONE call per pass for every (superblock, index) of the frame.
+ *   rec / src / skip_mi / scales / params / err_out / best_out: as r1_cdef_strength_search (with no
+ *     units the two calls return the same numbers);
+ *   units (DEVICE): the superblocks whose restoration unit holds a self-guided choice -- n_units[0]
+ *     luma entries, then n_units[1] of U, then n_units[2] of V (n_units: HOST, 3 ints).  (x, y, w, h):
+ *     the superblock's visible rectangle in pixels of that plane (w = vis_width, h = vis_height,
+ *     rdo.rs:2415-2428; multiples of 8 >> dec), set / xqd: the choice, edges: R1_SGR_EDGE_LEFT when the
+ *     superblock is not in column 0 of its area, R1_SGR_EDGE_ABOVE when not in row 0, sb = fby * n_sbx + fbx;
+ *   cdef_cur: the area working copies as r1_cdef_apply_area leaves them (read only where an edge flag is
+ *     set; any valid planes otherwise);
+ *   sb_sel (DEVICE, n_sb bytes, NULL = all): superblocks to evaluate.  In an area of several
+ *     superblocks a trial reads its left / upper neighbours' CURRENT output, which the same pass may
+ *     just have changed: such a host walks the area positions in raster order -- one call per position
+ *     with that position selected, r1_cdef_apply_area in between; areas of one superblock (64-pixel
+ *     luma units, every qindex <= 160) need one call;
+ *   err_planes_out (optional): [n_sb][8][3] the per-plane ScaledDistortion terms of err_out;
+ *   scratch: r1_cdef_lrf_trial_scratch_bytes() bytes -- it holds the trial output of every index as
+ *     whole planes (n_idx x frame), which the restoration trial reads back.
+ * The rate of a trial is the same for every index of a superblock (rdo.rs:2444-2456, 2499-2503): the
+ * host adds it to err_out before comparing costs when it wants the reference's f64 rounding;
+ * best_out compares the errors alone.
+ *
+ * r1_cdef_apply_area: cdef_filter_superblock with index_sb[sb] for every superblock into `out` -- the
+ * CDEF working copy of every area at once (rdo.rs:2546-2560: "keep cdef output up to date"), the input
+ * of the restoration leg (rdo.rs:2575-2582).  Superblocks with index < 0 or completely skipped, and
+ * skipped 8x8 blocks, are copied from rec.  Areas' borders are picture edges as in the search.  Only
+ * pixels of 8x8 blocks inside the block grid are written.  scratch: r1_cdef_strength_search_scratch_bytes(). */
+typedef struct R1TrialUnit {
+  int16_t x, y, w, h;
+  uint8_t set, edges;
+  int8_t xqd[2];
+  int32_t sb;
+} R1TrialUnit;
+long long r1_cdef_lrf_trial_scratch_bytes(int mi_cols, int mi_rows, int xdec, int ydec,
+                                          int bytes_per_px, int n_idx, int planes);
+int r1_cdef_lrf_trial_batch(r1_ctx *ctx, const R1Plane *rec, const R1Plane *cdef_cur, const R1Plane *src,
+                            const uint8_t *skip_mi, int mi_stride, int mi_cols, int mi_rows,
+                            const uint32_t *scales, int scale_stride, const R1CdefSearchParams *params,
+                            const R1TrialUnit *units, const int32_t *n_units, const uint8_t *sb_sel,
+                            uint64_t *err_out, uint64_t *err_planes_out, int8_t *best_out, void *scratch,
+                            void *stream);
+int r1_cdef_apply_area(r1_ctx *ctx, const R1Plane *rec, const R1Plane *out, const uint8_t *skip_mi,
+                       int mi_stride, int mi_cols, int mi_rows, const R1CdefSearchParams *params,
+                       const int8_t *index_sb, void *scratch, void *stream);
+
 /* ---- lookahead cost maps (SURVEY.md 8f "N1"; reference:
  * estimate_intra_costs src/api/lookahead.rs:30-123,
  * estimate_importance_block_difference 125-180, the SATD map of

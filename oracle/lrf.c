@@ -307,6 +307,58 @@ void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0,
   xqd_out[1] = (int8_t)xqd1;
 }
 
+/* rdo_loop_plane_error's sum over the blocks of a rectangle (src/rdo.rs:2027-2093), before
+ * `* fi.dist_scale[pli]`: `test` = the pixels under test, pixel (x0, y0) of the plane at test[0],
+ * row stride tstride pixels.  Per 8x8-luma block: cdef_dist_kernel * bias (luma) / sse_wxh with
+ * |_, _| bias on (8 >> xdec) x (8 >> ydec) pixels (chroma). */
+uint64_t r1o_loop_plane_error_rect(const r1o_plane *src, const void *test, int tstride, int x0, int y0,
+                                   int w, int h, int is_chroma, int xdec, int ydec, const uint32_t *scales,
+                                   int scale_stride, int bd) {
+  const int bw = 8 >> xdec, bh = 8 >> ydec, hbd = src->bytes_per_px == 2;
+  const size_t bpp = (size_t)src->bytes_per_px;
+  uint64_t plane_sum = 0;
+  for (int by = 0; by < h / bh; by++)
+    for (int bx = 0; bx < w / bw; bx++) {
+      const int px_ = x0 + bx * bw, py_ = y0 + by * bh;
+      const uint8_t *spx = (const uint8_t *)src->data +
+                           ((size_t)(src->yorigin + py_) * src->stride + src->xorigin + px_) * bpp;
+      const uint8_t *tpx = (const uint8_t *)test + ((size_t)by * bh * tstride + (size_t)bx * bw) * bpp;
+      const uint32_t bias = scales ? scales[(size_t)((py_ << ydec) >> 3) * scale_stride + ((px_ << xdec) >> 3)]
+                                   : (1u << 14);
+      if (!is_chroma) {
+        const uint64_t raw = r1o_cdef_dist_kernel(spx, src->stride, tpx, tstride, 8, 8, bd, hbd);
+        plane_sum += ((uint64_t)bias * raw + 8192) >> 14;               /* RawDistortion * bias */
+      } else {
+        uint32_t cell[4] = {bias, bias, bias, bias};                      /* sse_wxh: |_, _| bias */
+        plane_sum += r1o_get_weighted_sse(spx, src->stride, tpx, tstride, cell, 2, bw, bh, hbd);
+      }
+    }
+  return plane_sum;
+}
+
+/* A restoration unit's CURRENT choice applied to one rectangle of `plane`, as the later passes of
+ * rdo_loop_decision's CDEF leg do to the superblock under trial (src/rdo.rs:2458-2489):
+ * setup_integral_image with crop = stripe = the rectangle (hard-clipped right and below; left /
+ * above per `edges`, read from the same plane -- the area's working copy), sgrproj_stripe_filter
+ * with (set, xqd).  out: w * h pixels, dense. */
+int r1o_sgr_filter_rect(const r1o_plane *plane, int x0, int y0, int w, int h, int set, const int8_t *xqd,
+                        int edges, int bd, void *out_px) {
+  if (w <= 0 || h <= 0 || w > IMG_MAX || set < 0 || set > 15) return -1;
+  const int rows = h + (h & 1) + 6;
+  uint32_t *ii = (uint32_t *)calloc((size_t)IMG_STRIDE * rows * 2, sizeof(uint32_t));
+  uint32_t *sq = ii + (size_t)IMG_STRIDE * rows;
+  setup_integral_image(ii, sq, x0 + w, y0 + h, w, h, plane, plane, x0, y0, (edges & R1O_SGR_EDGE_LEFT) && x0 > 0,
+                       (edges & R1O_SGR_EDGE_ABOVE) ? 0 : y0);
+  r1o_plane out = *plane;
+  out.data = out_px;
+  out.stride = w;
+  out.xorigin = -x0;
+  out.yorigin = -y0;
+  stripe_filter(set, xqd, bd, ii, sq, plane, &out, x0, y0, w, h);
+  free(ii);
+  return 0;
+}
+
 /* The restoration leg of rdo_loop_decision for ONE plane, one (restoration unit, parameter set)
  * pair -- everything but the entropy coder's rate (src/rdo.rs:2575-2763):
  *   set < 16: sgrproj_solve on the unit (above), then the unit filtered with the weights it
@@ -330,7 +382,7 @@ int r1o_lrf_search_unit(const r1o_plane *lrf_in, const r1o_plane *src, int x0, i
                         int set, int edges, int is_chroma, int xdec, int ydec, const uint32_t *scales,
                         int scale_stride, uint32_t dist_scale, int bd, int8_t *xqd_out,
                         uint64_t *err_out) {
-  const int bw = 8 >> xdec, bh = 8 >> ydec, hbd = lrf_in->bytes_per_px == 2;
+  const int bw = 8 >> xdec, bh = 8 >> ydec;
   if (w <= 0 || h <= 0 || w > IMG_MAX || w % bw || h % bh || (set != 255 && (set < 0 || set > 15))) return -1;
   if (!is_chroma && (xdec || ydec)) return -1;
   const size_t bpp = (size_t)lrf_in->bytes_per_px;
@@ -358,23 +410,8 @@ int r1o_lrf_search_unit(const r1o_plane *lrf_in, const r1o_plane *src, int x0, i
     stripe_filter(set, xqd_out, bd, ii, sq, lrf_in, &out, x0, y0, w, h);
     free(ii);
   }
-  uint64_t plane_sum = 0;
-  for (int by = 0; by < h / bh; by++)
-    for (int bx = 0; bx < w / bw; bx++) {
-      const int px_ = x0 + bx * bw, py_ = y0 + by * bh;
-      const uint8_t *spx = (const uint8_t *)src->data +
-                           ((size_t)(src->yorigin + py_) * src->stride + src->xorigin + px_) * bpp;
-      const uint8_t *tpx = tmp + ((size_t)by * bh * w + (size_t)bx * bw) * bpp;
-      const uint32_t bias = scales ? scales[(size_t)((py_ << ydec) >> 3) * scale_stride + ((px_ << xdec) >> 3)]
-                                   : (1u << 14);
-      if (!is_chroma) {
-        const uint64_t raw = r1o_cdef_dist_kernel(spx, src->stride, tpx, w, 8, 8, bd, hbd);
-        plane_sum += ((uint64_t)bias * raw + 8192) >> 14;               /* RawDistortion * bias */
-      } else {
-        uint32_t cell[4] = {bias, bias, bias, bias};                      /* sse_wxh: |_, _| bias */
-        plane_sum += r1o_get_weighted_sse(spx, src->stride, tpx, w, cell, 2, bw, bh, hbd);
-      }
-    }
+  const uint64_t plane_sum = r1o_loop_plane_error_rect(src, tmp, w, x0, y0, w, h, is_chroma, xdec, ydec, scales,
+                                                       scale_stride, bd);
   free(tmp);
   *err_out = ((uint64_t)dist_scale * plane_sum + 8192) >> 14;            /* Distortion * dist_scale */
   return 0;

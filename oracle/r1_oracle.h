@@ -255,6 +255,24 @@ int r1o_lrf_search_unit(const r1o_plane *lrf_in, const r1o_plane *src, int x0, i
                         int set, int edges, int is_chroma, int xdec, int ydec, const uint32_t *scales,
                         int scale_stride, uint32_t dist_scale, int bd, int8_t *xqd_out,
                         uint64_t *err_out);
+uint64_t r1o_loop_plane_error_rect(const r1o_plane *src, const void *test, int tstride, int x0, int y0,
+                                   int w, int h, int is_chroma, int xdec, int ydec, const uint32_t *scales,
+                                   int scale_stride, int bd);
+int r1o_sgr_filter_rect(const r1o_plane *plane, int x0, int y0, int w, int h, int set, const int8_t *xqd,
+                        int edges, int bd, void *out_px);
+/* loop_decision.c: rdo_loop_decision with both filters on (src/rdo.rs:2377-2560) */
+typedef struct r1o_trial_unit {
+  int16_t x, y, w, h;
+  uint8_t set, edges;
+  int8_t xqd[2];
+  int32_t sb;
+} r1o_trial_unit;
+int r1o_cdef_apply_area(const r1o_plane *rec, const r1o_plane *out, const uint8_t *skip_mi, int mi_stride,
+                        int mi_cols, int mi_rows, const r1o_cdef_search_params *p, const int8_t *index_sb);
+int r1o_cdef_lrf_trial(const r1o_plane *rec, const r1o_plane *work, const r1o_plane *src, const uint8_t *skip_mi,
+                       int mi_stride, int mi_cols, int mi_rows, const uint32_t *scales, int scale_stride,
+                       const r1o_cdef_search_params *p, const r1o_trial_unit *units, const int32_t *n_units,
+                       const uint8_t *sb_sel, uint64_t *err, uint64_t *err_planes, int8_t *best);
 void r1o_sgrproj_solve(const r1o_plane *cdeffed, const r1o_plane *input, int x0, int y0, int w, int h,
                        int set, int edges, int bd, int8_t *xqd_out);
 void r1o_activity_scales(const r1o_plane *luma, uint32_t *variances, uint32_t *scales);

@@ -79,6 +79,10 @@ SYMBOLS = {
                                              _vp, _i, C.POINTER(R1CdefParams), _vp]),
     "r1_cdef_strength_search_scratch_bytes": (C.c_longlong, [_i, _i]),
     "r1_cdef_strength_search": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "r1_cdef_lrf_trial_scratch_bytes": (C.c_longlong, [_i, _i, _i, _i, _i, _i, _i]),
+    "r1_cdef_lrf_trial_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp]),
+    "r1_cdef_apply_area": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "r1_estimate_intra_costs": (_i, [_vp, _PP, _vp, _vp]),
     "r1_estimate_inter_costs": (_i, [_vp, _PP, _PP, _vp, _vp, _vp]),
     "r1_importance_block_difference": (_i, [_vp, _PP, _PP, _vp, _vp]),

@@ -83,6 +83,10 @@ SGR_SOLVE_UNIT = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"
                            ("reserved", "u1", (2,))])
 SGR_EDGE_LEFT, SGR_EDGE_ABOVE = 1, 2   # R1_SGR_EDGE_*: see include/rav1e_amd.h, R1SgrSolveUnit
 assert SGR_SOLVE_UNIT.itemsize == 12
+# R1TrialUnit: a superblock whose restoration unit holds a self-guided choice (r1_cdef_lrf_trial_batch)
+TRIAL_UNIT = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("set", "u1"), ("edges", "u1"),
+                       ("xqd", "i1", (2,)), ("sb", "<i4")])
+assert TRIAL_UNIT.itemsize == 16
 
 
 def me_lambdas(me_lambda):
@@ -435,6 +439,71 @@ class Context:
             scales.stride(0) if scales is not None else 0, C.byref(prm), err.data_ptr(), best.data_ptr(),
             scratch.data_ptr(), _stream_ptr()), "r1_cdef_strength_search")
         return err, best
+
+    def _cdef_search_params(self, n_planes, y_strengths, uv_strengths, damping, bit_depth, n_idx, xdec, ydec, crop_w,
+                            crop_h, area_sb, dist_scale):
+        prm = _lib.R1CdefSearchParams()
+        for i in range(8):
+            prm.y_strengths[i] = int(y_strengths[i])
+            prm.uv_strengths[i] = int(uv_strengths[i])
+        prm.damping, prm.bit_depth, prm.n_idx, prm.planes = int(damping), int(bit_depth), int(n_idx), n_planes
+        prm.xdec, prm.ydec, prm.crop_w, prm.crop_h = int(xdec), int(ydec), int(crop_w), int(crop_h)
+        prm.area_sb_w, prm.area_sb_h = int(area_sb[0]), int(area_sb[1])
+        for i in range(3):
+            prm.dist_scale[i] = int(dist_scale[i])
+        return prm
+
+    def cdef_lrf_trial_batch(self, rec, cdef_cur, src, skip_mi, units, y_strengths, uv_strengths, damping, bit_depth,
+                             n_idx, xdec, ydec, crop_w, crop_h, area_sb=(1, 1), scales=None,
+                             dist_scale=(1 << 14, 1 << 14, 1 << 14), sb_sel=None, scratch=None):
+        """a later pass of rdo_loop_decision's CDEF leg (src/rdo.rs:2377-2560): every (superblock, cdef_index) trial
+        with the restoration units' CURRENT choices applied to the trial's output before the error is taken.
+        units: three TRIAL_UNIT arrays (Y, U, V; may be empty) -- the superblocks under a self-guided choice;
+        cdef_cur: the working copy (cdef_apply_area) or None when no unit carries an edge flag.
+        -> (err (n_sby, n_sbx, 8) int64, err_planes (n_sby, n_sbx, 8, 3) int64, best (n_sby, n_sbx) int8)"""
+        prm = self._cdef_search_params(len(rec), y_strengths, uv_strengths, damping, bit_depth, n_idx, xdec, ydec, crop_w,
+                                       crop_h, area_sb, dist_scale)
+        mi_rows, mi_cols = skip_mi.shape
+        n_sbx, n_sby = (mi_cols + 15) // 16, (mi_rows + 15) // 16
+        cur = cdef_cur if cdef_cur is not None else rec
+        pr = (_lib.R1Plane * 3)(*[(rec[k] if k < len(rec) else rec[0]).cstruct() for k in range(3)])
+        pc = (_lib.R1Plane * 3)(*[(cur[k] if k < len(cur) else cur[0]).cstruct() for k in range(3)])
+        ps = (_lib.R1Plane * 3)(*[(src[k] if k < len(src) else src[0]).cstruct() for k in range(3)])
+        us = [np.ascontiguousarray(u, TRIAL_UNIT) for u in units] + [np.zeros(0, TRIAL_UNIT)] * (3 - len(units))
+        n_units = (C.c_int32 * 3)(*[len(u) for u in us])
+        allu = np.concatenate(us)
+        du = _dev_cands(allu, TRIAL_UNIT) if len(allu) else None
+        err = torch.empty((n_sby, n_sbx, 8), dtype=torch.int64, device="cuda")
+        errp = torch.empty((n_sby, n_sbx, 8, 3), dtype=torch.int64, device="cuda")
+        best = torch.empty((n_sby, n_sbx), dtype=torch.int8, device="cuda")
+        nb = self.lib.r1_cdef_lrf_trial_scratch_bytes(mi_cols, mi_rows, xdec if len(rec) == 3 else 0,
+                                                      ydec if len(rec) == 3 else 0, rec[0].bpp, n_idx, len(rec))
+        if scratch is None or scratch.numel() < nb:
+            scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        self._check(self.lib.r1_cdef_lrf_trial_batch(
+            self.h, pr, pc, ps, skip_mi.data_ptr(), skip_mi.stride(0), mi_cols, mi_rows,
+            scales.data_ptr() if scales is not None else None, scales.stride(0) if scales is not None else 0,
+            C.byref(prm), du.data_ptr() if du is not None else None, n_units,
+            sb_sel.data_ptr() if sb_sel is not None else None, err.data_ptr(), errp.data_ptr(), best.data_ptr(),
+            scratch.data_ptr(), _stream_ptr()), "r1_cdef_lrf_trial_batch")
+        return err, errp, best
+
+    def cdef_apply_area(self, rec, out, skip_mi, index_sb, y_strengths, uv_strengths, damping, bit_depth, n_idx, xdec,
+                        ydec, crop_w, crop_h, area_sb=(1, 1)):
+        """the CDEF working copy of every analysis area (src/rdo.rs:2546-2560): cdef_filter_superblock with
+        index_sb[sby, sbx] (int8 device tensor; < 0 = unfiltered) from rec into out (lists of 1 or 3 Planes)"""
+        prm = self._cdef_search_params(len(rec), y_strengths, uv_strengths, damping, bit_depth, n_idx, xdec, ydec, crop_w,
+                                       crop_h, area_sb, (1 << 14,) * 3)
+        mi_rows, mi_cols = skip_mi.shape
+        pr = (_lib.R1Plane * 3)(*[(rec[k] if k < len(rec) else rec[0]).cstruct() for k in range(3)])
+        po = (_lib.R1Plane * 3)(*[(out[k] if k < len(out) else out[0]).cstruct() for k in range(3)])
+        scratch = torch.empty(self.lib.r1_cdef_strength_search_scratch_bytes(mi_cols, mi_rows),
+                              dtype=torch.uint8, device="cuda")
+        assert index_sb.dtype == torch.int8 and index_sb.is_contiguous()
+        self._check(self.lib.r1_cdef_apply_area(
+            self.h, pr, po, skip_mi.data_ptr(), skip_mi.stride(0), mi_cols, mi_rows, C.byref(prm),
+            index_sb.data_ptr(), scratch.data_ptr(), _stream_ptr()), "r1_cdef_apply_area")
+        return out
 
     # ---- frame glue ----
     def plane_pad(self, plane, w, h, xdec=0, ydec=0):

@@ -39,6 +39,13 @@ struct SearchArgs {
   const uint8_t *dirs;        // [n_sby * 8][nbx] of k_cdef_analyze (rec luma)
   const int32_t *vars;
   int nbx;
+  // MODE 1 (a later pass of the CDEF leg, restoration choices in play) / MODE 2 (the final pass: the working copy)
+  const uint8_t *sb_lrf;      // [n_sb] bit p: plane p of the superblock has a self-guided choice -> the trial is STORED
+  const uint8_t *sb_sel;      // [n_sb] (null = all): superblocks this launch evaluates
+  R1Plane trial[3];           // the trial planes of cdef_index 0; index i at data + i * trial_idx_bytes
+  size_t trial_idx_bytes;
+  R1Plane out[3];             // MODE 2
+  const int8_t *index_sb;     // MODE 2: [n_sb] cdef_index per superblock, < 0 = not filtered
 };
 
 // geometry of the analysis area a superblock belongs to (rdo.rs:2149-2166, 2184-2190)
@@ -107,7 +114,11 @@ __device__ __forceinline__ uint32_t swz_xor4(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1f);
 }
 
-template <int BPP, int XD, int YD, bool LUMA>
+// MODE 0: the search (first pass).  MODE 1: a later pass -- planes of a superblock whose restoration unit has a
+// self-guided choice get their filtered pixels STORED per index (the restoration trial reads them, lrf.hip), the
+// others are measured as in MODE 0.  MODE 2: cdef_filter_superblock with the superblock's chosen index into `out`
+// (rdo.rs:2546-2560 "keep cdef output up to date"), everything else copied through: the CDEF working copy.
+template <int BPP, int XD, int YD, bool LUMA, int MODE = 0>
 __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[ST_ROWS * ST_STRIDE];
   __shared__ __attribute__((aligned(16))) uint32_t rec[32 * SR_REC];
@@ -121,7 +132,12 @@ __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
   const int fbx = (rx0 << XD) >> 6, fby = (ry0 << YD) >> 6;        // its superblock
   if (fbx >= a.n_sbx || fby >= a.n_sby) return;
   const AreaGeo g = area_of(a, fbx, fby);
-  if (sb_all_skip(a, g, lane)) return;                             // workgroup-uniform
+  const bool all_skip = sb_all_skip(a, g, lane);                   // workgroup-uniform
+  const int sb_i = fby * a.n_sbx + fbx;
+  if (MODE != 2 && all_skip) return;
+  if (MODE == 1 && a.sb_sel && !a.sb_sel[sb_i]) return;
+  const bool store = MODE == 2 || (MODE == 1 && ((a.sb_lrf[sb_i] >> pli) & 1));   // workgroup-uniform
+  const int apply_idx = MODE == 2 ? (all_skip ? -1 : (int)a.index_sb[sb_i]) : 0;
   const R1Plane &rp = a.rec[pli], &sp = a.src[pli];
   const int n_idx = a.p.n_idx;
   const uint8_t *strengths = LUMA ? a.p.y_strengths : a.p.uv_strengths;
@@ -202,12 +218,12 @@ __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
   const int blk = (ly / ys) * NBX + lx / xs;
   const uint32_t *rb = rec + blk * SR_REC;
   const uint32_t flags = rb[0];
-  const bool in_grid = flags & 1, filt = (flags & 2) != 0;
+  const bool in_grid = flags & 1, filt = (flags & 2) != 0 && (MODE != 2 || apply_idx >= 0);
   const uint32_t base = (uint32_t)(((ly + ST_Y0) * ST_STRIDE + lx + ST_X0) * 2);
   Pk x, s;
   x.u = *(const uint32_t *)((const uint8_t *)tile + base);
   s.u = 0;
-  if (in_grid) {
+  if (in_grid && !store) {
     const uint8_t *gp = px_addr<BPP>(sp, rx0 + lx, ry0 + ly);
     if constexpr (BPP == 1) s.u = __builtin_amdgcn_perm(0, (uint32_t) * (const uint16_t *)gp, 0x0c010c00u);
     else s.u = ld_u32(gp);
@@ -216,7 +232,8 @@ __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
   const uint32_t tbase = (uint32_t)(uintptr_t)(LdsU16 *)tile + base;
   // which direction sets the index set asks for (scalar)
   bool need_own = false, need_zero = false;
-  for (int idx = 0; idx < n_idx; idx++) {
+  const int idx_lo = MODE == 2 ? (apply_idx < 0 ? 0 : apply_idx) : 0, idx_hi = MODE == 2 ? idx_lo + 1 : n_idx;
+  for (int idx = idx_lo; idx < idx_hi; idx++) {
     const int st = strengths[idx];
     if ((st >> 2) != 0) need_own = true;
     else if ((st & 3) != 0) need_zero = true;
@@ -254,7 +271,7 @@ __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
     zero = load_set(offs);
   }
   // the source's two moments of a luma block do not depend on the index
-  if constexpr (LUMA) {
+  if (LUMA && !store) {
     Pk one;
     one.u = 0x00010001u;
     const uint32_t m_s = half_sum_last(__builtin_amdgcn_udot2(s.v, one.v, 0u, false));
@@ -266,8 +283,8 @@ __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
   }
   int sec_key = -1;
   i16x2 sec_sum = (i16x2)0;
-  for (int idx = 0; idx < n_idx; idx++) {
-    const int st = strengths[idx];
+  for (int idx = idx_lo; idx < idx_hi; idx++) {
+    const int st = (MODE == 2 && apply_idx < 0) ? 0 : strengths[idx];
     const int pri_raw = st >> 2;
     int sec_raw = st & 3;
     sec_raw += sec_raw == 3;
@@ -308,7 +325,15 @@ __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
       v.s = x.s + ((sum + (sum >> (i16x2)15) + (i16x2)8) >> (i16x2)4);
       v.s = __builtin_elementwise_min(__builtin_elementwise_max(v.s, (i16x2)ts.mn), ts.mx);
     }
-    if constexpr (LUMA) {
+    if (MODE != 0 && store) {
+      // the filtered pair itself: the trial plane of this index / the working copy
+      if (in_grid) {
+        const R1Plane &dp = MODE == 2 ? a.out[pli] : a.trial[pli];
+        uint8_t *d = (uint8_t *)px_addr<BPP>(dp, rx0 + lx, ry0 + ly) + (MODE == 2 ? (size_t)0 : (size_t)idx * a.trial_idx_bytes);
+        if constexpr (BPP == 1) *(uint16_t *)d = (uint16_t)((v.u & 0xffu) | ((v.u >> 8) & 0xff00u));
+        else *(uint32_t *)d = v.u;
+      }
+    } else if constexpr (LUMA) {
       // cdef_dist_kernel's moments of the filtered block (dist.rs:316-345)
       Pk one;
       one.u = 0x00010001u;
@@ -331,6 +356,7 @@ __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
       if ((pq & 1) == 0 && (row & 3) == 0) acc[((ly >> 2) * 8 + (lx >> 2)) * 8 + idx] = c;
     }
   }
+  if (MODE != 0 && store) return;                 // workgroup-uniform
   __syncthreads();
   // ---- one (block, index) pair per thread: tails and atomics
   unsigned long long *ps = a.psum + (size_t)(fby * a.n_sbx + fbx) * 24;
@@ -367,15 +393,21 @@ __global__ __launch_bounds__(256) void k_cdef_search_pk(SearchArgs a) {
 }
 
 // one wave per superblock: Distortion * dist_scale per plane, the sum, the first minimum
-__global__ __launch_bounds__(64) void k_cdef_search_final(SearchArgs a, unsigned long long *err, int8_t *best) {
+__global__ __launch_bounds__(64) void k_cdef_search_final(SearchArgs a, unsigned long long *err, int8_t *best,
+                                                          unsigned long long *err_planes) {
   const int fbx = blockIdx.x, fby = blockIdx.y, lane = threadIdx.x;
   const AreaGeo g = area_of(a, fbx, fby);
-  const bool skip = sb_all_skip(a, g, lane);
   const size_t sb = (size_t)fby * a.n_sbx + fbx;
+  const bool skip = sb_all_skip(a, g, lane) || (a.sb_sel && !a.sb_sel[sb]);
   unsigned long long e = 0;
   if (lane < 8 && lane < a.p.n_idx && !skip)
-    for (int pl = 0; pl < a.p.planes; pl++)
-      e += ((unsigned long long)a.p.dist_scale[pl] * a.psum[sb * 24 + lane * 3 + pl] + 8192) >> 14;
+    for (int pl = 0; pl < a.p.planes; pl++) {
+      const unsigned long long ep = ((unsigned long long)a.p.dist_scale[pl] * a.psum[sb * 24 + lane * 3 + pl] + 8192) >> 14;
+      if (err_planes) err_planes[sb * 24 + lane * 3 + pl] = ep;
+      e += ep;
+    }
+  if (err_planes && lane < 8 && (skip || lane >= a.p.n_idx || a.p.planes == 1))
+    for (int pl = (skip || lane >= a.p.n_idx) ? 0 : 1; pl < 3; pl++) err_planes[sb * 24 + lane * 3 + pl] = 0;
   if (lane < 8) err[sb * 8 + lane] = e;
   // compute_rd_cost with rate 0 is the error as f64 (exact below 2^53): first strict minimum
   int b = 0;
@@ -387,20 +419,20 @@ __global__ __launch_bounds__(64) void k_cdef_search_final(SearchArgs a, unsigned
   if (lane == 0) best[sb] = skip ? (int8_t)-1 : (int8_t)b;
 }
 
-}  // namespace
-
-// scratch: the per-superblock sums [n_sb][8][3] u64, then (var i32, dir u8) per 8x8 block of the grid
-extern "C" long long r1_cdef_strength_search_scratch_bytes(int mi_cols, int mi_rows) {
-  const long long n_sb = (long long)((mi_cols + 15) / 16) * ((mi_rows + 15) / 16);
-  return n_sb * 24 * 8 + n_sb * 64 * 5;
+// sb_lrf[sb] |= 1 << plane for every trial unit
+__global__ void k_trial_mark(const R1TrialUnit *__restrict__ units, int n0, int n1, int n2, int n_sb, uint32_t *mask_words) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n0 + n1 + n2) return;
+  const int pl = i < n0 ? 0 : (i < n0 + n1 ? 1 : 2);
+  const int sb = units[i].sb;
+  if (sb >= 0 && sb < n_sb) atomicOr(mask_words + (sb >> 2), (1u << pl) << (8 * (sb & 3)));
 }
 
-extern "C" int r1_cdef_strength_search(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src,
-                                       const uint8_t *skip_mi, int mi_stride, int mi_cols, int mi_rows,
-                                       const uint32_t *scales, int scale_stride,
-                                       const R1CdefSearchParams *params, uint64_t *err_out,
-                                       int8_t *best_out, void *scratch, void *stream) {
-  R1_REQUIRE(ctx && rec && src && skip_mi && params && err_out && best_out && scratch);
+// what the three entry points share: validation and the launch arguments
+int search_args(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src, const uint8_t *skip_mi, int mi_stride,
+                int mi_cols, int mi_rows, const uint32_t *scales, int scale_stride, const R1CdefSearchParams *params,
+                SearchArgs &a) {
+  R1_REQUIRE(ctx && rec && src && skip_mi && params);
   const R1CdefSearchParams &p = *params;
   R1_REQUIRE(p.n_idx >= 1 && p.n_idx <= 8 && (p.planes == 1 || p.planes == 3));
   R1_REQUIRE(p.area_sb_w >= 1 && p.area_sb_h >= 1 && p.crop_w > 0 && p.crop_h > 0);
@@ -418,8 +450,7 @@ extern "C" int r1_cdef_strength_search(r1_ctx *ctx, const R1Plane *rec, const R1
              (p.xdec == 0 && p.ydec == 0));
   // the frame is allocated in whole 8x8 blocks (coded frame sizes are padded to 8)
   R1_REQUIRE(mi_cols * 4 <= rec[0].width + 7 && mi_rows * 4 <= rec[0].height + 7);
-  R1DeviceGuard guard(ctx);
-  SearchArgs a = {};
+  a = SearchArgs{};
   for (int k = 0; k < 3; k++) {
     a.rec[k] = rec[k < np ? k : 0];
     a.src[k] = src[k < np ? k : 0];
@@ -429,6 +460,78 @@ extern "C" int r1_cdef_strength_search(r1_ctx *ctx, const R1Plane *rec, const R1
   a.p = p;
   a.n_sbx = (mi_cols + 15) / 16;
   a.n_sby = (mi_rows + 15) / 16;
+  a.nbx = a.n_sbx * 8;
+  return R1_OK;
+}
+
+template <int MODE>
+int search_launch(const SearchArgs &a, hipStream_t st) {
+  const int np = a.p.planes;
+  const int xd = np == 1 ? 0 : a.p.xdec, yd = np == 1 ? 0 : a.p.ydec;
+  const dim3 grid_y(a.n_sbx * 2, a.n_sby * 4), grid_c((a.n_sbx * 64 >> xd) / 32, (a.n_sby * 64 >> yd) / 16, 2);
+#define R1_CS_LAUNCH(B)                                                                                   \
+  do {                                                                                                    \
+    hipLaunchKernelGGL((k_cdef_search_pk<B, 0, 0, true, MODE>), grid_y, dim3(256), 0, st, a);             \
+    if (np == 3) {                                                                                        \
+      if (xd == 1 && yd == 1) hipLaunchKernelGGL((k_cdef_search_pk<B, 1, 1, false, MODE>), grid_c, dim3(256), 0, st, a); \
+      else if (xd == 1) hipLaunchKernelGGL((k_cdef_search_pk<B, 1, 0, false, MODE>), grid_c, dim3(256), 0, st, a);       \
+      else hipLaunchKernelGGL((k_cdef_search_pk<B, 0, 0, false, MODE>), grid_c, dim3(256), 0, st, a);     \
+    }                                                                                                     \
+  } while (0)
+  if (a.rec[0].bytes_per_px == 1) R1_CS_LAUNCH(1);
+  else R1_CS_LAUNCH(2);
+#undef R1_CS_LAUNCH
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+// scratch layout: per-superblock sums [n_sb][8][3] u64 | var i32 per 8x8 block | dir u8 per 8x8 block |
+// (trial only) plane mask u8 per superblock, padded to 256 B | trial planes [n_idx][Y | U | V]
+struct ScratchMap {
+  size_t n_sb, psum, vars, dirs, mask, planes, plane_bytes[3], idx_bytes, total;
+};
+ScratchMap scratch_map(int mi_cols, int mi_rows, int xdec, int ydec, int bpp, int n_idx, int planes) {
+  ScratchMap m = {};
+  const size_t n_sbx = (mi_cols + 15) / 16, n_sby = (mi_rows + 15) / 16;
+  m.n_sb = n_sbx * n_sby;
+  m.psum = 0;
+  m.vars = m.n_sb * 24 * 8;
+  m.dirs = m.vars + m.n_sb * 64 * 4;
+  m.mask = m.dirs + m.n_sb * 64;
+  m.planes = (m.mask + m.n_sb + 255) & ~(size_t)255;
+  for (int k = 0; k < planes; k++) {
+    const size_t w = (n_sbx * 64) >> (k ? xdec : 0), h = (n_sby * 64) >> (k ? ydec : 0);
+    m.plane_bytes[k] = (w * h * bpp + 255) & ~(size_t)255;
+    m.idx_bytes += m.plane_bytes[k];
+  }
+  m.total = m.planes + m.idx_bytes * (size_t)n_idx;
+  return m;
+}
+
+}  // namespace
+
+// lrf.hip: the restoration trial of one plane (sgr_tile lives there)
+__attribute__((visibility("hidden")))
+int r1i_sgr_trial_err_launch(const R1Plane &trial, size_t trial_idx_bytes, const R1Plane &cdef_cur, const R1Plane &src,
+                             const R1TrialUnit *units, int n_units, int n_idx, int pli, int xdec, int ydec,
+                             const uint32_t *scales, int scale_stride, unsigned long long *psum, hipStream_t st);
+
+// scratch: the per-superblock sums [n_sb][8][3] u64, then (var i32, dir u8) per 8x8 block of the grid
+extern "C" long long r1_cdef_strength_search_scratch_bytes(int mi_cols, int mi_rows) {
+  const long long n_sb = (long long)((mi_cols + 15) / 16) * ((mi_rows + 15) / 16);
+  return n_sb * 24 * 8 + n_sb * 64 * 5;
+}
+
+extern "C" int r1_cdef_strength_search(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src,
+                                       const uint8_t *skip_mi, int mi_stride, int mi_cols, int mi_rows,
+                                       const uint32_t *scales, int scale_stride,
+                                       const R1CdefSearchParams *params, uint64_t *err_out,
+                                       int8_t *best_out, void *scratch, void *stream) {
+  R1_REQUIRE(err_out && best_out && scratch);
+  SearchArgs a;
+  int rc = search_args(ctx, rec, src, skip_mi, mi_stride, mi_cols, mi_rows, scales, scale_stride, params, a);
+  if (rc != R1_OK) return rc;
+  R1DeviceGuard guard(ctx);
   a.psum = (unsigned long long *)scratch;
   hipStream_t st = (hipStream_t)stream;
   const size_t n_sb = (size_t)a.n_sbx * a.n_sby;
@@ -436,28 +539,113 @@ extern "C" int r1_cdef_strength_search(r1_ctx *ctx, const R1Plane *rec, const R1
   // cdef_analyze_superblock once for the frame (a thread per 8x8 block), shared by the planes
   int32_t *vars = (int32_t *)((uint8_t *)scratch + n_sb * 24 * 8);
   uint8_t *dirs = (uint8_t *)(vars + n_sb * 64);
-  a.nbx = a.n_sbx * 8;
   a.dirs = dirs;
   a.vars = vars;
-  const int rc = cdef_analyze_launch(&rec[0], a.nbx, a.n_sby * 8, mi_cols, mi_rows, dirs, vars, st);
+  rc = cdef_analyze_launch(&rec[0], a.nbx, a.n_sby * 8, mi_cols, mi_rows, dirs, vars, st);
   if (rc != R1_OK) return rc;
-  const int xd = np == 1 ? 0 : p.xdec, yd = np == 1 ? 0 : p.ydec;
-  const dim3 grid_y(a.n_sbx * 2, a.n_sby * 4), grid_c((a.n_sbx * 64 >> xd) / 32, (a.n_sby * 64 >> yd) / 16, 2);
-#define R1_CS_LAUNCH(B)                                                                                   \
-  do {                                                                                                    \
-    hipLaunchKernelGGL((k_cdef_search_pk<B, 0, 0, true>), grid_y, dim3(256), 0, st, a);                   \
-    if (np == 3) {                                                                                        \
-      if (xd == 1 && yd == 1) hipLaunchKernelGGL((k_cdef_search_pk<B, 1, 1, false>), grid_c, dim3(256), 0, st, a); \
-      else if (xd == 1) hipLaunchKernelGGL((k_cdef_search_pk<B, 1, 0, false>), grid_c, dim3(256), 0, st, a);       \
-      else hipLaunchKernelGGL((k_cdef_search_pk<B, 0, 0, false>), grid_c, dim3(256), 0, st, a);           \
-    }                                                                                                     \
-  } while (0)
-  if (rec[0].bytes_per_px == 1) R1_CS_LAUNCH(1);
-  else R1_CS_LAUNCH(2);
-#undef R1_CS_LAUNCH
-  R1_HIP_CHECK(hipGetLastError());
+  rc = search_launch<0>(a, st);
+  if (rc != R1_OK) return rc;
   hipLaunchKernelGGL(k_cdef_search_final, dim3(a.n_sbx, a.n_sby), dim3(64), 0, st, a,
-                     (unsigned long long *)err_out, best_out);
+                     (unsigned long long *)err_out, best_out, (unsigned long long *)nullptr);
   R1_HIP_CHECK(hipGetLastError());
   return R1_OK;
+}
+
+extern "C" long long r1_cdef_lrf_trial_scratch_bytes(int mi_cols, int mi_rows, int xdec, int ydec,
+                                                     int bytes_per_px, int n_idx, int planes) {
+  if (mi_cols <= 0 || mi_rows <= 0 || n_idx < 1 || n_idx > 8 || (planes != 1 && planes != 3)) return -1;
+  return (long long)scratch_map(mi_cols, mi_rows, xdec, ydec, bytes_per_px, n_idx, planes).total;
+}
+
+extern "C" int r1_cdef_lrf_trial_batch(r1_ctx *ctx, const R1Plane *rec, const R1Plane *cdef_cur, const R1Plane *src,
+                                       const uint8_t *skip_mi, int mi_stride, int mi_cols, int mi_rows,
+                                       const uint32_t *scales, int scale_stride, const R1CdefSearchParams *params,
+                                       const R1TrialUnit *units, const int32_t *n_units, const uint8_t *sb_sel,
+                                       uint64_t *err_out, uint64_t *err_planes_out, int8_t *best_out, void *scratch,
+                                       void *stream) {
+  R1_REQUIRE(err_out && best_out && scratch && n_units);
+  SearchArgs a;
+  int rc = search_args(ctx, rec, src, skip_mi, mi_stride, mi_cols, mi_rows, scales, scale_stride, params, a);
+  if (rc != R1_OK) return rc;
+  const int np = a.p.planes, bpp = rec[0].bytes_per_px;
+  int n_tot = 0;
+  for (int k = 0; k < 3; k++) {
+    R1_REQUIRE(n_units[k] >= 0 && (k < np || n_units[k] == 0));
+    n_tot += n_units[k];
+  }
+  R1_REQUIRE(n_tot == 0 || (units && cdef_cur));
+  if (n_tot)
+    for (int k = 0; k < np; k++)
+      R1_REQUIRE(cdef_cur[k].data && cdef_cur[k].bytes_per_px == bpp);
+  const ScratchMap m = scratch_map(mi_cols, mi_rows, np == 1 ? 0 : a.p.xdec, np == 1 ? 0 : a.p.ydec, bpp, a.p.n_idx, np);
+  for (int k = 0; k < np; k++) R1_REQUIRE(m.plane_bytes[k] < (1ull << 32));   // 32-bit byte offsets in lrf.hip's tile loads
+  R1DeviceGuard guard(ctx);
+  hipStream_t st = (hipStream_t)stream;
+  uint8_t *sc = (uint8_t *)scratch;
+  a.psum = (unsigned long long *)(sc + m.psum);
+  R1_HIP_CHECK(hipMemsetAsync(sc, 0, m.n_sb * 24 * 8, st));
+  R1_HIP_CHECK(hipMemsetAsync(sc + m.mask, 0, m.planes - m.mask, st));
+  a.vars = (const int32_t *)(sc + m.vars);
+  a.dirs = sc + m.dirs;
+  a.sb_lrf = sc + m.mask;
+  a.sb_sel = sb_sel;
+  size_t off = m.planes;
+  for (int k = 0; k < np; k++) {
+    R1Plane &t = a.trial[k];
+    t = R1Plane{};
+    t.data = sc + off;
+    t.stride = (a.n_sbx * 64) >> (k ? a.p.xdec : 0);
+    t.alloc_height = (a.n_sby * 64) >> (k ? a.p.ydec : 0);
+    t.width = t.stride;
+    t.height = t.alloc_height;
+    t.bytes_per_px = bpp;
+    t.bit_depth = a.p.bit_depth;
+    off += m.plane_bytes[k];
+  }
+  a.trial_idx_bytes = m.idx_bytes;
+  rc = cdef_analyze_launch(&rec[0], a.nbx, a.n_sby * 8, mi_cols, mi_rows, (uint8_t *)(sc + m.dirs), (int32_t *)(sc + m.vars), st);
+  if (rc != R1_OK) return rc;
+  if (n_tot)
+    hipLaunchKernelGGL(k_trial_mark, dim3((n_tot + 255) / 256), dim3(256), 0, st, units, n_units[0], n_units[1],
+                       n_units[2], (int)m.n_sb, (uint32_t *)(sc + m.mask));
+  rc = search_launch<1>(a, st);
+  if (rc != R1_OK) return rc;
+  int first = 0;
+  for (int k = 0; k < np; k++) {
+    if (n_units[k]) {
+      rc = r1i_sgr_trial_err_launch(a.trial[k], a.trial_idx_bytes, cdef_cur[k], a.src[k], units + first, n_units[k],
+                                    a.p.n_idx, k, k ? a.p.xdec : 0, k ? a.p.ydec : 0, scales, scale_stride, a.psum, st);
+      if (rc != R1_OK) return rc;
+    }
+    first += n_units[k];
+  }
+  hipLaunchKernelGGL(k_cdef_search_final, dim3(a.n_sbx, a.n_sby), dim3(64), 0, st, a,
+                     (unsigned long long *)err_out, best_out, (unsigned long long *)err_planes_out);
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
+
+extern "C" int r1_cdef_apply_area(r1_ctx *ctx, const R1Plane *rec, const R1Plane *out, const uint8_t *skip_mi,
+                                  int mi_stride, int mi_cols, int mi_rows, const R1CdefSearchParams *params,
+                                  const int8_t *index_sb, void *scratch, void *stream) {
+  R1_REQUIRE(out && index_sb && scratch);
+  SearchArgs a;
+  int rc = search_args(ctx, rec, rec, skip_mi, mi_stride, mi_cols, mi_rows, nullptr, 0, params, a);
+  if (rc != R1_OK) return rc;
+  for (int k = 0; k < a.p.planes; k++) {
+    R1_REQUIRE(out[k].data && out[k].data != rec[k].data && out[k].bytes_per_px == rec[0].bytes_per_px);
+    R1_REQUIRE(out[k].width >= rec[k].width && out[k].height >= rec[k].height);
+    a.out[k] = out[k];
+  }
+  R1DeviceGuard guard(ctx);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n_sb = (size_t)a.n_sbx * a.n_sby;
+  int32_t *vars = (int32_t *)((uint8_t *)scratch + n_sb * 24 * 8);
+  uint8_t *dirs = (uint8_t *)(vars + n_sb * 64);
+  a.dirs = dirs;
+  a.vars = vars;
+  a.index_sb = index_sb;
+  rc = cdef_analyze_launch(&rec[0], a.nbx, a.n_sby * 8, mi_cols, mi_rows, dirs, vars, st);
+  if (rc != R1_OK) return rc;
+  return search_launch<2>(a, st);
 }

@@ -146,7 +146,10 @@ __device__ __forceinline__ void sgr_unit_edges(SgrTile &t, int edges) {
 // division in the loop), every multiply whose operands are proven below 2^24 is the full-rate v_mul_u32_u24 /
 // v_mad_u32_u24 (v_mul_lo_u32 is quarter rate: 5 per (a, b) pair, 2 per pixel), and the stencil loop is unrolled
 // over the thread's rows (even / odd rows of the radius-2 pass resolved at compile time, no register rotation).
-template <int BPP, int TROWS, bool NARROW, class Emit, class Flush>
+//   STRICT  only the unit's own pixels come from inside_p: the columns left of it come from outside_p like the rows
+//           above it (the CDEF trial of ONE superblock inside an area whose other superblocks keep their current
+//           output, rdo.rs:2458-2489)
+template <int BPP, int TROWS, bool NARROW, bool STRICT = false, class Emit, class Flush>
 __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane &outside_p,
                                          const SgrTile &t, int set, int bd, const R1Plane *extra_p, int ex0, int ey0,
                                          Emit emit, Flush flush) {
@@ -195,7 +198,7 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
         const int j = jj + q * SROWS;
         const int cy = clampi(t.y0 + t.ty0 + j - 4, 0, t.crop_h - 1);   // (rows past the tile clamp to a valid address)
         const int ly = clampi(cy, t.y0 - t.top, t.y0 + h2 + 1);
-        const bool inside = ly >= t.y0 && ly < t.y0 + h2;
+        const bool inside = ly >= t.y0 && ly < t.y0 + h2 && (!STRICT || xa >= t.x0);
         if (one_plane) v[q] = ld_px_at<BPP>(inside_p, px_off<BPP>(inside_p, xa, ly));
         else v[q] = inside ? ld_px_at<BPP>(inside_p, px_off<BPP>(inside_p, xa, ly)) : ld_px_at<BPP>(outside_p, px_off<BPP>(outside_p, xa, ly));
       }
@@ -837,6 +840,55 @@ __global__ __launch_bounds__(256, BPP == 1 ? 5 : 1) void k_lrf_search_unit(R1Pla
   if (threadIdx.x == 0) err_out[pair] = ((unsigned long long)dist_scale * v + 8192) >> 14;
 }
 
+// A later pass of rdo_loop_decision's CDEF leg (rdo.rs:2407-2530): the superblock's trial output (cdef_search.hip,
+// MODE 1: the plane `trial` of cdef_index blockIdx.z) restored with the unit's CURRENT choice -- setup_integral_image
+// on the superblock alone (crop = the superblock; left / above it the area's working copy `cdef_cur` where the edge
+// flags say so), sgrproj_stripe_filter with the chosen (set, xqd) -- and rdo_loop_plane_error of the restored
+// superblock against the source, added to the (superblock, index, plane) sum the CDEF kernels use.
+template <int BPP, bool CHROMA>
+__global__ __launch_bounds__(256) void k_sgr_trial_err(R1Plane trial, size_t trial_idx_bytes, R1Plane cdef_cur, R1Plane src,
+                                                       const R1TrialUnit *__restrict__ units, int pli, int xdec, int ydec,
+                                                       const uint32_t *__restrict__ scales, int scale_stride,
+                                                       unsigned long long *__restrict__ psum) {
+  __shared__ uint16_t F[64][TW];
+  __shared__ unsigned long long part[4];
+  const R1TrialUnit u = units[blockIdx.y];
+  const int idx = blockIdx.z;
+  if (u.w <= 0 || u.h <= 0 || u.w > 64 || u.h > 64 || u.set > 15 || u.sb < 0) return;   // workgroup-uniform
+  const int ntx = (u.w + TW - 1) / TW;
+  if ((int)blockIdx.x >= ntx) return;
+  trial.data = (uint8_t *)trial.data + (size_t)idx * trial_idx_bytes;
+  SgrTile t;
+  t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
+  sgr_unit_edges(t, u.edges);
+  t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the superblock (rdo.rs:2458-2466)
+  t.cx0 = u.x + (int)blockIdx.x * TW;
+  t.ty0 = 0;
+  t.tw = (u.w - (int)blockIdx.x * TW) < TW ? (u.w - (int)blockIdx.x * TW) : TW;
+  t.th = u.h;
+  const int bd = BPP == 1 ? 8 : src.bit_depth;
+  const int w0 = u.xqd[0], w1 = u.xqd[1], w2 = 128 - w0 - w1;
+  const int32_t pmax = (1 << bd) - 1;
+  sgr_tile<BPP, 64, BPP == 1, true>(trial, cdef_cur, t, u.set, bd, nullptr, 0, 0,
+                                    [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2, uint32_t) {
+    // apply_filter (lrf.rs:796-815)
+    const int32_t v = w0 * (int32_t)f2 + w1 * (int32_t)(p << 4) + w2 * (int32_t)f1;
+    const int32_t sft = (v + (1 << 10)) >> 11;
+    F[y][x] = (uint16_t)(sft < 0 ? 0 : (sft > pmax ? pmax : sft));
+  }, [] {});
+  __syncthreads();
+  const int bw = CHROMA ? 8 >> xdec : 8, bh = CHROMA ? 8 >> ydec : 8;
+  const int nbx = t.tw / bw, nby = t.th / bh;
+  unsigned long long mine = 0;
+  if ((int)threadIdx.x < nbx * nby) {
+    const int by = (int)threadIdx.x / nbx, bx = (int)threadIdx.x - by * nbx;
+    mine = lrf_block_err<BPP, CHROMA, TW>(src, &F[by * bh][bx * bw], t.cx0 + bx * bw, u.y + by * bh, bw, bh,
+                                          xdec, ydec, scales, scale_stride, bd);
+  }
+  const unsigned long long v = wg_sum_u64(mine, part);
+  if (threadIdx.x == 0 && v) atomicAdd(psum + (size_t)u.sb * 24 + idx * 3 + pli, v);
+}
+
 // Distortion * fi.dist_scale[pli] (rdo.rs:2092; DistortionScale::mul_u64, rdo.rs:613-615)
 __global__ void k_lrf_err_finish(const unsigned long long *__restrict__ acc, int n, uint32_t dist_scale,
                                  unsigned long long *__restrict__ err) {
@@ -845,6 +897,27 @@ __global__ void k_lrf_err_finish(const unsigned long long *__restrict__ acc, int
 }
 
 }  // namespace
+
+// called by cdef_search.hip (r1_cdef_lrf_trial_batch); not part of the C ABI
+__attribute__((visibility("hidden")))
+int r1i_sgr_trial_err_launch(const R1Plane &trial, size_t trial_idx_bytes, const R1Plane &cdef_cur, const R1Plane &src,
+                             const R1TrialUnit *units, int n_units, int n_idx, int pli, int xdec, int ydec,
+                             const uint32_t *scales, int scale_stride, unsigned long long *psum, hipStream_t st) {
+  R1_REQUIRE(lrf_plane_ok(&trial) && lrf_plane_ok(&cdef_cur) && lrf_plane_ok(&src));
+  R1_REQUIRE(trial.bytes_per_px == src.bytes_per_px && cdef_cur.bytes_per_px == src.bytes_per_px);
+  const dim3 grid(64 / TW, n_units, n_idx);
+#define R1_TRIAL(BPP, CH)                                                                                         \
+  hipLaunchKernelGGL((k_sgr_trial_err<BPP, CH>), grid, dim3(256), 0, st, trial, trial_idx_bytes, cdef_cur, src, units, \
+                     pli, xdec, ydec, scales, scale_stride, psum)
+  if (src.bytes_per_px == 1) {
+    if (pli) R1_TRIAL(1, true); else R1_TRIAL(1, false);
+  } else {
+    if (pli) R1_TRIAL(2, true); else R1_TRIAL(2, false);
+  }
+#undef R1_TRIAL
+  R1_HIP_CHECK(hipGetLastError());
+  return R1_OK;
+}
 
 extern "C" int r1_lrf_sgrproj_plane(r1_ctx *ctx, const R1Plane *cdeffed, const R1Plane *deblocked,
                                     const R1Plane *out, int ydec, int crop_w, int crop_h,

@@ -1,0 +1,246 @@
+"""rdo_loop_decision for a whole frame, both filters on (reference: src/rdo.rs:2104-2763; the iteration 2366-2374).
+
+The HOST side of the loop -- what a Rust host keeps after handing the pixel work to the device: which superblocks and
+restoration units an analysis area has, the alternation of the two legs until no choice changes, the rate of an
+option (the entropy coder's: a callable here), compute_rd_cost and "first smallest cost wins", the limit-cycle guard
+(best_lrf_cost).  The pixel work goes through three batch operations of a backend, one call each per pass for ALL
+areas of the frame (areas are independent: each works on its own scratch copy of the reconstruction, rdo.rs:2277-2296):
+
+    backend.trial(units, sb_sel)   -> err_planes[n_sby][n_sbx][8][3]   r1_cdef_lrf_trial_batch
+    backend.apply(index_sb)        -> the CDEF working copy            r1_cdef_apply_area
+    backend.lrf_search(pli, rows)  -> (xqd[n][2], err[n])              r1_lrf_search_batch on the working copy
+
+`DeviceBackend` binds them to a rav1e_amd.api.Context; the tests bind the same driver to the CPU oracle.
+
+The reference decides area by area, every pass of an area before the next area; here pass k of every area runs in one
+launch.  The per-area order of events is the reference's, and `events` records them in that order (kind 0 rows of
+tests/golden/gen_loop_decision_ref.py's trace: pli, loop_sbx, loop_sby, sb_w, sb_h, frame -> ScaledDistortion).
+In an area of several superblocks a trial reads its left / upper neighbours' current CDEF output, which the same pass
+may just have changed (rdo.rs:2546-2560): such areas are walked position by position (one trial call per position of
+the area, all areas at once), with the working copy refreshed in between.
+"""
+import numpy as np
+
+from . import rdo_glue as RG
+
+SGR_SETS = {"Full": tuple(range(16)), "Reduced": (1, 3, 5, 7, 9, 11, 13, 15)}   # src/lrf.rs:76-93
+
+
+class LoopDecision:
+    def __init__(self, backend, width, height, xdec, ydec, base_q_idx, skip_mi, lam, rate_fn, n_idx, sgr_sets,
+                 enable_cdef=True, enable_restoration=True, lru_on_skip=True):
+        """skip_mi: (mi_rows, mi_cols) numpy uint8 (Block::skip per 4x4); rate_fn(pli, None | (set, xqd0, xqd1)) ->
+        cw.fc.count_lrf_switchable in 1/8 bit; lam: fi.lambda"""
+        self.b, self.W, self.H, self.xdec, self.ydec = backend, width, height, xdec, ydec
+        self.lam, self.rate_fn, self.n_idx, self.sets = float(lam), rate_fn, n_idx, tuple(sgr_sets)
+        self.enable_cdef, self.enable_restoration = enable_cdef, enable_restoration
+        assert lru_on_skip, "speed settings with lru_on_skip = false are not modelled (every preset sets it)"
+        self.skip = np.ascontiguousarray(skip_mi, np.uint8)
+        self.mi_rows, self.mi_cols = self.skip.shape
+        self.n_sbx, self.n_sby = (self.mi_cols + 15) // 16, (self.mi_rows + 15) // 16
+        self.cfgs = RG.restoration_plane_configs(width, height, xdec, ydec, base_q_idx,
+                                                 enable_restoration=enable_restoration)
+        self.area = RG.restoration_area_sb(self.cfgs) if enable_restoration else (1, 1)
+        self.dec = [(0, 0), (xdec, ydec), (xdec, ydec)]
+        # cdef_skip per superblock (rdo.rs:2196-2211): every 4x4 unit of the superblock inside the grid skipped
+        self.sb_skip = np.ones((self.n_sby, self.n_sbx), bool)
+        for sy in range(self.n_sby):
+            for sx in range(self.n_sbx):
+                self.sb_skip[sy, sx] = bool(self.skip[16 * sy:16 * sy + 16, 16 * sx:16 * sx + 16].all())
+        self.best_index = np.full((self.n_sby, self.n_sbx), -1, np.int8)
+        self.best_lrf = {}        # (pli, ux, uy) -> None | (set, xqd0, xqd1)
+        self.best_lrf_cost = {}   # (pli, ux, uy) -> f64
+        self.events = {}          # (ax0, ay0) -> [(pli, loop_sbx, loop_sby, sb_w, sb_h, frame, err)]
+        self.passes = 0
+
+    # ---- geometry ----
+    def areas(self):
+        aw, ah = self.area
+        return [(ax, ay) for ay in range(0, self.n_sby, ah) for ax in range(0, self.n_sbx, aw)]
+
+    def unit_of_sb(self, pli, sx, sy):
+        """restoration_unit_index(sbo, stretch = false) (tiling/tile_restoration_state.rs:196-216): the unit over a
+        superblock, None for the stretched remainder of a last unit"""
+        c = self.cfgs[pli]
+        ux, uy = sx >> c["sb_h_shift"], sy >> c["sb_v_shift"]
+        return (ux, uy) if ux < c["cols"] and uy < c["rows"] else None
+
+    def unit_offset(self, pli, ax, ay, sx, sy):
+        """restoration_unit_offset(base_sbo, loop_sbo, false) is Some(..) (rdo.rs:2430-2436)"""
+        return self.unit_of_sb(pli, sx, sy) if self.unit_of_sb(pli, ax, ay) is not None else None
+
+    def sb_vis(self, pli, ax, ay, sx, sy):
+        """(x, y, vis_w, vis_h) of a superblock in plane pixels (rdo.rs:2415-2428): crop_w / crop_h are the area's"""
+        xd, yd = self.dec[pli]
+        crop_w, crop_h = self.W - ax * 64, self.H - ay * 64
+        lx, ly = ((sx - ax) * 64) >> xd, ((sy - ay) * 64) >> yd
+        return ((sx * 64) >> xd, (sy * 64) >> yd, min(64 >> xd, (crop_w >> xd) - lx), min(64 >> yd, (crop_h >> yd) - ly))
+
+    def lru_rect(self, pli, ax, ay, ux, uy):
+        """the visible rectangle of a restoration unit as the restoration leg clips it (rdo.rs:2645-2654)"""
+        c = self.cfgs[pli]
+        xd, yd = self.dec[pli]
+        us = c["unit_size"]
+        crop_w, crop_h = self.W - ax * 64, self.H - ay * 64
+        lx = (((ux << c["sb_h_shift"]) - ax) * 64) >> xd
+        ly = (((uy << c["sb_v_shift"]) - ay) * 64) >> yd
+        return (ux * us, uy * us, min(us, (crop_w >> xd) - lx), min(us, (crop_h >> yd) - ly))
+
+    def _trial_rate(self, ax, ay, sx, sy):
+        rate = 0
+        for pli in range(3):
+            u = self.unit_offset(pli, ax, ay, sx, sy)
+            if u is not None:
+                f = self.best_lrf.get((pli,) + u)
+                if f is not None or self.enable_restoration:
+                    rate += self.rate_fn(pli, f)
+        return rate
+
+    # ---- the two legs, every active area at once ----
+    def _cdef_leg(self, active, changed):
+        from .api import TRIAL_UNIT
+        aw, ah = self.area
+        for py in range(ah):
+            for px in range(aw):
+                sel = np.zeros((self.n_sby, self.n_sbx), np.uint8)
+                units = [[], [], []]
+                todo = []
+                for (ax, ay) in active:
+                    sx, sy = ax + px, ay + py
+                    if sx >= self.n_sbx or sy >= self.n_sby or self.sb_skip[sy, sx]:
+                        continue
+                    sel[sy, sx] = 1
+                    todo.append((ax, ay, sx, sy))
+                    for pli in range(3):
+                        u = self.unit_offset(pli, ax, ay, sx, sy)
+                        f = self.best_lrf.get((pli,) + u) if u is not None else None
+                        if f is not None:
+                            x, y, w, h = self.sb_vis(pli, ax, ay, sx, sy)
+                            edges = (RG.SGR_EDGE_LEFT if sx > ax else 0) | (RG.SGR_EDGE_ABOVE if sy > ay else 0)
+                            units[pli].append((x, y, w, h, f[0], edges, (f[1], f[2]), sy * self.n_sbx + sx))
+                if not todo:
+                    continue
+                errp = self.b.trial([np.array(u, TRIAL_UNIT) for u in units], sel)
+                for (ax, ay, sx, sy) in todo:
+                    ev = self.events.setdefault((ax, ay), [])
+                    rate = self._trial_rate(ax, ay, sx, sy)
+                    best_cost, best_new = -1.0, -1
+                    for idx in range(self.n_idx):
+                        err = 0
+                        for pli in range(3):
+                            u = self.unit_offset(pli, ax, ay, sx, sy)
+                            f = self.best_lrf.get((pli,) + u) if u is not None else None
+                            e = int(errp[sy, sx, idx, pli])
+                            ev.append((pli, sx - ax, sy - ay, 1, 1, 1 if f is not None else 0, e))
+                            err += e
+                        cost = RG.compute_rd_cost(self.lam, rate, err)
+                        if best_cost < 0.0 or cost < best_cost:
+                            best_cost, best_new = cost, idx
+                    if best_new != int(self.best_index[sy, sx]):
+                        changed[(ax, ay)] = True
+                        self.best_index[sy, sx] = best_new
+                self.b.apply(self.best_index)          # "keep cdef output up to date" (rdo.rs:2546-2560)
+
+    def _lrf_leg(self, active, lrf_changed):
+        from .api import SGR_SOLVE_UNIT
+        for pli in range(3):
+            c = self.cfgs[pli]
+            xd, yd = self.dec[pli]
+            rows, owners = [], []
+            for (ax, ay) in active:
+                lw = max(1, self.area[0] >> c["sb_h_shift"])
+                lh = max(1, self.area[1] >> c["sb_v_shift"])
+                for ly in range(lh):
+                    for lx in range(lw):
+                        sx, sy = ax + (lx << c["sb_h_shift"]), ay + (ly << c["sb_v_shift"])
+                        if sx >= self.n_sbx or sy >= self.n_sby:
+                            continue
+                        u = self.unit_of_sb(pli, sx, sy)          # has_restoration_unit(base + loop, pli, false)
+                        if u is None:
+                            continue
+                        x, y, w, h = self.lru_rect(pli, ax, ay, u[0], u[1])
+                        if w <= 0 or h <= 0:
+                            continue
+                        edges = RG.restoration_unit_edges(x, y, xd, yd, self.area)
+                        owners.append((ax, ay, u, sx - ax, sy - ay, len(rows)))
+                        for s in (255,) + self.sets:
+                            rows.append((x, y, w, h, s, edges, (0, 0)))
+            if not rows:
+                continue
+            xqd, err = self.b.lrf_search(pli, np.array(rows, SGR_SOLVE_UNIT))
+            for (ax, ay, u, lsx, lsy, r0) in owners:
+                ev = self.events.setdefault((ax, ay), [])
+                key = (pli,) + u
+                cur = self.best_lrf.get(key)
+                best_cost = self.best_lrf_cost.get(key, -1.0)
+                best_new = cur
+                lsw, lsh = 1 << c["sb_h_shift"], 1 << c["sb_v_shift"]
+                # the no-filter option is priced with the CURRENT choice's rate (rdo.rs:2633-2638: best_new_lrf)
+                e0 = int(err[r0])
+                ev.append((pli, lsx, lsy, lsw, lsh, 0, e0))
+                cost = RG.compute_rd_cost(self.lam, self.rate_fn(pli, cur), e0)
+                if best_cost < 0.0 or cost < best_cost:
+                    best_cost, best_new = cost, None
+                for k, s in enumerate(self.sets):
+                    e = int(err[r0 + 1 + k])
+                    f = (s, int(xqd[r0 + 1 + k][0]), int(xqd[r0 + 1 + k][1]))
+                    ev.append((pli, lsx, lsy, lsw, lsh, 1, e))
+                    cost = RG.compute_rd_cost(self.lam, self.rate_fn(pli, f), e)
+                    if cost < best_cost:
+                        best_cost, best_new = cost, f
+                self.best_lrf_cost[key] = best_cost
+                if best_new != cur:                       # RestorationFilter::notequal
+                    self.best_lrf[key] = best_new
+                    lrf_changed[(ax, ay)] = True
+
+    def run(self, max_passes=64):
+        """-> (best_index (n_sby, n_sbx) int8, {(pli, ux, uy): None | (set, xqd0, xqd1)}).  The iteration of
+        rdo.rs:2366-2374, 2562-2566 with one pair of flags per area: `while cdef_change || lrf_change { CDEF leg;
+        if !cdef_change { break } cdef_change = false; lrf_change = false; restoration leg }`"""
+        active = self.areas()
+        cdef_change = {a: True for a in active}
+        while active and self.passes < max_passes:
+            self.passes += 1
+            if self.enable_cdef:
+                self._cdef_leg(active, cdef_change)
+            active = [a for a in active if cdef_change[a]]
+            lrf_change = {a: False for a in active}
+            for a in active:
+                cdef_change[a] = False
+            if active and self.enable_restoration:
+                self._lrf_leg(active, lrf_change)
+            active = [a for a in active if lrf_change[a]]
+        return self.best_index, dict(self.best_lrf)
+
+
+class DeviceBackend:
+    """The three batch operations on the GPU (rav1e_amd.api.Context).  rec / src: lists of 3 Planes (rec deblocked);
+    work: 3 Planes of rec's geometry for the CDEF working copy."""
+
+    def __init__(self, ctx, rec, work, src, skip_mi_dev, y_strengths, uv_strengths, damping, bit_depth, n_idx, xdec, ydec,
+                 width, height, area_sb, scales_dev, dist_scale):
+        self.ctx, self.rec, self.work, self.src, self.skip = ctx, rec, work, src, skip_mi_dev
+        self.kw = dict(y_strengths=y_strengths, uv_strengths=uv_strengths, damping=damping, bit_depth=bit_depth,
+                       n_idx=n_idx, xdec=xdec, ydec=ydec, crop_w=width, crop_h=height, area_sb=area_sb)
+        self.scales, self.dist_scale, self.xdec, self.ydec = scales_dev, dist_scale, xdec, ydec
+        self.scratch = None
+
+    def trial(self, units, sb_sel):
+        import torch
+        sel = torch.from_numpy(np.ascontiguousarray(sb_sel, np.uint8)).cuda()
+        _, errp, _ = self.ctx.cdef_lrf_trial_batch(self.rec, self.work, self.src, self.skip, units, scales=self.scales,
+                                                   dist_scale=self.dist_scale, sb_sel=sel, **self.kw)
+        return errp.cpu().numpy().view(np.uint64)
+
+    def apply(self, index_sb):
+        import torch
+        self.ctx.cdef_apply_area(self.rec, self.work, self.skip, torch.from_numpy(np.ascontiguousarray(index_sb)).cuda(),
+                                 **self.kw)
+
+    def lrf_search(self, pli, rows):
+        xd, yd = (0, 0) if pli == 0 else (self.xdec, self.ydec)
+        mw = int(rows["w"].max())
+        mh = int(rows["h"].max())
+        xqd, err = self.ctx.lrf_search_batch(self.work[pli], self.src[pli], rows, is_chroma=pli > 0, xdec=xd, ydec=yd,
+                                             scales=self.scales, dist_scale=self.dist_scale[pli], max_w=mw, max_h=mh)
+        return xqd.cpu().numpy(), err.cpu().numpy().view(np.uint64)

@@ -30,6 +30,7 @@ Cases, in the formats the existing tests read:
                                 _rate = [RATE_NONE, RATE_SGR, RATE_PER_SET], _lambda, _geo = RestorationPlaneConfig rows
   ldc<k>  CDEF only          -> <c>_meta, _rec{0,1,2}, _src{0,1,2}, _skip, _ystr, _uvstr, _scales, _dscale, _err, _best
                                 (= cdef_search_ref.npz) + _areas = [sbx0, sby0, sb_w, sb_h] per call
+  every case: <c>_q = [base_q_idx, 1 = all sixteen parameter sets / 0 = the reduced eight]
   ldb<k>  both filters on    -> the CDEF leg's first pass in the ldc format (_err, _best = the pick of that pass), the
                                 whole event trace (<c>_trace, <c>_trace_err) and the final choices (_best_final,
                                 _choice): the interleaving of the two legs, recorded for the host-side integration
@@ -62,6 +63,11 @@ CASES = [
     ("ldc1", 200, 136, 1, 1, 10, 180, "Full", 3, 0.3, 400.0),
     ("ldc2", 96, 80, 1, 0, 12, 100, "Full", 1, 0.2, 2000.0),
     ("ldb0", 136, 72, 1, 1, 8, 100, "Reduced", 2, 0.25, 90.0),
+    # round 6: the later passes on the device (r1_cdef_lrf_trial_batch) -- 10-bit 4:2:0 (BASELINE configs[3]'s format),
+    # and an area of SEVERAL superblocks (128-pixel luma units under qindex 180: a trial reads its neighbours' current
+    # CDEF output left of / above itself)
+    ("ldb1", 136, 72, 1, 1, 10, 100, "Reduced", 2, 0.25, 400.0),
+    ("ldb2", 192, 128, 1, 1, 8, 180, "Reduced", 1, 0.2, 90.0),
 ]
 
 
@@ -279,6 +285,7 @@ def main():
             for sx in range(sbw):
                 best[sy, sx] = int(fb.blocks[(sy * 16) * mi_cols + sx * 16].cdef_index) if kind in "cb" else -1
         out[name + "_geo"] = np.array(geo, np.int32)
+        out[name + "_q"] = np.array([q, 1 if sgr == "Full" else 0], np.int32)      # base_q_idx, all 16 sets / the reduced 8
         out[name + "_areas"] = np.array(areas, np.int32)
         out[name + "_rate"] = np.array([RATE_NONE, RATE_SGR, RATE_PER_SET], np.int32)
         out[name + "_lambda"] = np.array([lam], np.float64)

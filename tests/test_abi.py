@@ -61,7 +61,8 @@ def test_numpy_candidate_layouts_equal_the_header_compiled_as_c(tmp_path):
     pairs = {"R1DistCand": api.DIST_CAND, "R1McCand": api.MC_CAND, "R1RdoCand": api.RDO_CAND,
              "R1IntraEdgeCand": api.INTRA_EDGE_CAND, "R1IntraCand": api.INTRA_CAND, "R1CflAcCand": api.CFL_AC_CAND,
              "R1CflAlphaCand": api.CFL_ALPHA_CAND, "R1CdefBlockCand": api.CDEF_BLOCK_CAND,
-             "R1MeBlockCand": api.ME_BLOCK_CAND, "R1MeResult": api.ME_RESULT, "R1SgrSolveUnit": api.SGR_SOLVE_UNIT}
+             "R1MeBlockCand": api.ME_BLOCK_CAND, "R1MeResult": api.ME_RESULT, "R1SgrSolveUnit": api.SGR_SOLVE_UNIT,
+             "R1TrialUnit": api.TRIAL_UNIT}
     from rav1e_amd import _lib
     structs = {n: getattr(_lib, n) for n in dir(_lib)          # the ctypes mirrors of the parameter structs
                if n.startswith("R1") and isinstance(getattr(_lib, n), type) and issubclass(getattr(_lib, n), C.Structure)}

@@ -98,3 +98,38 @@ def test_the_both_filters_trace_alternates_the_legs_as_the_integration_notes_say
             k = int(np.argmax(later[:, 0] == 2))
             after = later[k:]
             assert (after[after[:, 0] == 0][:, 6] == 1).any()               # ... with errors on the restored copy
+
+
+# ---- round 6: the whole iteration, both filters on, through the host driver (rav1e_amd/loop_decision.py) ----
+import loop_decision_util as U   # noqa: E402
+
+BOTH = U.both_cases(L)
+
+
+@pytest.mark.parametrize("case", BOTH)
+def test_both_filters_iteration_on_the_oracle_reproduces_every_recorded_error(case):
+    """rdo_loop_decision executed whole (ldb*: 8-bit and 10-bit 4:2:0 with one superblock per area, and 128-pixel luma
+    units -- an area of 3 x 2 superblocks whose trials read their neighbours' current CDEF output) against the host
+    driver with the CPU oracle behind it: every rdo_loop_plane_error of every pass in the reference's call order
+    (CDEF trials on the CDEF output and, from the second pass on, on the RESTORED superblock; the restoration leg's
+    options), the final cdef_index per superblock and the final filter per unit.  Pins oracle/loop_decision.c and the
+    driver's host logic (areas, unit <-> superblock maps, rates, costs, the alternation)."""
+    c = U.case(L, case)
+    be = U.OracleBackend(c)
+    ld = U.driver(be, c)
+    n = U.check_against_trace(L, case, ld)
+    assert n > 100 and ld.passes >= 2
+    # the later passes really ran with restoration choices in play
+    assert any(ev[5] == 1 and ev[3] == 1 and ev[4] == 1 and ld.cfgs[ev[0]]["unit_size"] >= 32
+               for evs in ld.events.values() for ev in evs)
+
+
+def test_trial_without_units_is_the_first_pass_search():
+    """r1o_cdef_lrf_trial with no restoration choice = r1o_cdef_strength_search (the fixture's first-pass errors)"""
+    import ctypes as C
+    import oracle_lib as O
+    c = U.case(L, "ldb0")
+    be = U.OracleBackend(c)
+    be.apply(np.full(c["first_best"].shape, -1, np.int8))
+    errp = be.trial([np.zeros(0, U.TRIAL_UNIT)] * 3, np.ones(c["first_best"].shape, np.uint8))
+    assert np.array_equal(errp.sum(axis=3), c["first_err"])
