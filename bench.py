@@ -1079,7 +1079,9 @@ def frame_line(ctx, args, timed, launch_how):
             "config": {"workload": "%dx%d 10-bit 4:2:0, every device-resident stage of one coded frame (BASELINE configs[3]: speed-4 "
                                    "full RDO + CDEF, all kernels): tile ME 8 tiles x 3 refs, sub-pel search, 13-mode intra pre-screen, "
                                    "pixel-domain chain K=%d on luma and both chroma planes, 7-type transform search, deblock level "
-                                   "search + filter, CDEF strength search + filter, restoration search (8 sets) + filter" % (fw, fh, args.k),
+                                   "search + filter, CDEF strength search + filter, restoration search (8 sets) + filter, and rdo_loop_decision's "
+                                   "iteration with both filters on: working copy, restoration leg on it, the second pass of both legs" % (fw, fh, args.k),
+                       "loop_decision": F.get("loop_decision"),
                        "launch": "one call per stage, serialized; stage_ms by HIP events on the launch stream"},
             "stage_ms": {n: round(v, 4) for n, v in per.items()},
             "rdo_candidate_Mpixels_s": round(cand_px / (cand_ms * 1e-3) / 1e6, 1),

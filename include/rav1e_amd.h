@@ -109,7 +109,14 @@ const char *r1_last_error(void);
  * 6 (round 5): R1SgrSolveUnit.reserved[0] became `edges` (R1_SGR_EDGE_*): what r1_sgrproj_solve_batch /
  *    r1_lrf_search_batch see left of / above a unit is the caller's statement of the unit's place in its
  *    rdo_loop_decision area, no longer the unit's place in the frame (0 = nothing, the case of one unit per
- *    plane and area); the restoration entry points refuse planes of 4 GiB and more. */
+ *    plane and area); the restoration entry points refuse planes of 4 GiB and more.  MIGRATION from 5: a
+ *    caller that left reserved = 0 keeps its results only where a plane has ONE unit per area; with several
+ *    units per area (64-pixel luma units under 128-pixel chroma units, qindex > 160) it must now set `edges`
+ *     -- 0 means "the unit alone", no longer "as the unit lies in the frame".
+ * 7 (round 6): + r1_cdef_lrf_trial_batch, r1_cdef_lrf_trial_scratch_bytes, r1_cdef_apply_area, R1TrialUnit,
+ *    r1_comm_plane_pool_open / _close (additions only; nothing of 6 changed).
+ * Additions never changed an existing signature: the peer-store entry points (r1_comm_push_*, round 4) and
+ * r1_comm_push_frame (round 5) were added under versions 4 and 5 respectively. */
 int r1_abi_version(void);
 
 /* ---- dist:: (reference: src/dist.rs get_sad 31, get_satd 156; dispatch
@@ -712,6 +719,10 @@ int r1_deblock_sse_frame(r1_ctx *ctx, const R1Plane *rec, const R1Plane *src, in
  * unit_cols / unit_rows / stripe_height: RestorationPlaneConfig, units:
  * unit_rows x unit_cols entries (DEVICE), filter = RESTORE_NONE 0 or
  * RESTORE_SGRPROJ 3, set = index into SGRPROJ_PARAMS_S, xqd as coded.
+ * A unit with R1_SGR_EDGE_LEFT reads 4 columns left of its x, one with R1_SGR_EDGE_ABOVE 2 rows above its y:
+ * such a unit must lie at x >= 4 (y >= 2) or the plane must carry that much origin padding (xorigin >= 4,
+ * yorigin >= 2; rav1e's planes carry 88 / 44) -- the kernels clamp the read to the allocation's first
+ * column / row otherwise, which is not what the reference reads.
  * All three restoration entry points address pixels with 32-bit byte offsets:
  * R1_EINVAL for an input plane whose allocation (stride * alloc_height *
  * bytes_per_px) reaches 4 GiB or whose stride / alloc_height reach 2^24. */
@@ -927,7 +938,7 @@ int r1_comm_allgather_tiles(r1_comm *comm, const R1Plane *plane, const int32_t *
 int r1_comm_exchange_halos(r1_comm *comm, const R1Plane *plane, const R1HaloXfer *xfers, int n,
                            void *stream);
 
-/* ---- the same exchange as direct peer stores (an addition: the ABI version stays 4).  xGMI is a load / store fabric: once a
+/* ---- the same exchange as direct peer stores (added in round 4 under ABI 4; current version: r1_abi_version()).  xGMI is a load / store fabric: once a
  * peer's plane is mapped into this process, a kernel stores this rank's rectangles straight into
  * it -- N - 1 links at once, no staging copy, nothing to unpack.  Planes have the same geometry on
  * every rank.  INVARIANT: the destination plane is in no peer's live reference set -- nobody may still
@@ -935,8 +946,8 @@ int r1_comm_exchange_halos(r1_comm *comm, const R1Plane *plane, const R1HaloXfer
  * hand-shake (r1_comm_barrier) only orders the stores of THIS step before the kernels behind it.
  * The reconstruction of a frame is a new buffer (src/encoder.rs:3322) that then sits in up to 8
  * reference slots (encoder.rs rec -> ref_frames): a host keeps a pool of (live reference slots + 1)
- * planes per rank, maps every plane of the pool ONCE at start-up (r1_comm_open_peer_planes is a blocking
- * collective per plane: not a per-frame call) and stores a new reconstruction only into the plane that
+ * planes per rank, maps every plane of the pool ONCE at start-up (r1_comm_plane_pool_open: one blocking
+ * collective for the whole pool; not a per-frame call) and stores a new reconstruction only into the plane that
  * left every rank's reference set.  bench.py / rav1e_amd.tiles.TileRing model the two-plane case (the
  * previous frame as the only reference): one reader, so rotating two is enough THERE and only there. */
 typedef struct R1IpcMem {
@@ -965,6 +976,12 @@ int r1_push_rects(r1_ctx *ctx, const R1Plane *plane, void *const *peer_data, int
  * [rank] = plane->data; the exports travel in one all-gather; blocking, once per plane) */
 int r1_comm_open_peer_planes(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void **peer_data);
 int r1_comm_close_peer_planes(r1_comm *comm, r1_ctx *ctx, void **peer_data);
+/* the POOL of a host (live reference slots + 1 planes, see above) in ONE blocking collective: n_planes
+ * (<= 64) planes of the same geometry on every rank; peer_data: n_planes * world entries,
+ * [p * world + r] = plane p of rank r ([p * world + rank] = planes[p].data).  peer_data + p * world is what
+ * the r1_comm_push_* calls take for plane p.  (ABI 7) */
+int r1_comm_plane_pool_open(r1_comm *comm, r1_ctx *ctx, const R1Plane *planes, int n_planes, void **peer_data);
+int r1_comm_plane_pool_close(r1_comm *comm, r1_ctx *ctx, int n_planes, void **peer_data);
 /* stream-ordered hand-shake (a 4-byte all-reduce): what follows on `stream` starts after every
  * rank's stream reached this call */
 int r1_comm_barrier(r1_comm *comm, void *stream);
@@ -972,7 +989,7 @@ int r1_comm_barrier(r1_comm *comm, void *stream);
  * xfers list only the dir == 0 entries are used: a rank's receives are its peers' stores) */
 int r1_comm_push_tile(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
                       const int32_t *rects4, void *stream);
-/* both legs of a frame behind ONE hand-shake: the halo stores, the tile stores, r1_comm_barrier (ABI 5 addition) */
+/* both legs of a frame behind ONE hand-shake: the halo stores, the tile stores, r1_comm_barrier (added in round 5 under ABI 5) */
 int r1_comm_push_frame(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,
                        const R1HaloXfer *xfers, int n, const int32_t *rects4, void *stream);
 int r1_comm_push_halos(r1_comm *comm, r1_ctx *ctx, const R1Plane *plane, void *const *peer_data,

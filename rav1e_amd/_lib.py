@@ -106,6 +106,8 @@ SYMBOLS = {
     "r1_ipc_close": (_i, [_vp, _vp]),
     "r1_push_rects": (_i, [_vp, _PP, _vp, _i, _vp, _i, _vp]),
     "r1_comm_open_peer_planes": (_i, [_vp, _vp, _PP, _vp]),
+    "r1_comm_plane_pool_open": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "r1_comm_plane_pool_close": (_i, [_vp, _vp, _i, _vp]),
     "r1_comm_close_peer_planes": (_i, [_vp, _vp, _vp]),
     "r1_comm_barrier": (_i, [_vp, _vp]),
     "r1_comm_push_tile": (_i, [_vp, _vp, _PP, _vp, _vp, _vp]),

@@ -453,9 +453,16 @@ class Context:
             prm.dist_scale[i] = int(dist_scale[i])
         return prm
 
+    def cdef_lrf_trial_scratch(self, rec, skip_mi, n_idx, xdec, ydec):
+        """the scratch of cdef_lrf_trial_batch (it holds every index' trial output as whole planes), to allocate once"""
+        mi_rows, mi_cols = skip_mi.shape
+        nb = self.lib.r1_cdef_lrf_trial_scratch_bytes(mi_cols, mi_rows, xdec if len(rec) == 3 else 0,
+                                                      ydec if len(rec) == 3 else 0, rec[0].bpp, n_idx, len(rec))
+        return torch.empty(nb, dtype=torch.uint8, device="cuda")
+
     def cdef_lrf_trial_batch(self, rec, cdef_cur, src, skip_mi, units, y_strengths, uv_strengths, damping, bit_depth,
                              n_idx, xdec, ydec, crop_w, crop_h, area_sb=(1, 1), scales=None,
-                             dist_scale=(1 << 14, 1 << 14, 1 << 14), sb_sel=None, scratch=None):
+                             dist_scale=(1 << 14, 1 << 14, 1 << 14), sb_sel=None, scratch=None, outs=None):
         """a later pass of rdo_loop_decision's CDEF leg (src/rdo.rs:2377-2560): every (superblock, cdef_index) trial
         with the restoration units' CURRENT choices applied to the trial's output before the error is taken.
         units: three TRIAL_UNIT arrays (Y, U, V; may be empty) -- the superblocks under a self-guided choice;
@@ -469,13 +476,22 @@ class Context:
         pr = (_lib.R1Plane * 3)(*[(rec[k] if k < len(rec) else rec[0]).cstruct() for k in range(3)])
         pc = (_lib.R1Plane * 3)(*[(cur[k] if k < len(cur) else cur[0]).cstruct() for k in range(3)])
         ps = (_lib.R1Plane * 3)(*[(src[k] if k < len(src) else src[0]).cstruct() for k in range(3)])
-        us = [np.ascontiguousarray(u, TRIAL_UNIT) for u in units] + [np.zeros(0, TRIAL_UNIT)] * (3 - len(units))
-        n_units = (C.c_int32 * 3)(*[len(u) for u in us])
-        allu = np.concatenate(us)
-        du = _dev_cands(allu, TRIAL_UNIT) if len(allu) else None
-        err = torch.empty((n_sby, n_sbx, 8), dtype=torch.int64, device="cuda")
-        errp = torch.empty((n_sby, n_sbx, 8, 3), dtype=torch.int64, device="cuda")
-        best = torch.empty((n_sby, n_sbx), dtype=torch.int8, device="cuda")
+        if isinstance(units, tuple):          # (device byte tensor or None, (n_y, n_u, n_v)): uploaded once by the caller
+            du, counts = units
+            n_units = (C.c_int32 * 3)(*[int(v) for v in counts])
+        else:
+            us = [np.ascontiguousarray(u, TRIAL_UNIT) for u in units] + [np.zeros(0, TRIAL_UNIT)] * (3 - len(units))
+            n_units = (C.c_int32 * 3)(*[len(u) for u in us])
+            allu = np.concatenate(us)
+            du = _dev_cands(allu, TRIAL_UNIT) if len(allu) else None
+        o = outs if outs is not None else {}
+        if "err" not in o:
+            o["err"] = torch.empty((n_sby, n_sbx, 8), dtype=torch.int64, device="cuda")
+        if "err_planes" not in o:
+            o["err_planes"] = torch.empty((n_sby, n_sbx, 8, 3), dtype=torch.int64, device="cuda")
+        if "best" not in o:
+            o["best"] = torch.empty((n_sby, n_sbx), dtype=torch.int8, device="cuda")
+        err, errp, best = o["err"], o["err_planes"], o["best"]
         nb = self.lib.r1_cdef_lrf_trial_scratch_bytes(mi_cols, mi_rows, xdec if len(rec) == 3 else 0,
                                                       ydec if len(rec) == 3 else 0, rec[0].bpp, n_idx, len(rec))
         if scratch is None or scratch.numel() < nb:
@@ -659,18 +675,25 @@ class Context:
         n = dc.numel() // RDO_CAND.itemsize if n is None else n
         ct = torch.int16 if org.bpp == 1 else torch.int32
         o = outs if outs is not None else {}
-        o.setdefault("eob", torch.empty(n, dtype=torch.int16, device="cuda"))
-        o.setdefault("tx_dist", torch.empty(n, dtype=torch.int64, device="cuda"))
+        if "eob" not in o:
+            o["eob"] = torch.empty(n, dtype=torch.int16, device="cuda")
+        if "tx_dist" not in o:
+            o["tx_dist"] = torch.empty(n, dtype=torch.int64, device="cuda")
         if want_sad:
-            o.setdefault("sad", torch.empty(n, dtype=torch.int32, device="cuda"))
+            if "sad" not in o:
+                o["sad"] = torch.empty(n, dtype=torch.int32, device="cuda")
         if want_satd:
-            o.setdefault("satd", torch.empty(n, dtype=torch.int32, device="cuda"))
+            if "satd" not in o:
+                o["satd"] = torch.empty(n, dtype=torch.int32, device="cuda")
         if want_rate:
-            o.setdefault("est_rate", torch.empty(n, dtype=torch.int64, device="cuda"))
+            if "est_rate" not in o:
+                o["est_rate"] = torch.empty(n, dtype=torch.int64, device="cuda")
         if want_qcoeffs:
-            o.setdefault("qcoeffs", torch.empty((n, min(w, 32) * min(h, 32)), dtype=ct, device="cuda"))
+            if "qcoeffs" not in o:
+                o["qcoeffs"] = torch.empty((n, min(w, 32) * min(h, 32)), dtype=ct, device="cuda")
         if want_coeffs:
-            o.setdefault("coeffs", torch.empty((n, w * h), dtype=ct, device="cuda"))
+            if "coeffs" not in o:
+                o["coeffs"] = torch.empty((n, w * h), dtype=ct, device="cuda")
         po, pr = org.cstruct(), ref.cstruct()
         qp = self._qparams(qindex, org.bit_depth, is_intra, dc_delta_q, ac_delta_q)
 
@@ -828,17 +851,23 @@ class Context:
         n = dc.numel() // RDO_CAND.itemsize if n is None else n
         ct = torch.int16 if org.bpp == 1 else torch.int32
         o = outs if outs is not None else {}
-        o.setdefault("eob", torch.empty(n, dtype=torch.int16, device="cuda"))
-        o.setdefault("dist", torch.empty(n, dtype=torch.int64, device="cuda"))
+        if "eob" not in o:
+            o["eob"] = torch.empty(n, dtype=torch.int16, device="cuda")
+        if "dist" not in o:
+            o["dist"] = torch.empty(n, dtype=torch.int64, device="cuda")
         if want_sad:
-            o.setdefault("sad", torch.empty(n, dtype=torch.int32, device="cuda"))
+            if "sad" not in o:
+                o["sad"] = torch.empty(n, dtype=torch.int32, device="cuda")
         if want_satd:
-            o.setdefault("satd", torch.empty(n, dtype=torch.int32, device="cuda"))
+            if "satd" not in o:
+                o["satd"] = torch.empty(n, dtype=torch.int32, device="cuda")
         if want_qcoeffs:
-            o.setdefault("qcoeffs", torch.empty((n, min(w, 32) * min(h, 32)), dtype=ct, device="cuda"))
+            if "qcoeffs" not in o:
+                o["qcoeffs"] = torch.empty((n, min(w, 32) * min(h, 32)), dtype=ct, device="cuda")
         if want_rec:
-            o.setdefault("rec", torch.empty((n, h, w), dtype=torch.uint8 if org.bpp == 1 else torch.int16,
-                                            device="cuda"))
+            if "rec" not in o:
+                o["rec"] = torch.empty((n, h, w), dtype=torch.uint8 if org.bpp == 1 else torch.int16,
+                                            device="cuda")
         po = org.cstruct()
         qp = self._qparams(qindex, org.bit_depth, is_intra, dc_delta_q, ac_delta_q)
 
@@ -880,19 +909,26 @@ class Context:
         nt = bin(int(tx_type_mask)).count("1")
         ct = torch.int16 if org.bpp == 1 else torch.int32
         o = outs if outs is not None else {}
-        o.setdefault("eob", torch.empty((n, nt), dtype=torch.int16, device="cuda"))
-        o.setdefault("dist", torch.empty((n, nt), dtype=torch.int64, device="cuda"))
+        if "eob" not in o:
+            o["eob"] = torch.empty((n, nt), dtype=torch.int16, device="cuda")
+        if "dist" not in o:
+            o["dist"] = torch.empty((n, nt), dtype=torch.int64, device="cuda")
         if want_sad:
-            o.setdefault("sad", torch.empty(n, dtype=torch.int32, device="cuda"))
+            if "sad" not in o:
+                o["sad"] = torch.empty(n, dtype=torch.int32, device="cuda")
         if want_satd:
-            o.setdefault("satd", torch.empty(n, dtype=torch.int32, device="cuda"))
+            if "satd" not in o:
+                o["satd"] = torch.empty(n, dtype=torch.int32, device="cuda")
         if want_est_rate:
-            o.setdefault("est_rate", torch.empty((n, nt), dtype=torch.int64, device="cuda"))
+            if "est_rate" not in o:
+                o["est_rate"] = torch.empty((n, nt), dtype=torch.int64, device="cuda")
         if want_qcoeffs:
-            o.setdefault("qcoeffs", torch.empty((n, nt, min(w, 32) * min(h, 32)), dtype=ct, device="cuda"))
+            if "qcoeffs" not in o:
+                o["qcoeffs"] = torch.empty((n, nt, min(w, 32) * min(h, 32)), dtype=ct, device="cuda")
         if want_rec:
-            o.setdefault("rec", torch.empty((n, nt, h, w), dtype=torch.uint8 if org.bpp == 1 else torch.int16,
-                                            device="cuda"))
+            if "rec" not in o:
+                o["rec"] = torch.empty((n, nt, h, w), dtype=torch.uint8 if org.bpp == 1 else torch.int16,
+                                            device="cuda")
         po = org.cstruct()
         pr = ref.cstruct() if ref is not None else None
         qp = self._qparams(qindex, org.bit_depth, is_intra, dc_delta_q, ac_delta_q)

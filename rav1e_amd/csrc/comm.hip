@@ -639,26 +639,40 @@ extern "C" int r1_push_rects(r1_ctx *ctx, const R1Plane *plane, void *const *pee
 // Every rank's `plane` (same geometry everywhere) mapped on every rank: peer_data[r] = rank r's
 // plane as this rank addresses it (peer_data[rank] = plane->data itself).  The 80-byte exports
 // travel in one all-gather.  Blocking (done once per plane, not per frame).
-extern "C" int r1_comm_open_peer_planes(r1_comm *c, r1_ctx *ctx, const R1Plane *plane, void **peer_data) {
-  R1_REQUIRE(c && ctx && plane && plane->data && peer_data && ctx->device == c->device);
-  for (int r = 0; r < c->world; r++) peer_data[r] = nullptr;
-  peer_data[c->rank] = plane->data;
+extern "C" int r1_comm_plane_pool_close(r1_comm *c, r1_ctx *ctx, int n_planes, void **peer_data);
+
+// A POOL of planes (live reference slots + 1, see the header) mapped on every rank in ONE blocking collective:
+// peer_data[p * world + r] = plane p of rank r as this rank addresses it ([.. + rank] = planes[p].data itself).
+// The n_planes exports of a rank travel together in one all-gather of n_planes * 80 bytes per rank.
+extern "C" int r1_comm_plane_pool_open(r1_comm *c, r1_ctx *ctx, const R1Plane *planes, int n_planes, void **peer_data) {
+  R1_REQUIRE(c && ctx && planes && peer_data && n_planes >= 1 && n_planes <= 64 && ctx->device == c->device);
+  for (int p = 0; p < n_planes; p++) R1_REQUIRE(planes[p].data);
+  for (int i = 0; i < n_planes * c->world; i++) peer_data[i] = nullptr;
+  for (int p = 0; p < n_planes; p++) peer_data[p * c->world + c->rank] = planes[p].data;
   if (c->world == 1) return R1_OK;
-  const size_t bytes = (size_t)plane->stride * plane->alloc_height * plane->bytes_per_px;
   // every rank takes part in the all-gather whatever failed locally (a rank that returned early
   // would leave the others inside the collective); a failed export travels as bytes == 0
-  R1IpcMem mine;
-  memset(&mine, 0, sizeof(mine));
-  int rc = r1_ipc_export(ctx, plane->data, bytes, &mine);
-  if (rc != R1_OK) memset(&mine, 0, sizeof(mine));
+  std::vector<R1IpcMem> mine(n_planes);
+  std::vector<size_t> bytes(n_planes);
+  int rc = R1_OK;
+  for (int p = 0; p < n_planes; p++) {
+    bytes[p] = (size_t)planes[p].stride * planes[p].alloc_height * planes[p].bytes_per_px;
+    memset(&mine[p], 0, sizeof(R1IpcMem));
+    const int e = r1_ipc_export(ctx, planes[p].data, bytes[p], &mine[p]);
+    if (e != R1_OK) {
+      memset(&mine[p], 0, sizeof(R1IpcMem));
+      rc = e;
+    }
+  }
   CommDeviceGuard guard(c);
-  std::vector<R1IpcMem> all(c->world);
+  const size_t slot = sizeof(R1IpcMem) * (size_t)n_planes;
+  std::vector<R1IpcMem> all((size_t)c->world * n_planes);
   // the exports travel through the communicator's staging buffer (grown here if need be).  NOTHING returns
   // before the all-gather: if the buffer cannot be had or the upload fails, this rank still enters the
   // collective -- with whatever the buffer holds when there is one, its slot zeroed where possible (bytes == 0 =
   // "no export") -- and reports its error afterwards; only a rank with no device buffer at all cannot enter,
   // and that is an out-of-memory the peers see as an RCCL error / timeout rather than a silent hang here.
-  const size_t need = sizeof(R1IpcMem) * (size_t)(c->world + 1);
+  const size_t need = slot * (size_t)(c->world + 1);
   hipError_t he = hipSuccess;
   if (c->pack_bytes < need) {
     if (c->pack_used) (void)hipEventSynchronize(c->pack_done);
@@ -672,38 +686,58 @@ extern "C" int r1_comm_open_peer_planes(r1_comm *c, r1_ctx *ctx, const R1Plane *
   }
   ncclResult_t nr = ncclSuccess;
   if (c->pack) {
-    R1IpcMem *dev = (R1IpcMem *)c->pack;
-    hipError_t up = hipMemcpy(dev + c->world, &mine, sizeof(mine), hipMemcpyHostToDevice);
+    uint8_t *dev = (uint8_t *)c->pack;
+    uint8_t *send = dev + slot * (size_t)c->world;
+    hipError_t up = hipMemcpy(send, mine.data(), slot, hipMemcpyHostToDevice);
     if (up != hipSuccess) {
-      (void)hipMemset(dev + c->world, 0, sizeof(mine));   // best effort: travel as "no export"
+      (void)hipMemset(send, 0, slot);   // best effort: travel as "no export"
       he = up;
     }
-    nr = c->api->AllGather(dev + c->world, dev, sizeof(R1IpcMem), ncclUint8, c->nccl, (hipStream_t) nullptr);
+    nr = c->api->AllGather(send, dev, slot, ncclUint8, c->nccl, (hipStream_t) nullptr);
     hipError_t sy = nr == ncclSuccess ? hipStreamSynchronize(nullptr) : hipSuccess;
     if (nr == ncclSuccess && sy == hipSuccess)
-      sy = hipMemcpy(all.data(), dev, sizeof(R1IpcMem) * c->world, hipMemcpyDeviceToHost);
+      sy = hipMemcpy(all.data(), dev, slot * (size_t)c->world, hipMemcpyDeviceToHost);
     if (he == hipSuccess) he = sy;
   }
   if (nr != ncclSuccess) {
-    r1_set_error("r1_comm_open_peer_planes: %s", c->api->GetErrorString(nr));
+    r1_set_error("r1_comm_plane_pool_open: %s", c->api->GetErrorString(nr));
     return R1_ECOMM;
   }
   if (he != hipSuccess) {
-    r1_set_error("r1_comm_open_peer_planes: %s", hipGetErrorString(he));
+    r1_set_error("r1_comm_plane_pool_open: %s", hipGetErrorString(he));
     return R1_EHIP;
   }
   for (int r = 0; r < c->world && rc == R1_OK; r++) {
     if (r == c->rank) continue;
-    if (all[r].bytes != bytes) {
-      r1_set_error("r1_comm_open_peer_planes: rank %d exported %llu bytes, this rank's plane has %llu", r,
-                   (unsigned long long)all[r].bytes, (unsigned long long)bytes);
-      rc = R1_ECOMM;
-    } else {
-      rc = r1_ipc_open(ctx, &all[r], &peer_data[r]);
+    for (int p = 0; p < n_planes && rc == R1_OK; p++) {
+      const R1IpcMem &m = all[(size_t)r * n_planes + p];
+      if (m.bytes != bytes[p]) {
+        r1_set_error("r1_comm_plane_pool_open: rank %d exported %llu bytes for plane %d, this rank's plane has %llu", r,
+                     (unsigned long long)m.bytes, p, (unsigned long long)bytes[p]);
+        rc = R1_ECOMM;
+      } else {
+        rc = r1_ipc_open(ctx, &m, &peer_data[p * c->world + r]);
+      }
     }
   }
-  if (rc != R1_OK) (void)r1_comm_close_peer_planes(c, ctx, peer_data);
+  if (rc != R1_OK) (void)r1_comm_plane_pool_close(c, ctx, n_planes, peer_data);
   return rc;
+}
+
+extern "C" int r1_comm_plane_pool_close(r1_comm *c, r1_ctx *ctx, int n_planes, void **peer_data) {
+  R1_REQUIRE(c && ctx && peer_data && n_planes >= 1);
+  int rc = R1_OK;
+  for (int p = 0; p < n_planes; p++) {
+    const int e = r1_comm_close_peer_planes(c, ctx, peer_data + (size_t)p * c->world);
+    if (e != R1_OK) rc = e;
+  }
+  return rc;
+}
+
+// one plane: the pool of one
+extern "C" int r1_comm_open_peer_planes(r1_comm *c, r1_ctx *ctx, const R1Plane *plane, void **peer_data) {
+  R1_REQUIRE(c && ctx && plane && plane->data && peer_data && ctx->device == c->device);
+  return r1_comm_plane_pool_open(c, ctx, plane, 1, peer_data);
 }
 
 extern "C" int r1_comm_close_peer_planes(r1_comm *c, r1_ctx *ctx, void **peer_data) {

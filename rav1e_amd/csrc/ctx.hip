@@ -19,7 +19,7 @@ void r1_set_error(const char *fmt, ...) {
 extern "C" const char *r1_last_error(void) { return g_err; }
 // 3: round-3 additions (r1_me_status, r1_comm_library, the predict:: dispatch symbols), R1_ENOMEM /
 // R1_ETIMEDOUT got values of their own, R1MeParams.reserved became launch_mode (round 2)
-extern "C" int r1_abi_version(void) { return 6; }
+extern "C" int r1_abi_version(void) { return 7; }
 
 extern "C" int r1_ctx_create(int device, r1_ctx **out) {
   R1_REQUIRE(out);

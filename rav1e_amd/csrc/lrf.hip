@@ -188,7 +188,9 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
       const int lu = t.lu;
       int ru = (t.crop_w - t.x0) - t.uw;
       ru = ru < 3 ? ru : 3;
-      const int xa = t.x0 + clampi(t.cx0 - t.x0 + i - 4, -lu, t.uw + ru - 1);
+      // (never left of the allocation: px_off's unsigned arithmetic would wrap a negative column to +4 GiB)
+      const int xa_ = t.x0 + clampi(t.cx0 - t.x0 + i - 4, -lu, t.uw + ru - 1);
+      const int xa = xa_ > -inside_p.xorigin ? xa_ : -inside_p.xorigin;
       const bool one_plane = inside_p.data == outside_p.data;   // workgroup-uniform (the search filters a unit in isolation)
       const int rows = th2 + 6;
       constexpr int NPASS = (TROWS + 6 + SROWS - 1) / SROWS;
@@ -197,7 +199,8 @@ __device__ __forceinline__ void sgr_tile(const R1Plane &inside_p, const R1Plane 
       for (int q = 0; q < NPASS; q++) {
         const int j = jj + q * SROWS;
         const int cy = clampi(t.y0 + t.ty0 + j - 4, 0, t.crop_h - 1);   // (rows past the tile clamp to a valid address)
-        const int ly = clampi(cy, t.y0 - t.top, t.y0 + h2 + 1);
+        const int ly_ = clampi(cy, t.y0 - t.top, t.y0 + h2 + 1);
+        const int ly = ly_ > -inside_p.yorigin ? ly_ : -inside_p.yorigin;
         const bool inside = ly >= t.y0 && ly < t.y0 + h2 && (!STRICT || xa >= t.x0);
         if (one_plane) v[q] = ld_px_at<BPP>(inside_p, px_off<BPP>(inside_p, xa, ly));
         else v[q] = inside ? ld_px_at<BPP>(inside_p, px_off<BPP>(inside_p, xa, ly)) : ld_px_at<BPP>(outside_p, px_off<BPP>(outside_p, xa, ly));

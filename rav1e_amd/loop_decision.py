@@ -228,8 +228,10 @@ class DeviceBackend:
     def trial(self, units, sb_sel):
         import torch
         sel = torch.from_numpy(np.ascontiguousarray(sb_sel, np.uint8)).cuda()
+        if self.scratch is None:
+            self.scratch = self.ctx.cdef_lrf_trial_scratch(self.rec, self.skip, self.kw["n_idx"], self.xdec, self.ydec)
         _, errp, _ = self.ctx.cdef_lrf_trial_batch(self.rec, self.work, self.src, self.skip, units, scales=self.scales,
-                                                   dist_scale=self.dist_scale, sb_sel=sel, **self.kw)
+                                                   dist_scale=self.dist_scale, sb_sel=sel, scratch=self.scratch, **self.kw)
         return errp.cpu().numpy().view(np.uint64)
 
     def apply(self, index_sb):

@@ -122,11 +122,38 @@ class PeerPlanes:
     torch.distributed barrier -- the form the tests use to drive the stores between two processes
     that share ONE GPU, where RCCL refuses to form a communicator."""
 
+    @classmethod
+    def open_pool(cls, ctx, planes, rank, world, comm=None, group=None):
+        """The plane POOL of a host (live reference slots + 1 planes of one geometry) -> [PeerPlanes], one per plane.
+        With a communicator the whole pool is mapped in ONE blocking collective (r1_comm_plane_pool_open: n_planes x 80
+        bytes per rank in one all-gather) instead of one per plane; close() of the FIRST entry unmaps the pool.  Without
+        one (the torch.distributed form of the tests) the planes are opened one by one."""
+        if comm is None:
+            return [cls(ctx, p, rank, world, None, group) for p in planes]
+        from . import _lib
+        lib = _lib.load()
+        n = len(planes)
+        arr = (_lib.R1Plane * n)(*[p.cstruct() for p in planes])
+        ptrs = (C.c_void_p * (n * world))()
+        rc = lib.r1_comm_plane_pool_open(comm.h, ctx.h, arr, n, ptrs)
+        if rc != 0:
+            raise RuntimeError("r1_comm_plane_pool_open failed (%d): %s" % (rc, lib.r1_last_error().decode()))
+        out = []
+        for i, p in enumerate(planes):
+            pp = cls.__new__(cls)
+            pp.lib, pp.ctx, pp.plane, pp.rank, pp.world, pp.comm, pp.group = lib, ctx, p, rank, world, comm, group
+            pp.ptrs = (C.c_void_p * world).from_buffer(ptrs, i * world * C.sizeof(C.c_void_p))   # a view, not a copy
+            pp._pool = (ptrs, n) if i == 0 else None
+            pp._pooled = True
+            out.append(pp)
+        return out
+
     def __init__(self, ctx, plane, rank, world, comm=None, group=None):
         from . import _lib
         self.lib = _lib.load()
         self.ctx, self.plane, self.rank, self.world, self.comm, self.group = ctx, plane, rank, world, comm, group
         self.ptrs = (C.c_void_p * world)()
+        self._pool, self._pooled = None, False
         p = plane.cstruct()
         if comm is not None:
             self._check(self.lib.r1_comm_open_peer_planes(comm.h, ctx.h, C.byref(p), self.ptrs),
@@ -168,7 +195,11 @@ class PeerPlanes:
     def close(self):
         if self.ptrs is None:
             return
-        if self.comm is not None:
+        if self._pooled:
+            if self._pool is not None:      # the first entry of an open_pool list owns the mapping
+                self.lib.r1_comm_plane_pool_close(self.comm.h, self.ctx.h, self._pool[1], self._pool[0])
+                self._pool = None
+        elif self.comm is not None:
             self.lib.r1_comm_close_peer_planes(self.comm.h, self.ctx.h, self.ptrs)
         else:
             for r in range(self.world):

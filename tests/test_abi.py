@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "missing export: " + n
         assert n in _lib.SYMBOLS, "python binding table lacks " + n
-    assert L.r1_abi_version() == 6
+    assert L.r1_abi_version() == 7
 
 
 def test_struct_layouts():

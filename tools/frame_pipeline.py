@@ -62,6 +62,7 @@ def main():
            "frames_per_s_if_serial": round(1e3 / total, 1),
            "two_stream_ms (ME of the next frame beside the other stages)": ov,
            "frames_per_s_two_streams": round(1e3 / ov, 1)}
+    out["loop_decision"] = F.get("loop_decision")
     if parity is not None:
         out["parity"] = parity
     print(json.dumps(out))

@@ -6,7 +6,9 @@ speed-4 full RDO + CDEF, all kernels"), stage by stage, with every piece of this
   RDO-time sub-pel ME -> intra pre-screen (13 modes) ->
   RDO candidates, pixel-domain chain: luma ladder + both chroma planes ->
   transform-type search (7 RAV1E_TX_TYPES on one prediction per 16x16 / 8x8 block) ->
-  deblock level search -> deblock -> CDEF strength search -> CDEF -> restoration search -> loop restoration
+  deblock level search -> deblock -> CDEF strength search -> CDEF -> restoration search ->
+  rdo_loop_decision's iteration with both filters on (working copy, restoration leg on it, second pass of both legs) ->
+  loop restoration
 
 build() returns the stages as callables on resident inputs plus, for bench.py, a strided parity sample per stage
 against the CPU oracle (tests/oracle_lib.py; test infrastructure, outside every timed region).  Stage inputs are
@@ -316,34 +318,91 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
     stages.append(("cdef_luma", lambda: ctx.cdef_filter_frame_plane(refs[0][0], refs[0][0], dst, 0, 0, 0, fw, fh, skip, ci,
                                                                     [36] * 8, [36] * 8, 5, bd)))
 
-    # the restoration units of the frame as RestorationState::new lays them out for this quantizer (rdo_glue, pinned by
-    # lrf_geometry_ref.npz: 64-pixel luma / 32-pixel chroma units at qindex <= 160 on 4:2:0), every set per unit
-    rcfg = RG.restoration_plane_configs(fw, fh, 1, 1, qindex)
+    # the restoration units of the frame are laid out by the host driver below as RestorationState::new does for this
+    # quantizer (rdo_glue, pinned by lrf_geometry_ref.npz: 64-pixel luma / 32-pixel chroma units at qindex <= 160 on
+    # 4:2:0), every set per unit, edge flags from the unit's place in its area
 
-    def unit_list(cfg, dec):
-        u = [(x, y, w_, h_, s_, 0, (0, 0)) for (x, y, w_, h_) in RG.restoration_search_units(cfg, fw, fh, dec, dec)
-             for s_ in LRF_SETS]
-        return np.array(u, api.SGR_SOLVE_UNIT)
-    h_ul, h_uc = unit_list(rcfg[0], 0), unit_list(rcfg[1], 1)
-    us_l, us_c = rcfg[0]["unit_size"], rcfg[1]["unit_size"]
-    ul = torch.from_numpy(h_ul.view(np.uint8).reshape(-1).copy()).cuda()
-    uc = torch.from_numpy(h_uc.view(np.uint8).reshape(-1).copy()).cuda()
     lrf_res = {}
+    # 8b rdo_loop_decision with BOTH filters on (speed 4: cdef and lrf, src/api/config/speedsettings.rs:78-79,168-171):
+    # the reference alternates the two legs until no choice changes (src/rdo.rs:2366-2374).  The two stages above are
+    # the first pass of each leg.  Here the iteration's device calls as the host driver (rav1e_amd/loop_decision.py)
+    # makes them on THIS frame: the CDEF working copy, the restoration leg on it, and the SECOND pass -- every CDEF
+    # trial with the unit's restoration choice applied to the trial's output before the error is taken, the working
+    # copy again, the restoration leg again for the areas whose cdef_index moved.  The host decisions in between (costs,
+    # picks; stated rates as in tests/golden/gen_loop_decision_ref.py) are made once at build time and the calls
+    # replayed: what is timed is the device work of passes 1 and 2.
+    from rav1e_amd import loop_decision as LD
+    work3 = [Plane(fw, fh, bd, 88, 88), Plane(cw, ch, bd, 44, 44), Plane(cw, ch, bd, 44, 44)]
+    for wp, rp_ in zip(work3, rec3):
+        wp.data.copy_(rp_.data)
 
-    def lrf_search():
-        lrf_res[0] = ctx.lrf_search_batch(rec3[0], src3[0], ul, scales=scales, max_w=us_l, max_h=us_l)
-        for pl in (1, 2):
-            lrf_res[pl] = ctx.lrf_search_batch(rec3[pl], src3[pl], uc, is_chroma=True, xdec=1, ydec=1, scales=scales,
-                                               max_w=us_c, max_h=us_c)
-    stages.append(("lrf_search_8_sets_420", lrf_search))
+    class Recorder(LD.DeviceBackend):
+        log = []
+
+        def trial(self, units, sb_sel):
+            Recorder.log.append(("trial", [u.copy() for u in units], sb_sel.copy()))
+            return super().trial(units, sb_sel)
+
+        def apply(self, index_sb):
+            Recorder.log.append(("apply", index_sb.copy()))
+            return super().apply(index_sb)
+
+        def lrf_search(self, pli, rows):
+            Recorder.log.append(("lrf", pli, rows.copy()))
+            return super().lrf_search(pli, rows)
+    h_skip_s = np.zeros((2 * ((fh + 7) // 8), 2 * ((fw + 7) // 8)), np.uint8)
+    lam2 = 90.0 * (1 << (2 * (bd - 8)))
+    rec_be = Recorder(ctx, rec3, work3, src3, skip_s, PRESETS, PRESETS, 5, bd, 8, 1, 1, fw, fh, (1, 1), scales, [1 << 14] * 3)
+    ld = LD.LoopDecision(rec_be, fw, fh, 1, 1, qindex, h_skip_s, lam2, lambda pli, f_: 24 if f_ is None else 96 + 8 * f_[0],
+                         8, LD.SGR_SETS["Reduced"])
+    assert ld.area == (1, 1), "the replay below assumes one superblock per area (qindex <= 160)"
+    ld.run(max_passes=2)
+    torch.cuda.synchronize()
+    calls = Recorder.log
+    trials = [c_ for c_ in calls if c_[0] == "trial"]
+    apply_at = [i_ for i_, c_ in enumerate(calls) if c_[0] == "apply"]
+    applies = [calls[i_] for i_ in apply_at]
+    lrfs = [[c_ for c_ in calls[i_:] if c_[0] == "lrf"][:3] for i_ in apply_at]
+    loop_info = {"passes_run": ld.passes, "superblocks": int(ld.n_sbx * ld.n_sby),
+                 "pass2_trial_units": [int(len(u)) for u in trials[1][1]] if len(trials) > 1 else None,
+                 "pass1_choices_sgrproj": int(sum(len(u) for u in trials[1][1])) if len(trials) > 1 else 0,
+                 "pass2_restoration_units": [int(len(c_[2]) // 9) for c_ in lrfs[1]] if len(lrfs) > 1 else None}
+    dev_rows = lambda r_: torch.from_numpy(np.ascontiguousarray(r_).view(np.uint8).reshape(-1).copy()).cuda()
+    idx_dev = [torch.from_numpy(a_[1]).cuda() for a_ in applies]
+    ckw = dict(y_strengths=PRESETS, uv_strengths=PRESETS, damping=5, bit_depth=bd, n_idx=8, xdec=1, ydec=1, crop_w=fw, crop_h=fh)
+    stages.append(("cdef_apply_area_420", lambda: ctx.cdef_apply_area(rec3, work3, skip_s, idx_dev[0], **ckw)))
+
+    def lrf_replay(k):
+        rows_dev = [(c_[1], dev_rows(c_[2]), int(c_[2]["w"].max()), int(c_[2]["h"].max())) for c_ in lrfs[k]]
+
+        def run():
+            for (pl, rd, mw, mh) in rows_dev:
+                lrf_res[(k, pl)] = ctx.lrf_search_batch(work3[pl], src3[pl], rd, is_chroma=pl > 0, xdec=int(pl > 0), ydec=int(pl > 0),
+                                                        scales=scales, max_w=mw, max_h=mh)
+        return run
+    lrf_pass1 = lrf_replay(0)
+    stages.append(("lrf_search_8_sets_420", lrf_pass1))      # the restoration leg, on the CDEF working copy (rdo.rs:2575-2582)
+
+    def host_work():
+        hs = []
+        for wp in work3:
+            a_ = wp.data.cpu().numpy()
+            hp = O.HostPlane(wp.width, wp.height, bd, wp.xpad, wp.ypad)
+            hp.data = a_ if a_.dtype == np.uint8 else a_.view(np.uint16)
+            hs.append(hp)
+        return hs
 
     def chk_lrf_search():
         L = O.lib()
         n_chk, ok = 0, True
-        lrf_search()
-        for pl, (hu, xd) in enumerate(((h_ul, 0), (h_uc, 1), (h_uc, 1))):
-            xqd, err = lrf_res[pl][0].cpu().numpy(), lrf_res[pl][1].cpu().numpy().view(np.uint64)
-            pc, sc = h_rec3[pl].cstruct(), h_src3[pl].cstruct()
+        ctx.cdef_apply_area(rec3, work3, skip_s, idx_dev[0], **ckw)
+        lrf_pass1()
+        torch.cuda.synchronize()
+        h_work = host_work()
+        for (_, pl, hu) in lrfs[0]:
+            xd = int(pl > 0)
+            xqd, err = lrf_res[(0, pl)][0].cpu().numpy(), lrf_res[(0, pl)][1].cpu().numpy().view(np.uint64)
+            pc, sc = h_work[pl].cstruct(), h_src3[pl].cstruct()
             for i in sample(len(hu), 27):      # strided over (unit, set): every set appears
                 wx, we = np.zeros(2, np.int8), np.zeros(1, np.uint64)
                 assert L.r1o_lrf_search_unit(C.byref(pc), C.byref(sc), int(hu["x"][i]), int(hu["y"][i]), int(hu["w"][i]),
@@ -353,6 +412,53 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
                 n_chk += 1
         return n_chk, bool(ok)
     checks["lrf_search_8_sets_420"] = chk_lrf_search
+    if len(trials) > 1 and len(applies) > 1:
+        t2_units = np.concatenate(trials[1][1])
+        t2 = (dev_rows(t2_units), [len(u) for u in trials[1][1]])
+        t2_sel = torch.from_numpy(trials[1][2]).cuda()
+        t2_scratch = ctx.cdef_lrf_trial_scratch(rec3, skip_s, 8, 1, 1)
+        t2_outs = {}
+        trial2 = lambda: ctx.cdef_lrf_trial_batch(rec3, work3, src3, skip_s, t2, scales=scales, sb_sel=t2_sel, scratch=t2_scratch,
+                                                  outs=t2_outs, **ckw)
+        stages.append(("cdef_lrf_trial_pass2_420", trial2))
+        stages.append(("cdef_apply_area_pass2_420", lambda: ctx.cdef_apply_area(rec3, work3, skip_s, idx_dev[1], **ckw)))
+        if len(lrfs) > 1 and lrfs[1]:
+            stages.append(("lrf_search_pass2_420", lrf_replay(1)))
+
+        def chk_trial2():
+            # a strided sample of superblocks through oracle/loop_decision.c (r1o_cdef_lrf_trial with sb_sel = the sample):
+            # the per-plane errors of all eight indices, restored planes included
+            import loop_decision_util as U
+            L = U.sigs(O.lib())
+            ctx.cdef_apply_area(rec3, work3, skip_s, idx_dev[0], **ckw)
+            trial2()
+            torch.cuda.synchronize()
+            got = t2_outs["err_planes"].cpu().numpy().view(np.uint64)
+            n_sby, n_sbx = got.shape[:2]
+            sel = np.zeros((n_sby, n_sbx), np.uint8)
+            pick = sample(n_sby * n_sbx, 20)
+            sel.reshape(-1)[pick] = trials[1][2].reshape(-1)[pick]
+            h_work = host_work()
+            prm = O.CdefSearchParams()
+            prm.y_strengths[:] = PRESETS
+            prm.uv_strengths[:] = PRESETS
+            prm.damping, prm.bit_depth, prm.n_idx, prm.planes = 5, bd, 8, 3
+            prm.xdec, prm.ydec, prm.crop_w, prm.crop_h, prm.area_sb_w, prm.area_sb_h = 1, 1, fw, fh, 1, 1
+            prm.dist_scale[:] = [1 << 14] * 3
+            p3 = lambda hs: (O.Plane * 3)(*[h_.cstruct() for h_ in hs])
+            err = np.zeros((n_sby, n_sbx, 8), np.uint64)
+            errp = np.zeros((n_sby, n_sbx, 8, 3), np.uint64)
+            best = np.zeros((n_sby, n_sbx), np.int8)
+            n_units = (C.c_int32 * 3)(*t2[1])
+            hu = np.ascontiguousarray(t2_units)
+            assert L.r1o_cdef_lrf_trial(p3(h_rec3), p3(h_work), p3(h_src3), h_skip_s.ctypes.data, h_skip_s.shape[1],
+                                        h_skip_s.shape[1], h_skip_s.shape[0], h_scales.ctypes.data, h_scales.shape[1],
+                                        C.byref(prm), hu.ctypes.data, n_units, sel.ctypes.data, err.ctypes.data,
+                                        errp.ctypes.data, best.ctypes.data) == 0
+            m = sel.astype(bool)
+            return int(m.sum()) * 24, bool(np.array_equal(got[m], errp[m]) and m.sum() > 0)
+        checks["cdef_lrf_trial_pass2_420"] = chk_trial2
+
     us = 64
     units = np.zeros((max((fh + 32) // us, 1), max((fw + 32) // us, 1), 4), np.uint8)
     units[..., 0] = 3
@@ -394,7 +500,13 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
                                                   for kk, t in tsearch.items()),
            "deblock_level_search_420": 2 * fpx * 3 // 2, "deblock_filter_420": 2 * fpx * 3 // 2,
            "cdef_strength_search_8_presets_420": 2 * fpx * 3 // 2, "cdef_luma": 2 * fpx,
-           "lrf_search_8_sets_420": 2 * fpx * 3 // 2, "lrf_sgrproj_luma": 3 * fpx}
+           "lrf_search_8_sets_420": 2 * fpx * 3 // 2, "lrf_sgrproj_luma": 3 * fpx,
+           # the working copy: read rec, write work; the restoration leg: the working copy + the source once;
+           # a pass-2 trial: rec + source once, plus -- for the planes under a restoration choice -- every index' trial
+           # output written and read back (8 x), which is this implementation's traffic, not compulsory: not counted
+           "cdef_apply_area_420": 2 * fpx * 3 // 2, "cdef_apply_area_pass2_420": 2 * fpx * 3 // 2,
+           "lrf_search_pass2_420": 2 * fpx * 3 // 2,
+           "cdef_lrf_trial_pass2_420": 2 * fpx * 3 // 2}
     for kk in W.LADDER:
         nm = "rdo_pixel_luma_%dx%d_K%d" % (kk, kk, k)
         px[nm] = len(cands[kk]) * kk * kk
@@ -412,9 +524,10 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
                 res[name] = checks[name]()
         return res
     return dict(stages=stages, checks=checks, verify=verify, overlapped=overlapped, candidate_pixels=px, frame=(fw, fh, bd),
+                loop_decision=loop_info,
                 algorithmic_bytes=alg, luma_launch_n={kk: len(cands[kk]) for kk in W.LADDER},
                 working_set_bytes=sum(int(p.data.numel() * p.data.element_size()) for p in [org[0], refs[0][0]] + chroma),
-                keep=(org, refs, chroma, stats, outs, couts, tsearch, dblocks, dunits, lrf_out, dst))
+                keep=(org, refs, chroma, stats, outs, couts, tsearch, dblocks, dunits, lrf_out, dst, work3))
 
 
 def time_stages(stages, reps=20, warm=5, sustain_ms=300.0):
