@@ -339,9 +339,10 @@ def launch_pmc(key):
     d = json.load(open(f))
     prefix, grid = key
     for k, v in d.items():
-        if k.startswith(prefix) and k.endswith("@%d" % grid) and "hbm_traffic_bytes" in v:
-            return {"dominant_traffic_bytes": v["hbm_traffic_bytes"], "kernel": k,
+        if k.startswith(prefix) and k.endswith("@%d" % grid) and ("hbm_traffic_bytes" in v or "SQ_INSTS_VALU" in v):
+            return {"dominant_traffic_bytes": v.get("hbm_traffic_bytes"), "kernel": k,
                     "FETCH_SIZE_KiB": v.get("FETCH_SIZE"), "WRITE_SIZE_KiB": v.get("WRITE_SIZE"),
+                    "SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"), "SQ_WAVES": v.get("SQ_WAVES"),
                     "dispatches_averaged": v.get("n")}, os.path.basename(f)
     return None, None
 
@@ -420,8 +421,21 @@ def build_roofline(kname, abytes, launch_ms, pmc, pmc_src, mix, working_set=None
                 "clock_ghz_by_counters": round(clk, 3) if clk else None,
                 "frac_guide_at_measured_clock": round(ach / (N_SIMD * clk / 2.0), 4) if clk else None,
                 "sources": [pmc_src, mix["source"], "tools/ubench/valu_rate.hip", "tools/ubench/valu_rate2.hip"]}
-    if valu:
+    if not valu and line_counters and line_counters.get("SQ_INSTS_VALU"):
+        # a line's own launch: instruction counters of the same (kernel, grid) from the counter pass over this bench
+        # (tools/gpu_lease.sh pmc_lines), priced with the guide's constant only (no static mix for these kernels)
+        ach = line_counters["SQ_INSTS_VALU"] / sec / 1e9
+        peak_guide = N_SIMD * NOMINAL_GHZ / 2.0
+        valu = {"achieved": round(ach, 2), "unit": "G wave64-instr/s", "insts_per_launch": int(line_counters["SQ_INSTS_VALU"]),
+                "peak_guide": round(peak_guide, 2), "frac_guide": round(ach / peak_guide, 4), "frac_ubench_mix": None,
+                "sources": [line_src]}
+    if valu and valu.get("frac_ubench_mix") is not None:
         binding = "valu" if valu["frac_ubench_mix"] >= (hbm["frac_by_counters"] or hbm["frac"]) else "hbm"
+    elif valu:
+        hb = hbm["frac_by_counters"] if hbm["frac_by_counters"] is not None else (hbm.get("frac_unique") or hbm["frac"])
+        binding = "launch" if launch_ms < 0.02 else ("valu" if valu["frac_guide"] >= hb else "hbm")
+        if binding != "launch" and max(valu["frac_guide"], hb) < 0.15:
+            binding = "latency"       # neither roof within a factor of six: waves wait (dependent chains, barriers, occupancy)
     elif launch_ms < 0.02:
         binding = "launch"        # a launch of a few microseconds: neither roof is in sight
     elif "k_rdo_cand" in kname or "pixel" in kname or "x" in kname.split(":")[-1] and "fused" in kname:
@@ -432,6 +446,8 @@ def build_roofline(kname, abytes, launch_ms, pmc, pmc_src, mix, working_set=None
                 binding_note={"valu": "VALU issue bound: see valu.frac_ubench_mix / frac_guide; HBM is not the limit",
                               "hbm": "HBM / cache bandwidth",
                               "launch": "the launch lasts microseconds: launch-bound, neither roof applies",
+                              "latency": "neither the VALU-issue nor the HBM fraction reaches 0.15: the waves wait (dependent "
+                              "chains, barriers, low occupancy); see valu.frac_guide and hbm.frac_by_counters",
                               "valu (not measured for this launch)": "a fused-candidate launch: the headline's instruction counters say "
                               "this kernel family is VALU issue bound; no instruction counters were taken for this launch",
                               "not measured": "no instruction counters for this launch; `frac` / `frac_unique` / `traffic` are what "
@@ -852,6 +868,53 @@ def config_lines(ctx, args):
     line("config3_mc_1080p", "1920x1080 8-bit luma, ladder 64/32/16/8, K=8: put_8tap + prep_8tap REGULAR with random "
          "1/16-pel fractions, MV +-32 px (benches/mc.rs)", px, per, step, abytes, n_chk, bad,
          working_set=hr.nbytes, wbytes=wbytes, kkeys=kkeys)
+    # config 3: intra prediction (benches/predict.rs: edges uniform 0..255; here every transform block of the frame at
+    # 64/32/16/8/4, the 13 luma modes mixed per block -- DC variants, V, H, the six directional modes at their base
+    # angles with the edge filter on, the three smooth modes, Paeth)
+    from rav1e_amd.api import INTRA_CAND
+    fns, abytes, px, chk, wbytes, kkeys = [], {}, 0, [], {}, {}
+    rng = np.random.default_rng(6)
+    for sz in (64, 32, 16, 8, 4):
+        nb = (w // sz) * (h // sz)
+        ts = int(TxSize.by_dims(sz, sz))
+        edges = np.zeros((nb, 257), np.uint8)
+        il = ia = min(2 * sz, 128)
+        edges[:, 128 - il:129 + ia] = rng.integers(0, 256, (nb, il + ia + 1))
+        lens = np.tile(np.array([il, ia], np.uint8), (nb, 1))
+        ic = np.zeros(nb, INTRA_CAND)
+        pm = rng.integers(0, 13, nb)
+        bx, by = np.arange(nb) % (w // sz), np.arange(nb) // (w // sz)
+        var = np.where((bx == 0) & (by == 0), 0, np.where(by == 0, 1, np.where(bx == 0, 2, 3)))
+        pm = np.where((pm == 12) & (var == 0), 0, np.where((pm == 12) & (var == 2), 1, np.where((pm == 12) & (var == 1), 2, pm)))
+        ic["mode"], ic["variant"] = pm, var
+        ic["angle"] = np.array([0, 90, 180, 45, 135, 113, 157, 203, 67, 0, 0, 0, 0])[pm]
+        ic["ief"] = np.where((pm >= 1) & (pm <= 8), 1, 0)
+        ic["avail_w"] = ic["avail_h"] = sz
+        dic = torch.from_numpy(ic.view(np.uint8).reshape(-1).copy()).cuda()
+        de, dl = torch.from_numpy(edges).cuda(), torch.from_numpy(lens).cuda()
+        tag = "predict %dx%d" % (sz, sz)
+        keep = {}
+        fns.append((tag, lambda ts=ts, dic=dic, de=de, dl=dl, nb=nb, keep=keep: keep.__setitem__("o", ctx.predict_intra_batch(ts, dic, de, dl, 8, n=nb))))
+        abytes[tag] = nb * ((2 * (2 * sz) + 1) + sz * sz)          # (2 (W + H) + 1) bpp read + W H bpp write
+        wbytes[tag] = nb * sz * sz
+        px += nb * sz * sz
+        chk.append((sz, ts, ic, edges, keep))
+    per, step = timed(fns, graph_ok=False)      # the call allocates its output: not capturable
+    n_chk, bad = 0, []
+    for sz, ts, ic, edges, keep in chk:
+        got = keep["o"].cpu().numpy()
+        for i in sample(len(ic)):
+            out = np.zeros((sz, sz), np.uint8)
+            il = ia = min(2 * sz, 128)
+            assert L.r1o_dispatch_predict_intra(int(ic["mode"][i]), int(ic["variant"][i]), O.ptr(out), sz, ts, 8, None,
+                                                int(ic["angle"][i]), int(ic["ief"][i]), O.ptr(edges[i]), il, ia, sz, sz, 0) == 0
+            n_chk += 1
+            if not np.array_equal(got[i], out):
+                bad.append("predict %d mode %d" % (sz, int(ic["mode"][i])))
+                break
+    line("config3_predict_1080p", "every transform block of a 1920x1080 8-bit frame at 64/32/16/8/4: dispatch_predict_intra, the 13 "
+         "luma modes mixed per block, edges uniform 0..255 (benches/predict.rs)", px, per, step, abytes, n_chk, bad,
+         working_set=sum(v for v in wbytes.values()), wbytes=wbytes)
     del po, pr, fns, chk
     torch.cuda.empty_cache()
 
@@ -970,10 +1033,36 @@ def config_lines(ctx, args):
     c_n, c_bad = cdef_chk(L)
     n_chk += c_n
     bad += c_bad
+    # CPU beside it: the scalar oracle of the same chain (oracle/batch.c, OpenMP over candidates) on a strided sample of
+    # every launch, sized for a few seconds on the host cores the bench may use
+    proxy_cpu = None
+    if args.cpu_seconds > 0:
+        cores, _, _ = physical_cores()
+        L.r1o_set_threads(cores)
+        hs = scales.cpu().numpy().view(np.uint32)
+
+        def cpu_chain(frac):
+            t_px, t0_ = 0, time.perf_counter()
+            for s_, c_ in cands.items():
+                sub = np.ascontiguousarray(c_[::max(1, int(round(1 / frac)))])
+                eob, dist = np.zeros(len(sub), np.uint16), np.zeros(len(sub), np.uint64)
+                assert L.r1o_rdo_pixel_cand_batch(C.byref(pa), C.byref(pb), s_, s_, TS[s_], O.ptr(sub), len(sub), args.qindex, 0, 0, 0,
+                                                  3, O.ptr(hs), hs.shape[1], 0, 0, None, None, O.ptr(eob), O.ptr(dist), None,
+                                                  None, None) == 0
+                t_px += len(sub) * s_ * s_
+            return t_px, time.perf_counter() - t0_
+        p0, d0 = cpu_chain(1 / 256)                                   # calibrate
+        want_s = min(6.0, max(2.0, args.cpu_seconds / 3))
+        frac = min(1.0, max(1 / 256, (1 / 256) * want_s / max(d0, 1e-3)))
+        p1, d1 = cpu_chain(frac)
+        proxy_cpu = {"value": round(p1 / d1 / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                     "sample": "every %dth candidate of every ladder size, %.1f s" % (max(1, int(round(1 / frac))), d1),
+                     "impl": "oracle/batch.c r1o_rdo_pixel_cand_batch: scalar C restatement, one OpenMP thread per core"}
+        L.r1o_set_threads(os.cpu_count() or 1)
     line("config4_proxy_4k_10bit", "%dx%d 10-bit: pixel-domain candidate chain over the ladder (K=%d: mc -> dist -> fwd -> quantize "
          "-> inverse -> cdef_dist) + CDEF luma pass + CDEF strength search over rav1e's 8 presets (4:2:0)" % (w, h, k),
          px, per, step, abytes, n_chk, bad, {"dtype": "u16", "px_note": "Mpixels/s counts the candidate pixels of the chain; the "
-                                             "two CDEF launches are inside the step time"},
+                                             "two CDEF launches are inside the step time", "cpu_baseline": proxy_cpu},
          working_set=ho.nbytes + hr.nbytes,
          wbytes={"pixel %dx%d" % (s_, s_): 18 * len(c_) for s_, c_ in cands.items()},
          kkeys={"pixel %dx%d" % (s_, s_): rdo_launch_key(10, s_, 2, len(c_)) for s_, c_ in cands.items()})

@@ -167,6 +167,19 @@ import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['va
     pmc_stage_hbm)   # STAGES=substr: FETCH_SIZE of the kernels of those frame stages, 10-bit (its own pass)
       FP="python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --bit-depth ${ARG:-10} --reps 2 --sustain-ms 0 --stages $STAGES"
       PMC_TIMEOUT=60 pmc_pass stage_fetch "FETCH_SIZE" -- $FP ;;
+    pmc_lines)   # FETCH_SIZE / WRITE_SIZE / VALU counters of EVERY launch of bench.py, its extra / config / frame lines
+                 # included (three passes; csv rows of our kernels only) -> pmc_launches.json (bench.py launch_pmc reads
+                 # the newest profiles/r*_pmc_launches.json)
+      mkdir -p $OUT/pmcl
+      for pass in "tcc1 FETCH_SIZE" "tcc2 WRITE_SIZE" "sq1 SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+        set -- $pass; nm=$1; shift
+        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $@ --output-format csv -d /tmp/pmcl_$TAG/$nm -o p -- \
+          python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --prewarm-ms 0 --cpu-seconds 0 --no-events > /tmp/pmcl_$TAG.$nm.log 2>&1)
+        f=$(find /tmp/pmcl_$TAG/$nm -name "*counter_collection.csv" | head -1)
+        [ -n "$f" ] && (head -1 $f; grep -E 'k_[a-z]' $f) > $OUT/pmcl/$nm.csv || (echo "no counters for $nm"; tail -5 /tmp/pmcl_$TAG.$nm.log)
+      done
+      python3 tools/pmc_summary.py $OUT/pmcl $OUT/pmc_lines_summary.json $OUT/pmc_launches.json | tail -3
+      rm -rf $OUT/pmcl ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
