@@ -848,31 +848,36 @@ __global__ __launch_bounds__(256, BPP == 1 ? 5 : 1) void k_lrf_search_unit(R1Pla
 // on the superblock alone (crop = the superblock; left / above it the area's working copy `cdef_cur` where the edge
 // flags say so), sgrproj_stripe_filter with the chosen (set, xqd) -- and rdo_loop_plane_error of the restored
 // superblock against the source, added to the (superblock, index, plane) sum the CDEF kernels use.
+#ifndef R1_TRIAL_TROWS
+#define R1_TRIAL_TROWS 64   // rows per tile (A/B: 32)
+#endif
 template <int BPP, bool CHROMA>
 __global__ __launch_bounds__(256) void k_sgr_trial_err(R1Plane trial, size_t trial_idx_bytes, R1Plane cdef_cur, R1Plane src,
                                                        const R1TrialUnit *__restrict__ units, int pli, int xdec, int ydec,
                                                        const uint32_t *__restrict__ scales, int scale_stride,
                                                        unsigned long long *__restrict__ psum) {
-  __shared__ uint16_t F[64][TW];
+  constexpr int TR = R1_TRIAL_TROWS;
+  __shared__ __attribute__((aligned(16))) uint16_t F[TR][TW];
   __shared__ unsigned long long part[4];
   const R1TrialUnit u = units[blockIdx.y];
   const int idx = blockIdx.z;
   if (u.w <= 0 || u.h <= 0 || u.w > 64 || u.h > 64 || u.set > 15 || u.sb < 0) return;   // workgroup-uniform
-  const int ntx = (u.w + TW - 1) / TW;
-  if ((int)blockIdx.x >= ntx) return;
+  const int ntx = (u.w + TW - 1) / TW, nty = (u.h + TR - 1) / TR;
+  if ((int)blockIdx.x >= ntx * nty) return;
+  const int tx = (int)blockIdx.x % ntx, ty = (int)blockIdx.x / ntx;
   trial.data = (uint8_t *)trial.data + (size_t)idx * trial_idx_bytes;
   SgrTile t;
   t.x0 = u.x; t.y0 = u.y; t.uw = u.w; t.uh = u.h;
   sgr_unit_edges(t, u.edges);
   t.crop_w = u.x + u.w; t.crop_h = u.y + u.h;   // hard-clipped to the superblock (rdo.rs:2458-2466)
-  t.cx0 = u.x + (int)blockIdx.x * TW;
-  t.ty0 = 0;
-  t.tw = (u.w - (int)blockIdx.x * TW) < TW ? (u.w - (int)blockIdx.x * TW) : TW;
-  t.th = u.h;
+  t.cx0 = u.x + tx * TW;
+  t.ty0 = ty * TR;
+  t.tw = (u.w - tx * TW) < TW ? (u.w - tx * TW) : TW;
+  t.th = (u.h - ty * TR) < TR ? (u.h - ty * TR) : TR;
   const int bd = BPP == 1 ? 8 : src.bit_depth;
   const int w0 = u.xqd[0], w1 = u.xqd[1], w2 = 128 - w0 - w1;
   const int32_t pmax = (1 << bd) - 1;
-  sgr_tile<BPP, 64, BPP == 1, true>(trial, cdef_cur, t, u.set, bd, nullptr, 0, 0,
+  sgr_tile<BPP, TR, BPP == 1, true>(trial, cdef_cur, t, u.set, bd, nullptr, 0, 0,
                                     [&](int x, int y, uint32_t p, uint32_t f1, uint32_t f2, uint32_t) {
     // apply_filter (lrf.rs:796-815)
     const int32_t v = w0 * (int32_t)f2 + w1 * (int32_t)(p << 4) + w2 * (int32_t)f1;
@@ -883,9 +888,58 @@ __global__ __launch_bounds__(256) void k_sgr_trial_err(R1Plane trial, size_t tri
   const int bw = CHROMA ? 8 >> xdec : 8, bh = CHROMA ? 8 >> ydec : 8;
   const int nbx = t.tw / bw, nby = t.th / bh;
   unsigned long long mine = 0;
+#ifndef R1_TRIAL_COOP
+#define R1_TRIAL_COOP 1   // A/B switch: 0 = one thread per 8x8 block
+#endif
+  if constexpr (R1_TRIAL_COOP && !CHROMA) {
+    // rdo_loop_plane_error of the tile with the whole workgroup (as k_lrf_search_unit does): a thread owns an
+    // 8-pixel row segment of a block -- 16 contiguous source bytes, 16 bytes of LDS -- the 8 rows of a block meet by
+    // xor-shuffles (lanes 4 apart), the block sums are parked in LDS and 32 threads run the fixed-point tails
+    __shared__ uint32_t bs[TR / 2][5];
+    const int y = (int)threadIdx.x >> 2, xs = (int)threadIdx.x & 3;
+    uint32_t sum_s = 0, sum_d = 0, sum_s2 = 0, sum_d2 = 0, sum_sd = 0;
+    if (xs < nbx && y < nby * 8 && y < TR) {
+      typedef typename std::conditional<BPP == 1, uint8_t, uint16_t>::type PT;
+      const uint8_t *po = px_addr<BPP>(src, t.cx0 + xs * 8, u.y + t.ty0 + y);
+      PT sv8[8];
+      if (((uintptr_t)po & (8 * BPP - 1)) == 0) {
+        if constexpr (BPP == 1) *(uint2 *)sv8 = *(const uint2 *)po;
+        else *(uint4 *)sv8 = *(const uint4 *)po;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) sv8[i] = (PT)ld_px<BPP>(po + (size_t)i * BPP);
+      }
+      uint16_t dv8[8];
+      *(uint4 *)dv8 = *(const uint4 *)&F[y][xs * 8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint32_t sv = sv8[i], dv = dv8[i];
+        sum_s += sv; sum_d += dv;
+        sum_s2 += sv * sv; sum_d2 += dv * dv; sum_sd += sv * dv;
+      }
+    }
+#pragma unroll
+    for (int m = 4; m < 32; m <<= 1) {     // the 8 rows of a block: lanes 4 apart
+      sum_s += __shfl_xor(sum_s, m, 64); sum_d += __shfl_xor(sum_d, m, 64);
+      sum_s2 += __shfl_xor(sum_s2, m, 64); sum_d2 += __shfl_xor(sum_d2, m, 64);
+      sum_sd += __shfl_xor(sum_sd, m, 64);
+    }
+    if ((y & 7) == 0 && y < TR) {
+      uint32_t *b = bs[(y >> 3) * 4 + xs];
+      b[0] = sum_s; b[1] = sum_d; b[2] = sum_s2; b[3] = sum_d2; b[4] = sum_sd;
+    }
+    __syncthreads();
+    if (threadIdx.x < TR / 2) {
+      const int by = (int)threadIdx.x >> 2, bx = (int)threadIdx.x & 3;
+      if (bx < nbx && by < nby) {
+        const uint32_t *b = bs[threadIdx.x];
+        mine = r1dist::cdef_tile_tail<0>(b[0], b[1], b[2], b[3], b[4], 64, t.cx0 + bx * 8, u.y + t.ty0 + by * 8, scales, scale_stride, bd);
+      }
+    }
+  } else
   if ((int)threadIdx.x < nbx * nby) {
     const int by = (int)threadIdx.x / nbx, bx = (int)threadIdx.x - by * nbx;
-    mine = lrf_block_err<BPP, CHROMA, TW>(src, &F[by * bh][bx * bw], t.cx0 + bx * bw, u.y + by * bh, bw, bh,
+    mine = lrf_block_err<BPP, CHROMA, TW>(src, &F[by * bh][bx * bw], t.cx0 + bx * bw, u.y + t.ty0 + by * bh, bw, bh,
                                           xdec, ydec, scales, scale_stride, bd);
   }
   const unsigned long long v = wg_sum_u64(mine, part);
@@ -908,7 +962,7 @@ int r1i_sgr_trial_err_launch(const R1Plane &trial, size_t trial_idx_bytes, const
                              const uint32_t *scales, int scale_stride, unsigned long long *psum, hipStream_t st) {
   R1_REQUIRE(lrf_plane_ok(&trial) && lrf_plane_ok(&cdef_cur) && lrf_plane_ok(&src));
   R1_REQUIRE(trial.bytes_per_px == src.bytes_per_px && cdef_cur.bytes_per_px == src.bytes_per_px);
-  const dim3 grid(64 / TW, n_units, n_idx);
+  const dim3 grid((64 / TW) * (64 / R1_TRIAL_TROWS), n_units, n_idx);
 #define R1_TRIAL(BPP, CH)                                                                                         \
   hipLaunchKernelGGL((k_sgr_trial_err<BPP, CH>), grid, dim3(256), 0, st, trial, trial_idx_bytes, cdef_cur, src, units, \
                      pli, xdec, ydec, scales, scale_stride, psum)

@@ -167,6 +167,10 @@ import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['va
     pmc_stage_hbm)   # STAGES=substr: FETCH_SIZE of the kernels of those frame stages, 10-bit (its own pass)
       FP="python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --bit-depth ${ARG:-10} --reps 2 --sustain-ms 0 --stages $STAGES"
       PMC_TIMEOUT=60 pmc_pass stage_fetch "FETCH_SIZE" -- $FP ;;
+    prof_frame)   # rocprofv3 --kernel-trace --stats of the config-4 frame (tools/frame_pipeline.py, 10-bit) -> frame_kernel_stats.csv
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proff_$TAG -o prof -- python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --bit-depth ${ARG:-10} --reps 20 > /tmp/proff_$TAG.log 2>&1; tail -1 /tmp/proff_$TAG.log | cut -c1-200)
+      find /tmp/proff_$TAG -name "*kernel_stats*" -exec cp {} $OUT/frame_kernel_stats.csv \; 2>/dev/null
+      head -30 $OUT/frame_kernel_stats.csv | cut -c1-160 ;;
     pmc_lines)   # FETCH_SIZE / WRITE_SIZE / VALU counters of EVERY launch of bench.py, its extra / config / frame lines
                  # included (three passes; csv rows of our kernels only) -> pmc_launches.json (bench.py launch_pmc reads
                  # the newest profiles/r*_pmc_launches.json)
