@@ -1313,20 +1313,34 @@ __global__ __launch_bounds__(256) void k_me_blocks(R1MeJob job, R1MeParams p,
 // in the sub-pel diamond the four 16-lane groups of the wave each own one
 // candidate: window staging, put_8tap (lane = column), SATD / SAD with one lane
 // per Hadamard tile, all inside the group; the four costs meet by shuffles.
-template <int BPP>
+// PHASE 0: the whole search in one launch (the product path).  PHASE 1 / 2 (round 6 experiment, kept behind
+// R1_ME_SMALL_SPLIT): the full-pel search and the sub-pel refinement as two launches -- the result of the first travels
+// through `out` (row, col, sad, cost: the whole MotionSearchResult).  What it showed: the full-pel half needs 61 / 64
+// VGPRs; the 168 VGPRs + 168 / 196 B of scratch (381 MB of scratch writes per 4K launch, profiles/r05_pmc_frame.json)
+// are the sub-pel half's alone (eight inlined (size, bit depth) forms of the fused-candidate column filter + SATD), and
+// giving it 223 VGPRs (two workgroups per CU, 0 B scratch) is SLOWER than three with the spills: the launch is a
+// latency chain per block like the tile search, the scratch stores are not on it (profiles/r06_ab_notes.md, ab3).
 #ifndef R1_ME_SMALL_WAVES
 #define R1_ME_SMALL_WAVES(BPP) 3   // A/B: workgroups the register allocator makes room for (x 4 waves)
 #endif
-__global__ __launch_bounds__(256, R1_ME_SMALL_WAVES(BPP)) void k_me_blocks_small(R1MeJob job, R1MeParams p,
+#ifndef R1_ME_SMALL_WAVES_P1
+#define R1_ME_SMALL_WAVES_P1 4
+#endif
+#ifndef R1_ME_SMALL_WAVES_P2
+#define R1_ME_SMALL_WAVES_P2 3
+#endif
+template <int BPP, int PHASE>
+__global__ __launch_bounds__(256, PHASE == 0 ? R1_ME_SMALL_WAVES(BPP) : (PHASE == 1 ? R1_ME_SMALL_WAVES_P1 : R1_ME_SMALL_WAVES_P2))
+void k_me_blocks_small(R1MeJob job, R1MeParams p,
                                                          const R1MeBlockCand *__restrict__ cands,
                                                          int n, int max_w, int max_h, int use_satd,
                                                          int filter_mode,
                                                          R1MeResult *__restrict__ out) {
   constexpr int WS_MAX = (((16 + 7) * BPP + 3) >> 2) << 2;
   constexpr int GROUP_BYTES = ((23 * WS_MAX + 15) & ~15) + 16 * 16 * BPP;   // window + prediction
-  __shared__ __attribute__((aligned(16))) uint8_t sh_grp[4][4][GROUP_BYTES];
-  __shared__ int16_t sh_subsets[4][kSubsetWords];
-  __shared__ __attribute__((aligned(16))) uint8_t sh_src[4][16 * 16 * BPP];
+  __shared__ __attribute__((aligned(16))) uint8_t sh_grp[PHASE == 1 ? 1 : 4][PHASE == 1 ? 1 : 4][PHASE == 1 ? 16 : GROUP_BYTES];
+  __shared__ int16_t sh_subsets[PHASE == 2 ? 1 : 4][kSubsetWords];
+  __shared__ __attribute__((aligned(16))) uint8_t sh_src[PHASE == 1 ? 1 : 4][PHASE == 1 ? 16 : 16 * 16 * BPP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // an XCD takes a contiguous run of the block list (common.hpp): callers list blocks in raster order, and the search
   // windows of neighbouring blocks overlap -- dealt round-robin, every XCD's L2 fetched the whole reference
@@ -1354,8 +1368,25 @@ __global__ __launch_bounds__(256, R1_ME_SMALL_WAVES(BPP)) void k_me_blocks_small
   b.mc.lambda = p.lambda[0];
   b.mc.allow_hp = p.allow_hp;
   for (int k = 0; k < 2; k++) { b.mc.pmv_row[k] = cd.pmv[k][0]; b.mc.pmv_col[k] = cd.pmv[k][1]; }
-  b.init(org, ref, lane);
-  Msr best = full_pixel_me(b, t, p, cd.bx, cd.by, rng, cd.corner, false, 0, sh_subsets[wave]);
+  Msr best;
+  if constexpr (PHASE != 2) {
+    b.init(org, ref, lane);
+    best = full_pixel_me(b, t, p, cd.bx, cd.by, rng, cd.corner, false, 0, sh_subsets[PHASE == 2 ? 0 : wave]);
+    if constexpr (PHASE == 1) {
+      if (lane == 0) {
+        R1MeResult r;
+        r.row = (int16_t)best.row;
+        r.col = (int16_t)best.col;
+        r.sad = best.sad;
+        r.cost = best.cost;
+        out[bi] = r;
+      }
+      return;
+    }
+  } else {
+    const R1MeResult r = out[bi];      // what PHASE 1 left (the launch before this one on the stream)
+    best = Msr{(int)r.row, (int)r.col, r.cost, r.sad};
+  }
 
   auto in_range = [&](int row, int col) {
     return col >= b.mvx_min && col <= b.mvx_max && row >= b.mvy_min && row <= b.mvy_max;
@@ -1903,12 +1934,22 @@ extern "C" int r1_estimate_motion_batch(r1_ctx *ctx, const R1MeJob *tile, const 
   hipStream_t st = (hipStream_t)stream;
   if (max_w <= 16 && max_h <= 16) {   // one wave per block
     const unsigned grid = (unsigned)((n + 3) / 4);
-    if (bpp == 1)
-      hipLaunchKernelGGL(k_me_blocks_small<1>, dim3(grid), dim3(256), 0, st, *tile, *params, cands, n,
-                         max_w, max_h, use_satd, filter_mode, out);
-    else
-      hipLaunchKernelGGL(k_me_blocks_small<2>, dim3(grid), dim3(256), 0, st, *tile, *params, cands, n,
-                         max_w, max_h, use_satd, filter_mode, out);
+#ifndef R1_ME_SMALL_SPLIT
+#define R1_ME_SMALL_SPLIT 0   // 1 = two launches (round 6 A/B, profiles/r06_ab_notes.md ab3: 3-7 % SLOWER -- the scratch
+                              // traffic of the one-launch form is not what its waves wait for); env R1_ME_SMALL_SPLIT overrides
+#endif
+#define R1_SMALL(B, PH) hipLaunchKernelGGL((k_me_blocks_small<B, PH>), dim3(grid), dim3(256), 0, st, *tile, *params, cands, n, \
+                                           max_w, max_h, use_satd, filter_mode, out)
+    static const int split = [] {
+      const char *e = getenv("R1_ME_SMALL_SPLIT");
+      return e ? atoi(e) : R1_ME_SMALL_SPLIT;
+    }();
+    if (split) {
+      if (bpp == 1) { R1_SMALL(1, 1); R1_SMALL(1, 2); } else { R1_SMALL(2, 1); R1_SMALL(2, 2); }
+    } else {
+      if (bpp == 1) R1_SMALL(1, 0); else R1_SMALL(2, 0);
+    }
+#undef R1_SMALL
     R1_HIP_CHECK(hipGetLastError());
     return R1_OK;
   }
