@@ -30,6 +30,11 @@ struct QParams {
   // s = 18 + ceil(log2 q): exact for every a < 2^18; swept over every table q in
   // tests/test_oracle_quant.py::test_narrow_division_magic_is_exact)
   uint32_t ac_m24, ac_s24;
+  // i32 coefficients that come from PIXEL residuals (the fused kernels): |c << lts| <= 2^17 / 2^19 / 2^21 at 8 / 10 /
+  // 12 bits (L1 norms of the transform networks, tools/tx_range.py::shifted_coefficient_bound, tests/test_tx_range.py),
+  // so a + offset < 2^22 and floor(a / ac_q) = (a * ac_m22) >> ac_s22 with the same 24-bit multipliers
+  // (m = floor(2^s / q) + 1 < 2^23, s = 22 + ceil(log2 q) -- up to 37: past 32 the quotient is the high word shifted)
+  uint32_t ac_m22, ac_s22;
 };
 
 // ---- host side -----------------------------------------------------------
@@ -58,10 +63,11 @@ inline uint32_t dc_q(const R1QuantParams &p) {
 inline uint32_t ac_q(const R1QuantParams &p) {
   return kR1AcQLookup[bd_class(p.bit_depth)][clampq(p.qindex + p.ac_delta_q)];
 }
-inline void narrow_magic(uint32_t q, uint32_t *m, uint32_t *s) {
+// floor(a / q) = (a * m) >> s for every a < 2^nbits: m = floor(2^s / q) + 1, s = nbits + ceil(log2 q)
+inline void narrow_magic(uint32_t q, uint32_t *m, uint32_t *s, unsigned nbits = 18) {
   unsigned L = 0;
   while ((1u << L) < q) L++;
-  *s = 18 + L;
+  *s = nbits + L;
   *m = (uint32_t)((1ull << *s) / q) + 1;
 }
 // QuantizationContext::update (mod.rs:219-265) for one (tx size, coefficient type)
@@ -80,6 +86,7 @@ inline QParams make_qparams(const R1QuantParams &p, int tx_size, int coeff_bytes
   const uint32_t dz = (qp.ac_q - off_eob + (1u << qp.lts) - 1) >> qp.lts;
   qp.deadzone = coeff_bytes == 2 ? (int32_t)(int16_t)dz : (int32_t)dz;
   narrow_magic(qp.ac_q, &qp.ac_m24, &qp.ac_s24);
+  narrow_magic(qp.ac_q, &qp.ac_m22, &qp.ac_s22, 22);
   return qp;
 }
 
@@ -161,7 +168,10 @@ struct ScanRun {
 // area), already rounded and shifted.
 // LTS: log_tx_scale when the caller knows it at compile time (the fused kernels:
 // it follows from the block size), -1 = qp.lts.
-template <typename CT, int GL, int NPL, bool DIST, int LTS = -1>
+// MID (i32 coefficients only): the caller guarantees |c << lts| + ac_offset < 2^22 (coefficients of a pixel residual,
+// see QParams::ac_m22): the AC division and the dequantizer run on the full-rate 24-bit multipliers instead of the
+// quarter-rate 64-bit multiply-add / v_mul_lo_u32 of the general path (quantize.hip: coefficients from HBM, any value).
+template <typename CT, int GL, int NPL, bool DIST, int LTS = -1, bool MID = false>
 __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, bool live,
                                                const uint16_t *__restrict__ scan,
                                                const QParams &qp, unsigned long long tail,
@@ -231,6 +241,11 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
       const uint32_t lo = __umul24(a, qp.ac_m24), hi = umulhi24(qp.ac_m24, a);
       level0 = __builtin_amdgcn_alignbit(hi, lo, qp.ac_s24);   // (hi:lo) >> s, s < 32
       rem = a - __umul24(level0, qp.ac_q);
+    } else if constexpr (MID) {
+      const uint32_t lo = __umul24(a, qp.ac_m22), hi = umulhi24(qp.ac_m22, a);
+      // (hi:lo) >> s; s is wave-uniform: 24 .. 37
+      level0 = qp.ac_s22 < 32 ? __builtin_amdgcn_alignbit(hi, lo, qp.ac_s22) : hi >> (qp.ac_s22 - 32);
+      rem = a - __umul24(level0, qp.ac_q);
     } else {
       level0 = divu_pair(a, qp.ac_a, qp.ac_b, qp.ac_s);
       rem = a - level0 * qp.ac_q;
@@ -285,6 +300,11 @@ __device__ __forceinline__ void quantize_group(int32_t *mine, int g0, int l, boo
         r = (int32_t)(CT)((__mul24(qt, (int32_t)quant) + ((qt >> 31) & off)) >> lts);
         dd = cv[k] - r;                 // both i16: 17 bits
         sq = mul24_wrap(dd, dd);        // low 32 bits = the wrapping i32 product
+      } else if constexpr (MID) {
+        // |q| <= 2^22 / 4, quant < 2^15, |dd| < 2^22: the low 32 bits of the 24-bit products ARE the wrapping i32 products
+        r = (int32_t)((uint32_t)mul24_wrap(qt, (int32_t)quant) + (uint32_t)((qt >> 31) & off)) >> lts;
+        dd = (int32_t)((uint32_t)cv[k] - (uint32_t)r);
+        sq = mul24_wrap(dd, dd);
       } else {
         r = (int32_t)((uint32_t)qt * quant + (uint32_t)((qt >> 31) & off)) >> lts;
         dd = (int32_t)((uint32_t)cv[k] - (uint32_t)r);

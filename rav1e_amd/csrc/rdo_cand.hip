@@ -765,8 +765,15 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
     unsigned long long dist = 0;
     // log_tx_scale follows from the block size (quantize/mod.rs:get_log_tx_scale): a constant here
     constexpr int LTS = (W * H > 256) + (W * H > 1024);
-    r1q::quantize_group<CT, PL, NPLQ, QM == 1, LTS>(tile, cl2 * P, r, live2, qa.scan[kind], qa.qp, tail,
-                                                    eob, dist);
+#ifndef R1_QUANT_MID
+#define R1_QUANT_MID 0   // the 24-bit quantizer for i32 coefficients: exact (tests/test_tx_range.py, GPU-tested at the range
+                         // limits) and no faster -- 10-bit pixel chain 283-285 k -> 282 k Mpx/s, the 32x32 launch +5 % slower
+                         // (profiles/r06_ab_notes.md, ab4).  Off: the round-5 arithmetic stays the product path.
+#endif
+    // i32 coefficients here come from a pixel residual: |c << lts| <= 2^21 (quant_common.hpp, QParams::ac_m22)
+    constexpr bool QMID = R1_QUANT_MID && sizeof(CT) == 4;
+    r1q::quantize_group<CT, PL, NPLQ, QM == 1, LTS, QMID>(tile, cl2 * P, r, live2, qa.scan[kind], qa.qp, tail,
+                                                          eob, dist);
     if (live_st && r == 0) {
       qa.eob[oslot] = (uint16_t)eob;
       if constexpr (QM == 1) {
@@ -799,7 +806,8 @@ __global__ __launch_bounds__(64, rdo_waves_hint(BD, WL, HL, QM, MT)) void k_rdo_
           for (int k = 0; k < WC; k++) {
             const int32_t q = (int32_t)(CT)tile[k * OS + r];
             const uint32_t quant = (k == 0 && r == 0) ? qa.qp.dc_q : qa.qp.ac_q;
-            const T raw = (T)(CT)((int32_t)((uint32_t)q * quant + (uint32_t)((q >> 31) & off)) >> LTS);
+            const uint32_t prod = QMID ? (uint32_t)r1q::mul24_wrap(q, (int32_t)quant) : (uint32_t)q * quant;
+            const T raw = (T)(CT)((int32_t)(prod + (uint32_t)((q >> 31) & off)) >> LTS);
             const T val = RECT1 ? ((T)((uint32_t)raw * 2896u + 2048u) >> 12) : raw;
             w_[k] = r1itx::clamp3(val, lo, hi);
           }

@@ -1318,6 +1318,63 @@ def test_rdo_pixel_cand_vs_oracle(ctx, oracle, bd):
             assert np.array_equal(o2["dist"].cpu().numpy().view(np.uint64), wdist), key
 
 
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_quantizer_at_the_coefficient_range_limits(ctx, oracle, bd):
+    """The fused kernels divide |c << log_tx_scale| by ac_q on 24-bit multipliers (csrc/quant_common.hpp, NARROW for
+    i16 and -- round 6 -- MID for i32 coefficients), exact while the operand stays below 2^18 / 2^22.  The largest
+    coefficients a pixel residual can produce: source at one end of the pixel range against a prediction at the other
+    (flat: everything lands on DC), stripes and checkerboards of the two (energy on the highest AC basis), every
+    transform size, the smallest and the largest quantizer (qindex 0: the largest levels; 255), every valid type --
+    the pixel-domain chain (eob, qcoeffs, reconstruction, distortion) and the transform-domain chain (tx_dist) against
+    the oracle's general 32 / 64-bit arithmetic."""
+    import ctypes as C
+    from rav1e_amd.types import valid_av1_transform
+    W, H = 192, 128
+    mx = (1 << bd) - 1
+    yy, xx = np.mgrid[0:H, 0:W]
+    pats = {"flat": np.full((H, W), mx), "rows": np.where(yy & 1, mx, 0), "cols": np.where(xx & 1, mx, 0),
+            "checker": np.where((xx ^ yy) & 1, mx, 0), "blocks4": np.where(((xx >> 2) ^ (yy >> 2)) & 1, mx, 0)}
+    ct = np.int16 if bd == 8 else np.int32
+    dt = np.uint8 if bd == 8 else np.uint16
+    rng = np.random.default_rng(12 + bd)
+    for name, img in pats.items():
+        for flip in (False, True):
+            src_img = mx - img if flip else img
+            a = O.plane_from_image(src_img, bd, 88, 88)
+            b = O.plane_from_image(mx - src_img, bd, 88, 88)      # the prediction: every residual sample is +-max
+            da, db = dev_plane(a), dev_plane(b)
+            pa, pb = a.cstruct(), b.cstruct()
+            for ts, (w, h) in enumerate(TX_SIZES):
+                carea = min(w, 32) * min(h, 32)
+                valid = [t for t in range(16) if valid_av1_transform(ts, t)]
+                n = len(valid)
+                c = np.zeros(n, O.RDO_CAND)
+                c["ox"] = c["rx"] = rng.integers(0, (W - w) // 2 + 1, n) * 2      # even: the pattern's phase is kept
+                c["oy"] = c["ry"] = rng.integers(0, (H - h) // 2 + 1, n) * 2
+                c["tx_type"] = valid
+                for qi in (0, 255):
+                    weob, wdist = np.zeros(n, np.uint16), np.zeros(n, np.uint64)
+                    wq, wrec = np.zeros((n, carea), ct), np.zeros((n, h, w), dt)
+                    assert oracle.r1o_rdo_pixel_cand_batch(C.byref(pa), C.byref(pb), w, h, ts, O.ptr(c), n, qi, 0, 0, 0, 3, None, 0,
+                                                           0, 0, None, None, O.ptr(weob), O.ptr(wdist), O.ptr(wq), O.ptr(wrec),
+                                                           None) == 0
+                    o = ctx.rdo_pixel_cand_batch(da, db, w, h, c, qi, 3, want_qcoeffs=True, want_rec=True, want_sad=False,
+                                                 want_satd=False)
+                    key = (bd, name, flip, w, h, qi)
+                    assert np.array_equal(o["qcoeffs"].cpu().numpy(), wq), key
+                    assert np.array_equal(o["eob"].cpu().numpy().view(np.uint16), weob), key
+                    assert np.array_equal(o["rec"].cpu().numpy().view(dt), wrec), key
+                    assert np.array_equal(o["dist"].cpu().numpy().view(np.uint64), wdist), key
+                    feob, fdist = np.zeros(n, np.uint16), np.zeros(n, np.uint64)
+                    assert oracle.r1o_rdo_full_cand_batch(C.byref(pa), C.byref(pb), w, h, ts, O.ptr(c), n, qi, 0, 0, 0, None, None,
+                                                          O.ptr(feob), O.ptr(fdist), None, None) == 0
+                    f = ctx.rdo_full_cand_batch(da, db, w, h, c, qi, want_sad=False, want_satd=False)
+                    assert np.array_equal(f["eob"].cpu().numpy().view(np.uint16), feob), key
+                    assert np.array_equal(f["tx_dist"].cpu().numpy().view(np.uint64), fdist), key
+            if name == "flat":
+                assert int(np.abs(wq).max()) > 0
+
+
 @pytest.mark.parametrize("bd", [8, 10])
 def test_rdo_pred_cand_vs_oracle(ctx, oracle, bd):
     """r1_rdo_pred_cand_batch: the chains with the prediction taken from a dense buffer (intra

@@ -44,3 +44,31 @@ def test_transposed_tile_of_blocks_up_to_16x16_fits_int16():
                 _, go = R.l1_gain(tcol)
                 worst[bd] = max(worst[bd], (b0 * go + 64) * 2.0 ** sh[1] + 1)
     assert worst[8] <= 8193 and worst[10] <= 16433 and worst[12] <= 16445 and max(worst.values()) < 32767, worst
+
+
+def test_shifted_coefficients_of_pixel_residuals_leave_room_for_the_24_bit_quantizer():
+    """csrc/quant_common.hpp (MID): the fused kernels divide a = |c << log_tx_scale| + ac_offset by ac_q with
+    m = floor(2^s / q) + 1, s = 22 + ceil(log2 q), on v_mul_u32_u24 / v_mul_hi_u32_u24 -- exact for a < 2^22, operands
+    below 2^24.  (1) a < 2^22 for every size / type / bit depth when the residual comes from pixels; (2) the magic is
+    exact: floor(a * m >> s) is monotone in a, so agreeing with a // q at every k q - 1 and k q below 2^22 is agreeing
+    everywhere; every AC quantizer of the 8 / 10 / 12-bit tables."""
+    import re
+    import tx_range as R
+    w = R.shifted_coefficient_bound()
+    assert w[8] < 2 ** 17.01 and w[10] < 2 ** 19.01 and w[12] < 2 ** 21.01, {k: np.log2(v) for k, v in w.items()}
+    src = open(os.path.join(ROOT, "rav1e_amd", "csrc", "quant_tables.inc")).read()
+    tabs = re.findall(r"kR1AcQLookup\[3\]\[256\]\s*=\s*\{(.*?)\};", src, re.S)
+    assert tabs
+    qs = sorted({int(v) for v in re.findall(r"\d+", tabs[0])})
+    assert len(qs) > 300 and qs[0] == 4 and qs[-1] == 29247
+    for q in qs:
+        off = q * 109 // 256                      # the largest ac_offset (intra, ac_offset1)
+        assert w[12] + off < 2 ** 22
+        L = (q - 1).bit_length()
+        s = 22 + L
+        m = (1 << s) // q + 1
+        assert m < 1 << 24
+        k = np.arange(1, (1 << 22) // q + 1, dtype=np.uint64)
+        for a in (k * np.uint64(q) - np.uint64(1), k * np.uint64(q)):
+            a = a[a < (1 << 22)]
+            assert np.array_equal((a * np.uint64(m)) >> np.uint64(s), a // np.uint64(q)), q

@@ -58,6 +58,29 @@ def analyse():
     return rows
 
 
+def shifted_coefficient_bound():
+    """{bit depth: max over sizes / types of |c << log_tx_scale| for residuals that come from pixels}: the magnitude
+    the quantizer divides (quantize/mod.rs:296-318) -- what lets the fused kernels' quantizer run on 24-bit multipliers
+    (csrc/quant_common.hpp, QParams::ac_m22: a + ac_offset < 2^22)"""
+    worst = {8: 0.0, 10: 0.0, 12: 0.0}
+    for bd in worst:
+        for ts, (w, h) in enumerate(F.TX_DIMS):
+            for tt in range(16):
+                if not F.valid_av1_transform(ts, tt):
+                    continue
+                sh = F.FWD_SHIFT[ts][(bd - 8) // 2]
+                tcol = F.TXFM_TYPE_LS[h.bit_length() - 3][F.VTX_TAB[tt]]
+                trow = F.TXFM_TYPE_LS[w.bit_length() - 3][F.HTX_TAB[tt]]
+                b0 = ((1 << bd) - 1) * (1 << sh[0])
+                _, go = l1_gain(tcol)
+                b1 = (b0 * go + 64) * 2.0 ** sh[1] + 1
+                _, go2 = l1_gain(trow)
+                out = (b1 * go2 + 64) * 2.0 ** sh[2] + 1
+                lts = (w * h > 256) + (w * h > 1024)
+                worst[bd] = max(worst[bd], out * (1 << lts))
+    return worst
+
+
 if __name__ == "__main__":
     rows = analyse()
     worst = max(rows, key=lambda r: r[3])
