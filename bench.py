@@ -76,6 +76,10 @@ def parse():
                          "(r1_comm_push_*), p2p = grouped RCCL send / receive (r1_comm_exchange_halos + "
                          "r1_comm_allgather_tiles); auto = push if every rank can map its peers' planes and "
                          "the tagged-tile check passes through it, else p2p")
+    ap.add_argument("--overlap-exchange", action="store_true",
+                    help="N > 1 with peer stores: the halo stores of a step leave on a side stream as soon as the tile's "
+                         "border is written, beside the step's launches (tiles.TileRing.begin_overlapped / "
+                         "finish_overlapped); off by default -- never timed on hardware")
     ap.add_argument("--verify-exchange", action="store_true",
                     help="N = 1: run the tagged-tile self-check of the exchange through the C-ABI communicator "
                          "(world 1) as the N > 1 runs always do; the result is config.exchange_ok")
@@ -1355,12 +1359,20 @@ def main():
     else:
         size_streams = {s: torch.cuda.Stream() for s in W.LADDER} if fan else {}
 
+    overlap_side = [None]
+
     def step(timed, exchange=True):
         mark = timed and use_events and nstep[0] % EV_EVERY == 0
         split = timed and split_events and exchange and nstep[0] % EV_EVERY == 0
         if timed:
             nstep[0] += 1
         main = torch.cuda.current_stream()
+        overlapped = bool(args.overlap_exchange and world > 1 and exchange and ring_peers)
+        if overlapped:
+            # the border of this rank's new tile and its halo stores FIRST (side stream), the step's launches beside them
+            if overlap_side[0] is None:
+                overlap_side[0] = torch.cuda.Stream()
+            tile_ring[0].begin_overlapped(overlap_side[0])
         if fan and not split and (not mark or args.step_join):
             # independent launches, one stream per block size (each stream is in order with the
             # same size's launch of the previous step, which wrote the same output buffers).
@@ -1412,7 +1424,10 @@ def main():
             if ring_peers:
                 # peer stores: the new tile goes into the other plane of the ring, its borders and
                 # then the whole tile straight into the peers' copies of that plane (tiles.TileRing)
-                tile_ring[0].advance()
+                if overlapped:
+                    tile_ring[0].finish_overlapped()
+                else:
+                    tile_ring[0].advance()
                 cur[0] = tile_ring[0].cur
             elif comm is not None:
                 my_tile.bitwise_xor_(tiles.ring_delta(xsteps[0]))

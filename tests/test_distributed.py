@@ -485,7 +485,7 @@ def test_peer_stores_two_processes_one_gpu(bd):
         assert n == 1 and ok_halo and ok_all, (rank, n, ok_halo, ok_all)
 
 
-def _worker_ring(rank, world, port, q, bd, steps, devices):
+def _worker_ring(rank, world, port, q, bd, steps, devices, overlap=False):
     """tiles.TileRing -- the code bench.py --gpus N steps -- for `steps` ring steps with the check after
     EVERY step; devices: one GPU index per rank (the same one twice: two processes on one GPU)."""
     try:
@@ -508,8 +508,12 @@ def _worker_ring(rank, world, port, q, bd, steps, devices):
         tr = tiles.TileRing(ring, peers, rects, rank, tiles.visible(ring[0]).clone())
         ok0 = tr.check()                                   # t = 0: both planes are the original
         bad_at = -1
+        side = torch.cuda.Stream() if overlap else None
         for i in range(steps):
-            tr.advance()
+            if overlap:       # halo stores on a side stream beside the interior's work (TileRing.advance_overlapped)
+                tr.advance_overlapped(side)
+            else:
+                tr.advance()
             if not tr.check() and bad_at < 0:
                 bad_at = i
         # the check is not vacuous: a step whose tile store is skipped on ONE rank leaves a stale tag in
@@ -539,12 +543,12 @@ def _worker_ring(rank, world, port, q, bd, steps, devices):
         q.put((rank, False, 0, 0, traceback.format_exc()[-1500:]))
 
 
-def _run_ring(devices, bd, steps):
+def _run_ring(devices, bd, steps, overlap=False):
     import torch.multiprocessing as mp
     world = len(devices)
     ctx = mp.get_context("spawn")
     q, port = ctx.Queue(), _free_port()
-    ps = [ctx.Process(target=_worker_ring, args=(r, world, port, q, bd, steps, devices)) for r in range(world)]
+    ps = [ctx.Process(target=_worker_ring, args=(r, world, port, q, bd, steps, devices, overlap)) for r in range(world)]
     for p in ps:
         p.start()
     res = [q.get(timeout=600) for _ in ps]
@@ -568,6 +572,41 @@ def test_tile_ring_240_steps_two_processes_one_gpu(bd):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     _run_ring([0, 0], bd, 240)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bd", [8, 10])
+def test_tile_ring_overlapped_exchange_two_processes_one_gpu(bd):
+    """the ring with the exchange's halo leg on a side stream, gated by an event behind the tile's border and running
+    beside its interior (tiles.TileRing.advance_overlapped): 240 steps, every rank's copy of every tile after every
+    step, and the dropped-store detection, as for the serial schedule"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _run_ring([0, 0], bd, 240, overlap=True)
+
+
+@pytest.mark.gpu
+def test_tile_ring_overlapped_exchange_world_1_with_pool(ctx):
+    """world 1 through the C-ABI communicator: the plane POOL opened in one call (r1_comm_plane_pool_open), the
+    overlapped step's control flow (events, side stream, empty store lists), the ring check"""
+    import torch
+    from rav1e_amd import tiles, workload as W
+    from rav1e_amd.api import Plane
+    fw, fh = 640, 360
+    host = W.random_plane_array(fw, fh, 8, 17)
+    ring = [Plane.from_numpy(host, fw, fh, 8, 88, 88) for _ in range(2)]
+    comm = tiles.Comm(ctx, 0, 1)
+    peers = tiles.PeerPlanes.open_pool(ctx, ring, 0, 1, comm=comm)
+    assert len(peers) == 2 and peers[0].ptrs[0] == ring[0].data.data_ptr() and peers[1].ptrs[0] == ring[1].data.data_ptr()
+    tr = tiles.TileRing(ring, peers, W.tile_rects(1, fw, fh), 0, tiles.visible(ring[0]).clone())
+    side = torch.cuda.Stream()
+    for _ in range(12):
+        tr.advance_overlapped(side)
+        assert tr.check()
+    for pp in peers:
+        pp.close()
+    comm.close()
 
 
 @pytest.mark.gpu

@@ -71,7 +71,7 @@ def main():
         th = -(-(h // ny) // 64) * 64
         return [(x, y, min(tw, w - x), min(th, h - y)) for y in range(0, h, th) for x in range(0, w, tw)]
 
-    for ci, (nx, ny, nref) in enumerate(((1, 1, 1), (1, 1, 4), (4, 2, 1), (2, 2, 4), (4, 4, 4))):
+    for ci, (nx, ny, nref) in enumerate(((1, 1, 1), (1, 1, 4), (4, 2, 1), (2, 2, 4), (4, 4, 4), (4, 2, 3))):
         if args.only >= 0 and ci != args.only:
             continue
         tl = tiles_of(nx, ny)
@@ -95,6 +95,13 @@ def main():
                "launch": launch_label(len(jobs)),
                "Mpixels_s": round(w * h * nref / ms / 1e3, 1),
                "frames_refs_per_s": round(nref / ms * 1e3, 1)}
+        # the dependent chain of the largest tile: a block needs its left and its upper neighbour of the same pass
+        # (get_subset_predictors, src/me.rs:420-452), so pass 3 (16x16 blocks) of a tile of c x r blocks is c + r - 1
+        # block searches long whatever the number of waves; passes 1 and 2 run skewed beside it
+        tw_, th_ = max(t[2] for t in tl), max(t[3] for t in tl)
+        steps = -(-tw_ // 16) + -(-th_ // 16) - 1
+        row["chain_steps_pass3"] = steps
+        row["us_per_chain_step"] = round(ms * 1e3 / steps, 2)
         if args.cpu and len(jobs) > 1:
             # every job of the concurrent launch against the oracle run tile by tile
             L = O.lib()

@@ -116,10 +116,11 @@ d=json.loads(sys.stdin.read()); print('%-22s bd %2d %9.0f Mpx/s rdo_only %s kern
       done; done 2>&1 | tee $OUT/px_ab.txt
       cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
     dry)   # N = 2 and 4 control flow on ONE GPU (numbers mean nothing): the exchange, its pre-run and after-run self-checks
-      for n in 2 4; do
-        timeout 600 python bench.py --gpus $n --single-device --backend gloo --steps 30 --warmup 3 --cpu-seconds 0 --no-extra 2>$OUT/dry$n.err | grep "^{" > $OUT/dry$n.json
+      for n in 2 4 2o; do
+        extra=""; [ $n = 2o ] && extra="--overlap-exchange"
+        timeout 600 python bench.py --gpus ${n%o} --single-device --backend gloo --steps 30 --warmup 3 --cpu-seconds 0 --no-extra $extra --detail-out gpurun_out/$TAG/dry${n}_detail.json 2>$OUT/dry$n.err | grep "^{" > $OUT/dry$n.json
         python3 -c "
-import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['value'], d['config']['exchange'][:60], d['config']['exchange_ok'])" || tail -5 $OUT/dry$n.err
+import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['value'], d['config']['exchange'], d['config']['exchange_ok'])" || tail -5 $OUT/dry$n.err
       done ;;
     kernels) for bd in 8 10; do timeout 900 python tools/bench_kernels.py --bit-depth $bd 2>/dev/null | grep "^{" > $OUT/kernels_${bd}bit.jsonl; wc -l $OUT/kernels_${bd}bit.jsonl; done ;;
     frame) for bd in 8 10; do timeout 900 python tools/frame_pipeline.py --verify --bit-depth $bd 2>$OUT/frame_${bd}.err | grep "^{" | tee $OUT/frame_pipeline_${bd}bit.json | cut -c1-600; done ;;
