@@ -691,6 +691,9 @@ constexpr int kPassSkew = 2;
 // experiment build only: per pass, [0] workgroups, [1] sum of workgroup lifetimes, [2] longest
 // workgroup, [3] sum of the refinement phase (100 MHz wall-clock ticks)
 __device__ unsigned long long g_me_prof[3][4];
+// k_me_persist, search rows: per pass [0] block searches, [1] set-up + wait for the neighbours, [2] the search
+// (predictors, candidates, diamond), [3] result stores + publish (100 MHz ticks, summed over the waves)
+__device__ unsigned long long g_me_step[3][4];
 #endif
 #ifndef R1_ME_DIAG_WAVES
 #define R1_ME_DIAG_WAVES 5
@@ -982,6 +985,9 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
         const int w = imin(sz, sb_w - xin + (1 << ssdec) - 1) >> ssdec;
         const int h = imin(sz, sb_h - yin + (1 << ssdec) - 1) >> ssdec;
         // everything that does not depend on the neighbours first: source rows, masks, MV range
+#ifdef R1_ME_PROF
+        const unsigned long long st0 = wall_clock64();
+#endif
         Block<BPP, 16, 3> b;
         int rng[4];
         setup_block(b, org, ref, p, t, bx, by, w, h, ssdec, lane, rng);
@@ -1012,8 +1018,24 @@ __global__ __launch_bounds__(64, 2) void k_me_persist(MePersistArgs a) {
           if (row.gy > 0 || !init) ok = me_wait_lanes(mf, mn, a.epoch, a.spin) && ok;
         }
         const int corner = init ? 0 : (1 | ((xin & sz) ? 2 : 0) | ((yin & sz) ? 4 : 0));
+#ifdef R1_ME_PROF
+        const unsigned long long st1 = wall_clock64();
+#endif
         const Msr r = full_pixel_me<Block<BPP, 16, 3>, true>(b, t, p, bx, by, rng, corner, init, ssdec, sh_subsets);
+#ifdef R1_ME_PROF
+        const unsigned long long st2 = wall_clock64();
+#endif
         store_result<true, !PIN || R1_ME_FORMAL>(t, 1 << log2b, bx, by, r, w, h, ssdec, lane);
+#ifdef R1_ME_PROF
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) {
+          const unsigned long long st3 = wall_clock64();
+          atomicAdd(&g_me_step[pass][0], 1ull);
+          atomicAdd(&g_me_step[pass][1], st1 - st0);
+          atomicAdd(&g_me_step[pass][2], st2 - st1);
+          atomicAdd(&g_me_step[pass][3], st3 - st2);
+        }
+#endif
       }
       // publish: the statistics first (agent-scope stores, acknowledged), then the progress
 #if R1_ME_FORMAL
@@ -1517,6 +1539,15 @@ void k_me_blocks_small(R1MeJob job, R1MeParams p,
 }  // namespace
 
 #ifdef R1_ME_PROF
+extern "C" int r1_debug_me_step(unsigned long long *out, int reset) {   /* out[3][4] */
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_step), sizeof(g_me_step)) != hipSuccess) return -1;
+  if (reset) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_me_step)) != hipSuccess) return -1;
+    if (hipMemset(p, 0, sizeof(g_me_step)) != hipSuccess) return -1;
+  }
+  return 0;
+}
 extern "C" int r1_debug_me_prof(unsigned long long *out, int reset) {   /* out[3][4] */
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_prof), sizeof(g_me_prof)) != hipSuccess) return -1;
   if (reset) {

@@ -168,6 +168,10 @@ import json; d=json.loads(open('$OUT/dry$n.json').read()); print('dry $n', d['va
     pmc_stage_hbm)   # STAGES=substr: FETCH_SIZE of the kernels of those frame stages, 10-bit (its own pass)
       FP="python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --bit-depth ${ARG:-10} --reps 2 --sustain-ms 0 --stages $STAGES"
       PMC_TIMEOUT=60 pmc_pass stage_fetch "FETCH_SIZE" -- $FP ;;
+    me_step)   # ARG = a library built with -DR1_ME_PROF: where a block search of the persistent tile ME spends its time
+      cp $ARG rav1e_amd/librav1e_hip.so
+      for bd in 8 10; do R1_ME_PROF_BD=$bd timeout 300 python tools/me_prof.py 4 2>/dev/null | grep "^{" | sed "s/^/bd $bd /"; done | tee $OUT/me_step.txt
+      cp /tmp/lib_orig.so rav1e_amd/librav1e_hip.so ;;
     prof_frame)   # rocprofv3 --kernel-trace --stats of the config-4 frame (tools/frame_pipeline.py, 10-bit) -> frame_kernel_stats.csv
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/proff_$TAG -o prof -- python $GRAFT_REPO_ROOT/tools/frame_pipeline.py --bit-depth ${ARG:-10} --reps 20 > /tmp/proff_$TAG.log 2>&1; tail -1 /tmp/proff_$TAG.log | cut -c1-200)
       find /tmp/proff_$TAG -name "*kernel_stats*" -exec cp {} $OUT/frame_kernel_stats.csv \; 2>/dev/null

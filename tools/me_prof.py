@@ -19,12 +19,12 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("bench_me", os.path.join(ROOT, "tools", "bench_me.py"))
 bm = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bm)
-w, h, bd = 3840, 2160, 8
+w, h, bd = 3840, 2160, int(os.environ.get('R1_ME_PROF_BD', '8'))
 f = bm.texture(w, h, bd, 1)
 rng = np.random.default_rng(2)
 org = f[32:32 + h, 32:32 + w]
 shifts = [(5, -9), (-3, 2), (12, 7), (0, -1)]
-refs = [np.clip(f[32 + dy:32 + dy + h, 32 + dx:32 + dx + w] + rng.integers(-2, 3, (h, w)), 0, 255) for dx, dy in shifts]
+refs = [np.clip(f[32 + dy:32 + dy + h, 32 + dx:32 + dx + w] + rng.integers(-2, 3, (h, w)), 0, (1 << bd) - 1) for dx, dy in shifts]
 po = O.me_pyramid(org, bd)
 prs = [O.me_pyramid(r, bd) for r in refs]
 dev = lambda pyr: [Plane.from_numpy(p.data, p.width, p.height, bd, p.xpad, p.ypad) for p in pyr]
@@ -44,12 +44,24 @@ ctx.estimate_tile_motion(jobs, cols, rows, bd, lam)
 torch.cuda.synchronize()
 lib.r1_debug_me_prof.argtypes = [C.c_void_p, C.c_int]
 lib.r1_debug_me_prof(buf, 1)
+if hasattr(lib, "r1_debug_me_step"):
+    lib.r1_debug_me_step.argtypes = [C.c_void_p, C.c_int]
+    lib.r1_debug_me_step(buf, 1)
 for s in stats:
     s.zero_()
 ctx.estimate_tile_motion(jobs, cols, rows, bd, lam)
 torch.cuda.synchronize()
 lib.r1_debug_me_prof(buf, 0)
 v = np.array(list(buf), np.float64).reshape(3, 4)
+if hasattr(lib, "r1_debug_me_step"):
+    # the persistent launch (the product path from 8 jobs on): where a block search's time goes
+    lib.r1_debug_me_step.argtypes = [C.c_void_p, C.c_int]
+    lib.r1_debug_me_step(buf, 0)
+    sv = np.array(list(buf), np.float64).reshape(3, 4)
+    for q in range(3):
+        n = max(sv[q, 0], 1)
+        print(json.dumps({"persist_pass": q + 1, "block_searches": int(sv[q, 0]), "setup_wait_us": round(sv[q, 1] / n / 100, 2),
+                          "search_us": round(sv[q, 2] / n / 100, 2), "store_us": round(sv[q, 3] / n / 100, 2)}))
 for q in range(3):
     n = max(v[q, 0], 1)
     print(json.dumps({"pass": q, "jobs": len(jobs), "workgroups": int(v[q, 0]), "mean_us": round(v[q, 1] / n / 100, 1),
