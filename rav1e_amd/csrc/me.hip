@@ -207,6 +207,31 @@ struct Block {
     unsigned long long cost;
     uint32_t sad;
     finish(v, in, row, col, cost, sad);
+#ifndef R1_ME_SETTLE_SCALAR
+#define R1_ME_SETTLE_SCALAR 1   // A/B switch (profiles/r06_ab_notes.md, ab5): 0 = the xor-shuffle tournament
+#endif
+#if R1_ME_SETTLE_SCALAR
+    // Every lane of a slot holds its slot's (cost, sad, idx, row, col): the NCS costs go to SCALAR registers with
+    // v_readlane (a few cycles each, no LDS crossbar round trip as a ds_bpermute shuffle is) and the tournament runs
+    // on the scalar unit.  idx grows with the slot number, so "the lower index wins ties" is a strict less-than.
+    {
+      int ws = 0;
+      unsigned long long wc = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cost >> 32), 0) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cost, 0);
+#pragma unroll
+      for (int sl = 1; sl < NCS; sl++) {
+        const unsigned long long c = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cost >> 32), sl * RH) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cost, sl * RH);
+        if (c < wc) { wc = c; ws = sl; }
+      }
+      const int wl = ws * RH;
+      cost = wc;
+      idx = __builtin_amdgcn_readlane(idx, wl);
+      row = __builtin_amdgcn_readlane(row, wl);
+      col = __builtin_amdgcn_readlane(col, wl);
+      sad = (uint32_t)__builtin_amdgcn_readlane((int)sad, wl);
+    }
+#else
 #pragma unroll
     for (int s = RH; s < 64; s <<= 1) {
       // (v_permlane16/32_swap instead of these shuffles was tried: no gain, and together with the DPP
@@ -219,6 +244,7 @@ struct Block {
         cost = oc; idx = oi; row = orow; col = ocol; sad = os;
       }
     }
+#endif
     if (cost < best.cost) {
       best = Msr{row, col, cost, sad};
       if (best_idx) *best_idx = idx;
@@ -291,6 +317,10 @@ struct Block {
   }
 };
 
+#ifdef R1_ME_PROF
+// [0] predictor gather, [1] the candidate scan, [2] the diamond, [3] diamond iterations, [4] searches (non-extensive)
+__device__ unsigned long long g_me_fine[8];
+#endif
 __constant__ int8_t kDiamond[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};   // (row, col)
 __constant__ int8_t kHexagon[6][2] = {{-2, 0}, {-1, 2}, {1, 2}, {2, 0}, {1, -2}, {-1, -2}};
 __constant__ int8_t kSquare[8][2] = {{1, -1}, {1, 0}, {1, 1}, {0, -1}, {0, 1}, {-1, -1}, {-1, 0}, {-1, 1}};
@@ -307,6 +337,9 @@ __device__ __forceinline__ void fullpel_diamond_search(const B &b, Msr &cur) {
   // same comparisons, same order -- one memory latency less per search.
   int radius_log2 = 1;
   for (;;) {
+#ifdef R1_ME_PROF
+    if (threadIdx.x == 0) atomicAdd(&g_me_fine[3], 1ull);
+#endif
     Msr best = msr_empty();
     const int cr = cur.row, cc = cur.col;
     if (radius_log2 == 1) {
@@ -574,9 +607,22 @@ __device__ __forceinline__ void get_subset_predictors(const TileView &t, int bx,
 template <class B>
 __device__ __forceinline__ Msr try_cands(const B &b, const int16_t *list, int n, const Msr best) {
   Msr r = msr_empty();
+#ifdef R1_ME_PROF
+  const unsigned long long f0 = wall_clock64();
+#endif
   b.scan(n, [&](int i, int &row, int &col) { row = list[2 * i]; col = list[2 * i + 1]; }, true, r,
          nullptr);
+#ifdef R1_ME_PROF
+  const unsigned long long f1 = wall_clock64();
+#endif
   fullpel_diamond_search(b, r);
+#ifdef R1_ME_PROF
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_me_fine[1], f1 - f0);
+    atomicAdd(&g_me_fine[2], wall_clock64() - f1);
+    atomicAdd(&g_me_fine[4], 1ull);
+  }
+#endif
   return r.cost < best.cost ? r : best;
 }
 
@@ -589,7 +635,13 @@ __device__ __forceinline__ Msr full_pixel_me(const B &b, const TileView &t, cons
   s.b = lds + 2;
   s.c = lds + 12;
   s.all = lds + 22;
+#ifdef R1_ME_PROF
+  const unsigned long long g0 = wall_clock64();
+#endif
   get_subset_predictors<AGENT>(t, bx, by, b.w, b.h, rng, corner, ssdec, s);
+#ifdef R1_ME_PROF
+  if (threadIdx.x == 0) atomicAdd(&g_me_fine[0], wall_clock64() - g0);
+#endif
   Msr best = msr_empty();
   if (!extensive) {
     return try_cands(b, s.all, s.has_median + s.nb + s.nc, best);
@@ -656,8 +708,18 @@ __device__ __forceinline__ void setup_block(B &b, const R1MeJob &job, const R1Me
 template <bool AGENT = false, bool WIDE = false>
 __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, int bx, int by,
                                              const Msr &r, int w, int h, int ssdec, int lane) {
-  const uint32_t nsad = (uint32_t)((((unsigned long long)r.sad) << 14) / (unsigned long long)(w * h));
+#ifndef R1_ME_FAST_STORE
+#define R1_ME_FAST_STORE 1   // A/B switch (ab5): shifts where the block area / the entry count per row are powers of two
+#endif
+  // (wave-uniform branches: a 64-bit division and two 32-bit ones by run-time values are ~200 dependent instructions
+  // between a search's last compare and the progress word its neighbours wait for)
+  const uint32_t wh = (uint32_t)(w * h);
+  const uint32_t nsad = (R1_ME_FAST_STORE && (wh & (wh - 1)) == 0)
+                            ? (uint32_t)((((unsigned long long)r.sad) << 14) >> (31 - __clz(wh)))
+                            : (uint32_t)((((unsigned long long)r.sad) << 14) / (unsigned long long)wh);
   const int nx = imin(bx + size_in_b, t.tcols) - bx, ny = imin(by + size_in_b, t.trows) - by;
+  const bool nx_p2 = R1_ME_FAST_STORE && (nx & (nx - 1)) == 0;
+  const int nx_l2 = 31 - __clz((unsigned)nx);
   R1MeStats v;
   v.row = (int16_t)(r.row << ssdec);
   v.col = (int16_t)(r.col << ssdec);
@@ -669,12 +731,16 @@ __device__ __forceinline__ void store_result(const TileView &t, int size_in_b, i
     // XCD, see k_me_persist) read it with L1-bypassing loads
     // (WIDE: the job's waves sit on any XCD -- agent-scope stores, written through)
     for (int i = lane; i < nx * ny; i += 64) {
-      unsigned long long *d = (unsigned long long *)t.at(by + i / nx, bx + i % nx);
+      const int iy = nx_p2 ? i >> nx_l2 : i / nx, ix = nx_p2 ? i & (nx - 1) : i % nx;
+      unsigned long long *d = (unsigned long long *)t.at(by + iy, bx + ix);
       if constexpr (WIDE) __hip_atomic_store(d, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else *d = bits;
     }
   } else {
-    for (int i = lane; i < nx * ny; i += 64) *t.at(by + i / nx, bx + i % nx) = v;
+    for (int i = lane; i < nx * ny; i += 64) {
+      const int iy = nx_p2 ? i >> nx_l2 : i / nx, ix = nx_p2 ? i & (nx - 1) : i % nx;
+      *t.at(by + iy, bx + ix) = v;
+    }
   }
 }
 
@@ -1539,6 +1605,15 @@ void k_me_blocks_small(R1MeJob job, R1MeParams p,
 }  // namespace
 
 #ifdef R1_ME_PROF
+extern "C" int r1_debug_me_fine(unsigned long long *out, int reset) {   /* out[8] */
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_fine), sizeof(g_me_fine)) != hipSuccess) return -1;
+  if (reset) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_me_fine)) != hipSuccess) return -1;
+    if (hipMemset(p, 0, sizeof(g_me_fine)) != hipSuccess) return -1;
+  }
+  return 0;
+}
 extern "C" int r1_debug_me_step(unsigned long long *out, int reset) {   /* out[3][4] */
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_step), sizeof(g_me_step)) != hipSuccess) return -1;
   if (reset) {

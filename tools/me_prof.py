@@ -47,12 +47,24 @@ lib.r1_debug_me_prof(buf, 1)
 if hasattr(lib, "r1_debug_me_step"):
     lib.r1_debug_me_step.argtypes = [C.c_void_p, C.c_int]
     lib.r1_debug_me_step(buf, 1)
+if hasattr(lib, "r1_debug_me_fine"):
+    lib.r1_debug_me_fine.argtypes = [C.c_void_p, C.c_int]
+    lib.r1_debug_me_fine((C.c_ulonglong * 8)(), 1)
 for s in stats:
     s.zero_()
 ctx.estimate_tile_motion(jobs, cols, rows, bd, lam)
 torch.cuda.synchronize()
 lib.r1_debug_me_prof(buf, 0)
 v = np.array(list(buf), np.float64).reshape(3, 4)
+if hasattr(lib, "r1_debug_me_fine"):
+    fb = (C.c_ulonglong * 8)()
+    lib.r1_debug_me_fine.argtypes = [C.c_void_p, C.c_int]
+    lib.r1_debug_me_fine(fb, 0)
+    fv = np.array(list(fb), np.float64)
+    n = max(fv[4], 1)
+    print(json.dumps({"non_extensive_searches": int(fv[4]), "candidate_scan_us": round(fv[1] / n / 100, 2),
+                      "diamond_us": round(fv[2] / n / 100, 2), "diamond_iterations": round(fv[3] / n, 2),
+                      "predictor_gather_us (all searches)": round(fv[0] / max(n, 1) / 100, 2)}))
 if hasattr(lib, "r1_debug_me_step"):
     # the persistent launch (the product path from 8 jobs on): where a block search's time goes
     lib.r1_debug_me_step.argtypes = [C.c_void_p, C.c_int]
