@@ -84,3 +84,55 @@ def test_trial_and_apply_equal_the_oracle_with_random_choices(ctx, case):
         want = ob.trial(units, sel)
         assert np.array_equal(got, want), (case, rnd, np.argwhere(got != want)[:6])
         assert sum(len(u) for u in units) > 0
+
+
+@pytest.mark.parametrize("fmt", [(0, 0, 8, 100), (1, 0, 10, 100), (1, 1, 12, 100), (1, 1, 8, 180), (1, 1, 10, 220)])
+def test_whole_iteration_device_equals_oracle_on_other_formats(ctx, fmt):
+    """Formats and quantizers the executed fixtures do not have (4:4:4, 4:2:2, 12-bit; qindex 180 / 220: restoration
+    units of 128 / 256 luma pixels, areas of 2 x 2 / 4 x 4 superblocks, units stretched over the frame's remainder):
+    the whole iteration through the SAME host driver on the device and on the oracle -- every event, pick and choice
+    equal.  The oracle side is pinned by the fixtures (tests/test_loop_decision_ref.py); this widens the device's
+    coverage to geometries only the oracle reaches."""
+    import torch
+    xdec, ydec, bd, q = fmt
+    W, H = 264, 200                       # not a multiple of 64: partial superblocks at the right and bottom edge
+    rng = np.random.default_rng([9, xdec, ydec, bd, q])
+    yy, xx = np.mgrid[0:H, 0:W]
+    mx = (1 << bd) - 1
+    base = ((np.sin(xx / 7.0) + np.cos((yy + 2 * xx) / 11.0)) * 45 + 128) * (1 << (bd - 8))
+    src = [np.clip(base + rng.integers(-3, 4, (H, W)) * (1 << (bd - 8)), 0, mx).astype(np.int64)]
+    cw, chh = W >> xdec, H >> ydec
+    for k in (1, 2):
+        src.append(np.clip(src[0][::1 << ydec, ::1 << xdec][:chh, :cw] // (k + 1) + (30 << (bd - 8)) * k, 0, mx))
+    rec = [np.clip(p + rng.integers(-6 << (bd - 8), (6 << (bd - 8)) + 1, p.shape) * (rng.random(p.shape) < 0.6), 0, mx) for p in src]
+    c = {"rec": [O.plane_from_image(p, bd, 16, 16) for p in rec], "src": [O.plane_from_image(p, bd, 16, 16) for p in src]}
+    gw, gh = (W + 7) // 8, (H + 7) // 8
+    skip = (rng.random((2 * gh, 2 * gw)) < 0.2).astype(np.uint8)
+    skip[:16, 16:32] = 1
+    prm = O.CdefSearchParams()
+    ystr = [0, 9, 22, 63, 5, 40, 17, 50]
+    uvstr = [0, 4, 13, 55, 2, 33, 21, 63]
+    prm.y_strengths[:] = ystr
+    prm.uv_strengths[:] = uvstr
+    from rav1e_amd import rdo_glue as RG
+    area = RG.restoration_area_sb(RG.restoration_plane_configs(W, H, xdec, ydec, q))
+    prm.damping, prm.bit_depth, prm.n_idx, prm.planes = 5, bd, 4, 3
+    prm.xdec, prm.ydec, prm.crop_w, prm.crop_h, prm.area_sb_w, prm.area_sb_h = xdec, ydec, W, H, area[0], area[1]
+    dscale = [int(v) for v in rng.integers(1 << 13, 1 << 15, 3)]
+    prm.dist_scale[:] = dscale
+    scales = rng.integers(1 << 12, 1 << 16, (gh, gw)).astype(np.uint32)
+    c.update(skip=skip, scales=scales, prm=prm, W=W, H=H, xdec=xdec, ydec=ydec, bd=bd, damping=5, n_idx=4, area=area,
+             lam=90.0 * (1 << (2 * (bd - 8))), rate_fn=lambda pli, f: 24 if f is None else 96 + 8 * f[0], q=q,
+             sets=LD.SGR_SETS["Reduced"], ystr=ystr, uvstr=uvstr, dscale=dscale)
+    dev = U.driver(device_backend(ctx, c), c)
+    ora = U.driver(U.OracleBackend(c), c)
+    bd_, ld_ = dev.run()
+    bo_, lo_ = ora.run()
+    assert dev.area == area and dev.passes == ora.passes >= 2
+    assert np.array_equal(bd_, bo_) and ld_ == lo_, (fmt, bd_, bo_)
+    assert set(dev.events) == set(ora.events)
+    n = 0
+    for a in ora.events:
+        assert dev.events[a] == ora.events[a], (fmt, a, [(g, w) for g, w in zip(dev.events[a], ora.events[a]) if g != w][:3])
+        n += len(ora.events[a])
+    assert n > 300 and any(v is not None for v in lo_.values())
