@@ -342,6 +342,11 @@ def launch_pmc(key):
         return None, None
     d = json.load(open(f))
     prefix, grid = key
+    if grid is None:       # the kernel instantiation has ONE launch geometry in the counter pass: take it
+        hits = [k for k in d if k.startswith(prefix + "@")]
+        if len(hits) != 1:
+            return None, None
+        grid = int(hits[0].rsplit("@", 1)[1])
     for k, v in d.items():
         if k.startswith(prefix) and k.endswith("@%d" % grid) and ("hbm_traffic_bytes" in v or "SQ_INSTS_VALU" in v):
             return {"dominant_traffic_bytes": v.get("hbm_traffic_bytes"), "kernel": k,
@@ -515,6 +520,8 @@ def compact_record(res, detail_path=None):
         if cb:
             c["cpu"] = _num(cb.get("value"), 1)
             c["cpu_cores"] = cb.get("cores")
+        if isinstance(e.get("pipelined"), dict):
+            c["pipelined"] = _num(e["pipelined"].get("value"), 2)
         if "stage_ms" in e:          # the config-4 frame: its stages as numbers
             c["stage_ms"] = {k[:28]: _num(v_, 3) for k, v_ in e["stage_ms"].items()}
         lines.append(c)
@@ -897,6 +904,8 @@ def config_lines(ctx, args):
         dic = torch.from_numpy(ic.view(np.uint8).reshape(-1).copy()).cuda()
         de, dl = torch.from_numpy(edges).cuda(), torch.from_numpy(lens).cuda()
         tag = "predict %dx%d" % (sz, sz)
+        lg_ = sz.bit_length() - 1
+        kkeys[tag] = ("k_intra_predict<1,false,%d,%d>" % ((lg_, lg_) if sz <= 32 else (-1, -1)), None)
         keep = {}
         fns.append((tag, lambda ts=ts, dic=dic, de=de, dl=dl, nb=nb, keep=keep: keep.__setitem__("o", ctx.predict_intra_batch(ts, dic, de, dl, 8, n=nb))))
         abytes[tag] = nb * ((2 * (2 * sz) + 1) + sz * sz)          # (2 (W + H) + 1) bpp read + W H bpp write
@@ -918,7 +927,7 @@ def config_lines(ctx, args):
                 break
     line("config3_predict_1080p", "every transform block of a 1920x1080 8-bit frame at 64/32/16/8/4: dispatch_predict_intra, the 13 "
          "luma modes mixed per block, edges uniform 0..255 (benches/predict.rs)", px, per, step, abytes, n_chk, bad,
-         working_set=sum(v for v in wbytes.values()), wbytes=wbytes)
+         working_set=sum(v for v in wbytes.values()), wbytes=wbytes, kkeys=kkeys)
     del po, pr, fns, chk
     torch.cuda.empty_cache()
 
@@ -1165,6 +1174,20 @@ def frame_line(ctx, args, timed, launch_how):
         roof["binding_roof"] = "latency"
         roof["binding_note"] = ("the hierarchical ME is a dependent chain (block rows x pyramid levels per tile, ~128 steps of ~10 us): "
                                 "neither HBM nor VALU issue limits it; counters: profiles/r05_pmc_me.json")
+    # the same work as a frame PIPELINE keeps it in flight: four streams (frame n + 1's motion search and pre-screens |
+    # frame n's luma chain | its chroma chain + type search | frame n - 1's post-filter decisions), wall clock per pass
+    p4 = F["pipelined4"]
+    for _ in range(3):
+        p4()
+    torch.cuda.synchronize()
+    sustain(p4, args.prewarm_ms)
+    t4 = time.perf_counter()
+    for _ in range(20):
+        p4()
+    torch.cuda.synchronize()
+    four_ms = (time.perf_counter() - t4) / 20 * 1e3
+    if not bool(ctx.me_status(wait=True)[0]) and "tile ME flagged a timed-out wait" not in bad:
+        bad.append("tile ME flagged a timed-out wait")
     cand_px = sum(F["candidate_pixels"].values())
     cand_ms = sum(per[n] for n in F["candidate_pixels"])
     return {"name": "config4_frame_4k_10bit", "metric": "frames/s", "value": round(1e3 / sum(per.values()), 2), "unit": "frames/s",
@@ -1177,6 +1200,11 @@ def frame_line(ctx, args, timed, launch_how):
                        "loop_decision": F.get("loop_decision"),
                        "launch": "one call per stage, serialized; stage_ms by HIP events on the launch stream"},
             "stage_ms": {n: round(v, 4) for n, v in per.items()},
+            "pipelined": {"value": round(1e3 / four_ms, 2), "unit": "frames/s", "ms_per_frame": round(four_ms, 4),
+                          "plan": {k_: len(v_) for k_, v_ in F["plan4"].items()},
+                          "note": "the same stages on four free-running streams (groups of a frame pipeline: the next frame's "
+                                  "motion search + pre-screens | luma chain | chroma chain + type search | the previous frame's "
+                                  "post-filter decisions), wall clock; `value` stays the serialized sum of stage times"},
             "rdo_candidate_Mpixels_s": round(cand_px / (cand_ms * 1e-3) / 1e6, 1),
             "rdo_candidate_note": "luma + chroma candidates and (block, type) evaluations of the type search over their stages' time",
             "roofline": roof, "dominant_stage": dom,

@@ -58,7 +58,19 @@ def main():
         ov_fn()
     torch.cuda.synchronize()
     ov = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
+    p4 = F["pipelined4"]
+    p4()
+    torch.cuda.synchronize()
+    W.sustain_clocks(p4, args.sustain_ms)
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        p4()
+    torch.cuda.synchronize()
+    ov4 = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
+    assert ctx.me_status(wait=True)[0]
     out = {"frame": "%dx%d %d-bit 4:2:0" % (fw, fh, bd), "stage_ms": stages, "sum_ms": total, "wall_ms_per_pass": round(wall, 3),
+           "four_stream_ms (ME + pre-screens | luma chain | chroma chain + type search | post-filter decisions)": ov4,
+           "frames_per_s_four_streams": round(1e3 / ov4, 1),
            "frames_per_s_if_serial": round(1e3 / total, 1),
            "two_stream_ms (ME of the next frame beside the other stages)": ov,
            "frames_per_s_two_streams": round(1e3 / ov, 1)}

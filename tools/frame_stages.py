@@ -484,6 +484,35 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
             by_name["restore_reconstruction_untimed"]()
             for n in main_order:
                 by_name[n]()
+
+    # Four streams: what a frame PIPELINE keeps in flight together -- the motion search and pre-screens of frame n + 1,
+    # the candidate chains of frame n (luma; chroma + type search), the post-filter decisions of frame n - 1.  The
+    # groups touch disjoint buffers and have no order among themselves inside a pass (a real pipeline orders them
+    # ACROSS frames); the latency-bound groups fill the issue slots the VALU-bound chains leave.
+    s4 = [torch.cuda.Stream() for _ in range(4)]
+    post = [n for n in main_order if n.split("_")[0] in ("deblock", "cdef", "lrf")]
+    luma = [n for n in main_order if n.startswith("rdo_pixel_luma")]
+    chroma_tx = [n for n in main_order if n.startswith("rdo_pixel_candidates_chroma") or n.startswith("tx_type_search")]
+    front = [n for n in main_order if n not in post and n not in luma and n not in chroma_tx]
+    plan4 = {"me+importances+subpel+prescreen": front, "pixel chain luma": luma, "pixel chain chroma + type search": chroma_tx,
+             "post-filter decisions + filters": post}
+
+    def pipelined4():
+        with torch.cuda.stream(s4[0]):
+            tile_me()
+            importances()
+            for n in front:
+                by_name[n]()
+        with torch.cuda.stream(s4[1]):
+            for n in luma:
+                by_name[n]()
+        with torch.cuda.stream(s4[2]):
+            for n in chroma_tx:
+                by_name[n]()
+        with torch.cuda.stream(s4[3]):
+            by_name["restore_reconstruction_untimed"]()
+            for n in post:
+                by_name[n]()
     px = {"rdo_pixel_candidates_chroma_2planes_K%d" % k: 2 * sum(len(v) * kk * kk for kk, v in ccands.items()),
           "tx_type_search_16x16_8x8_7types": sum(len(t["c"]) * t["nt"] * kk * kk for kk, t in tsearch.items())}
     bpp = 1 if bd == 8 else 2
@@ -523,7 +552,8 @@ def build(ctx, bd, fw=3840, fh=2160, k=16, qindex=100, seed=0):
             if name in checks:
                 res[name] = checks[name]()
         return res
-    return dict(stages=stages, checks=checks, verify=verify, overlapped=overlapped, candidate_pixels=px, frame=(fw, fh, bd),
+    return dict(stages=stages, checks=checks, verify=verify, overlapped=overlapped, pipelined4=pipelined4, plan4=plan4,
+                candidate_pixels=px, frame=(fw, fh, bd),
                 loop_decision=loop_info,
                 algorithmic_bytes=alg, luma_launch_n={kk: len(cands[kk]) for kk in W.LADDER},
                 working_set_bytes=sum(int(p.data.numel() * p.data.element_size()) for p in [org[0], refs[0][0]] + chroma),
