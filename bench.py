@@ -1154,6 +1154,7 @@ def frame_line(ctx, args, timed, launch_how):
     chain on luma AND both chroma planes, the 7-type transform search, deblock level search + filter, CDEF search +
     filter, restoration search + filter), HIP events per stage, a strided parity sample per stage against the CPU
     oracle (outside the timed region), the dominant stage against its roofline."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import frame_stages
     F = frame_stages.build(ctx, 10, k=args.k, qindex=args.qindex)

@@ -64,3 +64,16 @@ def test_emit_prints_one_stdout_line(capsys, tmp_path, monkeypatch):
     assert json.loads(lines[0])["detail"] == "gpurun_out/bench_detail.json"
     assert json.load(open(tmp_path / "gpurun_out" / "bench_detail.json"))["value"] == _long()["value"]
     assert "extra_line " in err and "detail " in err
+
+
+def test_bench_functions_that_use_torch_import_it():
+    """bench.py keeps torch out of its module scope (the record builder is imported without it); a function that names
+    `torch` must import it itself -- a missing import only shows on the GPU box, at the end of a 30 s run"""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and any(a.name.split(".")[0] == "torch" for a in n.names)
+                   for n in tree.body)
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.Name) and n.id == "torch" for n in ast.walk(fn))
+        imports = any(isinstance(n, ast.Import) and any(a.name == "torch" for a in n.names) for n in ast.walk(fn))
+        assert not uses or imports, fn.name
