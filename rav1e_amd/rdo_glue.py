@@ -129,6 +129,22 @@ def tx_type_slots(tx_type_mask):
 RESTORATION_TILESIZE_MAX_LOG2 = 8
 
 
+def tx_split_blocks(bx, by, bw, bh, tw, th, mi_width, mi_height):
+    """The transform blocks write_tx_tree (src/encoder.rs:2440-2476) visits for a block at 4x4-unit position (bx, by) of
+    bw x bh pixels coded with tw x th transforms: raster order, blocks that START outside the tile's 4x4 grid skipped.
+    -> [(index in the bw/tw x bh/th grid, pixel x, pixel y)].  For an inter block these are the candidates of the next
+    transform depth (rdo_tx_size_type, src/rdo.rs:745-815): one r1_rdo_txsearch_batch launch in its dense-prediction
+    form, the block's prediction cut into the same rectangles."""
+    out = []
+    for j in range(bh // th):
+        for i in range(bw // tw):
+            tx, ty = bx + i * (tw // 4), by + j * (th // 4)
+            if tx >= mi_width or ty >= mi_height:
+                continue
+            out.append((j * (bw // tw) + i, tx * 4, ty * 4))
+    return out
+
+
 def restoration_plane_configs(width, height, xdec, ydec, base_q_idx, enable_large_lru=True, enable_restoration=True,
                               use_128x128_superblock=False, tiling=(1, 1, 0, 0)):
     """RestorationState::new (src/lrf.rs:1321-1480): the restoration-unit geometry of the three planes of a frame --

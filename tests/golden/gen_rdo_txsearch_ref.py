@@ -29,6 +29,18 @@ Part 3 -- compute_distortion with chroma ("cd_*"): is_chroma_block = true, luma_
   4 + visible rule of sub-8x8 blocks, fi.dist_scale[p]), both tunes, with the per-importance-block
   scale grid, blocks cut by the frame edge.
 
+Part 4 -- the NEXT TRANSFORM DEPTH of an inter block ("txs_*", round 6): rdo_tx_size_type (src/rdo.rs:745-815) tries
+  tx_size one step down; for an inter block that is rdo_tx_type_decision again with the smaller tx_size on the SAME
+  prediction (no re-prediction), i.e. per TxType
+  write_tx_tree(.., bsize, tx_size < bsize, tx_type, skip = false, luma_only = true, ..)   src/encoder.rs:2409-2483
+      (EXECUTED WHOLE: the bw x bh loop over transform blocks, the mi-grid clip, ts.qc.update, get_qidx ->
+      encode_tx_block per transform block)
+  compute_distortion(.., bsize, .., luma_only = true)                                        src/rdo.rs:254-347
+  on square and rectangular blocks (16x16 -> 4 x 8x8, 32x32 -> 4 x 16x16, 8x8 -> 4 x 4x4, 16x8 -> 2 x 8x8, 8x16,
+  64x64 -> 4 x 32x32 ...), bit depths 8 / 10 / 12, interior and frame-edge positions (the mi-grid clip drops transform
+  blocks that start outside the frame).  Per (case, type): eob and qcoeffs of every transform block in call order,
+  the reconstructed block, the four distortions of part 2.
+
 Stand-ins: as gen_rdo_pixel_ref.py (get_func = the impl_1d_tx! networks of gen_fwd_tx_golden.py; a
 ContextWriter that records what write_coeffs_lv_map is handed; v_frame's ChromaSampling).
 Hand-stated (plain data): FrameInvariants / Sequence / TileStateMut / CodedFrameData field values.
@@ -233,6 +245,72 @@ def main():
     out["tsr_keys"] = np.array(keys)
     out["tsr_frame"] = np.array([fw, fh, PAD], np.int32)
     print("type search:", len(keys), "cases", flush=True)
+
+    # ---------------- part 4: the next transform depth of an inter block (write_tx_tree executed whole)
+    wtt = c.get("write_tx_tree")
+
+    class Blocks:            # cw.bc.blocks[tile_bo].segmentation_idx (get_qidx, encoder.rs:1383-1394)
+        def __getitem__(self, _k):
+            return Obj(segmentation_idx=0)
+
+    class TreeRecorder(CoeffRecorder):
+        def __init__(self):
+            CoeffRecorder.__init__(self)
+            self.bc = Obj(blocks=Blocks())
+    seg = Obj(features=R.RSlice([R.RSlice([False] * 8) for _ in range(8)]), data=R.RSlice([R.RSlice([0] * 8) for _ in range(8)]))
+    # (block, transform size one depth down): BlockSize name, TxSize index
+    SPLITS = (("BLOCK_16X16", 1), ("BLOCK_32X32", 2), ("BLOCK_8X8", 0), ("BLOCK_16X8", 1), ("BLOCK_8X16", 1), ("BLOCK_64X64", 3),
+              ("BLOCK_32X16", 2), ("BLOCK_16X32", 2), ("BLOCK_8X4", 0), ("BLOCK_4X8", 0))
+    keys4 = []
+    ci = 0
+    for bd in (8, 10, 12):
+        g = dict(L.pixel_type(bd), W="BitCounter")
+        g1 = L.pixel_type(bd)
+        dt = L.np_dtype(bd)
+        src, pred = out["tsr_src_%d" % bd], out["tsr_pred_%d" % bd]
+        scales = np.ascontiguousarray(out["tsr_scales_%d" % bd][:imp_h, :imp_w])
+        for (bsn, ts) in SPLITS:
+            bw_, bh_ = [int(v) for v in bsn[6:].split("X")]
+            tw_, th_ = TX_W[ts], TX_H[ts]
+            types = [t for t in rav1e_ids if (int(masks[ts, 1, 0, 0]) >> t) & 1]
+            inner, edge = positions(bw_, bh_)
+            for (bx, by) in (inner[ci % 3], edge[ci % 3], edge[(ci + 1) % 3]):
+                qidx = (40, 100, 170, 230)[ci % 4]
+                k = "%d_%s_%d_%d_%d_%d" % (bd, bsn[6:], ts, qidx, bx, by)
+                keys4.append(k)
+                ox, oy = bx * 4, by * 4
+                eobs, qcs, recs, dists = [], [], [], []
+                for tt in types:
+                    p_in, p_rec = padded_to_plane(src, bd, PAD), padded_to_plane(pred, bd, PAD)
+                    qc = qc_default({})
+                    tsm = tile_state([p_in, p_in, p_in], [p_rec, p_rec, p_rec], qc)     # planes[1].cfg is read for (xdec, ydec)
+                    tsm.segmentation = seg
+                    fi = frame_invariants(bd, qidx, "Psnr", None)
+                    wr, cw = BitCounter(), TreeRecorder()
+                    bo = TBO(BO(x=bx, y=by))
+                    has_coeff, d0 = wtt(g, fi, tsm, cw, wr, NEWMV, 0, bo, BlockSize[bsn], TxSize[ts], TxType[tt], False, True,
+                                        RDO_PIX, False)
+                    assert d0._0 == 0 and not wr.bits
+                    eobs.append([cl[1] for cl in cw.calls])
+                    qcs.append(np.array([cl[0] for cl in cw.calls], np.int32))
+                    recs.append(plane_block(p_rec, ox, oy, bw_, bh_, dt))
+                    dd = []
+                    for (tune, sc) in (("Psnr", None), ("Psychovisual", None), ("Psnr", scales), ("Psychovisual", scales)):
+                        fi = frame_invariants(bd, qidx, tune, sc)
+                        dd.append(cdist(g1, fi, tsm, BlockSize[bsn], False, bo, True)._0)
+                    dists.append(dd)
+                n_tx = len(eobs[0])
+                assert all(len(e) == n_tx for e in eobs)
+                out["txs_types_" + k] = np.array(types, np.int32)
+                out["txs_eob_" + k] = np.array(eobs, np.int32)            # [type][transform block in call order]
+                out["txs_qc_" + k] = np.stack(qcs)                         # [type][transform block][coded area]
+                out["txs_rec_" + k] = np.stack(recs)                       # [type][bh][bw]
+                out["txs_dist_" + k] = np.array(dists, np.uint64)
+                out["txs_geom_" + k] = np.array([bw_, bh_, tw_, th_, n_tx], np.int32)
+                print("split", len(keys4), k, "types", types, "tx blocks", n_tx, "eob", eobs[0], flush=True)
+                ci += 1
+    out["txs_keys"] = np.array(keys4)
+    print("tx split:", len(keys4), "cases", flush=True)
 
     # ---------------- part 3: compute_distortion with chroma
     keys = []

@@ -199,6 +199,66 @@ def check_txsearch(G, txsearch, dist_scaled, bds=(8, 10, 12), stride=1):
     return n
 
 
+def check_txsplit(G, txsearch_pred, dist_scaled, bds=(8, 10, 12)):
+    """The next transform depth of an inter block (gen_rdo_txsearch_ref.py part 4: write_tx_tree executed whole with
+    tx_size < bsize, then compute_distortion on the block) as a COMPOSITION of the type search's dense-prediction form:
+    txsearch_pred(bd, ts, mask, qidx, src_plane, preds[n_tx, th, tw], positions[(x, y)], kind, grid) ->
+        (eob[n_tx, nt], dist[n_tx, nt], qcoeffs[n_tx, nt, coded], rec[n_tx, nt, th, tw])      -- ONE launch
+    The transform blocks are rdo_glue.tx_split_blocks', their predictions the same rectangles of the block's prediction.
+    Checked per type: eob and coefficients of every transform block in call order, the assembled reconstruction, the
+    block's four distortions over its visible part -- and, where every transform block is a whole number of 8x8 tiles
+    inside the frame, that the block's distortion IS the sum of the launch's own per-block distortions (cdef_dist, and
+    SSE without a scale grid)."""
+    fw, fh, pad = [int(v) for v in G["tsr_frame"]]
+    n, n_sum = 0, 0
+    planes = {}
+    for k in [str(k) for k in G["txs_keys"]]:
+        f = k.split("_")
+        bd, ts, qidx, bx, by = int(f[0]), int(f[2]), int(f[3]), int(f[4]), int(f[5])
+        if bd not in bds:
+            continue
+        if bd not in planes:
+            planes[bd] = (padded_plane(G["tsr_src_%d" % bd], bd, pad), padded_plane(G["tsr_pred_%d" % bd], bd, pad),
+                          np.ascontiguousarray(G["tsr_scales_%d" % bd]))
+        src, pred, grid = planes[bd]
+        bw, bh, tw, th, n_tx = [int(v) for v in G["txs_geom_" + k]]
+        types = [int(t) for t in G["txs_types_" + k]]
+        mask = sum(1 << t for t in types)
+        blocks = RG.tx_split_blocks(bx, by, bw, bh, tw, th, (fw + 3) // 4, (fh + 3) // 4)
+        assert len(blocks) == n_tx, (k, blocks)
+        pv = pred.data[pred.yorigin:, pred.xorigin:]
+        preds = np.stack([pv[y:y + th, x:x + tw] for (_, x, y) in blocks])
+        ox, oy = bx * 4, by * 4
+        vw, vh = min(bw, fw - ox), min(bh, fh - oy)
+        want = G["txs_dist_" + k]
+        for j, (kind, sc) in enumerate(((2, None), (3, None), (2, grid), (3, grid))):
+            eob, dist, qc, rec = txsearch_pred(bd, ts, mask, qidx, src, preds, [(x, y) for (_, x, y) in blocks], kind, sc)
+            eob = np.asarray(eob).astype(np.int64).reshape(n_tx, len(types))
+            assert np.array_equal(eob.T, G["txs_eob_" + k].astype(np.int64)), (k, "eob")
+            qc = np.asarray(qc).astype(np.int64).reshape(n_tx, len(types), -1)
+            assert np.array_equal(qc.transpose(1, 0, 2), G["txs_qc_" + k].astype(np.int64)), (k, "qcoeffs")
+            rec = np.asarray(rec).astype(np.int64).reshape(n_tx, len(types), th, tw)
+            dist = np.asarray(dist).astype(np.uint64).reshape(n_tx, len(types))
+            for s, t in enumerate(types):
+                blk = pv[oy:oy + bh, ox:ox + bw].astype(np.int64).copy()
+                for b, (_, x, y) in enumerate(blocks):
+                    blk[y - oy:y - oy + th, x - ox:x - ox + tw] = rec[b, s]
+                assert np.array_equal(blk, G["txs_rec_" + k][s].astype(np.int64)), (k, "rec", t)
+                rp = O.HostPlane(src.width, src.height, bd, src.xpad, src.ypad)
+                rp.data[...] = pred.data
+                rp.data[rp.yorigin + oy:rp.yorigin + oy + bh, rp.xorigin + ox:rp.xorigin + ox + bw] = blk
+                got = dist_scaled(kind, bd, src, rp, ox, oy, vw, vh, sc)
+                assert int(got) == int(want[s, j]), (k, "block dist", t, j, int(got), int(want[s, j]))
+                # (not for the weighted SSE with a scale grid: get_weighted_sse rounds ONCE per call, `(sum + 32) >> 6`,
+                # dist.rs:281 -- the sum of the quadrants' rounded values is not the block's; cdef_dist_wxh rounds per 8x8 tile)
+                if j != 2 and (vw, vh) == (bw, bh) and tw % 8 == 0 and th % 8 == 0 and len(blocks) == (bw // tw) * (bh // th):
+                    assert int(dist[:, s].sum()) == int(want[s, j]), (k, "sum of the transform blocks' distortions", t, j)
+                    n_sum += 1
+            n += len(types)
+    assert n_sum > 100
+    return n
+
+
 def check_compute_distortion(G, make_dist):
     """compute_distortion with chroma (gen_rdo_txsearch_ref.py part 3).
     make_dist(bd, planes_src, planes_rec, grid_or_None, xdec, ydec) -> dist_wxh(kind, plane, x, y, w, h)"""

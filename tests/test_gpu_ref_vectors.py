@@ -332,6 +332,35 @@ def test_rdo_txsearch_ref_every_visited_type_on_one_prediction(ctx):
     assert n == sum(len(G["tsr_types_" + str(k)]) for k in G["tsr_keys"]) * 4 and n > 5000
 
 
+def test_rdo_txsearch_ref_next_transform_depth_of_an_inter_block(ctx):
+    """rdo_tx_size_type's next depth for an inter block (src/rdo.rs:745-815) = write_tx_tree with tx_size < bsize on the
+    SAME prediction, EXECUTED WHOLE in the fixture (part 4: 90 cases x every visited type): r1_rdo_txsearch_batch in its
+    dense-prediction form, ONE launch per (block, distortion kind) over the block's transform blocks, reproduces eob and
+    coefficients of every transform block, the block's reconstruction and its four distortions; where the transform
+    blocks are whole 8x8 tiles the block's distortion is the sum of the launch's own outputs."""
+    import torch
+    import rdo_glue_cases as RC
+    from rav1e_amd.api import RDO_CAND
+    G = np.load(RC.GOLD_TXSEARCH)
+    cache = {}
+
+    def txsearch_pred(bd, ts, mask, qidx, src, preds, pos, kind, grid):
+        w, h = RC.TX_W[ts], RC.TX_H[ts]
+        if bd not in cache:
+            cache[bd] = (dev_plane(src), torch.from_numpy(np.ascontiguousarray(G["tsr_scales_%d" % bd]).view(np.int32)).cuda())
+        ds, dg = cache[bd]
+        c = np.zeros(len(pos), RDO_CAND)
+        c["ox"], c["oy"] = [p[0] for p in pos], [p[1] for p in pos]
+        pt = np.uint8 if bd == 8 else np.uint16
+        dp = torch.from_numpy(np.ascontiguousarray(preds.astype(pt)).view(np.uint8 if bd == 8 else np.int16)).cuda()
+        o = ctx.rdo_txsearch_batch(ds, None, w, h, c, mask, qidx, kind, scales=None if grid is None else dg, is_intra=0,
+                                   want_qcoeffs=True, want_rec=True, pred=dp)
+        return (o["eob"].cpu().numpy().view(np.uint16), o["dist"].cpu().numpy().view(np.uint64), o["qcoeffs"].cpu().numpy(),
+                o["rec"].cpu().numpy().view(pt))
+    n = RC.check_txsplit(G, txsearch_pred, _gpu_dist_scaled(ctx))
+    assert n == sum(len(G["txs_types_" + str(k)]) for k in G["txs_keys"]) * 4 and n > 1500
+
+
 def test_rdo_txsearch_ref_compute_distortion_with_chroma(ctx):
     """compute_distortion (src/rdo.rs:254-347) with is_chroma_block and !luma_only as executed from the
     reference's text on 4:2:0 / 4:2:2 / 4:4:4 planes, bit depths 8 / 10 / 12: rav1e_amd.rdo_glue's

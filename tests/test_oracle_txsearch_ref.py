@@ -68,6 +68,32 @@ def test_type_search_every_visited_type_on_one_prediction(oracle):
     assert n == sum(len(G["tsr_types_" + str(k)]) for k in G["tsr_keys"]) * 4 and n > 5000
 
 
+def test_next_transform_depth_of_an_inter_block_is_the_type_search_on_its_quadrants(oracle):
+    """write_tx_tree with tx_size < bsize, executed whole (90 cases: 16x16 -> 4 x 8x8 ... 64x64 -> 4 x 32x32, rectangles,
+    8x8 -> 4 x 4x4, bit depths 8 / 10 / 12, blocks cut by the frame edge), against r1o_rdo_txsearch_batch in its
+    dense-prediction form on the transform blocks rdo_glue.tx_split_blocks lists"""
+    G = np.load(RC.GOLD_TXSEARCH)
+
+    def txsearch_pred(bd, ts, mask, qidx, src, preds, pos, kind, grid):
+        w, h = RC.TX_W[ts], RC.TX_H[ts]
+        hbd = int(bd > 8)
+        nt, n = bin(mask).count("1"), len(pos)
+        c = np.zeros(n, O.RDO_CAND)
+        c["ox"], c["oy"] = [p[0] for p in pos], [p[1] for p in pos]
+        pa = src.cstruct()
+        pr = np.ascontiguousarray(preds.astype(np.uint16 if hbd else np.uint8))
+        eob, dist = np.zeros((n, nt), np.uint16), np.zeros((n, nt), np.uint64)
+        qc = np.zeros((n, nt, min(w, 32) * min(h, 32)), np.int32 if hbd else np.int16)
+        rec = np.zeros((n, nt, h, w), np.uint16 if hbd else np.uint8)
+        sc = None if grid is None else O.ptr(grid)
+        assert oracle.r1o_rdo_txsearch_batch(C.byref(pa), None, O.ptr(pr), w, h, ts, O.ptr(c), n, mask, qidx, 0, 0, 0, kind, sc,
+                                             0 if grid is None else grid.shape[1], 0, 0, None, None, O.ptr(eob), O.ptr(dist),
+                                             None, O.ptr(qc), O.ptr(rec)) == 0
+        return eob, dist, qc, rec
+    n = RC.check_txsplit(G, txsearch_pred, oracle_dist_scaled(oracle))
+    assert n == sum(len(G["txs_types_" + str(k)]) for k in G["txs_keys"]) * 4 and n > 1500
+
+
 def test_compute_distortion_with_chroma(oracle):
     """compute_distortion (src/rdo.rs:254-347) with is_chroma_block and !luma_only on 4:2:0 / 4:2:2 /
     4:4:4 planes: rav1e_amd.rdo_glue.compute_distortion over the oracle's sse_wxh / cdef_dist_wxh"""
