@@ -475,8 +475,8 @@ def compact_record(res, detail_path=None):
     `res` is the long document (kept: stderr + `detail_path`).  Nothing here measures anything."""
     cfg, roof, cpu = res.get("config", {}), res.get("roofline") or {}, res.get("cpu_baseline")
     xok = cfg.get("exchange_ok")
-    if isinstance(xok, dict):     # N > 1: the two booleans of the tagged-tile checks, not their notes
-        xok = {k: xok.get(k) for k in ("pre_run", "after_run", "ok") if k in xok} or bool(xok.get("ok", True))
+    if isinstance(xok, dict):     # N > 1: the booleans of the tagged-tile checks (before the run: halo, gather; after it), not their notes
+        xok = {k: xok.get(k) for k in ("halo", "gather", "after_run") if k in xok} or None
     valu = roof.get("valu") or {}
     out = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
