@@ -483,7 +483,8 @@ def compact_record(res, detail_path=None):
     out["config"] = {"workload": str(cfg.get("workload", ""))[:200],
                      "candidates_per_step": cfg.get("candidates_per_step"), "tiles": cfg.get("tiles"),
                      "exchange": str(cfg["exchange"])[:60] if cfg.get("exchange") else None, "exchange_ok": xok,
-                     "parallelism": cfg.get("parallelism")}
+                     "parallelism": cfg.get("parallelism"), "compute_ms": cfg.get("compute_ms"),
+                     "exchange_ms": cfg.get("exchange_ms")}
     out["roofline"] = {"bound": roof.get("bound"), "achieved": roof.get("achieved"), "peak": roof.get("peak"),
                        "unit": roof.get("unit"), "frac": roof.get("frac"), "traffic": roof.get("traffic"),
                        "kernel": roof.get("kernel"), "avg_launch_ms": roof.get("avg_launch_ms"),
