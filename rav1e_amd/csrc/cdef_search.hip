@@ -514,7 +514,7 @@ ScratchMap scratch_map(int mi_cols, int mi_rows, int xdec, int ydec, int bpp, in
 __attribute__((visibility("hidden")))
 int r1i_sgr_trial_err_launch(const R1Plane &trial, size_t trial_idx_bytes, const R1Plane &cdef_cur, const R1Plane &src,
                              const R1TrialUnit *units, int n_units, int n_idx, int pli, int xdec, int ydec,
-                             const uint32_t *scales, int scale_stride, unsigned long long *psum, hipStream_t st);
+                             const uint32_t *scales, int scale_stride, unsigned long long *psum, int n_sb, hipStream_t st);
 
 // scratch: the per-superblock sums [n_sb][8][3] u64, then (var i32, dir u8) per 8x8 block of the grid
 extern "C" long long r1_cdef_strength_search_scratch_bytes(int mi_cols, int mi_rows) {
@@ -614,7 +614,7 @@ extern "C" int r1_cdef_lrf_trial_batch(r1_ctx *ctx, const R1Plane *rec, const R1
   for (int k = 0; k < np; k++) {
     if (n_units[k]) {
       rc = r1i_sgr_trial_err_launch(a.trial[k], a.trial_idx_bytes, cdef_cur[k], a.src[k], units + first, n_units[k],
-                                    a.p.n_idx, k, k ? a.p.xdec : 0, k ? a.p.ydec : 0, scales, scale_stride, a.psum, st);
+                                    a.p.n_idx, k, k ? a.p.xdec : 0, k ? a.p.ydec : 0, scales, scale_stride, a.psum, (int)m.n_sb, st);
       if (rc != R1_OK) return rc;
     }
     first += n_units[k];

@@ -855,13 +855,17 @@ template <int BPP, bool CHROMA>
 __global__ __launch_bounds__(256) void k_sgr_trial_err(R1Plane trial, size_t trial_idx_bytes, R1Plane cdef_cur, R1Plane src,
                                                        const R1TrialUnit *__restrict__ units, int pli, int xdec, int ydec,
                                                        const uint32_t *__restrict__ scales, int scale_stride,
-                                                       unsigned long long *__restrict__ psum) {
+                                                       unsigned long long *__restrict__ psum, int n_sb) {
   constexpr int TR = R1_TRIAL_TROWS;
   __shared__ __attribute__((aligned(16))) uint16_t F[TR][TW];
   __shared__ unsigned long long part[4];
   const R1TrialUnit u = units[blockIdx.y];
   const int idx = blockIdx.z;
-  if (u.w <= 0 || u.h <= 0 || u.w > 64 || u.h > 64 || u.set > 15 || u.sb < 0) return;   // workgroup-uniform
+  // a unit that is not what the header promises (a superblock's visible rectangle inside the plane, a known parameter
+  // set, a superblock of this frame) is skipped, never read or accumulated: workgroup-uniform
+  if (u.w <= 0 || u.h <= 0 || u.w > 64 || u.h > 64 || u.set > 15 || u.sb < 0 || u.sb >= n_sb || u.x < 0 || u.y < 0 ||
+      u.x + u.w > trial.width || u.y + u.h > trial.height || u.x + u.w > src.width + 7 || u.y + u.h > src.height + 7)
+    return;
   const int ntx = (u.w + TW - 1) / TW, nty = (u.h + TR - 1) / TR;
   if ((int)blockIdx.x >= ntx * nty) return;
   const int tx = (int)blockIdx.x % ntx, ty = (int)blockIdx.x / ntx;
@@ -959,13 +963,13 @@ __global__ void k_lrf_err_finish(const unsigned long long *__restrict__ acc, int
 __attribute__((visibility("hidden")))
 int r1i_sgr_trial_err_launch(const R1Plane &trial, size_t trial_idx_bytes, const R1Plane &cdef_cur, const R1Plane &src,
                              const R1TrialUnit *units, int n_units, int n_idx, int pli, int xdec, int ydec,
-                             const uint32_t *scales, int scale_stride, unsigned long long *psum, hipStream_t st) {
+                             const uint32_t *scales, int scale_stride, unsigned long long *psum, int n_sb, hipStream_t st) {
   R1_REQUIRE(lrf_plane_ok(&trial) && lrf_plane_ok(&cdef_cur) && lrf_plane_ok(&src));
   R1_REQUIRE(trial.bytes_per_px == src.bytes_per_px && cdef_cur.bytes_per_px == src.bytes_per_px);
   const dim3 grid((64 / TW) * (64 / R1_TRIAL_TROWS), n_units, n_idx);
 #define R1_TRIAL(BPP, CH)                                                                                         \
   hipLaunchKernelGGL((k_sgr_trial_err<BPP, CH>), grid, dim3(256), 0, st, trial, trial_idx_bytes, cdef_cur, src, units, \
-                     pli, xdec, ydec, scales, scale_stride, psum)
+                     pli, xdec, ydec, scales, scale_stride, psum, n_sb)
   if (src.bytes_per_px == 1) {
     if (pli) R1_TRIAL(1, true); else R1_TRIAL(1, false);
   } else {
