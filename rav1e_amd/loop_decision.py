@@ -40,7 +40,9 @@ class LoopDecision:
         self.n_sbx, self.n_sby = (self.mi_cols + 15) // 16, (self.mi_rows + 15) // 16
         self.cfgs = RG.restoration_plane_configs(width, height, xdec, ydec, base_q_idx,
                                                  enable_restoration=enable_restoration)
-        self.area = RG.restoration_area_sb(self.cfgs) if enable_restoration else (1, 1)
+        # the area follows the restoration geometry even with restoration OFF (ts.restoration exists either way, rdo.rs:2119-2141:
+        # a 4:2:2 frame has 64-pixel chroma units spanning two superblocks -> areas of 2 x 1; loop_decision_ref `ldc2`)
+        self.area = RG.restoration_area_sb(self.cfgs)
         self.dec = [(0, 0), (xdec, ydec), (xdec, ydec)]
         # cdef_skip per superblock (rdo.rs:2196-2211): every 4x4 unit of the superblock inside the grid skipped
         self.sb_skip = np.ones((self.n_sby, self.n_sbx), bool)

@@ -143,3 +143,60 @@ class OracleBackend:
                                               err[k:].ctypes.data)
             assert rc == 0, (pli, r)
         return xqd, err
+
+
+def lrf_only_case(L, name):
+    """an `ldl*` case (restoration only: speed settings with cdef off) in the form `driver` takes"""
+    W, H, xdec, ydec, bd, asw = [int(v) for v in L[name + "_meta"]]
+    rec = [O.plane_from_image(L["%s_in%d" % (name, p)].astype(np.int64), bd, 16, 16) for p in range(3)]
+    src = [O.plane_from_image(L["%s_src%d" % (name, p)].astype(np.int64), bd, 16, 16) for p in range(3)]
+    rn, rs, rp = [int(v) for v in L[name + "_rate"]]
+    q, full = [int(v) for v in L[name + "_q"]]
+    prm = O.CdefSearchParams()
+    prm.damping, prm.bit_depth, prm.n_idx, prm.planes = 3, bd, 1, 3
+    prm.xdec, prm.ydec, prm.crop_w, prm.crop_h, prm.area_sb_w, prm.area_sb_h = xdec, ydec, W, H, asw, asw
+    dscale = [int(v) for v in L[name + "_dscale"]]
+    prm.dist_scale[:] = dscale
+    gw, gh = (W + 7) // 8, (H + 7) // 8
+    return dict(rec=rec, src=src, skip=np.zeros((2 * gh, 2 * gw), np.uint8), scales=np.ascontiguousarray(L[name + "_scales"]),
+                prm=prm, W=W, H=H, xdec=xdec, ydec=ydec, bd=bd, damping=3, n_idx=1, area=(asw, asw),
+                lam=float(L[name + "_lambda"][0]), rate_fn=lambda pli, f: rn if f is None else rs + rp * f[0], q=q,
+                sets=LD.SGR_SETS["Full" if full else "Reduced"], ystr=[0] * 8, uvstr=[0] * 8, dscale=dscale)
+
+
+def check_one_filter_cases(L, make_backend):
+    """The driver with ONE filter enabled against the executed function: `ldc*` (restoration off: every trial's error,
+    the pick per superblock) and `ldl*` (CDEF off: every option's error in call order, the choice per unit)."""
+    n = 0
+    for name in sorted(k[:-5] for k in L.files if k.startswith("ldc") and k.endswith("_meta")):
+        c = case(L, name)
+        ld = LD.LoopDecision(make_backend(c), c["W"], c["H"], c["xdec"], c["ydec"], c["q"], c["skip"], c["lam"], c["rate_fn"],
+                             c["n_idx"], c["sets"], enable_restoration=False)
+        best, lrf = ld.run()
+        assert ld.passes == 1 and not lrf and ld.area == c["area"], (name, ld.passes, ld.area, c["area"])
+        assert np.array_equal(best, L[name + "_best"]), (name, best, L[name + "_best"])
+        err = np.zeros_like(L[name + "_err"])
+        for (ax, ay), evs in ld.events.items():
+            k = {}
+            for (pli, lsx, lsy, _w, _h, fr, e) in evs:
+                assert fr == 0
+                sb = (ay + lsy, ax + lsx)
+                i = k.get((sb, pli), 0)
+                err[sb[0], sb[1], i] += np.uint64(e)
+                k[(sb, pli)] = i + 1
+        assert np.array_equal(err[..., :c["n_idx"]], L[name + "_err"][..., :c["n_idx"]]), name
+        n += int((best >= 0).sum()) * c["n_idx"]
+    for name in sorted(k[:-5] for k in L.files if k.startswith("ldl") and k.endswith("_meta")):
+        c = lrf_only_case(L, name)
+        ld = LD.LoopDecision(make_backend(c), c["W"], c["H"], c["xdec"], c["ydec"], c["q"], c["skip"], c["lam"], c["rate_fn"],
+                             1, c["sets"], enable_cdef=False)
+        best, lrf = ld.run()
+        assert ld.passes == 2 and (best == -1).all() and ld.area[0] == c["area"][0], (name, ld.passes, ld.area)
+        got = [e[6] for a in ld.areas() for e in ld.events.get(a, [])]
+        assert got == [int(v) for v in L[name + "_err"]], (name, len(got), len(L[name + "_err"]))
+        for (pli, x, y, s, x0, x1) in L[name + "_choice"].tolist():
+            us = ld.cfgs[pli]["unit_size"]
+            f = lrf.get((pli, x // us, y // us))
+            assert ((255, 0, 0) if f is None else f) == (s, x0, x1), (name, pli, x, y, f, (s, x0, x1))
+        n += len(got)
+    return n

@@ -136,3 +136,8 @@ def test_whole_iteration_device_equals_oracle_on_other_formats(ctx, fmt):
         assert dev.events[a] == ora.events[a], (fmt, a, [(g, w) for g, w in zip(dev.events[a], ora.events[a]) if g != w][:3])
         n += len(ora.events[a])
     assert n > 300 and any(v is not None for v in lo_.values())
+
+
+def test_driver_with_one_filter_enabled_on_the_device(ctx):
+    """ldc* (CDEF only) and ldl* (restoration only) through the driver on the device: every recorded error, pick, choice"""
+    assert U.check_one_filter_cases(L, lambda c: device_backend(ctx, c)) > 300

@@ -133,3 +133,9 @@ def test_trial_without_units_is_the_first_pass_search():
     be.apply(np.full(c["first_best"].shape, -1, np.int8))
     errp = be.trial([np.zeros(0, U.TRIAL_UNIT)] * 3, np.ones(c["first_best"].shape, np.uint8))
     assert np.array_equal(errp.sum(axis=3), c["first_err"])
+
+
+def test_driver_with_one_filter_enabled_on_the_oracle():
+    """speed settings with only CDEF (ldc0-2) or only restoration (ldl0-3): the same driver, enable_restoration / enable_cdef
+    off, against the executed function -- every error in call order, every pick and choice"""
+    assert U.check_one_filter_cases(L, lambda c: U.OracleBackend(c)) > 300
