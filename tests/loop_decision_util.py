@@ -200,3 +200,40 @@ def check_one_filter_cases(L, make_backend):
             assert ((255, 0, 0) if f is None else f) == (s, x0, x1), (name, pli, x, y, f, (s, x0, x1))
         n += len(got)
     return n
+
+
+def synthetic_case(W, H, xdec, ydec, bd, q, seed, n_idx=4, p_skip=0.2, noise=6):
+    """a frame the fixtures do not have, in the form `driver` / the backends take: smooth source + coding noise, random
+    skip flags (one superblock completely skipped), random strengths, scale grid and plane scales, the stated rate"""
+    from rav1e_amd import rdo_glue as RG
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    mx = (1 << bd) - 1
+    base = ((np.sin(xx / 7.0) + np.cos((yy + 2 * xx) / 11.0)) * 45 + 128) * (1 << (bd - 8))
+    src = [np.clip(base + rng.integers(-3, 4, (H, W)) * (1 << (bd - 8)), 0, mx).astype(np.int64)]
+    cw, chh = W >> xdec, H >> ydec
+    for k in (1, 2):
+        src.append(np.clip(src[0][::1 << ydec, ::1 << xdec][:chh, :cw] // (k + 1) + (30 << (bd - 8)) * k, 0, mx))
+    rec = [np.clip(p + rng.integers(-noise << (bd - 8), (noise << (bd - 8)) + 1, p.shape) * (rng.random(p.shape) < 0.6), 0, mx)
+           for p in src]
+    c = {"rec": [O.plane_from_image(p, bd, 16, 16) for p in rec], "src": [O.plane_from_image(p, bd, 16, 16) for p in src]}
+    gw, gh = (W + 7) // 8, (H + 7) // 8
+    skip = (rng.random((2 * gh, 2 * gw)) < p_skip).astype(np.uint8)
+    if 2 * gw >= 32:
+        skip[:16, 16:32] = 1
+    prm = O.CdefSearchParams()
+    ystr = [0, 9, 22, 63, 5, 40, 17, 50]
+    uvstr = [0, 4, 13, 55, 2, 33, 21, 63]
+    prm.y_strengths[:] = ystr
+    prm.uv_strengths[:] = uvstr
+    area = RG.restoration_area_sb(RG.restoration_plane_configs(W, H, xdec, ydec, q))
+    damping = int(rng.integers(3, 7))
+    prm.damping, prm.bit_depth, prm.n_idx, prm.planes = damping, bd, n_idx, 3
+    prm.xdec, prm.ydec, prm.crop_w, prm.crop_h, prm.area_sb_w, prm.area_sb_h = xdec, ydec, W, H, area[0], area[1]
+    dscale = [int(v) for v in rng.integers(1 << 13, 1 << 15, 3)]
+    prm.dist_scale[:] = dscale
+    scales = rng.integers(1 << 12, 1 << 16, (gh, gw)).astype(np.uint32)
+    c.update(skip=skip, scales=scales, prm=prm, W=W, H=H, xdec=xdec, ydec=ydec, bd=bd, damping=damping, n_idx=n_idx, area=area,
+             lam=90.0 * (1 << (2 * (bd - 8))), rate_fn=lambda pli, f: 24 if f is None else 96 + 8 * f[0], q=q,
+             sets=LD.SGR_SETS["Reduced"], ystr=ystr, uvstr=uvstr, dscale=dscale)
+    return c

@@ -93,37 +93,9 @@ def test_whole_iteration_device_equals_oracle_on_other_formats(ctx, fmt):
     the whole iteration through the SAME host driver on the device and on the oracle -- every event, pick and choice
     equal.  The oracle side is pinned by the fixtures (tests/test_loop_decision_ref.py); this widens the device's
     coverage to geometries only the oracle reaches."""
-    import torch
     xdec, ydec, bd, q = fmt
-    W, H = 264, 200                       # not a multiple of 64: partial superblocks at the right and bottom edge
-    rng = np.random.default_rng([9, xdec, ydec, bd, q])
-    yy, xx = np.mgrid[0:H, 0:W]
-    mx = (1 << bd) - 1
-    base = ((np.sin(xx / 7.0) + np.cos((yy + 2 * xx) / 11.0)) * 45 + 128) * (1 << (bd - 8))
-    src = [np.clip(base + rng.integers(-3, 4, (H, W)) * (1 << (bd - 8)), 0, mx).astype(np.int64)]
-    cw, chh = W >> xdec, H >> ydec
-    for k in (1, 2):
-        src.append(np.clip(src[0][::1 << ydec, ::1 << xdec][:chh, :cw] // (k + 1) + (30 << (bd - 8)) * k, 0, mx))
-    rec = [np.clip(p + rng.integers(-6 << (bd - 8), (6 << (bd - 8)) + 1, p.shape) * (rng.random(p.shape) < 0.6), 0, mx) for p in src]
-    c = {"rec": [O.plane_from_image(p, bd, 16, 16) for p in rec], "src": [O.plane_from_image(p, bd, 16, 16) for p in src]}
-    gw, gh = (W + 7) // 8, (H + 7) // 8
-    skip = (rng.random((2 * gh, 2 * gw)) < 0.2).astype(np.uint8)
-    skip[:16, 16:32] = 1
-    prm = O.CdefSearchParams()
-    ystr = [0, 9, 22, 63, 5, 40, 17, 50]
-    uvstr = [0, 4, 13, 55, 2, 33, 21, 63]
-    prm.y_strengths[:] = ystr
-    prm.uv_strengths[:] = uvstr
-    from rav1e_amd import rdo_glue as RG
-    area = RG.restoration_area_sb(RG.restoration_plane_configs(W, H, xdec, ydec, q))
-    prm.damping, prm.bit_depth, prm.n_idx, prm.planes = 5, bd, 4, 3
-    prm.xdec, prm.ydec, prm.crop_w, prm.crop_h, prm.area_sb_w, prm.area_sb_h = xdec, ydec, W, H, area[0], area[1]
-    dscale = [int(v) for v in rng.integers(1 << 13, 1 << 15, 3)]
-    prm.dist_scale[:] = dscale
-    scales = rng.integers(1 << 12, 1 << 16, (gh, gw)).astype(np.uint32)
-    c.update(skip=skip, scales=scales, prm=prm, W=W, H=H, xdec=xdec, ydec=ydec, bd=bd, damping=5, n_idx=4, area=area,
-             lam=90.0 * (1 << (2 * (bd - 8))), rate_fn=lambda pli, f: 24 if f is None else 96 + 8 * f[0], q=q,
-             sets=LD.SGR_SETS["Reduced"], ystr=ystr, uvstr=uvstr, dscale=dscale)
+    c = U.synthetic_case(264, 200, xdec, ydec, bd, q, [9, xdec, ydec, bd, q])
+    area = c["area"]
     dev = U.driver(device_backend(ctx, c), c)
     ora = U.driver(U.OracleBackend(c), c)
     bd_, ld_ = dev.run()

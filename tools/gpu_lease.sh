@@ -96,7 +96,8 @@ for l in sys.stdin:
     soak)   # seeded GPU parity tests re-run with shifted seeds (type search, chains, ME), then the persistent ME against the diagonal launches
       timeout 400 python tools/gpu_soak.py --rounds ${SOAK_ROUNDS:-12} -k txsearch 2>&1 | tail -3 | tee $OUT/soak_txsearch.log
       timeout 400 python tools/gpu_soak.py --rounds 3 2>&1 | tail -3 | tee $OUT/soak_all.log
-      timeout 200 python tools/me_persist_soak.py --seconds 90 2>&1 | tail -3 | tee $OUT/soak_me_persist.log ;;
+      timeout 200 python tools/me_persist_soak.py --seconds 90 2>&1 | tail -3 | tee $OUT/soak_me_persist.log
+      timeout 200 python tools/loop_decision_soak.py --seconds 90 2>&1 | tail -2 | tee $OUT/soak_loop_decision.log ;;
     bench_ab)   # the headline bench per library (BENCH_ARGS, e.g. "--bit-depth 10"), two passes
       for pass in 1 2; do for lib in ${ARG//,/ }; do
         cp $lib rav1e_amd/librav1e_hip.so
